@@ -1,0 +1,378 @@
+"""CPU oracle for the axial-trajectory-attention hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The shipped path
+(``axial_vs_amd``) never imports anything under ``oracle/`` and fails loudly when the
+HIP library is missing.
+
+It is an independent restatement (plain torch CPU ops, explicit per-frame loops, no
+einops) of the reference algorithm.  Every function cites the reference lines it
+follows, with the shorthands
+
+    WC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module
+    CC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/cross_clip_tracking_module
+    TL = MaXTron_Tube-Link
+
+Parity pinning: the reference has no tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself: ``oracle/gen_golden.py`` imports the reference modules from /root/reference
+in the build container and stores input/weight seeds + outputs in ``tests/golden``;
+``tests/test_oracle_golden.py`` replays them.
+
+All functions are dtype-generic: run them in float64 to obtain a reference that is
+tighter than the fp32 PyTorch path itself.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Weights = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+def _linear(x: Tensor, w: Weights, name: str) -> Tensor:
+    """y = x W^T + b with nn.Linear's [out, in] weight layout."""
+    y = x @ w[name + ".weight"].to(x.dtype).t()
+    b = w.get(name + ".bias")
+    return y if b is None else y + b.to(x.dtype)
+
+
+def _layer_norm(x: Tensor, w: Weights, name: str, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w[name + ".weight"].to(x.dtype) + w[name + ".bias"].to(x.dtype)
+
+
+def _sub(w: Weights, prefix: str) -> Weights:
+    p = prefix + "."
+    return {k[len(p):]: v for k, v in w.items() if k.startswith(p)}
+
+
+# --------------------------------------------------------------------------------------
+# (a2)+(a3) trajectory attention, q/k/v flavour (WC) and fused-qkv flavour (CC)
+# --------------------------------------------------------------------------------------
+def _trajectory_core(q: Tensor, k: Tensor, v: Tensor, w: Weights, num_frames: int, heads: int,
+                     want_attn: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """Shared by both flavours once q,k,v [S, N, C] are projected.
+
+    Spatial half   WC/temporal_attention.py:46-57   (CC/...:103-113)
+    Temporal half  WC/temporal_attention.py:60-75   (CC/...:116-129)
+    """
+    S, N, C = q.shape
+    T = num_frames
+    L = N // T
+    assert L * T == N, "tokens per sequence must be num_frames * axis_len"
+    d = C // heads
+    scale = d ** -0.5
+
+    qh = q.reshape(S, N, heads, d).permute(0, 2, 1, 3)            # [S,h,N,d]
+    kh = k.reshape(S, N, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(S, N, heads, d).permute(0, 2, 1, 3)
+
+    # spatial half: one softmax per (query, frame) over that frame's L keys
+    x = q.new_empty(S, N, T, C)                                   # x[s, q, f, (h d)]
+    attn_maps = q.new_empty(S, heads, N, T, L) if want_attn else None
+    for f in range(T):
+        kf = kh[:, :, f * L:(f + 1) * L]                          # [S,h,L,d]
+        vf = vh[:, :, f * L:(f + 1) * L]
+        logits = torch.matmul(qh, kf.transpose(-1, -2)) * scale   # [S,h,N,L]
+        p = torch.softmax(logits, dim=-1)
+        if want_attn:
+            attn_maps[:, :, :, f] = p
+        xf = torch.matmul(p, vf)                                  # [S,h,N,d]
+        x[:, :, f] = xf.permute(0, 2, 1, 3).reshape(S, N, C)
+
+    # temporal half: the query is the token's own-frame slot of x (the "diagonal")
+    own = torch.arange(N) // L                                    # frame of token n
+    x_diag = x[:, torch.arange(N), own]                           # [S,N,C]
+    q2 = _linear(x_diag, w, "proj_q") * scale                     # [S,N,C]
+    kv2 = _linear(x, w, "proj_kv")                                # [S,N,T,2C]
+    k2, v2 = kv2[..., :C], kv2[..., C:]
+    q2h = q2.reshape(S, N, heads, d)
+    k2h = k2.reshape(S, N, T, heads, d)
+    v2h = v2.reshape(S, N, T, heads, d)
+    tl = (q2h.unsqueeze(2) * k2h).sum(-1)                         # [S,N,T,h]
+    ta = torch.softmax(tl, dim=2)
+    o = (ta.unsqueeze(-1) * v2h).sum(2).reshape(S, N, C)          # [S,N,C]
+    out = _linear(o, w, "proj")
+    if want_attn:
+        # reference returns space_attn as [(S h), N, T, L]
+        attn_maps = attn_maps.reshape(S * heads, N, T, L)
+    return out, attn_maps
+
+
+def trajectory_attention(query: Tensor, key: Tensor, value: Tensor, w: Weights, num_frames: int,
+                         heads: int = 8, want_attn: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """WC/temporal_attention.py:35-76 (TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:667-708)."""
+    q = _linear(query, w, "q")
+    k = _linear(key, w, "k")
+    v = _linear(value, w, "v")
+    return _trajectory_core(q, k, v, w, num_frames, heads, want_attn)
+
+
+def cc_trajectory_attention(x: Tensor, w: Weights, seq_len: int, num_frames: int, heads: int = 8) -> Tensor:
+    """CC/maxtron_cross_clip_tracking_module.py:91-130 (fused qkv, no positional term)."""
+    assert x.shape[1] == seq_len * num_frames
+    C = x.shape[-1]
+    qkv = _linear(x, w, "qkv")
+    out, _ = _trajectory_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], w, num_frames, heads, False)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# (a4) axial layer, (a5) encoder, (a8) Tube-Link gamma wrapper
+# --------------------------------------------------------------------------------------
+def axial_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8, want_attn: bool = True
+                ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """WC/temporal_attention.py:187-220.  src [(B T),(H W),C], pos [B,T,H,W,C]."""
+    B, T, H, W, C = pos.shape
+    x = src.reshape(B, T, H, W, C)
+    # height pass: sequences (b, w), tokens (t, h)          (:197-204)
+    xs = x.permute(0, 3, 1, 2, 4).reshape(B * W, T * H, C)
+    ps = pos.permute(0, 3, 1, 2, 4).reshape(B * W, T * H, C).to(x.dtype)
+    kq = xs + ps
+    o, h_attn = trajectory_attention(kq, kq, xs, _sub(w, "height_attn"), T, heads, want_attn)
+    xs = xs + o
+    x = xs.reshape(B, W, T, H, C).permute(0, 2, 3, 1, 4)           # back to [B,T,H,W,C]
+    # width pass: sequences (b, h), tokens (t, w)           (:206-213)
+    xs = x.permute(0, 2, 1, 3, 4).reshape(B * H, T * W, C)
+    ps = pos.permute(0, 2, 1, 3, 4).reshape(B * H, T * W, C).to(x.dtype)
+    kq = xs + ps
+    o, w_attn = trajectory_attention(kq, kq, xs, _sub(w, "width_attn"), T, heads, want_attn)
+    xs = xs + o
+    x = xs.reshape(B, H, T, W, C).permute(0, 2, 1, 3, 4).reshape(B * T, H * W, C)   # (:215)
+    # norm1 + FFN + norm2                                   (:181-185, :217-218)
+    x = _layer_norm(x, w, "norm1")
+    ff = _linear(torch.relu(_linear(x, w, "linear1")), w, "linear2")
+    x = _layer_norm(x + ff, w, "norm2")
+    return x, h_attn, w_attn
+
+
+def temporal_encoder(src: Tensor, pos: Tensor, w: Weights, num_layers: int, heads: int = 8,
+                     want_attn: bool = True):
+    """WC/temporal_attention.py:90-100: layers in sequence; attention maps of the last layer."""
+    h_attn = w_attn = None
+    for i in range(num_layers):
+        src, h_attn, w_attn = axial_layer(src, pos, _sub(w, f"temporal_layers.{i}"), heads, want_attn)
+    return src, h_attn, w_attn
+
+
+def tubelink_temporal_residual(f: Tensor, pos3d: Tensor, gamma: Tensor, w: Weights, num_layers: int,
+                               heads: int = 8) -> Tensor:
+    """TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:623-627: f + gamma * encoder(f, pos)."""
+    y, _, _ = temporal_encoder(f, pos3d, w, num_layers, heads, want_attn=False)
+    return f + gamma.to(f.dtype) * y
+
+
+# --------------------------------------------------------------------------------------
+# (a6) 3-D sine positional embedding
+# --------------------------------------------------------------------------------------
+def pos_embed_sine_3d(B: int, T: int, H: int, W: int, num_pos_feats: int, temperature: float = 10000.0,
+                      normalize: bool = True, scale: float = 2 * math.pi,
+                      dtype: torch.dtype = torch.float32) -> Tensor:
+    """WC/pos_embeddings.py:86-130 with mask=None.  Returns channels-last [B,T,H,W,2*num_pos_feats]."""
+    z = torch.arange(1, T + 1, dtype=dtype)
+    y = torch.arange(1, H + 1, dtype=dtype)
+    xx = torch.arange(1, W + 1, dtype=dtype)
+    if normalize:
+        eps = 1e-6
+        z = z / (z[-1] + eps) * scale
+        y = y / (y[-1] + eps) * scale
+        xx = xx / (xx[-1] + eps) * scale
+    n = num_pos_feats
+    i = torch.arange(n, dtype=dtype)
+    dim_t = torch.as_tensor(temperature, dtype=dtype) ** (2 * torch.floor(i / 2) / n)
+    iz = torch.arange(2 * n, dtype=dtype)
+    dim_tz = torch.as_tensor(temperature, dtype=dtype) ** (2 * torch.floor(iz / 2) / (2 * n))
+
+    def interleave(coord: Tensor, dim: Tensor) -> Tensor:
+        a = coord[:, None] / dim                                   # [len, n]
+        out = torch.empty_like(a)
+        out[:, 0::2] = a[:, 0::2].sin()
+        out[:, 1::2] = a[:, 1::2].cos()
+        return out
+
+    py = interleave(y, dim_t)       # [H, n]
+    px = interleave(xx, dim_t)      # [W, n]
+    pz = interleave(z, dim_tz)      # [T, 2n]
+    pos = torch.empty(T, H, W, 2 * n, dtype=dtype)
+    pos[..., :n] = py[None, :, None, :]
+    pos[..., n:] = px[None, None, :, :]
+    pos = pos + pz[:, None, None, :]
+    return pos.unsqueeze(0).expand(B, T, H, W, 2 * n).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# cross-clip module (a9)-(a13)
+# --------------------------------------------------------------------------------------
+def _channels_first_ln(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-6) -> Tensor:
+    """kmax_deeplab/modeling/backbone/convnext.py:73-81 for [B,C,L]."""
+    u = x.mean(1, keepdim=True)
+    s = ((x - u) ** 2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return weight.to(x.dtype)[:, None] * x + bias.to(x.dtype)[:, None]
+
+
+def _batch_norm_eval(x: Tensor, w: Weights, name: str, eps: float = 1e-3) -> Tensor:
+    """nn.SyncBatchNorm(eps=1e-3) in eval mode = affine with running stats
+    (kmax_pixel_decoder.py:36-37).  Channel dim is 1."""
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    rm = w[name + ".running_mean"].to(x.dtype).reshape(shape)
+    rv = w[name + ".running_var"].to(x.dtype).reshape(shape)
+    g = w[name + ".weight"].to(x.dtype).reshape(shape)
+    b = w[name + ".bias"].to(x.dtype).reshape(shape)
+    return (x - rm) / torch.sqrt(rv + eps) * g + b
+
+
+def _conv1d_k1(x: Tensor, w: Weights, name: str) -> Tensor:
+    """1x1 Conv1d on [B,Cin,L] -> [B,Cout,L]."""
+    wt = w[name + ".weight"].to(x.dtype)[:, :, 0]
+    y = torch.einsum("oc,bcl->bol", wt, x)
+    b = w.get(name + ".bias")
+    return y if b is None else y + b.to(x.dtype)[None, :, None]
+
+
+def _gelu(x: Tensor) -> Tensor:
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def aspp(x: Tensor, w: Weights, kernel_sizes: Sequence[int], atrous_rates: Sequence[int], norm_fn: str = "ln") -> Tensor:
+    """CC/...:176-201.  x [(B Q), C, Tc].  Dilated k-tap Conv1d over the clip axis with
+    'same' replicate padding, concat, 1x1 proj (no bias) + norm + exact GELU."""
+    Bq, C, Tc = x.shape
+    branches = []
+    for bi, (ks, r) in enumerate(zip(kernel_sizes, atrous_rates)):
+        wt = w[f"_aspp_conv{bi}.weight"].to(x.dtype)               # [Cout, Cin, ks]
+        bias = w[f"_aspp_conv{bi}.bias"].to(x.dtype)
+        total = r * (ks - 1)
+        left = total // 2                                          # torch 'same': left = total//2
+        y = x.new_zeros(Bq, wt.shape[0], Tc)
+        for tap in range(ks):
+            idx = (torch.arange(Tc) - left + tap * r).clamp(0, Tc - 1)   # replicate padding
+            y = y + torch.einsum("oc,bct->bot", wt[:, :, tap], x[:, :, idx])
+        branches.append(y + bias[None, :, None])
+    cat = torch.cat(branches, dim=1)
+    y = _conv1d_k1(cat, w, "_proj_conv_bn_act.conv")
+    if norm_fn == "ln":
+        y = _channels_first_ln(y, w["_proj_conv_bn_act.norm.weight"], w["_proj_conv_bn_act.norm.bias"])
+    elif norm_fn == "syncbn":
+        y = _batch_norm_eval(y, w, "_proj_conv_bn_act.norm")
+    return _gelu(y)
+
+
+def cc_layer(clip_query: Tensor, w: Weights, i: int, kernel_sizes, atrous_rates, norm_fn: str, heads: int = 8) -> Tensor:
+    """One iteration of CC/...:286-297 on clip_query [B,Q,Tc,C] -> [B,Q,Tc,C]."""
+    B, Q, Tc, C = clip_query.shape
+    x = clip_query.permute(0, 2, 1, 3).reshape(B, Tc * Q, C)       # 'b q t c -> b (t q) c'
+    wl = _sub(w, f"transformer_trajectory_self_attention_layers.{i}")
+    x = _layer_norm(x + cc_trajectory_attention(x, _sub(wl, "self_attn"), Q, Tc, heads), wl, "norm")  # :156-161
+    x = x.reshape(B, Tc, Q, C).permute(0, 2, 3, 1).reshape(B * Q, C, Tc)                              # '(b q) c t'
+    y = aspp(x, _sub(w, f"conv_short_aggregate_layers.{i}"), kernel_sizes, atrous_rates, norm_fn) + x
+    y = _layer_norm(y.transpose(1, 2), w, f"conv_norms.{i}")       # [(B Q), Tc, C]
+    return y.reshape(B, Q, Tc, C)
+
+
+def _conv_bn_gelu_1d(x: Tensor, w: Weights, name: str) -> Tensor:
+    """ConvBN(256,256,k=1,bias=False,norm='syncbn',act='gelu',conv_type='1d') in eval (CC/...:266-270)."""
+    return _gelu(_batch_norm_eval(_conv1d_k1(x, w, name + ".conv"), w, name + ".norm"))
+
+
+def cc_predictor(mask_emb: Tensor, class_emb: Tensor, pixel_feature: Tensor, w: Weights,
+                 num_clips: int, num_clip_frames: int) -> Tuple[Tensor, Tensor]:
+    """CC/...:45-75 (eval branch).  mask_emb/class_emb [(B Tc), C, Q]; pixel_feature [(B Tc),128,(V H),W]."""
+    act = torch.softmax(_conv1d_k1(class_emb, w, "_transformer_class_activation_head.conv"), dim=0)   # :48-49
+    pooled = (class_emb * act).sum(0, keepdim=True)                                                    # :50
+    logits = _conv1d_k1(pooled, w, "_transformer_class_head.conv").permute(0, 2, 1)                   # :51
+    K1 = logits.shape[-1]
+    void = logits.new_zeros(K1)
+    void[-1] = math.log((K1 - 1) * 0.9 / (1 - 0.9))                # add_bias_towards_void, decoder :39-45
+    logits = logits + void
+    kern = _batch_norm_eval(_conv1d_k1(mask_emb, w, "_transformer_mask_head.conv"), w, "_transformer_mask_head.norm")
+    masks = torch.einsum("bchw,bcn->bnhw", pixel_feature, kern)                                        # :61-67
+    masks = _batch_norm_eval(masks.unsqueeze(1), w, "_pixel_space_mask_batch_norm").squeeze(1)         # :68
+    BT, Qn, VH, Wd = masks.shape
+    Bv = BT // num_clips
+    H = VH // num_clip_frames
+    masks = masks.reshape(Bv, num_clips, Qn, num_clip_frames, H, Wd).permute(0, 2, 1, 3, 4, 5)
+    masks = masks.reshape(Bv, Qn, num_clips * num_clip_frames, H, Wd)                                  # :69
+    return logits, masks
+
+
+def cross_clip_module(clip_query: Tensor, panoptic_features: Tensor, w: Weights, num_layers: int,
+                      num_clip_frames: int, kernel_sizes=(3, 3, 3), atrous_rates=(1, 2, 3), norm_fn: str = "ln",
+                      heads: int = 8) -> Dict[str, object]:
+    """CC/...:275-322 in eval mode (aux_outputs resized like :325-331)."""
+    B, Q, Tc, C = clip_query.shape
+    Bp, Cp, TV, H, W = panoptic_features.shape
+    V = num_clip_frames
+    pf = panoptic_features.reshape(Bp, Cp, Tc, V, H, W).permute(0, 2, 1, 3, 4, 5).reshape(Bp * Tc, Cp, V * H, W)
+    cls_all, mask_all = [], []
+    for i in range(num_layers):
+        clip_query = cc_layer(clip_query, w, i, kernel_sizes, atrous_rates, norm_fn, heads)
+        vq = clip_query.permute(0, 2, 3, 1).reshape(B * Tc, C, Q)                                     # '(b t) c q'
+        ce = _conv_bn_gelu_1d(vq, w, "_class_embedding_projection")
+        me = _conv_bn_gelu_1d(vq, w, "_mask_embedding_projection")
+        lg, mk = cc_predictor(me, ce, pf, _sub(w, "_predictor"), Tc, V)
+        cls_all.append(lg)
+        mask_all.append(mk)
+    size = mask_all[-1].shape[-3:]
+    ac = size[-1] % 2 == 1
+    aux = [{"pred_logits": a, "pred_masks": F.interpolate(b, size=size, mode="trilinear", align_corners=ac)}
+           for a, b in zip(cls_all[:-1], mask_all[:-1])]
+    return {"pred_logits": cls_all[-1], "pred_masks": mask_all[-1], "aux_outputs": aux, "clip_query": clip_query}
+
+
+# --------------------------------------------------------------------------------------
+# synthetic inputs / weights shared by tests, smoke and bench (SURVEY.md 8d recipe)
+# --------------------------------------------------------------------------------------
+def axial_layer_param_shapes(C: int, d_ffn: int) -> Dict[str, Tuple[int, ...]]:
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    for ax in ("height_attn", "width_attn"):
+        for name, out in (("q", C), ("k", C), ("v", C), ("proj_q", C), ("proj_kv", 2 * C), ("proj", C)):
+            shapes[f"{ax}.{name}.weight"] = (out, C)
+            shapes[f"{ax}.{name}.bias"] = (out,)
+    shapes["norm1.weight"] = (C,)
+    shapes["norm1.bias"] = (C,)
+    shapes["linear1.weight"] = (d_ffn, C)
+    shapes["linear1.bias"] = (d_ffn,)
+    shapes["linear2.weight"] = (C, d_ffn)
+    shapes["linear2.bias"] = (C,)
+    shapes["norm2.weight"] = (C,)
+    shapes["norm2.bias"] = (C,)
+    return shapes
+
+
+def random_weights(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Weights:
+    """xavier_uniform for matrices, U(-0.1,0.1) for biases, LN gains ~ 1 + U(-0.1,0.1).
+    Deterministic in (shapes order, seed); independent of torch's global RNG."""
+    g = torch.Generator().manual_seed(seed)
+    out: Weights = {}
+    for name, shp in shapes.items():
+        if len(shp) >= 2:
+            fan_out = shp[0] * (int(torch.tensor(shp[2:]).prod()) if len(shp) > 2 else 1)
+            fan_in = shp[1] * (int(torch.tensor(shp[2:]).prod()) if len(shp) > 2 else 1)
+            bound = math.sqrt(6.0 / (fan_in + fan_out))
+            out[name] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        elif name.endswith("running_var"):
+            out[name] = torch.rand(shp, generator=g) * 0.5 + 0.75
+        elif "norm" in name and name.endswith("weight"):
+            out[name] = 1.0 + (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+        else:
+            out[name] = (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+    return out
+
+
+def synthetic_clip(B: int, T: int, C: int, H: int, W: int, seed: int = 0) -> Tuple[Tensor, Tensor]:
+    """x ~ N(0,1) [B,T,C,H,W] -> src [(B T),(H W),C]; pos = 3-D sine embedding [B,T,H,W,C]."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, C, H, W, generator=g)
+    src = x.permute(0, 1, 3, 4, 2).reshape(B * T, H * W, C).contiguous()
+    pos = pos_embed_sine_3d(B, T, H, W, C // 2)
+    return src, pos

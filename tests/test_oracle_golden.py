@@ -1,0 +1,98 @@
+"""CPU: the oracle (oracle/axvs_oracle.py) against golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+import axvs_oracle as orc
+from golden_util import AXIAL, TRAJ, axial_inputs, checks, load, rel_err, t, weights
+
+TOL = 2e-5  # fp32 oracle vs fp32 reference: reassociation noise only
+
+
+@pytest.mark.parametrize("name", TRAJ)
+def test_trajectory_attention(name):
+    z, m = load(name)
+    w = weights(z, m)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    N = m["T"] * m["L"]
+    q = torch.randn(m["S"], N, m["C"], generator=g)
+    v = torch.randn(m["S"], N, m["C"], generator=g)
+    out, attn = orc.trajectory_attention(q, q, v, w, m["T"], m["heads"])
+    assert rel_err(out, t(z["out"])) < TOL
+    assert rel_err(attn[:: int(z["attn_stride"])], t(z["attn"])) < TOL
+    np.testing.assert_allclose(checks(attn), z["attn_checks"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", AXIAL)
+def test_axial_layer_and_pos(name):
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    s = m["stride"]
+    # G3: positional embedding
+    assert rel_err(pos[0, :, ::s, ::s], t(z["pos"])) < 1e-6
+    np.testing.assert_allclose(checks(pos), z["pos_checks"], rtol=1e-6)
+    out, ha, wa = orc.axial_layer(src, pos, w, m["heads"])
+    assert rel_err(out[:, ::s], t(z["out"])) < TOL
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
+    np.testing.assert_allclose(checks(ha), z["h_attn_checks"], rtol=1e-4)
+    np.testing.assert_allclose(checks(wa), z["w_attn_checks"], rtol=1e-4)
+    if z["h_attn"].shape == tuple(ha.shape):
+        assert rel_err(ha, t(z["h_attn"])) < TOL and rel_err(wa, t(z["w_attn"])) < TOL
+    else:
+        assert rel_err(ha[::64, ::16], t(z["h_attn"])) < TOL and rel_err(wa[::64, ::16], t(z["w_attn"])) < TOL
+
+
+def test_axial_layer_float64_is_closer_than_tol():
+    """The float64 oracle agrees with the fp32 reference to fp32 noise (it is the tighter reference)."""
+    z, m = load("g2_axial_B2_T3_C64_H5_W7")
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    out, _, _ = orc.axial_layer(src.double(), pos.double(), w, m["heads"], want_attn=False)
+    assert rel_err(out, t(z["out"])) < TOL
+
+
+def test_encoder():
+    z, m = load("g4_encoder_B2_T2_C64_H6_W5")
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    out, ha, wa = orc.temporal_encoder(src, pos, w, m["layers"], m["heads"])
+    assert rel_err(out, t(z["out"])) < TOL
+    assert rel_err(ha, t(z["h_attn"])) < TOL and rel_err(wa, t(z["w_attn"])) < TOL
+
+
+@pytest.mark.parametrize("name", ["g5_cc_trajlayer_B2_Q16_Tc3", "g5_cc_trajlayer_B1_Q16_Tc4"])
+def test_cc_trajectory_layer(name):
+    z, m = load(name)
+    w = weights(z, m)
+    g = torch.Generator().manual_seed(5100 + m["Tc"])
+    x = torch.randn(m["B"], m["Tc"] * m["Q"], 256, generator=g)
+    y = orc._layer_norm(x + orc.cc_trajectory_attention(x, orc._sub(w, "self_attn"), m["Q"], m["Tc"]), w, "norm")
+    assert rel_err(y, t(z["out"])) < TOL
+
+
+@pytest.mark.parametrize("name", ["g5_cc_aspp_ln_BQ32_Tc3", "g5_cc_aspp_ln_BQ16_Tc4"])
+def test_cc_aspp(name):
+    z, m = load(name)
+    w = weights(z, m)
+    y = orc.aspp(t(z["x"]), w, (3, 3, 3), (1, 2, 3), "ln")
+    assert rel_err(y, t(z["out"])) < TOL
+
+
+@pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2", "g5_cc_module_Q16_Tc4_V2_H8_L2",
+                                  "g5_cc_module_Q128_Tc4_V4_H64_L4"])
+def test_cc_module(name):
+    z, m = load(name)
+    w = weights(z, m)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Q"], m["Tc"], 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(m["B"], 128, m["Tc"] * m["V"], m["H"], m["W"], generator=g), dim=1)
+    out = orc.cross_clip_module(cq, pf, w, m["layers"], m["V"])
+    assert rel_err(out["pred_logits"], t(z["pred_logits"])) < 5e-5
+    np.testing.assert_allclose(checks(out["pred_masks"])[1:], z["masks_checks"][1:], rtol=1e-4)
+    if "aux0_logits" in z:
+        assert rel_err(out["pred_masks"], t(z["pred_masks"])) < 5e-5
+        assert rel_err(out["aux_outputs"][0]["pred_logits"], t(z["aux0_logits"])) < 5e-5
+        assert rel_err(out["aux_outputs"][0]["pred_masks"], t(z["aux0_masks"])) < 5e-5
+    else:
+        assert rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"])) < 5e-5
