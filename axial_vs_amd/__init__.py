@@ -1,0 +1,12 @@
+"""axial_vs_amd -- MI355X-native axial-trajectory attention (Axial-VS / MaXTron hot path).
+
+Python host mirroring the reference nn.Module surface; all compute runs in hand-written HIP kernels
+behind the C-ABI of libaxvs.so (include/axvs.h).
+"""
+from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, TemporalAxialTrajectoryAttentionLayer,
+                      TemporalEncoder, TemporalTrajectoryAttentionLayer, TrajectoryAttention, TubeLinkTemporalEncoder,
+                      set_default_dtype)
+
+__all__ = ["TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
+           "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
+           "set_default_dtype"]

@@ -1,0 +1,72 @@
+"""ctypes binding of libaxvs.so (C-ABI declared in include/axvs.h).
+
+There is no CPU or PyTorch fallback: if the HIP library is missing, importing succeeds but the
+first call raises, loudly.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaxvs.so")
+
+AXVS_F16 = 0
+AXVS_BF16 = 1
+DTYPES = {"f16": AXVS_F16, "fp16": AXVS_F16, "float16": AXVS_F16, "bf16": AXVS_BF16, "bfloat16": AXVS_BF16}
+
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class AxvsTrajParams(C.Structure):
+    _fields_ = [(n, _fp) for n in ("q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "proj_q_w", "proj_q_b",
+                                   "proj_kv_w", "proj_kv_b", "proj_w", "proj_b")]
+
+
+class AxvsAxialLayerParams(C.Structure):
+    _fields_ = [("height_attn", AxvsTrajParams), ("width_attn", AxvsTrajParams)] + \
+               [(n, _fp) for n in ("norm1_w", "norm1_b", "linear1_w", "linear1_b", "linear2_w", "linear2_b",
+                                   "norm2_w", "norm2_b")]
+
+
+# name -> (restype, argtypes); must list every symbol of include/axvs.h
+SIGNATURES = {
+    "axvs_version": (C.c_int, []),
+    "axvs_last_error": (C.c_char_p, []),
+    "axvs_traj_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "axvs_traj_pack": (C.c_int, [C.POINTER(AxvsTrajParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "axvs_axial_layer_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "axvs_axial_layer_pack": (C.c_int, [C.POINTER(AxvsAxialLayerParams), _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "axvs_traj_attn_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "axvs_traj_attn_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [C.c_int] * 6 + [_fp, C.c_size_t, _fp]),
+    "axvs_axial_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "axvs_axial_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
+    "axvs_pos3d": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, _fp]),
+    "axvs_scaled_residual": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libaxvs.so (once) and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"axial_vs_amd: {LIB_PATH} is missing -- the HIP extension has not been built and there is no "
+                "fallback path.  Run `python -c 'import __graft_entry__ as g; g.build()'` in the repo root.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().axvs_last_error().decode(errors="replace")
+        raise RuntimeError(f"axial_vs_amd: {what} failed (code {rc}): {msg}")

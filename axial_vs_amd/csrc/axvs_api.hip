@@ -1,0 +1,395 @@
+// C-ABI entry points of libaxvs.so (see include/axvs.h) and the launch sequences behind them.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/axvs.h"
+#include "axvs_attn.h"
+#include "axvs_common.h"
+#include "axvs_gemm.h"
+#include "axvs_misc.h"
+
+using namespace axvs;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Carver {  // bump allocator over a caller-owned buffer
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  template <class T>
+  T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off = align_up(off + n * sizeof(T));
+    return p;
+  }
+};
+
+int check_cfg(int C, int heads) {
+  if (C <= 0 || heads <= 0 || C % heads != 0) return fail(AXVS_ERR_ARG, "C=%d must be a positive multiple of heads=%d", C, heads);
+  if (C % 32 != 0) return fail(AXVS_ERR_ARG, "C=%d must be a multiple of 32", C);
+  if (C / heads > 32) return fail(AXVS_ERR_ARG, "head_dim=%d > 32 is not supported yet", C / heads);
+  return AXVS_OK;
+}
+
+// ---------------- packed weights ----------------
+struct TrajPacked {  // pointers into the packed blob
+  u16 *wq, *wk, *wv, *wpq, *wpkv, *wp;
+  float *bq, *bk, *bv, *bpq, *bpkv, *bp;
+};
+
+TrajPacked carve_traj(Carver& c, int C, int heads) {
+  const size_t Cp = (size_t)heads * 32;
+  TrajPacked t;
+  t.wq = c.take<u16>(Cp * C);
+  t.wk = c.take<u16>(Cp * C);
+  t.wv = c.take<u16>(Cp * C);
+  t.wpq = c.take<u16>(Cp * Cp);
+  t.wpkv = c.take<u16>(2 * Cp * Cp);
+  t.wp = c.take<u16>((size_t)C * Cp);
+  t.bq = c.take<float>(Cp);
+  t.bk = c.take<float>(Cp);
+  t.bv = c.take<float>(Cp);
+  t.bpq = c.take<float>(Cp);
+  t.bpkv = c.take<float>(2 * Cp);
+  t.bp = c.take<float>(C);
+  return t;
+}
+
+struct LayerPacked {
+  TrajPacked th, tw;
+  u16 *w1, *w2;
+  float *b1, *b2, *g1, *be1, *g2, *be2;
+};
+
+LayerPacked carve_layer(Carver& c, int C, int heads, int F) {
+  LayerPacked l;
+  l.th = carve_traj(c, C, heads);
+  l.tw = carve_traj(c, C, heads);
+  l.w1 = c.take<u16>((size_t)F * C);
+  l.w2 = c.take<u16>((size_t)F * C);
+  l.b1 = c.take<float>(F);
+  l.b2 = c.take<float>(C);
+  l.g1 = c.take<float>(C);
+  l.be1 = c.take<float>(C);
+  l.g2 = c.take<float>(C);
+  l.be2 = c.take<float>(C);
+  return l;
+}
+
+template <bool BF>
+void pack_w(const float* W, u16* out, PackDim nd, PackDim kd, hipStream_t st) {
+  long long total = (long long)nd.padded * kd.padded;
+  hipLaunchKernelGGL((pack_weight_kernel<BF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, nd, kd);
+}
+void pack_b(const float* b, float* out, PackDim nd, hipStream_t st) {
+  hipLaunchKernelGGL(pack_bias_kernel, dim3((nd.padded + 255) / 256), dim3(256), 0, st, b, out, nd);
+}
+
+template <bool BF>
+void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, hipStream_t st) {
+  const int d = C / heads, Cp = heads * 32;
+  PackDim plainC{C, C, 0, 0}, headC{C, Cp, heads, d}, head2C{2 * C, 2 * Cp, heads, d};
+  pack_w<BF>(p.q_w, t.wq, headC, plainC, st);
+  pack_w<BF>(p.k_w, t.wk, headC, plainC, st);
+  pack_w<BF>(p.v_w, t.wv, headC, plainC, st);
+  pack_w<BF>(p.proj_q_w, t.wpq, headC, headC, st);
+  pack_w<BF>(p.proj_kv_w, t.wpkv, head2C, headC, st);
+  pack_w<BF>(p.proj_w, t.wp, plainC, headC, st);
+  pack_b(p.q_b, t.bq, headC, st);
+  pack_b(p.k_b, t.bk, headC, st);
+  pack_b(p.v_b, t.bv, headC, st);
+  pack_b(p.proj_q_b, t.bpq, headC, st);
+  pack_b(p.proj_kv_b, t.bpkv, head2C, st);
+  pack_b(p.proj_b, t.bp, plainC, st);
+}
+
+// ---------------- one trajectory attention over sequence-ordered rows ----------------
+struct TrajWs {
+  u16 *q16, *k16, *v16, *x16, *o16;
+  float *q2, *kv2;
+};
+
+TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads) {
+  const size_t Cp = (size_t)heads * 32;
+  TrajWs w;
+  w.q16 = c.take<u16>(Cp * Mp);
+  w.k16 = c.take<u16>(Cp * Mp);
+  w.v16 = c.take<u16>(Cp * Mp);
+  w.x16 = c.take<u16>(Cp * Mp * T);
+  w.o16 = c.take<u16>(Cp * Mp);
+  w.q2 = c.take<float>(Cp * Mp);
+  w.kv2 = c.take<float>(2 * Cp * Mp * T);
+  return w;
+}
+
+RowMap identity_map(long long rows) {
+  int n = (int)(rows > 0 ? rows : 1);
+  return RowMap{n, n, 1, 0, 0, 1, 0};
+}
+
+template <bool BF, int NKS>
+int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int heads, long long Mp, hipStream_t st) {
+  static bool configured = false;
+  const size_t lds = (size_t)T * NKS * 32 * 32 * 2 * sizeof(u16);
+  if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "sequence too long for the LDS-resident K/V (T=%d, L=%d)", T, L);
+  if (!configured || lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<BF, NKS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+    configured = true;
+  }
+  dim3 grid((N + 63) / 64, heads, S);
+  hipLaunchKernelGGL((spatial_attn_kernel<BF, NKS>), grid, dim3(256), lds, st, w.q16, w.k16, w.v16, w.x16, attn, N, T, L,
+                     heads, Mp);
+  return AXVS_OK;
+}
+
+// q/k/v inputs are fp32 token rows addressed through `rm`; `qk_add` (nullable) is added to the q and k inputs.
+// Result (+ bias, + optional residual `res`) goes to fp32 rows of `out` through `rm`.
+template <bool BF>
+int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
+             float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
+             hipStream_t st) {
+  const int N = T * L, Cp = heads * 32, d = C / heads;
+  const long long Mp = (long long)S * N;
+  if (Mp * T > 2147483647LL / 2) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
+  if (T > 8) return fail(AXVS_ERR_ARG, "num_frames=%d > 8 is not supported yet", T);
+  const int M = (int)Mp;
+  const float scale = 1.0f / sqrtf((float)d);
+  const float kLog2e = 1.4426950408889634f;
+
+  // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
+  ALoadRowsF32<BF> aq{qsrc, qk_add, rm, M, C}, ak{ksrc, qk_add, rm, M, C}, av{vsrc, nullptr, rm, M, C};
+  launch_gemm<BF>(aq, p.wq, EpiBlocked16<BF>{w.q16, Mp, p.bq, scale * kLog2e, Cp, 0}, M, Cp, C, st);
+  launch_gemm<BF>(ak, p.wk, EpiBlocked16<BF>{w.k16, Mp, p.bk, 1.f, 0, 0}, M, Cp, C, st);
+  launch_gemm<BF>(av, p.wv, EpiBlocked16<BF>{w.v16, Mp, p.bv, 1.f, 0, 0}, M, Cp, C, st);
+
+  // spatial half
+  int nks = (L + 31) / 32, rc;
+  switch (nks) {
+    case 1: rc = launch_attn<BF, 1>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 2: rc = launch_attn<BF, 2>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 3: rc = launch_attn<BF, 3>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 4: rc = launch_attn<BF, 4>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 5: rc = launch_attn<BF, 5>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 6: rc = launch_attn<BF, 6>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 7: rc = launch_attn<BF, 7>(w, attn, S, N, T, L, heads, Mp, st); break;
+    case 8: rc = launch_attn<BF, 8>(w, attn, S, N, T, L, heads, Mp, st); break;
+    default: return fail(AXVS_ERR_ARG, "axis length L=%d > 256 is not supported yet", L);
+  }
+  if (rc != AXVS_OK) return rc;
+
+  // temporal half
+  ALoadBlocked<BF> adiag{w.x16, Mp * T, M, T, N, L};
+  launch_gemm<BF>(adiag, p.wpq, EpiRowsF32{w.q2, nullptr, p.bpq, identity_map(Mp), Cp, scale}, M, Cp, Cp, st);
+  ALoadBlocked<BF> aall{w.x16, Mp * T, M * T, 0, 1, 1};
+  launch_gemm<BF>(aall, p.wpkv, EpiRowsF32{w.kv2, nullptr, p.bpkv, identity_map(Mp * T), 2 * Cp, 1.f}, M * T, 2 * Cp, Cp, st);
+  {
+    long long threads = Mp * heads * 8;
+    hipLaunchKernelGGL((temporal_attn_kernel<BF>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, w.q2, w.kv2,
+                       w.o16, Mp, T, heads);
+  }
+  ALoadBlocked<BF> ao{w.o16, Mp, M, 0, 1, 1};
+  launch_gemm<BF>(ao, p.wp, EpiRowsF32{out, res, p.bp, rm, C, 1.f}, M, C, Cp, st);
+  return AXVS_OK;
+}
+
+int last_launch_status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AXVS_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return AXVS_OK;
+}
+
+template <bool BF>
+int traj_attn_fwd_t(const float* query, const float* key, const float* value, float* out, float* attn, const void* packed,
+                    int S, int T, int L, int C, int heads, void* ws, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  TrajPacked p = carve_traj(pc, C, heads);
+  Carver wc(ws);
+  TrajWs w = carve_traj_ws(wc, (long long)S * T * L, T, heads);
+  RowMap rm{T * L, L, 1, (long long)T * L, L, 1, 0};
+  int rc = run_traj<BF>(query, key, value, nullptr, nullptr, out, attn, p, w, rm, S, T, L, C, heads, st);
+  return rc != AXVS_OK ? rc : last_launch_status();
+}
+
+template <bool BF>
+int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W, int C,
+                      int heads, int F, void* ws, float* h_attn, float* w_attn, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  LayerPacked p = carve_layer(pc, C, heads, F);
+  const long long M = (long long)B * T * H * W;
+  Carver wc(ws);
+  TrajWs tw = carve_traj_ws(wc, M, T, heads);
+  float* buf1 = wc.take<float>((size_t)M * C);
+  float* buf2 = wc.take<float>((size_t)M * C);
+  u16* y16 = wc.take<u16>((size_t)M * C);
+  u16* h16 = wc.take<u16>((size_t)M * F);
+  const long long sB = (long long)T * H * W, sT = (long long)H * W;
+
+  // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
+  RowMap rmh{T * H, H, W, sB, sT, W, 1};
+  int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st);
+  if (rc != AXVS_OK) return rc;
+  // width pass: sequences (b, h), tokens (t, w)         :206-213
+  RowMap rmw{T * W, W, H, sB, sT, 1, W};
+  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st);
+  if (rc != AXVS_OK) return rc;
+
+  // norm1 -> FFN -> norm2                               :181-185, :217-218
+  const unsigned lnblocks = (unsigned)((M + 3) / 4);
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, buf2, p.g1, p.be1, buf1, y16, M, C, 1e-5f);
+  ALoadBlocked<BF> ay{y16, M, (int)M, 0, 1, 1};
+  launch_gemm<BF>(ay, p.w1, EpiBlocked16<BF>{h16, M, p.b1, 1.f, 0, 1}, (int)M, F, C, st);
+  ALoadBlocked<BF> ah{h16, M, (int)M, 0, 1, 1};
+  launch_gemm<BF>(ah, p.w2, EpiRowsF32{buf2, buf1, p.b2, identity_map(M), C, 1.f}, (int)M, C, F, st);
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, buf2, p.g2, p.be2, out, (u16*)nullptr, M, C,
+                     1e-5f);
+  return last_launch_status();
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int axvs_version(void) { return 1; }
+const char* axvs_last_error(void) { return g_err; }
+
+size_t axvs_traj_packed_bytes(int C, int heads) {
+  Carver c(nullptr);
+  carve_traj(c, C, heads);
+  return c.off;
+}
+
+int axvs_traj_pack(const AxvsTrajParams* p, void* packed, int C, int heads, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (int rc = check_cfg(C, heads)) return rc;
+  Carver c(packed);
+  TrajPacked t = carve_traj(c, C, heads);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) pack_traj<true>(*p, t, C, heads, st);
+  else if (dtype == AXVS_F16) pack_traj<false>(*p, t, C, heads, st);
+  else return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  return last_launch_status();
+}
+
+size_t axvs_axial_layer_packed_bytes(int C, int heads, int d_ffn) {
+  Carver c(nullptr);
+  carve_layer(c, C, heads, d_ffn);
+  return c.off;
+}
+
+int axvs_axial_layer_pack(const AxvsAxialLayerParams* p, void* packed, int C, int heads, int d_ffn, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  LayerPacked l = carve_layer(c, C, heads, d_ffn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PackDim plainC{C, C, 0, 0}, plainF{d_ffn, d_ffn, 0, 0};
+  if (dtype == AXVS_BF16) {
+    pack_traj<true>(p->height_attn, l.th, C, heads, st);
+    pack_traj<true>(p->width_attn, l.tw, C, heads, st);
+    pack_w<true>(p->linear1_w, l.w1, plainF, plainC, st);
+    pack_w<true>(p->linear2_w, l.w2, plainC, plainF, st);
+  } else {
+    pack_traj<false>(p->height_attn, l.th, C, heads, st);
+    pack_traj<false>(p->width_attn, l.tw, C, heads, st);
+    pack_w<false>(p->linear1_w, l.w1, plainF, plainC, st);
+    pack_w<false>(p->linear2_w, l.w2, plainC, plainF, st);
+  }
+  pack_b(p->linear1_b, l.b1, plainF, st);
+  pack_b(p->linear2_b, l.b2, plainC, st);
+  pack_b(p->norm1_w, l.g1, plainC, st);
+  pack_b(p->norm1_b, l.be1, plainC, st);
+  pack_b(p->norm2_w, l.g2, plainC, st);
+  pack_b(p->norm2_b, l.be2, plainC, st);
+  return last_launch_status();
+}
+
+size_t axvs_traj_attn_workspace_bytes(int S, int T, int L, int C, int heads) {
+  (void)C;
+  Carver c(nullptr);
+  carve_traj_ws(c, (long long)S * T * L, T, heads);
+  return c.off;
+}
+
+int axvs_traj_attn_fwd(const float* query, const float* key, const float* value, float* out, float* space_attn,
+                       const void* packed, int S, int T, int L, int C, int heads, int dtype, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (!query || !key || !value || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (S <= 0 || T <= 0 || L <= 0) return fail(AXVS_ERR_ARG, "empty shape S=%d T=%d L=%d", S, T, L);
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (workspace_bytes < axvs_traj_attn_workspace_bytes(S, T, L, C, heads))
+    return fail(AXVS_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes,
+                axvs_traj_attn_workspace_bytes(S, T, L, C, heads));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return traj_attn_fwd_t<true>(query, key, value, out, space_attn, packed, S, T, L, C, heads, workspace, st);
+  if (dtype == AXVS_F16) return traj_attn_fwd_t<false>(query, key, value, out, space_attn, packed, S, T, L, C, heads, workspace, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
+  const long long M = (long long)B * T * H * W;
+  Carver c(nullptr);
+  carve_traj_ws(c, M, T, heads);
+  c.take<float>((size_t)M * C);
+  c.take<float>((size_t)M * C);
+  c.take<u16>((size_t)M * C);
+  c.take<u16>((size_t)M * d_ffn);
+  return c.off;
+}
+
+int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W,
+                         int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, float* h_attn,
+                         float* w_attn, void* stream) {
+  if (!src || !pos || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return fail(AXVS_ERR_ARG, "empty shape B=%d T=%d H=%d W=%d", B, T, H, W);
+  if (src == out) return fail(AXVS_ERR_ARG, "out may not alias src");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (workspace_bytes < axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn))
+    return fail(AXVS_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes,
+                axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16)
+    return axial_layer_fwd_t<true>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st);
+  if (dtype == AXVS_F16)
+    return axial_layer_fwd_t<false>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale, void* stream) {
+  if (!pos) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 2) return fail(AXVS_ERR_ARG, "bad shape");
+  long long total = (long long)T * H * W * C;
+  hipLaunchKernelGGL(pos3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
+                     B, T, H, W, C, temperature, normalize, scale);
+  return last_launch_status();
+}
+
+int axvs_scaled_residual(const float* a, const float* b, const float* gamma, float* out, size_t n, int C, void* stream) {
+  if (!a || !b || !gamma || !out || C <= 0) return fail(AXVS_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(scaled_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     a, b, gamma, out, n, C);
+  return last_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// Spatial half of trajectory attention (WC/temporal_attention.py:46-57):
+//   for every query q of a sequence and every frame f:  x[q, f, :] = softmax_l(scale * q . k[f, l]) @ v[f, l, :]
+// One softmax per (query, frame) -- the N x N logits never leave registers.
+//
+// Inputs are the blocked 16-bit q/k/v written by the QKV GEMM ([heads][Mtot][32], sequence-order rows, q already
+// multiplied by scale*log2(e)).  Workgroup = (64 queries, head, sequence); wave = 16 queries.  K and V of the
+// (sequence, head) live in LDS for the whole workgroup.
+//
+// MFMA orientation ("keys on rows"):  S^T = K . Q^T  gives D[key][query] with the query on the lane (lane&15) and
+// the keys in registers/lane-groups, so the softmax statistics are in-lane reductions plus two cross-lane steps, and
+// the exponentiated tile is directly the B operand of  x^T = V^T . P^T  (accumulator-as-operand, k-permuted: slot
+// (g, j) of a 32-key step holds key 16*(j>>2) + 4*g + (j&3); V^T fragments follow the same permutation through
+// ds_read_b64_tr_b16).  x^T = D[d][query] leaves 4 consecutive channels of one (query, frame) row per lane.
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+// LDS images (16-bit elements):  K: [T*LP][32] rows with swz_chunk;  V: [T*LP][32] rows, the two 16-column halves
+// swapped on rows with (key>>2)&1 so the transposed reads of a 32-lane half hit distinct banks.
+__device__ __forceinline__ int v_lds_off(int key, int dcol) {
+  return key * 32 + (((dcol >> 4) ^ ((key >> 2) & 1)) << 4) + (dcol & 15);
+}
+
+template <bool BF, int NKS>  // NKS = 32-key steps per frame; LP = 32*NKS >= L
+__global__ __launch_bounds__(256) void spatial_attn_kernel(const u16* __restrict__ Q16, const u16* __restrict__ K16,
+                                                           const u16* __restrict__ V16, u16* __restrict__ X,
+                                                           float* __restrict__ attn, int N, int T, int L, int heads,
+                                                           long long Mtot) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int LP = NKS * 32;
+  u16* sK = smem;
+  u16* sV = smem + (size_t)T * LP * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, s = blockIdx.z;
+  const int fi = lane & 15, fg = lane >> 4;
+  const long long seq0 = (long long)s * N;
+  const u16* Kh = K16 + (long long)h * Mtot * 32;
+  const u16* Vh = V16 + (long long)h * Mtot * 32;
+  const u16* Qh = Q16 + (long long)h * Mtot * 32;
+
+  // ---- stage K, V of this (sequence, head): 64-byte rows, 4 chunks of 16 B; pad keys are zero ----
+  for (int c = tid; c < T * LP * 4; c += 256) {
+    int row = c >> 2, g = c & 3;
+    int f = row / LP, l = row - f * LP;
+    u16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+    if (l < L) {
+      long long r = seq0 + f * L + l;
+      kv = *reinterpret_cast<const u16x8*>(Kh + r * 32 + g * 8);
+      vv = *reinterpret_cast<const u16x8*>(Vh + r * 32 + g * 8);
+    }
+    *reinterpret_cast<u16x8*>(sK + row * 32 + swz_chunk(row, g) * 8) = kv;
+    *reinterpret_cast<u16x8*>(sV + v_lds_off(row, g * 8)) = vv;
+  }
+
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int qi = min(q0 + fi, N - 1);          // clamp: every lane stays active (transposed LDS reads need EXEC = all)
+  const bool qvalid = (q0 + fi) < N;
+  const u16x8 qfrag = *reinterpret_cast<const u16x8*>(Qh + (seq0 + qi) * 32 + fg * 8);
+  __syncthreads();
+  if (q0 >= N) return;                          // whole wave out of range (wave-uniform)
+
+  u16* Xh = X + (long long)h * Mtot * T * 32;
+  for (int f = 0; f < T; ++f) {
+    // S^T tiles: D[key][query]
+    f32x4 sc[2 * NKS];
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKS; ++kt) {
+      int row = f * LP + kt * 16 + fi;
+      u16x8 kf = *reinterpret_cast<const u16x8*>(sK + row * 32 + swz_chunk(row, fg) * 8);
+      sc[kt] = H16<BF>::mfma(kf, qfrag, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * 16 + fg * 4 + r >= L) sc[kt][r] = -INFINITY;
+        mx = fmaxf(mx, sc[kt][r]);
+      }
+    mx = wave_xor_max(mx, 16);
+    mx = wave_xor_max(mx, 32);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc[kt][r] = exp2f(sc[kt][r] - mx);
+        sum += sc[kt][r];
+      }
+    sum = wave_xor_sum(sum, 16);
+    sum = wave_xor_sum(sum, 32);
+    const float inv = 1.f / sum;
+
+    if (attn != nullptr && qvalid) {            // optional reference output space_attn[(s h), q, f, l]
+      float* ap = attn + ((((long long)s * heads + h) * N + qi) * T + f) * L;
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = kt * 16 + fg * 4 + r;
+          if (key < L) ap[key] = sc[kt][r] * inv;
+        }
+    }
+
+    // P^T fragments (B operand), unnormalised; normalise the fp32 result instead
+    u16x8 pf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[ks][j] = H16<BF>::from_f32(sc[2 * ks + (j >> 2)][j & 3]);
+
+#pragma unroll
+    for (int nd = 0; nd < 2; ++nd) {
+      f32x4 xa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        // lane i of 16-lane group g supplies the address of row (i>>2), columns 4*(i&3).. of the 4x16 block
+        int key0 = f * LP + ks * 32 + fg * 4 + (fi >> 2);
+        int dcol = nd * 16 + (fi & 3) * 4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(sV + v_lds_off(key0, dcol)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(sV + v_lds_off(key0 + 16, dcol)));
+        u16x8 vf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vf[j] = (u16)lo[j];
+          vf[4 + j] = (u16)hi[j];
+        }
+        xa = H16<BF>::mfma(vf, pf[ks], xa);    // D[d][query]
+      }
+      xa *= inv;
+      if (qvalid) {
+        long long row = (seq0 + qi) * T + f;
+        *reinterpret_cast<u16x4*>(Xh + row * 32 + nd * 16 + fg * 4) = cvt4<BF>(xa);
+      }
+    }
+  }
+}
+
+}  // namespace axvs

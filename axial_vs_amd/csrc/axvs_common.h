@@ -1,0 +1,91 @@
+// Device-side building blocks shared by the axvs kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace axvs {
+
+typedef unsigned short u16;
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;     // CDNA wavefront
+constexpr int kBlk = 32;      // K-block width of the "blocked" 16-bit activation/weight layout
+
+// 16-bit MFMA operand type: fp16 (BF=false) or bf16 (BF=true).  Accumulation is always fp32.
+template <bool BF>
+struct H16;
+
+template <>
+struct H16<false> {
+  static __device__ __forceinline__ u16 from_f32(float x) { return __builtin_bit_cast(u16, (_Float16)x); }
+  static __device__ __forceinline__ float to_f32(u16 x) { return (float)__builtin_bit_cast(_Float16, x); }
+  // D[i][j] += sum_k A[i][k] * B[k][j];  lane l holds A[l&15][8(l>>4)+e], B[8(l>>4)+e][l&15], D[4(l>>4)+r][l&15]
+  static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <>
+struct H16<true> {
+  static __device__ __forceinline__ u16 from_f32(float x) { return __builtin_bit_cast(u16, (__bf16)x); }
+  static __device__ __forceinline__ float to_f32(u16 x) { return __uint_as_float(((unsigned)x) << 16); }
+  static __device__ __forceinline__ f32x4 mfma(u16x8 a, u16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <bool BF>
+__device__ __forceinline__ u16x8 cvt8(const float (&v)[8]) {
+  u16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = H16<BF>::from_f32(v[i]);
+  return r;
+}
+
+template <bool BF>
+__device__ __forceinline__ u16x4 cvt4(f32x4 v) {
+  u16x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = H16<BF>::from_f32(v[i]);
+  return r;
+}
+
+// Sequence-order row m' = s*N + n  ->  row of the natural [B,T,H,W] token grid.
+//   s = b*Loff + o (o = off-axis coordinate), n = t*L + l (l = on-axis coordinate)
+//   nat = b*sB + t*sT + l*sL + o*sO           (rows; multiply by C for elements)
+// height pass: L=H, Loff=W, sL=W, sO=1.  width pass: L=W, Loff=H, sL=1, sO=W.
+// identity ([S,N,C] input): Loff=1, sB=N, sT=L, sL=1, sO=0.
+struct RowMap {
+  int N, L, Loff;
+  long long sB, sT, sL, sO;
+};
+
+__device__ __forceinline__ long long nat_row(const RowMap& rm, int mp) {
+  int s = mp / rm.N, n = mp - s * rm.N;
+  int b = s / rm.Loff, o = s - b * rm.Loff;
+  int t = n / rm.L, l = n - t * rm.L;
+  return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
+}
+
+// Blocked 16-bit matrix [K/32][R][32]: element (row r, col k).
+__device__ __forceinline__ long long blk_off(long long R, long long r, int k) {
+  return ((long long)(k >> 5) * R + r) * kBlk + (k & 31);
+}
+
+// LDS image of a [rows][32] 16-bit tile (64-byte rows) read as MFMA fragments with ds_read_b128:
+// lane (i = lane&15, g = lane>>4) reads the 16-byte chunk g of row i.  XOR-ing the chunk index with
+// kSwz[(row>>2)&3] makes the four 16-lane ds_read_b128 groups hit 16 distinct 16-byte slots.
+__device__ __forceinline__ int swz_chunk(int row, int g) {
+  // f = [0,3,2,1]  ==  (4 - h) & 3
+  return g ^ ((4 - ((row >> 2) & 3)) & 3);
+}
+
+__device__ __forceinline__ float wave_xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, kWave)); }
+__device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shfl_xor(v, m, kWave); }
+
+}  // namespace axvs

@@ -1,0 +1,150 @@
+// Token-GEMM  Y[m, n] = sum_k X[m, k] * W[n, k]  (+bias, epilogue), 16-bit MFMA operands, fp32 accumulate.
+//
+// X comes from a loader functor (fp32 token rows gathered through a RowMap, or a blocked 16-bit
+// activation matrix), W is a pre-packed blocked 16-bit weight [K/32][Nout][32].  The MFMA is issued
+// "transposed" -- weights as the A operand, activations as the B operand -- so that every lane ends up
+// with 4 consecutive output channels of one token (D[n][m]: m = lane&15, n = 4*(lane>>4)+r): 8-byte
+// (16-bit) or 16-byte (fp32) stores per lane.
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+// ---------------- loaders: 8 consecutive k of token row m, converted to the 16-bit operand type ----------------
+template <bool BF>
+struct ALoadRowsF32 {
+  const float* src;   // [rows, K] fp32
+  const float* add;   // nullable: added element-wise (positional embedding)
+  RowMap rm;
+  int M, K;
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    long long off = nat_row(rm, m) * K + k;
+    const float4* p = reinterpret_cast<const float4*>(src + off);
+    float4 a = p[0], b = p[1];
+    if (add) {
+      const float4* q = reinterpret_cast<const float4*>(add + off);
+      float4 c = q[0], d = q[1];
+      a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+      b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+    }
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return cvt8<BF>(v);
+  }
+};
+
+template <bool BF>
+struct ALoadBlocked {
+  const u16* X;       // blocked [K/32][R][32]
+  long long R;
+  int M;
+  int diagT, diagN, diagL;  // diagT > 0: row m -> m*T + frame(m)   (own-frame slot of the T-expanded tensor)
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    long long r = m;
+    if (diagT > 0) r = (long long)m * diagT + (m % diagN) / diagL;
+    return *reinterpret_cast<const u16x8*>(X + blk_off(R, r, k));
+  }
+};
+
+// ---------------- epilogues: 4 consecutive output channels n..n+3 of token m ----------------
+template <bool BF>
+struct EpiBlocked16 {
+  u16* Y;             // blocked [Nout/32][R][32]
+  long long R;
+  const float* bias;  // [Nout]
+  float scale;        // applied to channels < nscale after the bias (softmax scale folded into q)
+  int nscale;
+  int relu;
+  __device__ __forceinline__ void store(int m, int n, f32x4 v) const {
+    float4 b = *reinterpret_cast<const float4*>(bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    if (n < nscale) v *= scale;
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    *reinterpret_cast<u16x4*>(Y + blk_off(R, m, n)) = cvt4<BF>(v);
+  }
+};
+
+struct EpiRowsF32 {
+  float* Y;           // [rows, ld] fp32, rows through rm
+  const float* res;   // nullable residual, same indexing as Y
+  const float* bias;
+  RowMap rm;
+  int ld;
+  float scale;
+  __device__ __forceinline__ void store(int m, int n, f32x4 v) const {
+    float4 b = *reinterpret_cast<const float4*>(bias + n);
+    long long off = nat_row(rm, m) * ld + n;
+    float4 o = {(v[0] + b.x) * scale, (v[1] + b.y) * scale, (v[2] + b.z) * scale, (v[3] + b.w) * scale};
+    if (res) {
+      float4 r = *reinterpret_cast<const float4*>(res + off);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    *reinterpret_cast<float4*>(Y + off) = o;
+  }
+};
+
+// ---------------- v1 kernel: 64x64 tile, 4 waves (2x2), both operands staged through LDS ----------------
+template <bool BF, class ALoad, class Epi>
+__global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
+  __shared__ __attribute__((aligned(16))) u16 sX[64 * 32];
+  __shared__ __attribute__((aligned(16))) u16 sW[64 * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int lrow = tid >> 2, lg = tid & 3;                 // staging: one 16-byte chunk per thread and operand
+  const int wrow = min(n0 + lrow, Nout - 1);
+  const int st_off = lrow * 32 + swz_chunk(lrow, lg) * 8;
+  const int fi = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = K >> 5;
+  u16x8 rx = al.load(m0 + lrow, lg * 8);
+  u16x8 rw = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, lg * 8));
+  for (int kb = 0; kb < nkb; ++kb) {
+    *reinterpret_cast<u16x8*>(sX + st_off) = rx;
+    *reinterpret_cast<u16x8*>(sW + st_off) = rw;
+    __syncthreads();
+    if (kb + 1 < nkb) {
+      rx = al.load(m0 + lrow, (kb + 1) * 32 + lg * 8);
+      rw = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, (kb + 1) * 32 + lg * 8));
+    }
+    u16x8 fx[2], fw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = wm * 32 + i * 16 + fi;
+      fx[i] = *reinterpret_cast<const u16x8*>(sX + r * 32 + swz_chunk(r, fg) * 8);
+      int c = wn * 32 + i * 16 + fi;
+      fw[i] = *reinterpret_cast<const u16x8*>(sW + c * 32 + swz_chunk(c, fg) * 8);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = H16<BF>::mfma(fw[ni], fx[mi], acc[ni][mi]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      int m = m0 + wm * 32 + mi * 16 + fi;
+      int n = n0 + wn * 32 + ni * 16 + fg * 4;
+      if (m < M && n < Nout) epi.store(m, n, acc[ni][mi]);
+    }
+}
+
+template <bool BF, class ALoad, class Epi>
+inline void launch_gemm(const ALoad& al, const u16* Wp, const Epi& epi, int M, int Nout, int K, hipStream_t st) {
+  dim3 grid((M + 63) / 64, (Nout + 63) / 64);
+  hipLaunchKernelGGL((gemm64_kernel<BF, ALoad, Epi>), grid, dim3(256), 0, st, al, Wp, epi, M, Nout, K);
+}
+
+}  // namespace axvs

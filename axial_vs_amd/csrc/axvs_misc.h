@@ -1,0 +1,165 @@
+// Small kernels around the GEMMs: weight packing, LayerNorm, the temporal attention (v1, unfused),
+// positional embedding, scaled residual.
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+// ---------------- weight packing: fp32 nn.Linear [Nout, K] -> blocked 16-bit [Kp/32][Np][32] ----------------
+// Either dimension may be "head structured": `parts` consecutive groups of (heads x d) channels, each head padded
+// from d to 32 (zero rows / columns), so that kernels always see 32-wide head blocks.
+struct PackDim {
+  int orig;    // original size
+  int padded;  // padded size
+  int heads;   // 0: plain (identity up to `orig`, zero beyond); >0: head structured
+  int d;       // head dim (when heads > 0)
+  __device__ __host__ int to_orig(int i) const {
+    if (heads == 0) return i < orig ? i : -1;
+    int per = heads * 32;
+    int part = i / per, w = i - part * per;
+    int h = w >> 5, dd = w & 31;
+    if (dd >= d) return -1;
+    int o = part * heads * d + h * d + dd;
+    return o < orig ? o : -1;
+  }
+};
+
+template <bool BF>
+__global__ void pack_weight_kernel(const float* __restrict__ W, u16* __restrict__ out, PackDim nd, PackDim kd) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)nd.padded * kd.padded;
+  if (idx >= total) return;
+  int kk = idx & 31;
+  long long t = idx >> 5;
+  int n = t % nd.padded;
+  int kb = t / nd.padded;
+  int no = nd.to_orig(n), ko = kd.to_orig(kb * 32 + kk);
+  float v = (no >= 0 && ko >= 0) ? W[(long long)no * kd.orig + ko] : 0.f;
+  out[idx] = H16<BF>::from_f32(v);
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, PackDim nd) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nd.padded) return;
+  int o = nd.to_orig(i);
+  out[i] = o >= 0 ? b[o] : 0.f;
+}
+
+// ---------------- LayerNorm over C (one wave per row); optional blocked 16-bit copy for the next GEMM ----------------
+template <bool BF>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ Y,
+                                                        u16* __restrict__ Y16, long long M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* x = X + row * C;
+  float s = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(x + c);
+    s += v.x + v.y + v.z + v.w;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s = wave_xor_sum(s, m);
+  const float mu = s / C;
+  float q = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(x + c);
+    float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+    q += a * a + b * b + cc * cc + d * d;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) q = wave_xor_sum(q, m);
+  const float rstd = rsqrtf(q / C + eps);
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(x + c);
+    float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    float4 b = *reinterpret_cast<const float4*>(beta + c);
+    f32x4 o = {(v.x - mu) * rstd * g.x + b.x, (v.y - mu) * rstd * g.y + b.y, (v.z - mu) * rstd * g.z + b.z,
+               (v.w - mu) * rstd * g.w + b.w};
+    if (Y) *reinterpret_cast<float4*>(Y + row * C + c) = float4{o[0], o[1], o[2], o[3]};
+    if (Y16) *reinterpret_cast<u16x4*>(Y16 + blk_off(M, row, c)) = cvt4<BF>(o);
+  }
+}
+
+// ---------------- temporal half, v1 (WC/temporal_attention.py:66-73) ----------------
+// q2: fp32 [M, Cp] (already * scale);  kv2: fp32 [M*T, 2*Cp] (k2 | v2);  O16: blocked [Cp/32][M][32].
+// One thread per (token, head, 4 channels); 8 threads cooperate on a head's 32-channel dot product.
+template <bool BF>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ q2, const float* __restrict__ kv2,
+                                                            u16* __restrict__ O16, long long M, int T, int heads) {
+  const int Cp = heads * 32;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long grp = gid >> 3;                 // (token, head)
+  const int sub = (int)(gid & 7);
+  const long long m = min(grp / heads, M - 1);
+  const bool valid = (grp / heads) < M;
+  const int h = (int)(grp % heads);
+  const int c = h * 32 + sub * 4;
+  const float4 q = *reinterpret_cast<const float4*>(q2 + m * Cp + c);
+  float lg[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    lg[f] = -INFINITY;
+    if (f < T) {
+      float4 k = *reinterpret_cast<const float4*>(kv2 + (m * T + f) * 2 * Cp + c);
+      float p = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+      p += __shfl_xor(p, 1, 64);
+      p += __shfl_xor(p, 2, 64);
+      p += __shfl_xor(p, 4, 64);
+      lg[f] = p;
+      mx = fmaxf(mx, p);
+    }
+  }
+  float sum = 0.f;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    if (f < T) {
+      float e = __expf(lg[f] - mx);
+      sum += e;
+      float4 v = *reinterpret_cast<const float4*>(kv2 + (m * T + f) * 2 * Cp + Cp + c);
+      o[0] += e * v.x; o[1] += e * v.y; o[2] += e * v.z; o[3] += e * v.w;
+    }
+  }
+  o *= 1.f / sum;
+  if (valid) *reinterpret_cast<u16x4*>(O16 + blk_off(M, m, c)) = cvt4<BF>(o);
+}
+
+// ---------------- PositionEmbeddingSine3D, mask=None, channels-last (WC/pos_embeddings.py:86-130) ----------------
+__global__ void pos3d_kernel(float* __restrict__ pos, int B, int T, int H, int W, int C, float temperature, int normalize,
+                             float scale) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)T * H * W * C;
+  if (idx >= total) return;
+  int c = idx % C;
+  long long r = idx / C;
+  int w = r % W; r /= W;
+  int h = r % H;
+  int t = r / H;
+  const int n = C / 2;
+  float z = (float)(t + 1), y = (float)(h + 1), x = (float)(w + 1);
+  if (normalize) {
+    const float eps = 1e-6f;
+    z = z / ((float)T + eps) * scale;
+    y = y / ((float)H + eps) * scale;
+    x = x / ((float)W + eps) * scale;
+  }
+  int cc = c < n ? c : c - n;
+  float dim_t = powf(temperature, 2.f * (float)(cc / 2) / (float)n);
+  float a = (c < n ? y : x) / dim_t;
+  float v = (cc & 1) ? cosf(a) : sinf(a);
+  float dim_z = powf(temperature, 2.f * (float)(c / 2) / (float)C);
+  float az = z / dim_z;
+  v += (c & 1) ? cosf(az) : sinf(az);
+  for (int b = 0; b < B; ++b) pos[(long long)b * total + idx] = v;
+}
+
+__global__ void scaled_residual_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                       const float* __restrict__ gamma, float* __restrict__ out, size_t n, int C) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + gamma[i % C] * b[i];
+}
+
+}  // namespace axvs

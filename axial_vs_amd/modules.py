@@ -1,0 +1,378 @@
+"""nn.Module mirrors of the reference's within-clip trajectory-attention classes.
+
+Same constructor arguments, attribute / parameter names (state-dict keys) and call signatures as
+
+    WC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module/temporal_attention.py
+    TL = MaXTron_Tube-Link/mmdet/models/plugins/msdeformattn_pixel_decoder.py
+
+so checkpoints load with ``strict=True`` and the callers (WC/msdeformattn.py:262, TL:623-627) are unchanged.
+``forward`` hands raw device pointers to libaxvs.so; PyTorch only owns the memory and the stream.
+
+Forward-only: modules must be in ``eval()`` mode (the training path with dropout / autograd is out of scope,
+SURVEY.md section 8f).  There is no CPU fallback -- tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+
+_DEFAULT_DTYPE = "f16"
+
+
+def set_default_dtype(name: str) -> None:
+    """MFMA operand type used by modules that were not given an explicit ``mfma_dtype``: 'f16' | 'bf16'."""
+    global _DEFAULT_DTYPE
+    if name not in _lib.DTYPES:
+        raise ValueError(f"unknown dtype {name!r}")
+    _DEFAULT_DTYPE = name
+
+
+# ---------------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------------
+_workspaces: Dict[Tuple[str, int], Tensor] = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> Tensor:
+    """Grow-only scratch buffer per (device, stream) from torch's caching allocator."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _dev_f32(t: Tensor, what: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"axial_vs_amd: {what} must be a GPU tensor (got {t.device}); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_eval(m: nn.Module) -> None:
+    if m.training:
+        raise NotImplementedError("axial_vs_amd: forward-only HIP path -- call .eval() (training/autograd is out of scope)")
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _param_key(mod: nn.Module, dtype: str):
+    return (dtype,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in mod.parameters())
+
+
+def _traj_struct(m: "TrajectoryAttention", keep: list) -> _lib.AxvsTrajParams:
+    C_ = m.proj.weight.shape[0]
+    if hasattr(m, "qkv"):  # cross-clip flavour: slices of the fused projection
+        w, b = _dev_f32(m.qkv.weight.detach(), "qkv.weight"), _dev_f32(m.qkv.bias.detach(), "qkv.bias")
+        qw, kw, vw = w[:C_], w[C_:2 * C_], w[2 * C_:]
+        qb, kb, vb = b[:C_], b[C_:2 * C_], b[2 * C_:]
+    else:
+        qw, qb = m.q.weight, m.q.bias
+        kw, kb = m.k.weight, m.k.bias
+        vw, vb = m.v.weight, m.v.bias
+    ts = [_dev_f32(t.detach(), "parameter") for t in (qw, qb, kw, kb, vw, vb, m.proj_q.weight, m.proj_q.bias,
+                                                      m.proj_kv.weight, m.proj_kv.bias, m.proj.weight, m.proj.bias)]
+    keep.extend(ts)
+    return _lib.AxvsTrajParams(*[t.data_ptr() for t in ts])
+
+
+# ---------------------------------------------------------------------------------------------
+# TrajectoryAttention   (WC/temporal_attention.py:20-76, TL:652-708)
+# ---------------------------------------------------------------------------------------------
+class TrajectoryAttention(nn.Module):
+    def __init__(self, dim, num_heads=8, attn_drop=0., mfma_dtype: Optional[str] = None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+
+        self.q = nn.Linear(dim, dim, bias=True)
+        self.k = nn.Linear(dim, dim, bias=True)
+        self.v = nn.Linear(dim, dim, bias=True)
+        self.proj_q = nn.Linear(dim, dim, bias=True)
+        self.proj_kv = nn.Linear(dim, dim * 2, bias=True)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+
+        self.mfma_dtype = mfma_dtype
+        self.return_attn = False     # the [(S h), N, T, L] map is opt-in: materialising it defeats the fusion
+        self._packed: Optional[Tensor] = None
+        self._packed_key = None
+
+    def _dtype(self) -> str:
+        return self.mfma_dtype or _DEFAULT_DTYPE
+
+    def _pack(self) -> Tensor:
+        dt = self._dtype()
+        key = _param_key(self, dt)
+        if self._packed is None or key != self._packed_key:
+            L = _lib.lib()
+            C_, dev = self.proj.weight.shape[0], self.proj.weight.device
+            keep: list = []
+            ps = _traj_struct(self, keep)
+            buf = torch.empty(L.axvs_traj_packed_bytes(C_, self.num_heads), dtype=torch.uint8, device=dev)
+            _lib.check(L.axvs_traj_pack(C.byref(ps), buf.data_ptr(), C_, self.num_heads, _lib.DTYPES[dt], _stream(dev)),
+                       "axvs_traj_pack")
+            self._packed, self._packed_key = buf, key
+        return self._packed
+
+    def forward(self, query, key, value, num_frames=2):
+        """query/key/value: [S, num_frames*L, C] -> (x [S, N, C], space_attn [(S h), N, T, L] or None)."""
+        _require_eval(self)
+        q, k, v = _dev_f32(query, "query"), _dev_f32(key, "key"), _dev_f32(value, "value")
+        S, N, C_ = q.shape
+        T = int(num_frames)
+        if N % T:
+            raise RuntimeError(f"tokens per sequence ({N}) must be a multiple of num_frames ({T})")
+        Lx = N // T
+        L = _lib.lib()
+        out = torch.empty_like(q)
+        attn = torch.empty(S * self.num_heads, N, T, Lx, dtype=torch.float32, device=q.device) if self.return_attn else None
+        packed = self._pack()
+        nws = L.axvs_traj_attn_workspace_bytes(S, T, Lx, C_, self.num_heads)
+        ws = _workspace(q.device, nws)
+        _lib.check(L.axvs_traj_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _ptr(attn),
+                                        packed.data_ptr(), S, T, Lx, C_, self.num_heads, _lib.DTYPES[self._dtype()],
+                                        ws.data_ptr(), ws.numel(), _stream(q.device)), "axvs_traj_attn_fwd")
+        return out, attn
+
+
+def _get_activation_name(activation):
+    if activation in ("relu", "gelu", "glu"):
+        return activation
+    raise RuntimeError(f"activation should be relu/gelu, not {activation}.")   # WC/temporal_attention.py:9-17
+
+
+# ---------------------------------------------------------------------------------------------
+# TemporalAxialTrajectoryAttentionLayer   (WC/temporal_attention.py:158-220, TL:730-791)
+# ---------------------------------------------------------------------------------------------
+class TemporalAxialTrajectoryAttentionLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, attn_drop=0.0, activation="relu", n_heads=8,
+                 mfma_dtype: Optional[str] = None):
+        super().__init__()
+        # self attention (note the reference's swapped naming: `dropout` feeds the attention-prob dropout)
+        self.height_attn = TrajectoryAttention(d_model, n_heads, dropout, mfma_dtype)
+        self.width_attn = TrajectoryAttention(d_model, n_heads, dropout, mfma_dtype)
+        self.dropout1 = nn.Dropout(attn_drop)
+        self.norm1 = nn.LayerNorm(d_model)
+        # ffn
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_name(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+        self.n_heads = n_heads
+        self.mfma_dtype = mfma_dtype
+        self.return_attn = False
+        self._packed: Optional[Tensor] = None
+        self._packed_key = None
+
+    def _dtype(self) -> str:
+        return self.mfma_dtype or _DEFAULT_DTYPE
+
+    def _pack(self) -> Tensor:
+        dt = self._dtype()
+        key = _param_key(self, dt)
+        if self._packed is None or key != self._packed_key:
+            if self.activation != "relu":
+                raise NotImplementedError("axial_vs_amd: only activation='relu' (every shipped config) has a HIP path")
+            if abs(self.norm1.eps - 1e-5) > 0 or abs(self.norm2.eps - 1e-5) > 0:
+                raise NotImplementedError("axial_vs_amd: LayerNorm eps must be 1e-5")
+            L = _lib.lib()
+            C_, F, dev = self.linear1.in_features, self.linear1.out_features, self.linear1.weight.device
+            keep: list = []
+            ps = _lib.AxvsAxialLayerParams()
+            ps.height_attn = _traj_struct(self.height_attn, keep)
+            ps.width_attn = _traj_struct(self.width_attn, keep)
+            for name, t in (("norm1_w", self.norm1.weight), ("norm1_b", self.norm1.bias),
+                            ("linear1_w", self.linear1.weight), ("linear1_b", self.linear1.bias),
+                            ("linear2_w", self.linear2.weight), ("linear2_b", self.linear2.bias),
+                            ("norm2_w", self.norm2.weight), ("norm2_b", self.norm2.bias)):
+                tt = _dev_f32(t.detach(), name)
+                keep.append(tt)
+                setattr(ps, name, tt.data_ptr())
+            buf = torch.empty(L.axvs_axial_layer_packed_bytes(C_, self.n_heads, F), dtype=torch.uint8, device=dev)
+            _lib.check(L.axvs_axial_layer_pack(C.byref(ps), buf.data_ptr(), C_, self.n_heads, F, _lib.DTYPES[dt],
+                                               _stream(dev)), "axvs_axial_layer_pack")
+            self._packed, self._packed_key = buf, key
+        return self._packed
+
+    def forward(self, src: Tensor, pos: Tensor):
+        """
+        :param src: tensor of shape [B*T, H*W, C]
+        :param pos: tensor of shape [B, T, H, W, C]
+        :return: (src', height_traj_attn, width_traj_attn); the maps are None unless ``return_attn`` is set
+        """
+        _require_eval(self)
+        B, T, H, W = pos.shape[:4]
+        s, p = _dev_f32(src, "src"), _dev_f32(pos, "pos")
+        C_ = s.shape[-1]
+        if s.numel() != B * T * H * W * C_ or p.shape[-1] != C_:
+            raise RuntimeError(f"src {tuple(src.shape)} does not match pos {tuple(pos.shape)}")
+        L = _lib.lib()
+        F = self.linear1.out_features
+        out = torch.empty_like(s)
+        ha = wa = None
+        if self.return_attn:
+            ha = torch.empty(B * W * self.n_heads, T * H, T, H, dtype=torch.float32, device=s.device)
+            wa = torch.empty(B * H * self.n_heads, T * W, T, W, dtype=torch.float32, device=s.device)
+        packed = self._pack()
+        nws = L.axvs_axial_layer_workspace_bytes(B, T, H, W, C_, self.n_heads, F)
+        ws = _workspace(s.device, nws)
+        _lib.check(L.axvs_axial_layer_fwd(s.data_ptr(), p.data_ptr(), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
+                                          self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(),
+                                          _ptr(ha), _ptr(wa), _stream(s.device)), "axvs_axial_layer_fwd")
+        return out, ha, wa
+
+
+class TemporalTrajectoryAttentionLayer(nn.Module):
+    """Full T*H*W trajectory attention (WC/temporal_attention.py:103-155).  Unused by every shipped config
+    (all select 'axial-trajectory'); kept for state-dict compatibility, no HIP path."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, attn_drop=0.0, activation="relu", n_heads=8):
+        super().__init__()
+        self.temporal_attn = TrajectoryAttention(d_model, n_heads, dropout)
+        self.dropout1 = nn.Dropout(attn_drop)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_name(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src: Tensor, pos: Tensor):
+        raise NotImplementedError("axial_vs_amd: temporal_attn_type='trajectory' (full T*H*W attention) has no HIP path; "
+                                  "use 'axial-trajectory' as every shipped config does")
+
+
+# ---------------------------------------------------------------------------------------------
+# TemporalEncoder   (WC/temporal_attention.py:79-100;  TL:711-727)
+# ---------------------------------------------------------------------------------------------
+class TemporalEncoder(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, attn_drop=0.0, activation="relu", n_heads=8,
+                 temporal_attn_type="trajectory", num_temporal_layer=2, mfma_dtype: Optional[str] = None):
+        super().__init__()
+        if temporal_attn_type == "trajectory":
+            self.temporal_layers = nn.ModuleList([TemporalTrajectoryAttentionLayer(
+                d_model, d_ffn, dropout, attn_drop, activation, n_heads) for _ in range(num_temporal_layer)])
+        elif temporal_attn_type == "axial-trajectory":
+            self.temporal_layers = nn.ModuleList([TemporalAxialTrajectoryAttentionLayer(
+                d_model, d_ffn, dropout, attn_drop, activation, n_heads, mfma_dtype) for _ in range(num_temporal_layer)])
+        # any other string: no layers are created, exactly like the reference (:85-88)
+
+    def forward(self, src: Tensor, pos: Tensor):
+        """
+        :param src: tensor of shape [B*T, H*W, C]
+        :param pos: tensor of shape [B, T, H, W, C]
+        """
+        for layer in self.temporal_layers:
+            src, height_traj_attn, width_traj_attn = layer(src, pos)
+        return src, height_traj_attn, width_traj_attn
+
+
+class TubeLinkTemporalEncoder(nn.Module):
+    """Tube-Link flavour (TL:711-727): axial layers only, returns ``src`` alone."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, attn_drop=0.0, activation="relu", n_heads=8,
+                 num_temporal_layer=2, mfma_dtype: Optional[str] = None):
+        super().__init__()
+        self.temporal_layers = nn.ModuleList([TemporalAxialTrajectoryAttentionLayer(
+            d_model, d_ffn, dropout, attn_drop, activation, n_heads, mfma_dtype) for _ in range(num_temporal_layer)])
+
+    def forward(self, src: Tensor, pos: Tensor):
+        for layer in self.temporal_layers:
+            src = layer(src, pos)[0]
+        return src
+
+
+# ---------------------------------------------------------------------------------------------
+# PositionEmbeddingSine3D   (WC/pos_embeddings.py:68-130)
+# ---------------------------------------------------------------------------------------------
+class PositionEmbeddingSine3D(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        self.num_pos_feats = num_pos_feats
+        self.temperature = temperature
+        self.normalize = normalize
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        if scale is None:
+            scale = 2 * math.pi
+        self.scale = scale
+        self.is_3d = True
+
+    @torch.no_grad()
+    def channels_last(self, B: int, T: int, H: int, W: int, device) -> Tensor:
+        """[B,T,H,W,C] fp32 -- the layout the trajectory layers consume."""
+        Cc = 2 * self.num_pos_feats
+        pos = torch.empty(B, T, H, W, Cc, dtype=torch.float32, device=device)
+        _lib.check(_lib.lib().axvs_pos3d(pos.data_ptr(), B, T, H, W, Cc, float(self.temperature), int(self.normalize),
+                                         float(self.scale), _stream(pos.device)), "axvs_pos3d")
+        return pos
+
+    @torch.no_grad()
+    def forward(self, x, mask=None, fmt="btchw"):
+        assert x.dim() == 5, f"{x.shape} should be a 5-dimensional Tensor, got {x.dim()}-dimensional Tensor instead"
+        if mask is not None:
+            raise NotImplementedError("axial_vs_amd: PositionEmbeddingSine3D with a padding mask has no HIP path")
+        if fmt == "btchw":
+            B, T, _, H, W = x.shape
+        elif fmt == "bcthw":
+            B, _, T, H, W = x.shape
+        else:
+            raise ValueError(f"Invalid format given: {fmt})")
+        if not x.is_cuda:
+            raise RuntimeError("axial_vs_amd: x must be a GPU tensor; there is no CPU fallback")
+        pos = self.channels_last(B, T, H, W, x.device)
+        return pos.permute(0, 1, 4, 2, 3) if fmt == "btchw" else pos.permute(0, 4, 1, 2, 3)
+
+
+# ---------------------------------------------------------------------------------------------
+# [B,T,C,H,W] convenience surface named by the north star
+# ---------------------------------------------------------------------------------------------
+class AxialTrajectoryAttention5D(nn.Module):
+    """forward(x: [B,T,C,H,W]) -> [B,T,C,H,W]: builds the 3-D sine embedding (+ optional learned level embedding,
+    WC/msdeformattn.py:112-115) and runs a TemporalEncoder of axial-trajectory layers."""
+
+    def __init__(self, d_model=256, d_ffn=1024, n_heads=8, num_temporal_layer=1, level_embed: bool = False,
+                 mfma_dtype: Optional[str] = None):
+        super().__init__()
+        self.encoder = TemporalEncoder(d_model, d_ffn, 0.0, 0.0, "relu", n_heads, "axial-trajectory", num_temporal_layer,
+                                       mfma_dtype)
+        self.pos_embed = PositionEmbeddingSine3D(d_model // 2, normalize=True)
+        self.level_embed_3d = nn.Parameter(torch.zeros(d_model)) if level_embed else None
+        self._pos_cache: Dict[Tuple, Tensor] = {}
+
+    def position(self, B, T, H, W, device) -> Tensor:
+        key = (B, T, H, W, str(device))
+        pos = self._pos_cache.get(key)
+        if pos is None:
+            pos = self.pos_embed.channels_last(B, T, H, W, device)
+            self._pos_cache = {key: pos}
+        if self.level_embed_3d is not None:
+            pos = pos + self.level_embed_3d.view(1, 1, 1, 1, -1)
+        return pos
+
+    def forward(self, x: Tensor) -> Tensor:
+        B, T, C_, H, W = x.shape
+        src = x.permute(0, 1, 3, 4, 2).reshape(B * T, H * W, C_)
+        out, _, _ = self.encoder(src, self.position(B, T, H, W, x.device))
+        return out.reshape(B, T, H, W, C_).permute(0, 1, 4, 2, 3)

@@ -1,0 +1,101 @@
+/* axvs.h -- C-ABI of libaxvs.so: MI355X (gfx950) kernels for the Axial-VS / MaXTron
+ * axial-trajectory-attention hot path.
+ *
+ * Plain pointers and sizes only; no torch types.  Every function is asynchronous on the
+ * hipStream_t it is given (passed as void*), never allocates or frees device memory and
+ * never synchronises: the caller owns every buffer (inputs, outputs, packed weights,
+ * workspace).  Return value 0 = success, negative = error (message: axvs_last_error()).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference):
+ *   WC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module
+ *   CC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/cross_clip_tracking_module
+ *   TL = MaXTron_Tube-Link
+ *
+ * Row-major fp32 tensors use nn.Linear's [out, in] weight layout.  "dtype" selects the
+ * 16-bit MFMA operand type (accumulation, softmax, LayerNorm and the residual stream are
+ * always fp32): AXVS_F16 meets the 1e-3 parity bar; AXVS_BF16 trades accuracy (about 3e-3)
+ * for fp32-like range.
+ */
+#ifndef AXVS_H
+#define AXVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AXVS_F16 0
+#define AXVS_BF16 1
+
+#define AXVS_OK 0
+#define AXVS_ERR_ARG (-1)       /* bad shape / null pointer / unsupported configuration */
+#define AXVS_ERR_WORKSPACE (-2) /* workspace too small */
+#define AXVS_ERR_LAUNCH (-3)    /* HIP launch failure */
+
+/* fp32 parameters of one TrajectoryAttention (WC/temporal_attention.py:21-33,
+ * TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:653-665).  Device pointers.
+ * CC flavour (CC/maxtron_cross_clip_tracking_module.py:79-89): the fused qkv Linear is
+ * passed as three row slices of qkv.weight / qkv.bias. */
+typedef struct AxvsTrajParams {
+  const float *q_w, *q_b;         /* [C,C], [C]   */
+  const float *k_w, *k_b;         /* [C,C], [C]   */
+  const float *v_w, *v_b;         /* [C,C], [C]   */
+  const float *proj_q_w, *proj_q_b;   /* [C,C], [C]   */
+  const float *proj_kv_w, *proj_kv_b; /* [2C,C], [2C] */
+  const float *proj_w, *proj_b;   /* [C,C], [C]   */
+} AxvsTrajParams;
+
+/* fp32 parameters of one TemporalAxialTrajectoryAttentionLayer
+ * (WC/temporal_attention.py:158-178; TL/...pixel_decoder.py:730-756). */
+typedef struct AxvsAxialLayerParams {
+  AxvsTrajParams height_attn, width_attn;
+  const float *norm1_w, *norm1_b;       /* [C] */
+  const float *linear1_w, *linear1_b;   /* [F,C], [F] */
+  const float *linear2_w, *linear2_b;   /* [C,F], [C] */
+  const float *norm2_w, *norm2_b;       /* [C] */
+} AxvsAxialLayerParams;
+
+int axvs_version(void);
+const char* axvs_last_error(void);
+
+/* ---- weight packing (once per load_state_dict; result is opaque, device-resident) ---- */
+size_t axvs_traj_packed_bytes(int C, int heads);
+int axvs_traj_pack(const AxvsTrajParams* p, void* packed, int C, int heads, int dtype, void* stream);
+size_t axvs_axial_layer_packed_bytes(int C, int heads, int d_ffn);
+int axvs_axial_layer_pack(const AxvsAxialLayerParams* p, void* packed, int C, int heads, int d_ffn, int dtype,
+                          void* stream);
+
+/* ---- TrajectoryAttention.forward(query, key, value, num_frames)
+ *      WC/temporal_attention.py:35-76.  query/key/value/out: fp32 [S, T*L, C].
+ *      space_attn: NULL or fp32 [(S*heads), T*L, T, L] (the reference's second return value). */
+size_t axvs_traj_attn_workspace_bytes(int S, int T, int L, int C, int heads);
+int axvs_traj_attn_fwd(const float* query, const float* key, const float* value, float* out, float* space_attn,
+                       const void* packed, int S, int T, int L, int C, int heads, int dtype, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ---- TemporalAxialTrajectoryAttentionLayer.forward(src, pos)
+ *      WC/temporal_attention.py:187-220 (TL/...pixel_decoder.py:758-791).
+ *      src/out: fp32 [(B*T), (H*W), C]; pos: fp32 [B,T,H,W,C]; out may not alias src.
+ *      h_attn: NULL or fp32 [(B*W*heads), T*H, T, H]; w_attn: NULL or fp32 [(B*H*heads), T*W, T, W].
+ *      gamma: NULL, or fp32 [C]: out = src + gamma * layer(src)   (Tube-Link wrapper,
+ *      TL/...pixel_decoder.py:623-627, for the last layer of an encoder). */
+size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn);
+int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H,
+                         int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
+                         float* h_attn, float* w_attn, void* stream);
+
+/* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
+ *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
+int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,
+               void* stream);
+
+/* ---- out[i] = a[i] + gamma[i % C] * b[i]   (Tube-Link residual, TL/...pixel_decoder.py:625-627) */
+int axvs_scaled_residual(const float* a, const float* b, const float* gamma, float* out, size_t n, int C,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AXVS_H */

@@ -1,0 +1,94 @@
+"""CPU: the C-ABI library loads and exports every symbol include/axvs.h declares; host-side module surface."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from golden_util import AXIAL, TRAJ, load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    ge.build()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "axvs.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(axvs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from axial_vs_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 10
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/axvs.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes prototypes out of sync with include/axvs.h"
+    assert _lib.lib().axvs_version() >= 1
+
+
+def test_size_queries_need_no_gpu():
+    from axial_vs_amd import _lib
+    L = _lib.lib()
+    C, h, F = 256, 8, 1024
+    packed = L.axvs_axial_layer_packed_bytes(C, h, F)
+    # 2 x (7 C^2) 16-bit attention weights + 2 C F 16-bit FFN weights, plus fp32 biases / norms
+    assert packed >= 2 * (2 * 7 * C * C) + 2 * (2 * C * F)
+    assert packed < 1.1 * (2 * (2 * 7 * C * C) + 2 * (2 * C * F)) + 65536
+    ws = L.axvs_axial_layer_workspace_bytes(1, 4, 64, 64, C, h, F)
+    assert ws > 0
+    assert L.axvs_traj_attn_workspace_bytes(4, 4, 16, C, h) > 0
+
+
+def test_argument_errors_are_reported_not_raised_across_the_boundary():
+    from axial_vs_amd import _lib
+    L = _lib.lib()
+    rc = L.axvs_axial_layer_fwd(None, None, None, None, 1, 4, 8, 8, 256, 8, 1024, 0, None, 0, None, None, None)
+    assert rc == -1 and b"null" in L.axvs_last_error()
+    rc = L.axvs_traj_pack(None, None, 250, 8, 0, None)
+    assert rc == -1
+
+
+@pytest.mark.parametrize("name", AXIAL[:2] + ["g4_encoder_B2_T2_C64_H6_W5"])
+def test_state_dict_keys_match_reference(name):
+    """strict load of a state dict with exactly the reference's parameter names and shapes."""
+    import axial_vs_amd as ax
+    import axvs_oracle as orc
+    z, m = load(name)
+    w = orc.random_weights(m["shapes"], 1)
+    if "layers" in m:
+        mod = ax.TemporalEncoder(m["C"], m["d_ffn"], n_heads=8, temporal_attn_type="axial-trajectory", num_temporal_layer=m["layers"])
+    else:
+        mod = ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=8)
+    mod.load_state_dict(w, strict=True)
+    assert set(mod.state_dict().keys()) == set(m["shapes"].keys())
+
+
+def test_traj_state_dict_keys_match_reference():
+    import axial_vs_amd as ax
+    import axvs_oracle as orc
+    z, m = load(TRAJ[0])
+    mod = ax.TrajectoryAttention(m["C"], 8)
+    mod.load_state_dict(orc.random_weights(m["shapes"], 1), strict=True)
+
+
+def test_no_cpu_fallback_and_forward_only():
+    import axial_vs_amd as ax
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(64, 128, n_heads=8)
+    src, pos = torch.zeros(2, 12, 64), torch.zeros(1, 2, 3, 4, 64)
+    with pytest.raises(NotImplementedError):
+        layer(src, pos)                       # training mode
+    layer.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(src, pos)
+    with pytest.raises(RuntimeError):
+        ax.TemporalAxialTrajectoryAttentionLayer(64, 128, activation="swish")
+    enc = ax.TemporalEncoder(64, 128, temporal_attn_type="axial_trajectory")   # the reference's default-string gotcha
+    assert not hasattr(enc, "temporal_layers")
