@@ -34,6 +34,8 @@ class AxvsAxialLayerParams(C.Structure):
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
     "axvs_last_error": (C.c_char_p, []),
+    "axvs_profile_stages": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "axvs_profile_stage_name": (C.c_char_p, [C.c_int]),
     "axvs_traj_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_traj_pack": (C.c_int, [C.POINTER(AxvsTrajParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "axvs_axial_layer_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

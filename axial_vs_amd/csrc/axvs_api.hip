@@ -26,6 +26,21 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// optional per-stage event recording (bench.py / tuning): events[i] is recorded on the stream after stage i
+thread_local hipEvent_t* g_prof_events = nullptr;
+thread_local int g_prof_cap = 0;
+thread_local int g_prof_next = 0;
+const char* const kStageNames[] = {"begin",
+                                   "h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj",
+                                   "w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj",
+                                   "norm1", "ffn.linear1", "ffn.linear2", "norm2"};
+constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
+
+inline void mark(hipStream_t st) {
+  if (g_prof_events && g_prof_next < g_prof_cap) (void)hipEventRecord(g_prof_events[g_prof_next], st);
+  ++g_prof_next;
+}
+
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Carver {  // bump allocator over a caller-owned buffer
@@ -179,6 +194,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   launch_gemm<BF>(aq, p.wq, EpiBlocked16<BF>{w.q16, Mp, p.bq, scale * kLog2e, Cp, 0}, M, Cp, C, st);
   launch_gemm<BF>(ak, p.wk, EpiBlocked16<BF>{w.k16, Mp, p.bk, 1.f, 0, 0}, M, Cp, C, st);
   launch_gemm<BF>(av, p.wv, EpiBlocked16<BF>{w.v16, Mp, p.bv, 1.f, 0, 0}, M, Cp, C, st);
+  mark(st);
 
   // spatial half
   int nks = (L + 31) / 32, rc;
@@ -194,19 +210,24 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
     default: return fail(AXVS_ERR_ARG, "axis length L=%d > 256 is not supported yet", L);
   }
   if (rc != AXVS_OK) return rc;
+  mark(st);
 
   // temporal half
   ALoadBlocked<BF> adiag{w.x16, Mp * T, M, T, N, L};
   launch_gemm<BF>(adiag, p.wpq, EpiRowsF32{w.q2, nullptr, p.bpq, identity_map(Mp), Cp, scale}, M, Cp, Cp, st);
+  mark(st);
   ALoadBlocked<BF> aall{w.x16, Mp * T, M * T, 0, 1, 1};
   launch_gemm<BF>(aall, p.wpkv, EpiRowsF32{w.kv2, nullptr, p.bpkv, identity_map(Mp * T), 2 * Cp, 1.f}, M * T, 2 * Cp, Cp, st);
+  mark(st);
   {
     long long threads = Mp * heads * 8;
     hipLaunchKernelGGL((temporal_attn_kernel<BF>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, w.q2, w.kv2,
                        w.o16, Mp, T, heads);
   }
+  mark(st);
   ALoadBlocked<BF> ao{w.o16, Mp, M, 0, 1, 1};
   launch_gemm<BF>(ao, p.wp, EpiRowsF32{out, res, p.bp, rm, C, 1.f}, M, C, Cp, st);
+  mark(st);
   return AXVS_OK;
 }
 
@@ -242,6 +263,8 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   u16* h16 = wc.take<u16>((size_t)M * F);
   const long long sB = (long long)T * H * W, sT = (long long)H * W;
 
+  g_prof_next = 0;
+  mark(st);
   // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
   RowMap rmh{T * H, H, W, sB, sT, W, 1};
   int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st);
@@ -254,12 +277,16 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   // norm1 -> FFN -> norm2                               :181-185, :217-218
   const unsigned lnblocks = (unsigned)((M + 3) / 4);
   hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, buf2, p.g1, p.be1, buf1, y16, M, C, 1e-5f);
+  mark(st);
   ALoadBlocked<BF> ay{y16, M, (int)M, 0, 1, 1};
   launch_gemm<BF>(ay, p.w1, EpiBlocked16<BF>{h16, M, p.b1, 1.f, 0, 1}, (int)M, F, C, st);
+  mark(st);
   ALoadBlocked<BF> ah{h16, M, (int)M, 0, 1, 1};
   launch_gemm<BF>(ah, p.w2, EpiRowsF32{buf2, buf1, p.b2, identity_map(M), C, 1.f}, (int)M, C, F, st);
+  mark(st);
   hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, buf2, p.g2, p.be2, out, (u16*)nullptr, M, C,
                      1e-5f);
+  mark(st);
   return last_launch_status();
 }
 
@@ -269,6 +296,13 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
 extern "C" {
 
 int axvs_version(void) { return 1; }
+
+int axvs_profile_stages(void** events, int capacity) {
+  g_prof_events = reinterpret_cast<hipEvent_t*>(events);
+  g_prof_cap = events ? capacity : 0;
+  return kNumStages;
+}
+const char* axvs_profile_stage_name(int i) { return (i >= 0 && i < kNumStages) ? kStageNames[i] : ""; }
 const char* axvs_last_error(void) { return g_err; }
 
 size_t axvs_traj_packed_bytes(int C, int heads) {

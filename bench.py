@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: axial-trajectory-attention forward, frames/s at [B=1,T=4,C=256,H=W=64] per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one TemporalAxialTrajectoryAttentionLayer forward (height pass + width pass + LN + FFN + LN,
+WC/temporal_attention.py:187-220) over one clip resident in HBM.  With N ranks every rank owns its own clip
+(the path shards over B with no data-path collective: SURVEY.md 8e) -> "scaling": "weak"; `--gather` adds the
+north star's RCCL all-gather of the output maps, overlapped on a side stream.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     -- algorithmic FLOPs of the layer / mean forward time from HIP events on the launch stream,
+                  against the dense 16-bit MFMA peak (2.5 PFLOP/s), and the per-kernel split of that time
+  cpu_baseline -- the CPU oracle (torch port of the reference, oracle/axvs_oracle.py) timed on this host
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def layer_flops(B, T, H, W, C, F):
+    """algorithmic FLOPs (2*MACs) of one layer in the reference's formulation."""
+    def f_pass(S, L):
+        N = T * L
+        return S * (N * C * C * (10 + 4 * T) + 4 * N * N * C + 4 * N * T * C)
+    return f_pass(B * W, H) + f_pass(B * H, W) + 4 * B * T * H * W * C * F
+
+
+def layer_bytes(B, T, H, W, C, F, e=4):
+    """src + pos read, out written (fp32 at the boundary) + 16-bit weights once."""
+    P = 2 * (7 * C * C + 8 * C) + 2 * C * F + F + 5 * C
+    return 3 * B * T * H * W * C * e + P * 2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--shape", default="1,4,256,64,64", help="B,T,C,H,W per rank")
+    ap.add_argument("--d-ffn", type=int, default=1024)
+    ap.add_argument("--gather", action="store_true", help="all-gather every step's output across ranks (RCCL, side stream)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ge.build()
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import axvs_oracle as orc
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, T, C, H, W = (int(v) for v in args.shape.split(","))
+    F = args.d_ffn
+    heads = 8
+    # synthetic workload (SURVEY.md 8d recipe); every rank gets its own clip
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 0)
+    src_cpu, pos_cpu = orc.synthetic_clip(B, T, C, H, W, seed=rank)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=heads, mfma_dtype=args.dtype).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.to(dev)
+    src, pos = src_cpu.to(dev), pos_cpu.to(dev)
+
+    gathered = None
+    side = None
+    if args.gather and world > 1:
+        gathered = torch.empty(world * B * T, H * W, C, device=dev)
+        side = torch.cuda.Stream(dev)
+
+    def step():
+        out = layer(src, pos)[0]
+        if gathered is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered, out)
+                out.record_stream(side)
+        return out
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides ----
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    frames = world * B * T * args.steps
+    value = frames / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    result = {
+        "metric": "axial-trajectory-attn fwd frames/sec at [B=1,T=4,C=256,H=W=64]; 1/2/4/8 GPU",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"TemporalAxialTrajectoryAttentionLayer fwd, [B={B},T={T},C={C},H={H},W={W}] per GPU, "
+                               f"heads={heads}, d_ffn={F}, fp32 in/out, {args.dtype} MFMA operands",
+                   "shape_per_gpu": [B, T, C, H, W], "parallelism": f"dp{world} (clips sharded over ranks"
+                   + (", RCCL all-gather of outputs overlapped)" if gathered is not None else ", no collective)")},
+    }
+
+    if rank == 0:
+        # ---- roofline: HIP events on the launch stream (torch's current stream), averaged over the same K steps ----
+        L = _lib.lib()
+        hip = ctypes.CDLL("libamdhip64.so")
+        nst = L.axvs_profile_stages(None, 0)
+        evs = (ctypes.c_void_p * nst)()
+        for i in range(nst):
+            e = ctypes.c_void_p()
+            assert hip.hipEventCreate(ctypes.byref(e)) == 0
+            evs[i] = e
+        stage_ms = [0.0] * nst
+        reps = min(args.steps, 50)
+        L.axvs_profile_stages(evs, nst)
+        for _ in range(reps):
+            layer(src, pos)
+            torch.cuda.synchronize(dev)
+            for i in range(1, nst):
+                ms = ctypes.c_float()
+                assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[i - 1], evs[i]) == 0
+                stage_ms[i] += ms.value / reps
+        L.axvs_profile_stages(None, 0)
+        # whole-forward duration with events bracketing K back-to-back forwards (no host sync inside)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            layer(src, pos)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        fwd_ms = e0.elapsed_time(e1) / args.steps
+        flops = layer_flops(B, T, H, W, C, F)
+        achieved = flops / (fwd_ms * 1e-3) / 1e12
+        names = [L.axvs_profile_stage_name(i).decode() for i in range(nst)]
+        kernels = {names[i]: round(stage_ms[i] * 1e3, 2) for i in range(1, nst)}
+        dom = max(kernels, key=kernels.get)
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "axial layer forward (all launches of one step)", "launch_us": round(fwd_ms * 1e3, 2),
+            "algorithmic_gflop": round(flops / 1e9, 2), "algorithmic_mbytes": round(layer_bytes(B, T, H, W, C, F) / 1e6, 2),
+            "hbm_frac_if_memory_bound": round(layer_bytes(B, T, H, W, C, F) / (fwd_ms * 1e-3) / 8e12, 4),
+            "stage_us": kernels, "dominant_stage": dom,
+        }
+
+        # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            torch.set_num_threads(cores)
+            with torch.no_grad():
+                t_first = time.perf_counter()
+                orc.axial_layer(src_cpu, pos_cpu, w, heads, want_attn=False)
+                first = time.perf_counter() - t_first
+                times = []
+                budget = time.perf_counter() + max(args.cpu_seconds - first, 0.0)
+                while len(times) < 3 or (time.perf_counter() < budget and len(times) < 50):
+                    t1 = time.perf_counter()
+                    orc.axial_layer(src_cpu, pos_cpu, w, heads, want_attn=False)
+                    times.append(time.perf_counter() - t1)
+            med = statistics.median(times)
+            result["cpu_baseline"] = {
+                "value": round(B * T / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                "sample": f"{len(times)} forwards of the same [B={B},T={T},C={C},H={H},W={W}] layer after 1 warm-up, "
+                          f"fp32, torch CPU {torch.get_num_threads()} threads, median {med * 1e3:.1f} ms"}
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

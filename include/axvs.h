@@ -60,6 +60,12 @@ typedef struct AxvsAxialLayerParams {
 int axvs_version(void);
 const char* axvs_last_error(void);
 
+/* ---- optional per-stage timing of axvs_axial_layer_fwd (used by bench.py; thread-local).
+ *      events: array of `capacity` hipEvent_t created by the caller, or NULL to switch off.  While set, the layer
+ *      records events[i] on its stream after stage i (events[0] at entry).  Returns the number of stages. */
+int axvs_profile_stages(void** events, int capacity);
+const char* axvs_profile_stage_name(int i);
+
 /* ---- weight packing (once per load_state_dict; result is opaque, device-resident) ---- */
 size_t axvs_traj_packed_bytes(int C, int heads);
 int axvs_traj_pack(const AxvsTrajParams* p, void* packed, int C, int heads, int dtype, void* stream);
@@ -79,8 +85,7 @@ int axvs_traj_attn_fwd(const float* query, const float* key, const float* value,
  *      WC/temporal_attention.py:187-220 (TL/...pixel_decoder.py:758-791).
  *      src/out: fp32 [(B*T), (H*W), C]; pos: fp32 [B,T,H,W,C]; out may not alias src.
  *      h_attn: NULL or fp32 [(B*W*heads), T*H, T, H]; w_attn: NULL or fp32 [(B*H*heads), T*W, T, W].
- *      gamma: NULL, or fp32 [C]: out = src + gamma * layer(src)   (Tube-Link wrapper,
- *      TL/...pixel_decoder.py:623-627, for the last layer of an encoder). */
+ *      (Tube-Link's `f + gamma * encoder(f)`, TL/...pixel_decoder.py:623-627: axvs_scaled_residual below.) */
 size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn);
 int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H,
                          int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
