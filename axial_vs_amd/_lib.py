@@ -35,7 +35,9 @@ SIGNATURES = {
     "axvs_version": (C.c_int, []),
     "axvs_last_error": (C.c_char_p, []),
     "axvs_profile_stages": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "axvs_profile_stage_count": (C.c_int, []),
     "axvs_profile_stage_name": (C.c_char_p, [C.c_int]),
+    "axvs_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "axvs_traj_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_traj_pack": (C.c_int, [C.POINTER(AxvsTrajParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "axvs_axial_layer_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -44,6 +46,8 @@ SIGNATURES = {
     "axvs_traj_attn_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [C.c_int] * 6 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_axial_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
+    "axvs_ffn_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int, C.c_int]),
+    "axvs_ffn_fwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_pos3d": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_scaled_residual": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
 }

@@ -9,6 +9,7 @@
 #include "../../include/axvs.h"
 #include "axvs_attn.h"
 #include "axvs_common.h"
+#include "axvs_fused.h"
 #include "axvs_gemm.h"
 #include "axvs_misc.h"
 
@@ -30,13 +31,13 @@ int fail(int code, const char* fmt, ...) {
 thread_local hipEvent_t* g_prof_events = nullptr;
 thread_local int g_prof_cap = 0;
 thread_local int g_prof_next = 0;
-const char* const kStageNames[] = {"begin",
-                                   "h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj",
-                                   "w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj",
-                                   "norm1", "ffn.linear1", "ffn.linear2", "norm2"};
-constexpr int kNumStages = sizeof(kStageNames) / sizeof(kStageNames[0]);
+constexpr int kMaxStages = 32;
+thread_local const char* g_stage_names[kMaxStages] = {};
+thread_local int g_generic_only = 0;
+   // option "generic_only": 1 = always use the shape-generic v1 kernels
 
-inline void mark(hipStream_t st) {
+inline void mark(hipStream_t st, const char* name) {
+  if (g_prof_next < kMaxStages) g_stage_names[g_prof_next] = name;
   if (g_prof_events && g_prof_next < g_prof_cap) (void)hipEventRecord(g_prof_events[g_prof_next], st);
   ++g_prof_next;
 }
@@ -180,7 +181,12 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
 template <bool BF>
 int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
-             hipStream_t st) {
+             hipStream_t st, int pass = 0) {
+  static const char* const kNames[3][6] = {
+      {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj"},
+      {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj"},
+      {"w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj"}};
+  const char* const* nm = kNames[pass];
   const int N = T * L, Cp = heads * 32, d = C / heads;
   const long long Mp = (long long)S * N;
   if (Mp * T > 2147483647LL / 2) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
@@ -194,7 +200,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   launch_gemm<BF>(aq, p.wq, EpiBlocked16<BF>{w.q16, Mp, p.bq, scale * kLog2e, Cp, 0}, M, Cp, C, st);
   launch_gemm<BF>(ak, p.wk, EpiBlocked16<BF>{w.k16, Mp, p.bk, 1.f, 0, 0}, M, Cp, C, st);
   launch_gemm<BF>(av, p.wv, EpiBlocked16<BF>{w.v16, Mp, p.bv, 1.f, 0, 0}, M, Cp, C, st);
-  mark(st);
+  mark(st, nm[0]);
 
   // spatial half
   int nks = (L + 31) / 32, rc;
@@ -210,24 +216,57 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
     default: return fail(AXVS_ERR_ARG, "axis length L=%d > 256 is not supported yet", L);
   }
   if (rc != AXVS_OK) return rc;
-  mark(st);
+  mark(st, nm[1]);
 
   // temporal half
   ALoadBlocked<BF> adiag{w.x16, Mp * T, M, T, N, L};
   launch_gemm<BF>(adiag, p.wpq, EpiRowsF32{w.q2, nullptr, p.bpq, identity_map(Mp), Cp, scale}, M, Cp, Cp, st);
-  mark(st);
+  mark(st, nm[2]);
   ALoadBlocked<BF> aall{w.x16, Mp * T, M * T, 0, 1, 1};
   launch_gemm<BF>(aall, p.wpkv, EpiRowsF32{w.kv2, nullptr, p.bpkv, identity_map(Mp * T), 2 * Cp, 1.f}, M * T, 2 * Cp, Cp, st);
-  mark(st);
+  mark(st, nm[3]);
   {
     long long threads = Mp * heads * 8;
     hipLaunchKernelGGL((temporal_attn_kernel<BF>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, w.q2, w.kv2,
                        w.o16, Mp, T, heads);
   }
-  mark(st);
+  mark(st, nm[4]);
   ALoadBlocked<BF> ao{w.o16, Mp, M, 0, 1, 1};
   launch_gemm<BF>(ao, p.wp, EpiRowsF32{out, res, p.bp, rm, C, 1.f}, M, C, Cp, st);
-  mark(st);
+  mark(st, nm[5]);
+  return AXVS_OK;
+}
+
+// norm1 -> linear1 -> ReLU -> linear2 -> +residual -> norm2 on fp32 rows X[M][C] (X is clobbered by the generic path)
+template <bool BF>
+int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
+            hipStream_t st) {
+  if (!g_generic_only && C == 256 && heads == 8 && F % 256 == 0) {
+    static bool configured = false;
+    const size_t lds = ffn_lds_bytes(F);
+    if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "d_ffn=%d too large for the fused FFN kernel", F);
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+      configured = true;
+    }
+    hipLaunchKernelGGL((ffn_fused_kernel<BF>), dim3((unsigned)((M + kRows - 1) / kRows)), dim3(512), lds, st, X, p.w1, p.b1,
+                       p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+    mark(st, "norm1+ffn+norm2");
+    return AXVS_OK;
+  }
+  const unsigned lnblocks = (unsigned)((M + 3) / 4);
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, X, p.g1, p.be1, tmp, y16, M, C, 1e-5f);
+  mark(st, "norm1");
+  ALoadBlocked<BF> ay{y16, M, (int)M, 0, 1, 1};
+  launch_gemm<BF>(ay, p.w1, EpiBlocked16<BF>{h16, M, p.b1, 1.f, 0, 1}, (int)M, F, C, st);
+  mark(st, "ffn.linear1");
+  ALoadBlocked<BF> ah{h16, M, (int)M, 0, 1, 1};
+  launch_gemm<BF>(ah, p.w2, EpiRowsF32{X, tmp, p.b2, identity_map(M), C, 1.f}, (int)M, C, F, st);
+  mark(st, "ffn.linear2");
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, X, p.g2, p.be2, out, (u16*)nullptr, M, C, 1e-5f);
+  mark(st, "norm2");
   return AXVS_OK;
 }
 
@@ -264,29 +303,19 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   const long long sB = (long long)T * H * W, sT = (long long)H * W;
 
   g_prof_next = 0;
-  mark(st);
+  mark(st, "begin");
   // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
   RowMap rmh{T * H, H, W, sB, sT, W, 1};
-  int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st);
+  int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1);
   if (rc != AXVS_OK) return rc;
   // width pass: sequences (b, h), tokens (t, w)         :206-213
   RowMap rmw{T * W, W, H, sB, sT, 1, W};
-  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st);
+  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st, 2);
   if (rc != AXVS_OK) return rc;
 
   // norm1 -> FFN -> norm2                               :181-185, :217-218
-  const unsigned lnblocks = (unsigned)((M + 3) / 4);
-  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, buf2, p.g1, p.be1, buf1, y16, M, C, 1e-5f);
-  mark(st);
-  ALoadBlocked<BF> ay{y16, M, (int)M, 0, 1, 1};
-  launch_gemm<BF>(ay, p.w1, EpiBlocked16<BF>{h16, M, p.b1, 1.f, 0, 1}, (int)M, F, C, st);
-  mark(st);
-  ALoadBlocked<BF> ah{h16, M, (int)M, 0, 1, 1};
-  launch_gemm<BF>(ah, p.w2, EpiRowsF32{buf2, buf1, p.b2, identity_map(M), C, 1.f}, (int)M, C, F, st);
-  mark(st);
-  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, buf2, p.g2, p.be2, out, (u16*)nullptr, M, C,
-                     1e-5f);
-  mark(st);
+  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, buf1, y16, h16, st);
+  if (rc2 != AXVS_OK) return rc2;
   return last_launch_status();
 }
 
@@ -300,9 +329,15 @@ int axvs_version(void) { return 1; }
 int axvs_profile_stages(void** events, int capacity) {
   g_prof_events = reinterpret_cast<hipEvent_t*>(events);
   g_prof_cap = events ? capacity : 0;
-  return kNumStages;
+  return kMaxStages;
 }
-const char* axvs_profile_stage_name(int i) { return (i >= 0 && i < kNumStages) ? kStageNames[i] : ""; }
+int axvs_profile_stage_count(void) { return g_prof_next < kMaxStages ? g_prof_next : kMaxStages; }
+const char* axvs_profile_stage_name(int i) { return (i >= 0 && i < kMaxStages && g_stage_names[i]) ? g_stage_names[i] : ""; }
+
+int axvs_set_option(const char* key, int value) {
+  if (key && !strcmp(key, "generic_only")) { g_generic_only = value; return AXVS_OK; }
+  return fail(AXVS_ERR_ARG, "unknown option");
+}
 const char* axvs_last_error(void) { return g_err; }
 
 size_t axvs_traj_packed_bytes(int C, int heads) {
@@ -408,6 +443,37 @@ int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const v
   if (dtype == AXVS_F16)
     return axial_layer_fwd_t<false>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn) {
+  Carver c(nullptr);
+  c.take<float>((size_t)M * C);
+  c.take<float>((size_t)M * C);
+  c.take<u16>((size_t)M * C);
+  c.take<u16>((size_t)M * d_ffn);
+  return c.off;
+}
+
+int axvs_ffn_fwd(const float* x, float* out, const void* packed_layer, long long M, int C, int heads, int d_ffn, int dtype,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !out || !packed_layer || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (M <= 0) return fail(AXVS_ERR_ARG, "empty input");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (workspace_bytes < axvs_ffn_workspace_bytes(M, C, d_ffn)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Carver pc(const_cast<void*>(packed_layer));
+  LayerPacked p = carve_layer(pc, C, heads, d_ffn);
+  Carver wc(workspace);
+  float* xin = wc.take<float>((size_t)M * C);
+  float* tmp = wc.take<float>((size_t)M * C);
+  u16* y16 = wc.take<u16>((size_t)M * C);
+  u16* h16 = wc.take<u16>((size_t)M * d_ffn);
+  if (hipMemcpyAsync(xin, x, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(AXVS_ERR_LAUNCH, "copy failed");
+  g_prof_next = 0;
+  int rc = dtype == AXVS_BF16 ? run_ffn<true>(xin, out, p, M, C, heads, d_ffn, tmp, y16, h16, st)
+                              : run_ffn<false>(xin, out, p, M, C, heads, d_ffn, tmp, y16, h16, st);
+  return rc != AXVS_OK ? rc : last_launch_status();
 }
 
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale, void* stream) {

@@ -88,4 +88,14 @@ __device__ __forceinline__ int swz_chunk(int row, int g) {
 __device__ __forceinline__ float wave_xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, kWave)); }
 __device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shfl_xor(v, m, kWave); }
 
+// lgkmcnt is a 4-bit counter.  hipcc (ROCm 7.2) will happily leave 16 or more LDS/SMEM operations in flight before one
+// `s_waitcnt lgkmcnt(0)`; when the LDS is busy enough that none of them has returned by the time the 16th issues, the
+// counter wraps and the wait falls through early (observed on gfx950: intermittent stale reads in a fused epilogue with
+// 15 ds_read + 1 s_load outstanding).  Call this between batches of LDS reads so no path ever has more than ~12 in flight;
+// tools/check_lgkm.py scans the generated ISA for violations.
+__device__ __forceinline__ void lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 }  // namespace axvs

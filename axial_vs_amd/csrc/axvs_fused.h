@@ -1,0 +1,252 @@
+// Fused row-block kernels for the C = 256, heads = 8 configuration (every shipped config):
+//   ffn_fused_kernel      norm1 -> linear1 -> ReLU -> linear2 -> +residual -> norm2   (WC/temporal_attention.py:181-185,217-218)
+//
+// Common structure ("N-split"): a workgroup owns 64 token rows; its 8 waves split the OUTPUT channels of every
+// GEMM.  Activations live in LDS as [K/32][64 rows][32] 16-bit tiles (64-byte rows, chunk-swizzled so the
+// ds_read_b128 fragment reads are conflict free) and are shared by all waves; every weight fragment is needed by
+// exactly one wave, so weights go L2 -> VGPR directly (1 KiB coalesced loads from the blocked layout), a whole GEMM
+// phase ahead of their use, and never touch LDS.  MFMA orientation is D[channel][token] (weights = A operand).
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+constexpr int kRows = 64;                       // token rows per workgroup
+constexpr int kTileElems = kRows * 32;          // one k-block of an activation tile
+
+// element offset of 16-byte chunk `c` (0..3) of row `row` in k-block `kb`
+__device__ __forceinline__ int act_off(int kb, int row, int c) { return (kb * kRows + row) * 32 + swz_chunk(row, c) * 8; }
+
+// B-operand fragment (activations) of m-tile mt, k-block kb
+__device__ __forceinline__ u16x8 act_frag(const u16* tile, int kb, int mt, int fi, int fg) {
+  return *reinterpret_cast<const u16x8*>(tile + act_off(kb, mt * 16 + fi, fg));
+}
+
+// A-operand fragment (weights) straight from the blocked global layout [K/32][NR][32]
+__device__ __forceinline__ u16x8 w_frag(const u16* __restrict__ W, int NR, int kb, int nrow, int fg) {
+  return *reinterpret_cast<const u16x8*>(W + ((long long)kb * NR + nrow) * 32 + fg * 8);
+}
+
+// store 4 consecutive channels (D layout: n = 16*nt16 + 4*fg + r) of token `row` into an activation tile
+template <bool BF>
+__device__ __forceinline__ void act_store4(u16* tile, int n, int row, f32x4 v) {
+  const int kb = n >> 5, k = n & 31;
+  *reinterpret_cast<u16x4*>(tile + act_off(kb, row, k >> 3) + (k & 7)) = cvt4<BF>(v);
+}
+
+template <bool BF, int NT, int MT, int KB>
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[NT][MT], const u16x8 (&wf)[NT][KB], const u16* tile, int fi, int fg) {
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    u16x8 b[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b[mt] = act_frag(tile, kb, mt, fi, fg);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][kb], b[mt], acc[nt][mt]);
+  }
+}
+
+template <int NT, int KB>
+__device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __restrict__ W, int NR, int kb0, int nrow0, int fi, int fg) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) wf[nt][kb] = w_frag(W, NR, kb0 + kb, nrow0 + nt * 16 + fi, fg);
+}
+
+// =====================================================================================================
+// norm1 -> FFN -> norm2, C = 256.  X: fp32 [M][256] (the residual stream after the width pass).
+// LDS: y tile 32 KB | h tiles 2 x 32 KB | row stats.
+// =====================================================================================================
+template <bool BF>
+__global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict__ X, const u16* __restrict__ W1,
+                                                        const float* __restrict__ b1, const u16* __restrict__ W2,
+                                                        const float* __restrict__ b2, const float* __restrict__ g1,
+                                                        const float* __restrict__ be1, const float* __restrict__ g2,
+                                                        const float* __restrict__ be2, float* __restrict__ out,
+                                                        long long M, int F) {
+  constexpr int C = 256, KB = C / 32;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* ytile = smem;                                   // [8][64][32]
+  u16* htile = smem + KB * kTileElems;                 // 2 x [8][64][32]
+  float* stats = reinterpret_cast<float*>(smem + 3 * KB * kTileElems);
+  float* part = stats + 2 * kRows;                     // [8 waves][64] partial sums for norm2
+  // biases / norm parameters are staged in LDS: a global load inside the pipelined loop would have to wait (vmcnt is
+  // in-order) for every weight fragment prefetched before it
+  float* sb1 = part + 8 * kRows;                       // [F]
+  float* sb2 = sb1 + F;                                // [256] each: b2, g1, be1, g2, be2
+  float* sg1 = sb2 + C;
+  float* sbe1 = sg1 + C;
+  float* sg2 = sbe1 + C;
+  float* sbe2 = sg2 + C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * kRows;
+
+  // prefetch the first linear1 weight fragments while norm1 runs
+  u16x8 w1f[2][KB], w2f[2][KB];
+  load_wfrags<2, KB>(w1f, W1, F, 0, wave * 32, fi, fg);
+
+  for (int i = tid; i < F; i += 512) sb1[i] = b1[i];
+  if (tid < C) {
+    sb2[tid] = b2[tid];
+    sg1[tid] = g1[tid];
+    sbe1[tid] = be1[tid];
+    sg2[tid] = g2[tid];
+    sbe2[tid] = be2[tid];
+  }
+  // ---- norm1: wave handles rows 8w..8w+7, one row per pass (64 lanes x float4) ----
+  {
+    const float4 gg = *reinterpret_cast<const float4*>(g1 + lane * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(be1 + lane * 4);
+    float4 rows[8];                      // all 8 row loads in flight together
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const long long m = min(m0 + wave * 8 + rr, M - 1);
+      rows[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr;
+      const float4 v = rows[rr];
+      float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+      for (int k = 1; k < 64; k <<= 1) s = wave_xor_sum(s, k);
+      const float mu = s * (1.f / C);
+      const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+      float q = a * a + b * b + c * c + d * d;
+#pragma unroll
+      for (int k = 1; k < 64; k <<= 1) q = wave_xor_sum(q, k);
+      const float rstd = rsqrtf(q * (1.f / C) + 1e-5f);
+      f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
+      act_store4<BF>(ytile, lane * 4, r, y);
+      if (lane == 0) {
+        stats[2 * r] = mu;
+        stats[2 * r + 1] = rstd;
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc2[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = F / 256;
+  for (int c = 0; c < nchunk; ++c) {
+    u16* hbuf = htile + (c & 1) * KB * kTileElems;
+    // linear2 fragments of this chunk: rows = my 32 output channels, k-blocks = this chunk's 256 hidden units
+    load_wfrags<2, KB>(w2f, W2, C, c * 8, wave * 32, fi, fg);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- linear1 + ReLU: my 32 hidden units of the chunk, all 64 rows ----
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    gemm_phase<BF, 2, 4, KB>(acc1, w1f, ytile, fi, fg);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int hn = c * 256 + wave * 32 + nt * 16 + fg * 4;          // global hidden index
+      const float4 bias = *reinterpret_cast<const float4*>(sb1 + hn);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4 v = acc1[nt][mt];
+        v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
+        v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+        act_store4<BF>(hbuf, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
+      }
+    }
+    // next chunk's linear1 fragments (their registers are free now).  Unconditional (the last iteration re-loads its own
+    // chunk): a branch here would merge two different in-flight counts and force the compiler's vmcnt to the smaller one.
+    load_wfrags<2, KB>(w1f, W1, F, 0, min(c + 1, nchunk - 1) * 256 + wave * 32, fi, fg);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- linear2 partial: += W2[my 32 channels, chunk] . h ----
+    gemm_phase<BF, 2, 4, KB>(acc2, w2f, hbuf, fi, fg);
+  }
+
+  // ---- epilogue: + b2 + y (norm1 recomputed in the output layout) -> norm2 -> out ----
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = wave * 32 + nt * 16 + fg * 4;
+    const float4 bias = *reinterpret_cast<const float4*>(sb2 + n);
+    const float4 gg = *reinterpret_cast<const float4*>(sg1 + n);
+    const float4 bb = *reinterpret_cast<const float4*>(sbe1 + n);
+    lds_fence();   // keep the number of LDS reads in flight small (see lds_fence)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int r = mt * 16 + fi;
+      const long long m = min(m0 + r, M - 1);
+      const float4 x = *reinterpret_cast<const float4*>(X + m * C + n);
+      const float2 st = *reinterpret_cast<const float2*>(stats + 2 * r);
+      const float mu = st.x, rstd = st.y;
+      f32x4& v = acc2[nt][mt];
+      v[0] += bias.x + ((x.x - mu) * rstd * gg.x + bb.x);
+      v[1] += bias.y + ((x.y - mu) * rstd * gg.y + bb.y);
+      v[2] += bias.z + ((x.z - mu) * rstd * gg.z + bb.z);
+      v[3] += bias.w + ((x.w - mu) * rstd * gg.w + bb.w);
+      rs[mt] += v[0] + v[1] + v[2] + v[3];
+    }
+  }
+  // norm2 statistics: my 32 channels -> across the 4 lane groups -> across the 8 waves (LDS)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    rs[mt] = wave_xor_sum(wave_xor_sum(rs[mt], 16), 32);
+    if (fg == 0) part[wave * kRows + mt * 16 + fi] = rs[mt];
+  }
+  __syncthreads();
+  float mu2[4], rq[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += part[w * kRows + mt * 16 + fi];
+    mu2[mt] = s * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc2[nt][mt][r] - mu2[mt];
+        q += d * d;
+      }
+    rq[mt] = wave_xor_sum(wave_xor_sum(q, 16), 32);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+    if (fg == 0) part[wave * kRows + mt * 16 + fi] = rq[mt];
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q += part[w * kRows + mt * 16 + fi];
+    const float rstd2 = rsqrtf(q * (1.f / C) + 1e-5f);
+    const long long m = m0 + mt * 16 + fi;
+    if (m < M) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = wave * 32 + nt * 16 + fg * 4;
+        const float4 gg = *reinterpret_cast<const float4*>(sg2 + n);
+        const float4 bb = *reinterpret_cast<const float4*>(sbe2 + n);
+        const f32x4 v = acc2[nt][mt];
+        float4 o = {(v[0] - mu2[mt]) * rstd2 * gg.x + bb.x, (v[1] - mu2[mt]) * rstd2 * gg.y + bb.y,
+                    (v[2] - mu2[mt]) * rstd2 * gg.z + bb.z, (v[3] - mu2[mt]) * rstd2 * gg.w + bb.w};
+        *reinterpret_cast<float4*>(out + m * C + n) = o;
+      }
+    }
+  }
+}
+
+inline size_t ffn_lds_bytes(int F) { return 3 * 8 * kTileElems * sizeof(u16) + (2 * kRows + 8 * kRows + F + 5 * 256) * sizeof(float); }
+
+}  // namespace axvs

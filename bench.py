@@ -161,7 +161,7 @@ def main():
         for _ in range(reps):
             layer(src, pos)
             torch.cuda.synchronize(dev)
-            for i in range(1, nst):
+            for i in range(1, L.axvs_profile_stage_count()):
                 ms = ctypes.c_float()
                 assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[i - 1], evs[i]) == 0
                 stage_ms[i] += ms.value / reps
@@ -176,8 +176,9 @@ def main():
         fwd_ms = e0.elapsed_time(e1) / args.steps
         flops = layer_flops(B, T, H, W, C, F)
         achieved = flops / (fwd_ms * 1e-3) / 1e12
-        names = [L.axvs_profile_stage_name(i).decode() for i in range(nst)]
-        kernels = {names[i]: round(stage_ms[i] * 1e3, 2) for i in range(1, nst)}
+        nrun = L.axvs_profile_stage_count()
+        names = [L.axvs_profile_stage_name(i).decode() for i in range(nrun)]
+        kernels = {names[i]: round(stage_ms[i] * 1e3, 2) for i in range(1, nrun)}
         dom = max(kernels, key=kernels.get)
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -62,9 +62,15 @@ const char* axvs_last_error(void);
 
 /* ---- optional per-stage timing of axvs_axial_layer_fwd (used by bench.py; thread-local).
  *      events: array of `capacity` hipEvent_t created by the caller, or NULL to switch off.  While set, the layer
- *      records events[i] on its stream after stage i (events[0] at entry).  Returns the number of stages. */
+ *      records events[i] on its stream after stage i (events[0] at entry).  Returns the maximum stage count;
+ *      after a forward, axvs_profile_stage_count() / _name(i) describe the stages that forward actually ran. */
 int axvs_profile_stages(void** events, int capacity);
+int axvs_profile_stage_count(void);
 const char* axvs_profile_stage_name(int i);
+
+/* ---- tuning / test switches (thread-local).  "generic_only" = 1: always use the shape-generic kernels
+ *      instead of the fused C=256 ones (A/B comparisons, parity tests of both paths). */
+int axvs_set_option(const char* key, int value);
 
 /* ---- weight packing (once per load_state_dict; result is opaque, device-resident) ---- */
 size_t axvs_traj_packed_bytes(int C, int heads);
@@ -90,6 +96,12 @@ size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int h
 int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H,
                          int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
                          float* h_attn, float* w_attn, void* stream);
+
+/* ---- the layer's feed-forward tail alone: out = norm2(y + linear2(relu(linear1(y)))), y = norm1(x)
+ *      WC/temporal_attention.py:181-185 + :217.  x/out fp32 [M, C]; weights from a packed AxvsAxialLayerParams. */
+size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn);
+int axvs_ffn_fwd(const float* x, float* out, const void* packed_layer, long long M, int C, int heads, int d_ffn,
+                 int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */

@@ -151,3 +151,26 @@ def test_workspace_and_alias_errors():
     rc = L.axvs_axial_layer_fwd(x.data_ptr(), x.data_ptr(), y.data_ptr(), x.data_ptr(), 1, 2, 3, 4, 64, 8, 128, 0,
                                 x.data_ptr(), 16, None, None, None)
     assert rc == -2 and b"workspace" in L.axvs_last_error()
+
+
+@pytest.mark.parametrize("name", ["g2_axial_B1_T4_C256_H64_W64"])
+def test_generic_kernels_also_match_golden(name):
+    """The shape-generic (v1) kernels stay selectable and parity-green next to the fused C=256 path."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=m["heads"]).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    fused = layer(dev(src), dev(pos))[0].cpu()
+    assert _lib.lib().axvs_set_option(b"generic_only", 1) == 0
+    try:
+        generic = layer(dev(src), dev(pos))[0].cpu()
+    finally:
+        _lib.lib().axvs_set_option(b"generic_only", 0)
+    s = m["stride"]
+    assert rel_err(generic[:, ::s], t(z["out"])) < TOL_F16
+    assert rel_err(fused[:, ::s], t(z["out"])) < TOL_F16
+    assert rel_err(fused, generic) < TOL_F16
