@@ -85,6 +85,46 @@ __device__ __forceinline__ int swz_chunk(int row, int g) {
   return g ^ ((4 - ((row >> 2) & 3)) & 3);
 }
 
+// ---- cross-lane exchange on the VALU (DPP / v_permlane*_swap): no trip through the LDS crossbar, no lgkmcnt ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+// value of lane ^ m for m in {1, 2, 4*, 8*, 16, 32}.  (* within the butterfly order 1,2,4,8: after the xor-1 and
+// xor-2 steps every lane of a quad holds the same value, so row_half_mirror / row_mirror stand in for xor 4 / xor 8.)
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_mov<0xB1>(v); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ float lane_xor2(float v) { return dpp_mov<0x4E>(v); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ float lane_hmirror(float v) { return dpp_mov<0x141>(v); } // row_half_mirror
+__device__ __forceinline__ float lane_mirror(float v) { return dpp_mov<0x140>(v); }  // row_mirror
+__device__ __forceinline__ float lane_xor16(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+// all-reduce over the 16 lanes of a DPP row (lanes 16k..16k+15)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += lane_xor1(v);
+  v += lane_xor2(v);
+  v += lane_hmirror(v);
+  v += lane_mirror(v);
+  return v;
+}
+// all-reduce across the four 16-lane groups (same lane&15)
+__device__ __forceinline__ float groups_sum(float v) {
+  v += lane_xor16(v);
+  v += lane_xor32(v);
+  return v;
+}
+__device__ __forceinline__ float groups_max(float v) {
+  v = fmaxf(v, lane_xor16(v));
+  v = fmaxf(v, lane_xor32(v));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return groups_sum(row16_sum(v)); }
+
 __device__ __forceinline__ float wave_xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, kWave)); }
 __device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shfl_xor(v, m, kWave); }
 

@@ -34,26 +34,61 @@ __device__ __forceinline__ void act_store4(u16* tile, int n, int row, f32x4 v) {
   *reinterpret_cast<u16x4*>(tile + act_off(kb, row, k >> 3) + (k & 7)) = cvt4<BF>(v);
 }
 
+// `rot` rotates the order in which the k-blocks are visited (register slot j holds k-block (j + rot) % KB).  Workgroups
+// use different rotations so that the CUs of an XCD do not all stream the same weight lines from the same L2 channel at
+// the same moment.
 template <bool BF, int NT, int MT, int KB>
-__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[NT][MT], const u16x8 (&wf)[NT][KB], const u16* tile, int fi, int fg) {
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[NT][MT], const u16x8 (&wf)[NT][KB], const u16* tile, int fi, int fg,
+                                           int rot = 0) {
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
+  for (int j = 0; j < KB; ++j) {
+    const int kb = (j + rot) & (KB - 1);
     u16x8 b[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) b[mt] = act_frag(tile, kb, mt, fi, fg);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][kb], b[mt], acc[nt][mt]);
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], b[mt], acc[nt][mt]);
+  }
+}
+
+// Same, but while computing with `wf` it also issues the loads of the NEXT phase's fragments, NT per k-step, so the
+// 1-KiB weight loads are spread between the MFMAs instead of arriving as one burst that backs up the address path.
+template <bool BF, int NT, int MT, int KB, int NTN>
+__device__ __forceinline__ void gemm_phase_pf(f32x4 (&acc)[NT][MT], const u16x8 (&wf)[NT][KB], const u16* tile, int fi, int fg,
+                                              int rot, u16x8 (&wnext)[NTN][KB], const u16* __restrict__ Wn, int NRn, int kb0n,
+                                              int nrow0n, int rotn) {
+  u16x8 bcur[MT], bnxt[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bcur[mt] = act_frag(tile, rot & (KB - 1), mt, fi, fg);
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    if (j + 1 < KB) {
+      const int kb = (j + 1 + rot) & (KB - 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bnxt[mt] = act_frag(tile, kb, mt, fi, fg);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) wnext[nt][j] = w_frag(Wn, NRn, kb0n + ((j + rotn) & (KB - 1)), nrow0n + nt * 16 + fi, fg);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], bcur[mt], acc[nt][mt]);
+    // one k-step of B fragments ahead, never more: keeps the LDS reads in flight far below the 4-bit lgkmcnt limit
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bcur[mt] = bnxt[mt];
   }
 }
 
 template <int NT, int KB>
-__device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __restrict__ W, int NR, int kb0, int nrow0, int fi, int fg) {
+__device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __restrict__ W, int NR, int kb0, int nrow0, int fi, int fg,
+                                            int rot = 0) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int j = 0; j < KB; ++j)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) wf[nt][kb] = w_frag(W, NR, kb0 + kb, nrow0 + nt * 16 + fi, fg);
+    for (int nt = 0; nt < NT; ++nt) wf[nt][j] = w_frag(W, NR, kb0 + ((j + rot) & (KB - 1)), nrow0 + nt * 16 + fi, fg);
 }
 
 // =====================================================================================================
@@ -84,10 +119,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * kRows;
+  const int nchunk = F / 256;
+  // blocks b and b+8 share an XCD (round-robin placement; speed only): give the 32 CUs of an XCD different k-block
+  // rotations and chunk orders
+  const int rot = (blockIdx.x >> 3) & 7;
+  const int crot = (blockIdx.x >> 6) % nchunk;
 
   // prefetch the first linear1 weight fragments while norm1 runs
   u16x8 w1f[2][KB], w2f[2][KB];
-  load_wfrags<2, KB>(w1f, W1, F, 0, wave * 32, fi, fg);
+  load_wfrags<2, KB>(w1f, W1, F, 0, crot * 256 + wave * 32, fi, fg, rot);
 
   for (int i = tid; i < F; i += 512) sb1[i] = b1[i];
   if (tid < C) {
@@ -111,21 +151,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr;
       const float4 v = rows[rr];
-      float s = v.x + v.y + v.z + v.w;
-#pragma unroll
-      for (int k = 1; k < 64; k <<= 1) s = wave_xor_sum(s, k);
-      const float mu = s * (1.f / C);
+      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
       const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
-      float q = a * a + b * b + c * c + d * d;
-#pragma unroll
-      for (int k = 1; k < 64; k <<= 1) q = wave_xor_sum(q, k);
-      const float rstd = rsqrtf(q * (1.f / C) + 1e-5f);
+      const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
       f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
       act_store4<BF>(ytile, lane * 4, r, y);
-      if (lane == 0) {
-        stats[2 * r] = mu;
-        stats[2 * r + 1] = rstd;
-      }
+      if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * r) = float2{mu, rstd};
+      if (rr == 3) lds_fence();
     }
   }
   __syncthreads();
@@ -136,21 +168,19 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = F / 256;
-  for (int c = 0; c < nchunk; ++c) {
-    u16* hbuf = htile + (c & 1) * KB * kTileElems;
-    // linear2 fragments of this chunk: rows = my 32 output channels, k-blocks = this chunk's 256 hidden units
-    load_wfrags<2, KB>(w2f, W2, C, c * 8, wave * 32, fi, fg);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- linear1 + ReLU: my 32 hidden units of the chunk, all 64 rows ----
+  // w2f of the first chunk (later ones are fetched while the previous chunk's linear2 runs... see below)
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int c = (ci + crot) % nchunk;                 // hidden-unit chunk handled in this iteration
+    const int cn = (min(ci + 1, nchunk - 1) + crot) % nchunk;
+    u16* hbuf = htile + (ci & 1) * KB * kTileElems;
+    // ---- linear1 + ReLU: my 32 hidden units of the chunk, all 64 rows; meanwhile fetch this chunk's linear2 fragments
+    //      (rows = my 32 output channels, k-blocks = this chunk's 256 hidden units) ----
     f32x4 acc1[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    gemm_phase<BF, 2, 4, KB>(acc1, w1f, ytile, fi, fg);
+      for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_phase_pf<BF, 2, 4, KB, 2>(acc1, w1f, ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int hn = c * 256 + wave * 32 + nt * 16 + fg * 4;          // global hidden index
@@ -163,13 +193,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
         act_store4<BF>(hbuf, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
       }
     }
-    // next chunk's linear1 fragments (their registers are free now).  Unconditional (the last iteration re-loads its own
-    // chunk): a branch here would merge two different in-flight counts and force the compiler's vmcnt to the smaller one.
-    load_wfrags<2, KB>(w1f, W1, F, 0, min(c + 1, nchunk - 1) * 256 + wave * 32, fi, fg);
-    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    // ---- linear2 partial: += W2[my 32 channels, chunk] . h ----
-    gemm_phase<BF, 2, 4, KB>(acc2, w2f, hbuf, fi, fg);
+    // ---- linear2 partial: += W2[my 32 channels, chunk] . h ; meanwhile fetch the next chunk's linear1 fragments
+    //      (unconditional: the last iteration re-loads its own chunk, which keeps the vmcnt bookkeeping branch-free) ----
+    gemm_phase_pf<BF, 2, 4, KB, 2>(acc2, w2f, hbuf, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
   }
 
   // ---- epilogue: + b2 + y (norm1 recomputed in the output layout) -> norm2 -> out ----
@@ -199,7 +226,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   // norm2 statistics: my 32 channels -> across the 4 lane groups -> across the 8 waves (LDS)
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    rs[mt] = wave_xor_sum(wave_xor_sum(rs[mt], 16), 32);
+    rs[mt] = groups_sum(rs[mt]);
     if (fg == 0) part[wave * kRows + mt * 16 + fi] = rs[mt];
   }
   __syncthreads();
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
         const float d = acc2[nt][mt][r] - mu2[mt];
         q += d * d;
       }
-    rq[mt] = wave_xor_sum(wave_xor_sum(q, 16), 32);
+    rq[mt] = groups_sum(q);
   }
   __syncthreads();
 #pragma unroll
