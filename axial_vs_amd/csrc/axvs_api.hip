@@ -176,16 +176,46 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
   return AXVS_OK;
 }
 
+template <bool BF, int T, int MT>
+int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
+                      float scale, hipStream_t st) {
+  static bool configured = false;
+  constexpr size_t lds = temporal_lds_bytes<T, MT>();
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+    configured = true;
+  }
+  const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
+  hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp,
+                     p.bp, res, out, rm, Mp, N, L, scale);
+  return AXVS_OK;
+}
+
+template <bool BF>
+int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
+                    float scale, hipStream_t st) {
+  switch (T) {
+    case 1: return launch_temporal_t<BF, 1, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 2: return launch_temporal_t<BF, 2, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 3: return launch_temporal_t<BF, 3, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 4: return launch_temporal_t<BF, 4, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 5: return launch_temporal_t<BF, 5, 2>(w, p, res, out, rm, Mp, N, L, scale, st);
+    default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 5");
+  }
+}
+
 // q/k/v inputs are fp32 token rows addressed through `rm`; `qk_add` (nullable) is added to the q and k inputs.
 // Result (+ bias, + optional residual `res`) goes to fp32 rows of `out` through `rm`.
 template <bool BF>
 int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
              hipStream_t st, int pass = 0) {
-  static const char* const kNames[3][6] = {
-      {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj"},
-      {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj"},
-      {"w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj"}};
+  static const char* const kNames[3][7] = {
+      {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused"},
+      {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused"},
+      {"w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj", "w.temporal_fused"}};
   const char* const* nm = kNames[pass];
   const int N = T * L, Cp = heads * 32, d = C / heads;
   const long long Mp = (long long)S * N;
@@ -218,7 +248,13 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   if (rc != AXVS_OK) return rc;
   mark(st, nm[1]);
 
-  // temporal half
+  // temporal half + output projection + residual
+  if (!g_generic_only && C == 256 && heads == 8 && T <= 5) {
+    rc = launch_temporal<BF>(w, p, res, out, rm, Mp, N, L, T, scale, st);
+    if (rc != AXVS_OK) return rc;
+    mark(st, nm[6]);
+    return AXVS_OK;
+  }
   ALoadBlocked<BF> adiag{w.x16, Mp * T, M, T, N, L};
   launch_gemm<BF>(adiag, p.wpq, EpiRowsF32{w.q2, nullptr, p.bpq, identity_map(Mp), Cp, scale}, M, Cp, Cp, st);
   mark(st, nm[2]);

@@ -2,6 +2,7 @@
 //   for every query q of a sequence and every frame f:  x[q, f, :] = softmax_l(scale * q . k[f, l]) @ v[f, l, :]
 // One softmax per (query, frame) -- the N x N logits never leave registers.
 //
+// Output x: 16-bit [heads][T][Mtot][32] (frame-major planes of the blocked layout).
 // Inputs are the blocked 16-bit q/k/v written by the QKV GEMM ([heads][Mtot][32], sequence-order rows, q already
 // multiplied by scale*log2(e)).  Workgroup = (64 queries, head, sequence); wave = 16 queries.  K and V of the
 // (sequence, head) live in LDS for the whole workgroup.
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const u16* __restrict
       }
       xa *= inv;
       if (qvalid) {
-        long long row = (seq0 + qi) * T + f;
+        long long row = (long long)f * Mtot + seq0 + qi;       // x layout: [head][frame][row][32]
         *reinterpret_cast<u16x4*>(Xh + row * 32 + nd * 16 + fg * 4) = cvt4<BF>(xa);
       }
     }

@@ -277,3 +277,257 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
 inline size_t ffn_lds_bytes(int F) { return 3 * 8 * kTileElems * sizeof(u16) + (2 * kRows + 8 * kRows + F + 5 * 256) * sizeof(float); }
 
 }  // namespace axvs
+
+namespace axvs {
+
+// =====================================================================================================
+// Temporal half of trajectory attention + output projection + residual, C = 256, 8 heads (d = 32).
+//   WC/temporal_attention.py:60-75:  q2 = scale * proj_q(x[own frame]);  k2, v2 = proj_kv(x[frame f]) for every f;
+//   a = softmax_f(q2 . k2);  o = sum_f a_f v2_f;  out = proj(o) (+ residual).
+//
+// Workgroup = MT*16 queries (sequence-order rows m'), 8 waves; wave w owns head w for the q2/k2/v2 projections and output
+// channels 32w..32w+31 for the final projection.  The T-expanded tile x[f][k-block][row][32] sits in LDS (T * MT * 8 KiB);
+// k2 and v2 never exist outside accumulators:
+//   pass 1 (per frame): k2_f = Wk2_h x_f  ->  logit_f = q2 . k2_f   (k2 bias drops out of the softmax over f)
+//   pass 2 (per frame): v2_f = Wv2_h x_f  ->  o += a_f * v2_f        (v2 bias added once: sum_f a_f = 1)
+// Each wave streams exactly its own weight rows L2 -> VGPR (Wpq_h, Wk2_h, Wv2_h, Wp[32w..]: 64 KiB), one 64-VGPR fragment
+// set that is refilled in place, slot by slot, right after a slot's last use.
+// =====================================================================================================
+template <int MT>
+__device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // element offset in the x tile
+  return ((f * 8 + kb) * (MT * 16) + row) * 32 + swz_chunk(row, c) * 8;
+}
+
+// one GEMM sweep over the 8 k-blocks: acc[nt][mt] += W[slot j] . B(kb=j);  B fragments come from `bbase[mt] + kb*kbstride`
+// (per-lane LDS element offsets), one k-step of lookahead.  If REFILL, slot j is re-loaded from Wn right after its use.
+template <bool BF, int MT, bool REFILL>
+__device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], const u16* xt, const int (&bbase)[MT], int kbstride,
+                                       const u16* __restrict__ Wn, int NRn, int nrow0n, int fi, int fg) {
+  u16x8 bcur[MT], bnxt[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bcur[mt] = *reinterpret_cast<const u16x8*>(xt + bbase[mt]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j + 1 < 8) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bnxt[mt] = *reinterpret_cast<const u16x8*>(xt + bbase[mt] + (j + 1) * kbstride);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], bcur[mt], acc[nt][mt]);
+    if (REFILL) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[nt][j] = w_frag(Wn, NRn, j, nrow0n + nt * 16 + fi, fg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bcur[mt] = bnxt[mt];
+  }
+}
+
+template <bool BF, int T, int MT>
+__global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
+                                                             const u16* __restrict__ Wpq, const float* __restrict__ bpq,
+                                                             const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
+                                                             const u16* __restrict__ Wp, const float* __restrict__ bp,
+                                                             const float* __restrict__ res, float* __restrict__ out, RowMap rm,
+                                                             long long Mp, int N, int L, float scale) {
+  constexpr int C = 256, ROWS = MT * 16;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
+  float* sbias = reinterpret_cast<float*>(smem + (size_t)T * 8 * ROWS * 32);   // bpq[256] | bv2[256] | bp[256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * ROWS;
+
+  // first weight set: Wpq rows of my head
+  u16x8 wf[2][8];
+  load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
+
+  // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
+  {
+    constexpr int NCH = T * 8 * ROWS * 4;                       // 16-byte chunks
+    constexpr int PER = (NCH + 511) / 512;
+#pragma unroll
+    for (int p0 = 0; p0 < PER; p0 += 8) {
+      u16x8 v[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int c = tid + (p0 + p) * 512;
+        if (p0 + p < PER && c < NCH) {
+          const int g = c & 3, row = (c >> 2) % ROWS, blk = (c >> 2) / ROWS;   // blk = f*8 + kb
+          const int f = blk >> 3, kb = blk & 7;
+          const long long m = min(m0 + row, Mp - 1);
+          v[p] = *reinterpret_cast<const u16x8*>(X16 + (((long long)(kb * T + f)) * Mp + m) * 32 + g * 8);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int c = tid + (p0 + p) * 512;
+        if (p0 + p < PER && c < NCH) {
+          const int g = c & 3, row = (c >> 2) % ROWS, blk = (c >> 2) / ROWS;
+          *reinterpret_cast<u16x8*>(xt + (blk * ROWS + row) * 32 + swz_chunk(row, g) * 8) = v[p];
+        }
+      }
+      lds_fence();
+    }
+    if (tid < C) {
+      sbias[tid] = bpq[tid];
+      sbias[C + tid] = bpkv[C + tid];     // v2 half of the proj_kv bias
+      sbias[2 * C + tid] = bp[tid];
+    }
+  }
+  __syncthreads();
+
+  // per-lane query bookkeeping
+  int bown[MT], bfr[MT];                  // element offsets of my B fragment rows: own-frame slot / frame 0
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = mt * 16 + fi;
+    const long long m = min(m0 + row, Mp - 1);
+    const int fown = (int)((m % N) / L);
+    bown[mt] = xt_off<MT>(fown, 0, row, fg);
+    bfr[mt] = xt_off<MT>(0, 0, row, fg);
+  }
+  constexpr int KBS = ROWS * 32;          // k-block stride (elements)
+  constexpr int FS = 8 * ROWS * 32;       // frame stride
+
+  // ---- q2 = scale * (Wpq_h x_own + bpq_h); refill the fragment set with Wk2_h as it goes ----
+  f32x4 q2[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) q2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  sweep8<BF, MT, true>(q2, wf, xt, bown, KBS, Wpkv, 2 * C, wave * 32, fi, fg);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float4 b = *reinterpret_cast<const float4*>(sbias + wave * 32 + nt * 16 + fg * 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      q2[nt][mt][0] = (q2[nt][mt][0] + b.x) * scale; q2[nt][mt][1] = (q2[nt][mt][1] + b.y) * scale;
+      q2[nt][mt][2] = (q2[nt][mt][2] + b.z) * scale; q2[nt][mt][3] = (q2[nt][mt][3] + b.w) * scale;
+    }
+  }
+
+  // ---- pass 1: logits over frames ----
+  float lg[T][MT];
+#pragma unroll
+  for (int f = 0; f < T; ++f) {
+    f32x4 k2[2][MT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) k2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int bb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bb[mt] = bfr[mt] + f * FS;
+    if (f == T - 1) sweep8<BF, MT, true>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, C + wave * 32, fi, fg);   // refill with Wv2_h
+    else sweep8<BF, MT, false>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, 0, fi, fg);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float p = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p += q2[nt][mt][r] * k2[nt][mt][r];
+      lg[f][mt] = groups_sum(p);
+    }
+  }
+  // softmax over frames
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float mx = lg[0][mt];
+#pragma unroll
+    for (int f = 1; f < T; ++f) mx = fmaxf(mx, lg[f][mt]);
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < T; ++f) {
+      lg[f][mt] = __expf(lg[f][mt] - mx);
+      s += lg[f][mt];
+    }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int f = 0; f < T; ++f) lg[f][mt] *= inv;
+  }
+
+  // ---- pass 2: o = sum_f a_f * (Wv2_h x_f) + bv2_h; the last frame refills the set with Wp[32w..32w+31] ----
+  f32x4 o[2][MT];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float4 b = *reinterpret_cast<const float4*>(sbias + C + wave * 32 + nt * 16 + fg * 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) o[nt][mt] = f32x4{b.x, b.y, b.z, b.w};
+  }
+#pragma unroll
+  for (int f = 0; f < T; ++f) {
+    f32x4 v2[2][MT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) v2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int bb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bb[mt] = bfr[mt] + f * FS;
+    if (f == T - 1) sweep8<BF, MT, true>(v2, wf, xt, bb, KBS, Wp, C, wave * 32, fi, fg);
+    else sweep8<BF, MT, false>(v2, wf, xt, bb, KBS, Wp, C, 0, fi, fg);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) o[nt][mt] += lg[f][mt] * v2[nt][mt];
+  }
+
+  // ---- o (all heads) -> LDS as the [8][ROWS][32] tile of the output projection (aliases the x tile) ----
+  __syncthreads();                        // every wave is done reading x
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int n = wave * 32 + nt * 16 + fg * 4, row = mt * 16 + fi;
+      *reinterpret_cast<u16x4*>(xt + ((n >> 5) * ROWS + row) * 32 + swz_chunk(row, (n & 31) >> 3) * 8 + (n & 7)) = cvt4<BF>(o[nt][mt]);
+    }
+  // residual rows for the epilogue: issue the loads now, use them after the GEMM
+  long long nat[MT];
+  float4 rres[2][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = min(m0 + mt * 16 + fi, Mp - 1);
+    nat[mt] = nat_row(rm, (int)m) * C;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      rres[nt][mt] = res ? *reinterpret_cast<const float4*>(res + nat[mt] + wave * 32 + nt * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+
+  // ---- out[:, 32w..32w+31] = Wp[32w.., :] . o + bp (+ residual) ----
+  f32x4 po[2][MT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) po[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int bo[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = mt * 16 + fi;
+    bo[mt] = row * 32 + swz_chunk(row, fg) * 8;
+  }
+  sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = wave * 32 + nt * 16 + fg * 4;
+    const float4 b = *reinterpret_cast<const float4*>(sbias + 2 * C + n);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (m0 + mt * 16 + fi < Mp) {
+        const float4 r = rres[nt][mt];
+        float4 v = {po[nt][mt][0] + b.x + r.x, po[nt][mt][1] + b.y + r.y, po[nt][mt][2] + b.z + r.z, po[nt][mt][3] + b.w + r.w};
+        *reinterpret_cast<float4*>(out + nat[mt] + n) = v;
+      }
+    }
+  }
+}
+
+template <int T, int MT>
+constexpr size_t temporal_lds_bytes() { return (size_t)T * 8 * MT * 16 * 32 * sizeof(u16) + 3 * 256 * sizeof(float); }
+
+}  // namespace axvs

@@ -38,11 +38,11 @@ struct ALoadBlocked {
   const u16* X;       // blocked [K/32][R][32]
   long long R;
   int M;
-  int diagT, diagN, diagL;  // diagT > 0: row m -> m*T + frame(m)   (own-frame slot of the T-expanded tensor)
+  int diagT, diagN, diagL;  // diagT > 0: row m -> frame(m)*M + m   (own-frame slot of the [T][M] T-expanded tensor)
   __device__ __forceinline__ u16x8 load(int m, int k) const {
     m = min(m, M - 1);
     long long r = m;
-    if (diagT > 0) r = (long long)m * diagT + (m % diagN) / diagL;
+    if (diagT > 0) r = (long long)((m % diagN) / diagL) * M + m;
     return *reinterpret_cast<const u16x8*>(X + blk_off(R, r, k));
   }
 };

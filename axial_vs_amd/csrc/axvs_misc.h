@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---------------- temporal half, v1 (WC/temporal_attention.py:66-73) ----------------
-// q2: fp32 [M, Cp] (already * scale);  kv2: fp32 [M*T, 2*Cp] (k2 | v2);  O16: blocked [Cp/32][M][32].
+// q2: fp32 [M, Cp] (already * scale);  kv2: fp32 [T*M, 2*Cp] (k2 | v2; row f*M + m);  O16: blocked [Cp/32][M][32].
 // One thread per (token, head, 4 channels); 8 threads cooperate on a head's 32-channel dot product.
 template <bool BF>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ q2, const float* __restrict__ kv2,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
   for (int f = 0; f < 8; ++f) {
     lg[f] = -INFINITY;
     if (f < T) {
-      float4 k = *reinterpret_cast<const float4*>(kv2 + (m * T + f) * 2 * Cp + c);
+      float4 k = *reinterpret_cast<const float4*>(kv2 + ((long long)f * M + m) * 2 * Cp + c);
       float p = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
       p += __shfl_xor(p, 1, 64);
       p += __shfl_xor(p, 2, 64);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     if (f < T) {
       float e = __expf(lg[f] - mx);
       sum += e;
-      float4 v = *reinterpret_cast<const float4*>(kv2 + (m * T + f) * 2 * Cp + Cp + c);
+      float4 v = *reinterpret_cast<const float4*>(kv2 + ((long long)f * M + m) * 2 * Cp + Cp + c);
       o[0] += e * v.x; o[1] += e * v.y; o[2] += e * v.z; o[3] += e * v.w;
     }
   }
