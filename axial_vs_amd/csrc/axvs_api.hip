@@ -226,10 +226,28 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const float kLog2e = 1.4426950408889634f;
 
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
-  ALoadRowsF32<BF> aq{qsrc, qk_add, rm, M, C}, ak{ksrc, qk_add, rm, M, C}, av{vsrc, nullptr, rm, M, C};
-  launch_gemm<BF>(aq, p.wq, EpiBlocked16<BF>{w.q16, Mp, p.bq, scale * kLog2e, Cp, 0}, M, Cp, C, st);
-  launch_gemm<BF>(ak, p.wk, EpiBlocked16<BF>{w.k16, Mp, p.bk, 1.f, 0, 0}, M, Cp, C, st);
-  launch_gemm<BF>(av, p.wv, EpiBlocked16<BF>{w.v16, Mp, p.bv, 1.f, 0, 0}, M, Cp, C, st);
+  if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_fused_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+      configured = true;
+    }
+    // the fused kernel reads the value rows from the same tensor as the q/k rows (+ optional additive term)
+    if (vsrc == qsrc) {
+      hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3((unsigned)((Mp + 63) / 64)), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
+                         p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e);
+      goto qkv_done;
+    }
+  }
+  {
+    ALoadRowsF32<BF> aq{qsrc, qk_add, rm, M, C}, ak{ksrc, qk_add, rm, M, C}, av{vsrc, nullptr, rm, M, C};
+    launch_gemm<BF>(aq, p.wq, EpiBlocked16<BF>{w.q16, Mp, p.bq, scale * kLog2e, Cp, 0}, M, Cp, C, st);
+    launch_gemm<BF>(ak, p.wk, EpiBlocked16<BF>{w.k16, Mp, p.bk, 1.f, 0, 0}, M, Cp, C, st);
+    launch_gemm<BF>(av, p.wv, EpiBlocked16<BF>{w.v16, Mp, p.bv, 1.f, 0, 0}, M, Cp, C, st);
+  }
+qkv_done:
   mark(st, nm[0]);
 
   // spatial half

@@ -531,3 +531,101 @@ template <int T, int MT>
 constexpr size_t temporal_lds_bytes() { return (size_t)T * 8 * MT * 16 * 32 * sizeof(u16) + 3 * 256 * sizeof(float); }
 
 }  // namespace axvs
+
+namespace axvs {
+
+// =====================================================================================================
+// q/k/v projections of one pass, C = 256, 8 heads:  q = (Wq (src+pos) + bq) * scale*log2e,  k = Wk (src+pos) + bk,
+// v = Wv src + bv  (WC/temporal_attention.py:42-44 with query = key = src+pos, value = src, :200-203).
+// Workgroup = 64 sequence-order rows; the fp32 token rows are gathered through the RowMap (1 KiB contiguous each),
+// converted once into two LDS tiles (src+pos | src); wave w produces head w of q, k and v (blocked [8][Mp][32] outputs).
+// =====================================================================================================
+template <bool BF>
+__global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict__ src, const float* __restrict__ pos, RowMap rm,
+                                                        const u16* __restrict__ Wq, const u16* __restrict__ Wk,
+                                                        const u16* __restrict__ Wv, const float* __restrict__ bq,
+                                                        const float* __restrict__ bk, const float* __restrict__ bv,
+                                                        u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
+                                                        long long Mp, float qscale) {
+  constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* tqk = smem;                       // (src + pos) tile [8][64][32]
+  u16* tv = smem + 8 * KBS;              // src tile
+  float* sbias = reinterpret_cast<float*>(smem + 16 * KBS);   // bq | bk | bv
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * ROWS;
+
+  u16x8 wf[2][8];
+  load_wfrags<2, 8>(wf, Wq, C, 0, wave * 32, fi, fg);
+
+  // ---- gather + convert the 64 token rows: thread -> (row, float4 column), 64 consecutive threads cover one row ----
+  {
+    const int c4 = tid & 63;             // float4 index within the row
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 a[4], p[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 6) + 8 * (half * 4 + i);
+        const long long m = min(m0 + row, Mp - 1);
+        const long long off = nat_row(rm, (int)m) * C + c4 * 4;
+        a[i] = *reinterpret_cast<const float4*>(src + off);
+        p[i] = pos ? *reinterpret_cast<const float4*>(pos + off) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 6) + 8 * (half * 4 + i);
+        const int n = c4 * 4, kb = n >> 5, k = n & 31;
+        const int o = (kb * ROWS + row) * 32 + swz_chunk(row, k >> 3) * 8 + (k & 7);
+        *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{a[i].x, a[i].y, a[i].z, a[i].w});
+        *reinterpret_cast<u16x4*>(tqk + o) = cvt4<BF>(f32x4{a[i].x + p[i].x, a[i].y + p[i].y, a[i].z + p[i].z, a[i].w + p[i].w});
+      }
+      lds_fence();
+    }
+    if (tid < C) {
+      sbias[tid] = bq[tid];
+      sbias[C + tid] = bk[tid];
+      sbias[2 * C + tid] = bv[tid];
+    }
+  }
+  __syncthreads();
+
+  int bb[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = mt * 16 + fi;
+    bb[mt] = row * 32 + swz_chunk(row, fg) * 8;
+  }
+  // q, k from the (src+pos) tile, v from the src tile; each sweep refills the fragment set for the next one
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (which == 0) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wk, C, wave * 32, fi, fg);
+    else if (which == 1) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wv, C, wave * 32, fi, fg);
+    else sweep8<BF, MT, false>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);
+    u16* dst = which == 0 ? Q16 : which == 1 ? K16 : V16;
+    const float sc = which == 0 ? qscale : 1.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float4 b = *reinterpret_cast<const float4*>(sbias + which * C + wave * 32 + nt * 16 + fg * 4);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const long long m = m0 + mt * 16 + fi;
+        if (m < Mp) {
+          f32x4 v = acc[nt][mt];
+          v[0] = (v[0] + b.x) * sc; v[1] = (v[1] + b.y) * sc; v[2] = (v[2] + b.z) * sc; v[3] = (v[3] + b.w) * sc;
+          *reinterpret_cast<u16x4*>(dst + ((long long)wave * Mp + m) * 32 + nt * 16 + fg * 4) = cvt4<BF>(v);
+        }
+      }
+    }
+  }
+}
+
+constexpr size_t kQkvLdsBytes = 16 * 64 * 32 * sizeof(u16) + 3 * 256 * sizeof(float);
+
+}  // namespace axvs
