@@ -120,12 +120,15 @@ void pack_b(const float* b, float* out, PackDim nd, hipStream_t st) {
 template <bool BF>
 void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, hipStream_t st) {
   const int d = C / heads, Cp = heads * 32;
-  PackDim plainC{C, C, 0, 0}, headC{C, Cp, heads, d}, head2C{2 * C, 2 * Cp, heads, d};
+  // The kernels store q, k and x (the spatial-attention output) with the 32 channels of a head block in perm32 order
+  // (16-byte stores per lane).  q.k is invariant to a common permutation of d; proj_q / proj_kv consume x, so their K
+  // columns are packed in the same order.
+  PackDim plainC{C, C, 0, 0, 0}, headC{C, Cp, heads, d, 0}, head2C{2 * C, 2 * Cp, heads, d, 0}, headCp{C, Cp, heads, d, 1};
   pack_w<BF>(p.q_w, t.wq, headC, plainC, st);
   pack_w<BF>(p.k_w, t.wk, headC, plainC, st);
   pack_w<BF>(p.v_w, t.wv, headC, plainC, st);
-  pack_w<BF>(p.proj_q_w, t.wpq, headC, headC, st);
-  pack_w<BF>(p.proj_kv_w, t.wpkv, head2C, headC, st);
+  pack_w<BF>(p.proj_q_w, t.wpq, headC, headCp, st);
+  pack_w<BF>(p.proj_kv_w, t.wpkv, head2C, headCp, st);
   pack_w<BF>(p.proj_w, t.wp, plainC, headC, st);
   pack_b(p.q_b, t.bq, headC, st);
   pack_b(p.k_b, t.bk, headC, st);
@@ -170,8 +173,9 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
       return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
     configured = true;
   }
-  dim3 grid((N + 63) / 64, heads, S);
-  hipLaunchKernelGGL((spatial_attn_kernel<BF, NKS>), grid, dim3(256), lds, st, w.q16, w.k16, w.v16, w.x16, attn, N, T, L,
+  const int nwaves = (N + 31) / 32 >= 8 ? 8 : (N + 31) / 32;        // 32 queries per wave, at most 8 waves
+  dim3 grid((N + 32 * nwaves - 1) / (32 * nwaves), heads, S);
+  hipLaunchKernelGGL((spatial_attn_kernel<BF, NKS>), grid, dim3(64 * nwaves), lds, st, w.q16, w.k16, w.v16, w.x16, attn, N, T, L,
                      heads, Mp);
   return AXVS_OK;
 }
@@ -426,7 +430,7 @@ int axvs_axial_layer_pack(const AxvsAxialLayerParams* p, void* packed, int C, in
   Carver c(packed);
   LayerPacked l = carve_layer(c, C, heads, d_ffn);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  PackDim plainC{C, C, 0, 0}, plainF{d_ffn, d_ffn, 0, 0};
+  PackDim plainC{C, C, 0, 0, 0}, plainF{d_ffn, d_ffn, 0, 0, 0};
   if (dtype == AXVS_BF16) {
     pack_traj<true>(p->height_attn, l.th, C, heads, st);
     pack_traj<true>(p->width_attn, l.tw, C, heads, st);

@@ -2,9 +2,10 @@
 //   for every query q of a sequence and every frame f:  x[q, f, :] = softmax_l(scale * q . k[f, l]) @ v[f, l, :]
 // One softmax per (query, frame) -- the N x N logits never leave registers.
 //
-// Output x: 16-bit [heads][T][Mtot][32] (frame-major planes of the blocked layout).
+// Output x: 16-bit [heads][T][Mtot][32] (frame-major planes of the blocked layout), the 32 channels of a head block in
+// perm32 order (axvs_misc.h) so every lane stores 16 contiguous bytes.
 // Inputs are the blocked 16-bit q/k/v written by the QKV GEMM ([heads][Mtot][32], sequence-order rows, q already
-// multiplied by scale*log2(e)).  Workgroup = (64 queries, head, sequence); wave = 16 queries.  K and V of the
+// multiplied by scale*log2(e)).  Workgroup = (up to 256 queries, head, sequence); wave = 32 queries.  K and V of the
 // (sequence, head) live in LDS for the whole workgroup.
 //
 // MFMA orientation ("keys on rows"):  S^T = K . Q^T  gives D[key][query] with the query on the lane (lane&15) and
@@ -24,15 +25,16 @@ __device__ __forceinline__ int v_lds_off(int key, int dcol) {
 }
 
 template <bool BF, int NKS>  // NKS = 32-key steps per frame; LP = 32*NKS >= L
-__global__ __launch_bounds__(256) void spatial_attn_kernel(const u16* __restrict__ Q16, const u16* __restrict__ K16,
+__global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict__ Q16, const u16* __restrict__ K16,
                                                            const u16* __restrict__ V16, u16* __restrict__ X,
                                                            float* __restrict__ attn, int N, int T, int L, int heads,
                                                            long long Mtot) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   constexpr int LP = NKS * 32;
+  constexpr int QT = 2;                         // 16-query tiles per wave: every K / V fragment read feeds two MFMAs
   u16* sK = smem;
   u16* sV = smem + (size_t)T * LP * 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int h = blockIdx.y, s = blockIdx.z;
   const int fi = lane & 15, fg = lane >> 4;
   const long long seq0 = (long long)s * N;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const u16* __restrict
   const u16* Qh = Q16 + (long long)h * Mtot * 32;
 
   // ---- stage K, V of this (sequence, head): 64-byte rows, 4 chunks of 16 B; pad keys are zero ----
-  for (int c = tid; c < T * LP * 4; c += 256) {
+  for (int c = tid; c < T * LP * 4; c += nthreads) {
     int row = c >> 2, g = c & 3;
     int f = row / LP, l = row - f * LP;
     u16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
@@ -54,66 +56,83 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const u16* __restrict
     *reinterpret_cast<u16x8*>(sV + v_lds_off(row, g * 8)) = vv;
   }
 
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  const int qi = min(q0 + fi, N - 1);          // clamp: every lane stays active (transposed LDS reads need EXEC = all)
-  const bool qvalid = (q0 + fi) < N;
-  const u16x8 qfrag = *reinterpret_cast<const u16x8*>(Qh + (seq0 + qi) * 32 + fg * 8);
+  const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * (16 * QT);
+  int qi[QT];
+  bool qvalid[QT];
+  u16x8 qfrag[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qi[t] = min(q0 + t * 16 + fi, N - 1);      // clamp: every lane stays active (transposed LDS reads need EXEC = all)
+    qvalid[t] = (q0 + t * 16 + fi) < N;
+    qfrag[t] = *reinterpret_cast<const u16x8*>(Qh + (seq0 + qi[t]) * 32 + fg * 8);
+  }
   __syncthreads();
   if (q0 >= N) return;                          // whole wave out of range (wave-uniform)
 
   u16* Xh = X + (long long)h * Mtot * T * 32;
+  const bool ragged = L != LP;                  // wave-uniform: pad keys need masking
   for (int f = 0; f < T; ++f) {
     // S^T tiles: D[key][query]
-    f32x4 sc[2 * NKS];
+    f32x4 sc[QT][2 * NKS];
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) {
       int row = f * LP + kt * 16 + fi;
       u16x8 kf = *reinterpret_cast<const u16x8*>(sK + row * 32 + swz_chunk(row, fg) * 8);
-      sc[kt] = H16<BF>::mfma(kf, qfrag, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int t = 0; t < QT; ++t) sc[t][kt] = H16<BF>::mfma(kf, qfrag[t], f32x4{0.f, 0.f, 0.f, 0.f});
     }
-    float mx = -INFINITY;
+    if (ragged) {
 #pragma unroll
-    for (int kt = 0; kt < 2 * NKS; ++kt)
+      for (int kt = 0; kt < 2 * NKS; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (kt * 16 + fg * 4 + r >= L) sc[kt][r] = -INFINITY;
-        mx = fmaxf(mx, sc[kt][r]);
-      }
-    mx = wave_xor_max(mx, 16);
-    mx = wave_xor_max(mx, 32);
-    float sum = 0.f;
+        for (int r = 0; r < 4; ++r)
+          if (kt * 16 + fg * 4 + r >= L) {
 #pragma unroll
-    for (int kt = 0; kt < 2 * NKS; ++kt)
+            for (int t = 0; t < QT; ++t) sc[t][kt][r] = -INFINITY;
+          }
+    }
+    float inv[QT];
+    u16x8 pf[QT][NKS];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sc[kt][r] = exp2f(sc[kt][r] - mx);
-        sum += sc[kt][r];
-      }
-    sum = wave_xor_sum(sum, 16);
-    sum = wave_xor_sum(sum, 32);
-    const float inv = 1.f / sum;
-
-    if (attn != nullptr && qvalid) {            // optional reference output space_attn[(s h), q, f, l]
-      float* ap = attn + ((((long long)s * heads + h) * N + qi) * T + f) * L;
+    for (int t = 0; t < QT; ++t) {
+      float mx = sc[t][0][0];
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][kt][r]);
+      mx = groups_max(mx);
+      float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2 * NKS; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int key = kt * 16 + fg * 4 + r;
-          if (key < L) ap[key] = sc[kt][r] * inv;
+          sc[t][kt][r] = __builtin_amdgcn_exp2f(sc[t][kt][r] - mx);   // q carries scale*log2(e)
+          sum += sc[t][kt][r];
         }
+      inv[t] = 1.f / groups_sum(sum);
+
+      if (attn != nullptr && qvalid[t]) {       // optional reference output space_attn[(s h), q, f, l]
+        float* ap = attn + ((((long long)s * heads + h) * N + qi[t]) * T + f) * L;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = kt * 16 + fg * 4 + r;
+            if (key < L) ap[key] = sc[t][kt][r] * inv[t];
+          }
+      }
+      // P^T fragments (B operand), unnormalised; the fp32 result is normalised instead
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[t][ks][j] = H16<BF>::from_f32(sc[t][2 * ks + (j >> 2)][j & 3]);
     }
 
-    // P^T fragments (B operand), unnormalised; normalise the fp32 result instead
-    u16x8 pf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[ks][j] = H16<BF>::from_f32(sc[2 * ks + (j >> 2)][j & 3]);
-
+    f32x4 xa[QT][2];
 #pragma unroll
     for (int nd = 0; nd < 2; ++nd) {
-      f32x4 xa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < QT; ++t) xa[t][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         // lane i of 16-lane group g supplies the address of row (i>>2), columns 4*(i&3).. of the 4x16 block
@@ -129,12 +148,19 @@ __global__ __launch_bounds__(256) void spatial_attn_kernel(const u16* __restrict
           vf[j] = (u16)lo[j];
           vf[4 + j] = (u16)hi[j];
         }
-        xa = H16<BF>::mfma(vf, pf[ks], xa);    // D[d][query]
+#pragma unroll
+        for (int t = 0; t < QT; ++t) xa[t][nd] = H16<BF>::mfma(vf, pf[t][ks], xa[t][nd]);    // D[d][query]
       }
-      xa *= inv;
-      if (qvalid) {
-        long long row = (long long)f * Mtot + seq0 + qi;       // x layout: [head][frame][row][32]
-        *reinterpret_cast<u16x4*>(Xh + row * 32 + nd * 16 + fg * 4) = cvt4<BF>(xa);
+    }
+    // lane holds channels nd*16 + 4g + r of its query: stored at position g*8 + nd*4 + r (perm32 order) -> 16 B per lane,
+    // 1 KiB contiguous per wave store ([head][frame][row][32] layout, consecutive queries are consecutive rows)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (qvalid[t]) {
+        float v[8] = {xa[t][0][0] * inv[t], xa[t][0][1] * inv[t], xa[t][0][2] * inv[t], xa[t][0][3] * inv[t],
+                      xa[t][1][0] * inv[t], xa[t][1][1] * inv[t], xa[t][1][2] * inv[t], xa[t][1][3] * inv[t]};
+        long long row = (long long)f * Mtot + seq0 + qi[t];
+        *reinterpret_cast<u16x8*>(Xh + row * 32 + fg * 8) = cvt8<BF>(v);
       }
     }
   }

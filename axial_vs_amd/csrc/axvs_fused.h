@@ -610,16 +610,25 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
     else sweep8<BF, MT, false>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);
     u16* dst = which == 0 ? Q16 : which == 1 ? K16 : V16;
     const float sc = which == 0 ? qscale : 1.f;
+    const float4 b0 = *reinterpret_cast<const float4*>(sbias + which * C + wave * 32 + fg * 4);
+    const float4 b1 = *reinterpret_cast<const float4*>(sbias + which * C + wave * 32 + 16 + fg * 4);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const float4 b = *reinterpret_cast<const float4*>(sbias + which * C + wave * 32 + nt * 16 + fg * 4);
+    for (int mt = 0; mt < MT; ++mt) {
+      const long long m = m0 + mt * 16 + fi;
+      if (m < Mp) {
+        if (which < 2) {   // q, k: stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r: 16 contiguous bytes per lane
+          float v[8] = {(acc[0][mt][0] + b0.x) * sc, (acc[0][mt][1] + b0.y) * sc, (acc[0][mt][2] + b0.z) * sc,
+                        (acc[0][mt][3] + b0.w) * sc, (acc[1][mt][0] + b1.x) * sc, (acc[1][mt][1] + b1.y) * sc,
+                        (acc[1][mt][2] + b1.z) * sc, (acc[1][mt][3] + b1.w) * sc};
+          *reinterpret_cast<u16x8*>(dst + ((long long)wave * Mp + m) * 32 + fg * 8) = cvt8<BF>(v);
+        } else {           // v: natural channel order
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const long long m = m0 + mt * 16 + fi;
-        if (m < Mp) {
-          f32x4 v = acc[nt][mt];
-          v[0] = (v[0] + b.x) * sc; v[1] = (v[1] + b.y) * sc; v[2] = (v[2] + b.z) * sc; v[3] = (v[3] + b.w) * sc;
-          *reinterpret_cast<u16x4*>(dst + ((long long)wave * Mp + m) * 32 + nt * 16 + fg * 4) = cvt4<BF>(v);
+          for (int nt = 0; nt < 2; ++nt) {
+            const float4 b = *reinterpret_cast<const float4*>(sbias + 2 * C + wave * 32 + nt * 16 + fg * 4);
+            f32x4 v = acc[nt][mt];
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            *reinterpret_cast<u16x4*>(dst + ((long long)wave * Mp + m) * 32 + nt * 16 + fg * 4) = cvt4<BF>(v);
+          }
         }
       }
     }

@@ -8,16 +8,21 @@ namespace axvs {
 // ---------------- weight packing: fp32 nn.Linear [Nout, K] -> blocked 16-bit [Kp/32][Np][32] ----------------
 // Either dimension may be "head structured": `parts` consecutive groups of (heads x d) channels, each head padded
 // from d to 32 (zero rows / columns), so that kernels always see 32-wide head blocks.
+// Stored position p (0..31) of a permuted head block holds channel perm32(p): the order in which an MFMA D tile pair
+// (two 16-row tiles, rows 4g+r) leaves 8 consecutive values per lane, so attention/QKV epilogues store 16 B per lane.
+__device__ __host__ inline int perm32(int p) { return ((p >> 2) & 1) * 16 + (p >> 3) * 4 + (p & 3); }
+
 struct PackDim {
   int orig;    // original size
   int padded;  // padded size
   int heads;   // 0: plain (identity up to `orig`, zero beyond); >0: head structured
   int d;       // head dim (when heads > 0)
+  int perm;    // head structured only: positions within a 32-block are stored in perm32 order
   __device__ __host__ int to_orig(int i) const {
     if (heads == 0) return i < orig ? i : -1;
     int per = heads * 32;
     int part = i / per, w = i - part * per;
-    int h = w >> 5, dd = w & 31;
+    int h = w >> 5, dd = perm ? perm32(w & 31) : (w & 31);
     if (dd >= d) return -1;
     int o = part * heads * d + h * d + dd;
     return o < orig ? o : -1;
