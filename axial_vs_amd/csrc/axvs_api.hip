@@ -341,8 +341,11 @@ int traj_attn_fwd_t(const float* query, const float* key, const float* value, fl
   TrajPacked p = carve_traj(pc, C, heads);
   Carver wc(ws);
   TrajWs w = carve_traj_ws(wc, (long long)S * T * L, T, heads);
+  // the fused kernels always add a residual: feed zeros here (TrajectoryAttention.forward itself has none)
+  float* zeros = wc.take<float>((size_t)S * T * L * C);
+  if (hipMemsetAsync(zeros, 0, (size_t)S * T * L * C * sizeof(float), st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "memset failed");
   RowMap rm{T * L, L, 1, (long long)T * L, L, 1, 0};
-  int rc = run_traj<BF>(query, key, value, nullptr, nullptr, out, attn, p, w, rm, S, T, L, C, heads, st);
+  int rc = run_traj<BF>(query, key, value, nullptr, zeros, out, attn, p, w, rm, S, T, L, C, heads, st);
   return rc != AXVS_OK ? rc : last_launch_status();
 }
 
@@ -391,6 +394,12 @@ int axvs_profile_stages(void** events, int capacity) {
 }
 int axvs_profile_stage_count(void) { return g_prof_next < kMaxStages ? g_prof_next : kMaxStages; }
 const char* axvs_profile_stage_name(int i) { return (i >= 0 && i < kMaxStages && g_stage_names[i]) ? g_stage_names[i] : ""; }
+
+#ifdef AXVS_STAMPS
+int axvs_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(axvs::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "generic_only")) { g_generic_only = value; return AXVS_OK; }
@@ -452,9 +461,9 @@ int axvs_axial_layer_pack(const AxvsAxialLayerParams* p, void* packed, int C, in
 }
 
 size_t axvs_traj_attn_workspace_bytes(int S, int T, int L, int C, int heads) {
-  (void)C;
   Carver c(nullptr);
   carve_traj_ws(c, (long long)S * T * L, T, heads);
+  c.take<float>((size_t)S * T * L * C);
   return c.off;
 }
 

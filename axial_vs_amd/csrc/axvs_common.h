@@ -128,6 +128,22 @@ __device__ __forceinline__ float wave_sum(float v) { return groups_sum(row16_sum
 __device__ __forceinline__ float wave_xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, kWave)); }
 __device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shfl_xor(v, m, kWave); }
 
+// ---- in-kernel phase stamps: diagnostic builds only (-DAXVS_STAMPS); the shipped library contains none ----
+#ifdef AXVS_STAMPS
+__device__ unsigned long long g_stamps[64 * 32];   // [slot][wave-global id % 64]... slot-major: g_stamps[slot * 64 + id]
+__device__ __forceinline__ void stamp(int slot) {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const int id = (blockIdx.x & 7) * 8 + (threadIdx.x >> 6);   // 8 workgroups x 8 waves
+  if (blockIdx.x < 8 && (threadIdx.x & 63) == 0) g_stamps[slot * 64 + id] = t;
+}
+#define AXVS_STAMP(slot) ::axvs::stamp(slot)
+#else
+#define AXVS_STAMP(slot)
+#endif
+
 // lgkmcnt is a 4-bit counter.  hipcc (ROCm 7.2) will happily leave 16 or more LDS/SMEM operations in flight before one
 // `s_waitcnt lgkmcnt(0)`; when the LDS is busy enough that none of them has returned by the time the 16th issues, the
 // counter wraps and the wait falls through early (observed on gfx950: intermittent stale reads in a fused epilogue with

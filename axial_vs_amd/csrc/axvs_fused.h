@@ -331,8 +331,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const u16* __restrict__ Wpq, const float* __restrict__ bpq,
                                                              const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
                                                              const u16* __restrict__ Wp, const float* __restrict__ bp,
-                                                             const float* __restrict__ res, float* __restrict__ out, RowMap rm,
-                                                             long long Mp, int N, int L, float scale) {
+                                                             const float* __restrict__ res /* required */, float* __restrict__ out,
+                                                             RowMap rm, long long Mp, int N, int L, float scale) {
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   const int fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * ROWS;
 
+  AXVS_STAMP(0);
   // first weight set: Wpq rows of my head
   u16x8 wf[2][8];
   load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
@@ -348,29 +349,24 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
   {
     constexpr int NCH = T * 8 * ROWS * 4;                       // 16-byte chunks
-    constexpr int PER = (NCH + 511) / 512;
+    constexpr int PER = (NCH + 511) / 512;                      // <= 16 for the instantiated (T, MT)
+    const int mrow_max = (int)(Mp - 1 - m0);                    // last valid row of this workgroup
+    u16x8 v[PER];
 #pragma unroll
-    for (int p0 = 0; p0 < PER; p0 += 8) {
-      u16x8 v[8];
+    for (int p = 0; p < PER; ++p) {                             // every load in flight before the first LDS write
+      const int c = min(tid + p * 512, NCH - 1);
+      const int g = c & 3, row = (c >> 2) % ROWS, blk = (c >> 2) / ROWS;   // blk = f*8 + kb
+      const int f = blk >> 3, kb = blk & 7;
+      v[p] = *reinterpret_cast<const u16x8*>(X16 + (((long long)(kb * T + f)) * Mp + m0 + min(row, mrow_max)) * 32 + g * 8);
+    }
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int c = tid + (p0 + p) * 512;
-        if (p0 + p < PER && c < NCH) {
-          const int g = c & 3, row = (c >> 2) % ROWS, blk = (c >> 2) / ROWS;   // blk = f*8 + kb
-          const int f = blk >> 3, kb = blk & 7;
-          const long long m = min(m0 + row, Mp - 1);
-          v[p] = *reinterpret_cast<const u16x8*>(X16 + (((long long)(kb * T + f)) * Mp + m) * 32 + g * 8);
-        }
+    for (int p = 0; p < PER; ++p) {
+      const int c = tid + p * 512;
+      if (c < NCH) {
+        const int g = c & 3, row = (c >> 2) % ROWS, blk = (c >> 2) / ROWS;
+        *reinterpret_cast<u16x8*>(xt + (blk * ROWS + row) * 32 + swz_chunk(row, g) * 8) = v[p];
       }
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int c = tid + (p0 + p) * 512;
-        if (p0 + p < PER && c < NCH) {
-          const int g = c & 3, row = (c >> 2) % ROWS, blk = (c >> 2) / ROWS;
-          *reinterpret_cast<u16x8*>(xt + (blk * ROWS + row) * 32 + swz_chunk(row, g) * 8) = v[p];
-        }
-      }
-      lds_fence();
+      if ((p & 7) == 7) lds_fence();
     }
     if (tid < C) {
       sbias[tid] = bpq[tid];
@@ -380,13 +376,14 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   __syncthreads();
 
+  AXVS_STAMP(1);
   // per-lane query bookkeeping
   int bown[MT], bfr[MT];                  // element offsets of my B fragment rows: own-frame slot / frame 0
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + fi;
-    const long long m = min(m0 + row, Mp - 1);
-    const int fown = (int)((m % N) / L);
+    const int m = (int)m0 + min(row, (int)(Mp - 1 - m0));
+    const int fown = (m % N) / L;
     bown[mt] = xt_off<MT>(fown, 0, row, fg);
     bfr[mt] = xt_off<MT>(0, 0, row, fg);
   }
@@ -410,30 +407,38 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
 
-  // ---- pass 1: logits over frames ----
+  AXVS_STAMP(2);
+  // ---- pass 1: logits over frames.  The row tiles are swept in halves (HM at a time) against the same fragment set:
+  //      same MFMAs and LDS reads, half the accumulator / B-fragment registers ----
+  constexpr int HM = MT >= 2 ? MT / 2 : 1, NH = MT / HM;
   float lg[T][MT];
 #pragma unroll
   for (int f = 0; f < T; ++f) {
-    f32x4 k2[2][MT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int hh = 0; hh < NH; ++hh) {
+      f32x4 k2[2][HM];
 #pragma unroll
-      for (int b = 0; b < MT; ++b) k2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int bb[MT];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bb[mt] = bfr[mt] + f * FS;
-    if (f == T - 1) sweep8<BF, MT, true>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, C + wave * 32, fi, fg);   // refill with Wv2_h
-    else sweep8<BF, MT, false>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, 0, fi, fg);
+        for (int b = 0; b < HM; ++b) k2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int bb[HM];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float p = 0.f;
+      for (int b = 0; b < HM; ++b) bb[b] = bfr[hh * HM + b] + f * FS;
+      if (f == T - 1 && hh == NH - 1) sweep8<BF, HM, true>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, C + wave * 32, fi, fg);   // -> Wv2_h
+      else sweep8<BF, HM, false>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, 0, fi, fg);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int b = 0; b < HM; ++b) {
+        const int mt = hh * HM + b;
+        float p = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p += q2[nt][mt][r] * k2[nt][mt][r];
-      lg[f][mt] = groups_sum(p);
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p += q2[nt][mt][r] * k2[nt][b][r];
+        lg[f][mt] = groups_sum(p);
+      }
     }
   }
+  AXVS_STAMP(3);
   // softmax over frames
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int f = 0; f < T; ++f) lg[f][mt] *= inv;
   }
 
-  // ---- pass 2: o = sum_f a_f * (Wv2_h x_f) + bv2_h; the last frame refills the set with Wp[32w..32w+31] ----
+  // ---- pass 2: o = sum_f a_f * (Wv2_h x_f) + bv2_h; the last sweep refills the set with Wp[32w..32w+31] ----
   f32x4 o[2][MT];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -461,24 +466,29 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
 #pragma unroll
   for (int f = 0; f < T; ++f) {
-    f32x4 v2[2][MT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int hh = 0; hh < NH; ++hh) {
+      f32x4 v2[2][HM];
 #pragma unroll
-      for (int b = 0; b < MT; ++b) v2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int bb[MT];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bb[mt] = bfr[mt] + f * FS;
-    if (f == T - 1) sweep8<BF, MT, true>(v2, wf, xt, bb, KBS, Wp, C, wave * 32, fi, fg);
-    else sweep8<BF, MT, false>(v2, wf, xt, bb, KBS, Wp, C, 0, fi, fg);
+        for (int b = 0; b < HM; ++b) v2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int bb[HM];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int b = 0; b < HM; ++b) bb[b] = bfr[hh * HM + b] + f * FS;
+      if (f == T - 1 && hh == NH - 1) sweep8<BF, HM, true>(v2, wf, xt, bb, KBS, Wp, C, wave * 32, fi, fg);
+      else sweep8<BF, HM, false>(v2, wf, xt, bb, KBS, Wp, C, 0, fi, fg);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) o[nt][mt] += lg[f][mt] * v2[nt][mt];
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int b = 0; b < HM; ++b) o[nt][hh * HM + b] += lg[f][hh * HM + b] * v2[nt][b];
+    }
   }
 
+  AXVS_STAMP(4);
   // ---- o (all heads) -> LDS as the [8][ROWS][32] tile of the output projection (aliases the x tile) ----
   __syncthreads();                        // every wave is done reading x
+  AXVS_STAMP(5);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -486,20 +496,20 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       const int n = wave * 32 + nt * 16 + fg * 4, row = mt * 16 + fi;
       *reinterpret_cast<u16x4*>(xt + ((n >> 5) * ROWS + row) * 32 + swz_chunk(row, (n & 31) >> 3) * 8 + (n & 7)) = cvt4<BF>(o[nt][mt]);
     }
-  // residual rows for the epilogue: issue the loads now, use them after the GEMM
+  // residual rows for the epilogue: issue the loads now (no branches, no early values kept alive), use them after the GEMM
   long long nat[MT];
   float4 rres[2][MT];
+  int fi_e = fi, fg_e = fg;                      // laundered copies: keeps hipcc from hoisting the row-index arithmetic (and its
+  asm volatile("" : "+v"(fi_e), "+v"(fg_e));     // live ranges -> spills) from here up to the top of the kernel
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const long long m = min(m0 + mt * 16 + fi, Mp - 1);
-    nat[mt] = nat_row(rm, (int)m) * C;
+    const int m = (int)m0 + min(mt * 16 + fi_e, (int)(Mp - 1 - m0));
+    nat[mt] = nat_row(rm, m) * C + wave * 32 + fg_e * 4;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-      rres[nt][mt] = res ? *reinterpret_cast<const float4*>(res + nat[mt] + wave * 32 + nt * 16 + fg * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 2; ++nt) rres[nt][mt] = *reinterpret_cast<const float4*>(res + nat[mt] + nt * 16);
   }
   __syncthreads();
-
-  // ---- out[:, 32w..32w+31] = Wp[32w.., :] . o + bp (+ residual) ----
+  // ---- out[:, 32w..32w+31] = Wp[32w.., :] . o + bp + residual ----
   f32x4 po[2][MT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     bo[mt] = row * 32 + swz_chunk(row, fg) * 8;
   }
   sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
+  AXVS_STAMP(7);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = wave * 32 + nt * 16 + fg * 4;
@@ -521,10 +532,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       if (m0 + mt * 16 + fi < Mp) {
         const float4 r = rres[nt][mt];
         float4 v = {po[nt][mt][0] + b.x + r.x, po[nt][mt][1] + b.y + r.y, po[nt][mt][2] + b.z + r.z, po[nt][mt][3] + b.w + r.w};
-        *reinterpret_cast<float4*>(out + nat[mt] + n) = v;
+        *reinterpret_cast<float4*>(out + nat[mt] + nt * 16) = v;
       }
     }
   }
+  AXVS_STAMP(8);
 }
 
 template <int T, int MT>

@@ -1,0 +1,26 @@
+"""Phase timeline from a -DAXVS_STAMPS diagnostic build (tools only): python tools/stamps.py <nslots>"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+import torch, numpy as np
+import axvs_oracle as orc
+import axial_vs_amd as ax
+from axial_vs_amd import _lib
+nslots = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
+w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 0)
+src, pos = orc.synthetic_clip(B, T, C, H, W, 0)
+layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+layer.load_state_dict(w, strict=True)
+layer = layer.cuda()
+s, p = src.cuda(), pos.cuda()
+for _ in range(3): layer(s, p)
+torch.cuda.synchronize()
+raw = ctypes.CDLL(_lib.LIB_PATH)
+buf = (ctypes.c_ulonglong * (64 * 32))()
+raw.axvs_debug_read_stamps(buf, 64 * 32)
+a = np.array(buf, dtype=np.uint64).reshape(32, 64)[:nslots].astype(np.int64)
+d = np.diff(a, axis=0)
+print("per-phase cycles (s_memtime ticks = shader cycles... 100MHz const clock on some parts), median over 64 waves:")
+for i in range(nslots - 1): print(f"  phase {i}->{i+1}: median {int(np.median(d[i])):8d}  min {int(d[i].min()):8d}  max {int(d[i].max()):8d}")
+print("  total", int(np.median(a[nslots-1] - a[0])))
