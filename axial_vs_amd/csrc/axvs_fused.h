@@ -82,6 +82,18 @@ __device__ __forceinline__ void gemm_phase_pf(f32x4 (&acc)[NT][MT], const u16x8 
   }
 }
 
+
+// ---- row-wise epilogue ---------------------------------------------------------------------------------------------
+// The MFMA result layout gives a lane 4 consecutive channels of 16 different token rows: touching fp32 [rows][256]
+// tensors that way means 64-byte column slices at a 1-KiB stride (measured: ~20k cycles just to issue 8 such loads per
+// lane).  Instead the accumulators go to an LDS fp32 tile [64][kEpiLd] and every wave then handles whole rows: one
+// 1-KiB coalesced access per wave instruction for the residual read and for the output store.
+constexpr int kEpiLd = 256 + 4;   // floats per LDS row (+16 B pad: the 16 lanes of a D-layout write hit distinct banks)
+
+__device__ __forceinline__ void epi_put(float* tile, int row, int n, f32x4 v) {
+  *reinterpret_cast<float4*>(tile + row * kEpiLd + n) = float4{v[0], v[1], v[2], v[3]};
+}
+
 template <int NT, int KB>
 __device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __restrict__ W, int NR, int kb0, int nrow0, int fi, int fg,
                                             int rot = 0) {
@@ -199,77 +211,42 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
     gemm_phase_pf<BF, 2, 4, KB, 2>(acc2, w2f, hbuf, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
   }
 
-  // ---- epilogue: + b2 + y (norm1 recomputed in the output layout) -> norm2 -> out ----
-  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- epilogue, row-wise: acc2 + b2 -> LDS fp32 tile (over the dead y/h tiles) -> each wave finishes 8 whole rows:
+  //      + y (norm1 recomputed from the row), norm2, one coalesced 1-KiB store per row ----
+  __syncthreads();                                   // every wave is done with the y / h tiles
+  float* etile = reinterpret_cast<float*>(smem);     // 64 x kEpiLd floats = 65 KiB over the (dead) y + h tiles (96 KiB)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = wave * 32 + nt * 16 + fg * 4;
-    const float4 bias = *reinterpret_cast<const float4*>(sb2 + n);
-    const float4 gg = *reinterpret_cast<const float4*>(sg1 + n);
-    const float4 bb = *reinterpret_cast<const float4*>(sbe1 + n);
-    lds_fence();   // keep the number of LDS reads in flight small (see lds_fence)
+    const float4 b = *reinterpret_cast<const float4*>(sb2 + n);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int r = mt * 16 + fi;
-      const long long m = min(m0 + r, M - 1);
-      const float4 x = *reinterpret_cast<const float4*>(X + m * C + n);
-      const float2 st = *reinterpret_cast<const float2*>(stats + 2 * r);
-      const float mu = st.x, rstd = st.y;
-      f32x4& v = acc2[nt][mt];
-      v[0] += bias.x + ((x.x - mu) * rstd * gg.x + bb.x);
-      v[1] += bias.y + ((x.y - mu) * rstd * gg.y + bb.y);
-      v[2] += bias.z + ((x.z - mu) * rstd * gg.z + bb.z);
-      v[3] += bias.w + ((x.w - mu) * rstd * gg.w + bb.w);
-      rs[mt] += v[0] + v[1] + v[2] + v[3];
+    for (int mt = 0; mt < 4; ++mt)
+      epi_put(etile, mt * 16 + fi, n, f32x4{acc2[nt][mt][0] + b.x, acc2[nt][mt][1] + b.y, acc2[nt][mt][2] + b.z, acc2[nt][mt][3] + b.w});
+  }
+  __syncthreads();
+  {
+    const float4 g1v = *reinterpret_cast<const float4*>(sg1 + lane * 4), be1v = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
+    const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
+    float4 xr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long m = min(m0 + wave * 8 + i, M - 1);
+      xr[i] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
     }
-  }
-  // norm2 statistics: my 32 channels -> across the 4 lane groups -> across the 8 waves (LDS)
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    rs[mt] = groups_sum(rs[mt]);
-    if (fg == 0) part[wave * kRows + mt * 16 + fi] = rs[mt];
-  }
-  __syncthreads();
-  float mu2[4], rq[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) s += part[w * kRows + mt * 16 + fi];
-    mu2[mt] = s * (1.f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = acc2[nt][mt][r] - mu2[mt];
-        q += d * d;
-      }
-    rq[mt] = groups_sum(q);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-    if (fg == 0) part[wave * kRows + mt * 16 + fi] = rq[mt];
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    float q = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) q += part[w * kRows + mt * 16 + fi];
-    const float rstd2 = rsqrtf(q * (1.f / C) + 1e-5f);
-    const long long m = m0 + mt * 16 + fi;
-    if (m < M) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = wave * 32 + nt * 16 + fg * 4;
-        const float4 gg = *reinterpret_cast<const float4*>(sg2 + n);
-        const float4 bb = *reinterpret_cast<const float4*>(sbe2 + n);
-        const f32x4 v = acc2[nt][mt];
-        float4 o = {(v[0] - mu2[mt]) * rstd2 * gg.x + bb.x, (v[1] - mu2[mt]) * rstd2 * gg.y + bb.y,
-                    (v[2] - mu2[mt]) * rstd2 * gg.z + bb.z, (v[3] - mu2[mt]) * rstd2 * gg.w + bb.w};
-        *reinterpret_cast<float4*>(out + m * C + n) = o;
-      }
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i;
+      const float2 st = *reinterpret_cast<const float2*>(stats + 2 * r);
+      const float4 a = *reinterpret_cast<const float4*>(etile + r * kEpiLd + lane * 4);
+      const float v0 = a.x + ((xr[i].x - st.x) * st.y * g1v.x + be1v.x), v1 = a.y + ((xr[i].y - st.x) * st.y * g1v.y + be1v.y);
+      const float v2 = a.z + ((xr[i].z - st.x) * st.y * g1v.z + be1v.z), v3 = a.w + ((xr[i].w - st.x) * st.y * g1v.w + be1v.w);
+      const float mu = wave_sum(v0 + v1 + v2 + v3) * (1.f / C);
+      const float d0 = v0 - mu, d1 = v1 - mu, d2 = v2 - mu, d3 = v3 - mu;
+      const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
+      if (m0 + r < M)
+        *reinterpret_cast<float4*>(out + (m0 + r) * C + lane * 4) =
+            float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
+      if (i == 3) lds_fence();
     }
   }
 }
@@ -293,6 +270,14 @@ namespace axvs {
 // Each wave streams exactly its own weight rows L2 -> VGPR (Wpq_h, Wk2_h, Wv2_h, Wp[32w..]: 64 KiB), one 64-VGPR fragment
 // set that is refilled in place, slot by slot, right after a slot's last use.
 // =====================================================================================================
+template <int T, int MT>
+constexpr size_t temporal_lds_bytes() {
+  // x tile (re-used: o tile + fp32 epilogue tile) | biases
+  size_t xt = (size_t)T * 8 * MT * 16 * 32 * sizeof(u16);
+  size_t epi = (size_t)8 * MT * 16 * 32 * sizeof(u16) + (size_t)MT * 16 * kEpiLd * sizeof(float);
+  return (xt > epi ? xt : epi) + 3 * 256 * sizeof(float);
+}
+
 template <int MT>
 __device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // element offset in the x tile
   return ((f * 8 + kb) * (MT * 16) + row) * 32 + swz_chunk(row, c) * 8;
@@ -303,26 +288,28 @@ __device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // elem
 template <bool BF, int MT, bool REFILL>
 __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], const u16* xt, const int (&bbase)[MT], int kbstride,
                                        const u16* __restrict__ Wn, int NRn, int nrow0n, int fi, int fg) {
-  u16x8 bcur[MT], bnxt[MT];
+  // B fragments run LA k-steps ahead of the MFMAs (LDS latency ~ 2 steps of 4 MFMAs); at most (LA+1)*MT <= 12 reads in flight
+  constexpr int LA = MT <= 2 ? 2 : 1;
+  u16x8 b[LA + 1][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) bcur[mt] = *reinterpret_cast<const u16x8*>(xt + bbase[mt]);
+  for (int l = 0; l < LA; ++l)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) b[l][mt] = *reinterpret_cast<const u16x8*>(xt + bbase[mt] + l * kbstride);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (j + 1 < 8) {
+    if (j + LA < 8) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) bnxt[mt] = *reinterpret_cast<const u16x8*>(xt + bbase[mt] + (j + 1) * kbstride);
+      for (int mt = 0; mt < MT; ++mt) b[(j + LA) % (LA + 1)][mt] = *reinterpret_cast<const u16x8*>(xt + bbase[mt] + (j + LA) * kbstride);
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], bcur[mt], acc[nt][mt]);
+      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], b[j % (LA + 1)][mt], acc[nt][mt]);
     if (REFILL) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) wf[nt][j] = w_frag(Wn, NRn, j, nrow0n + nt * 16 + fi, fg);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bcur[mt] = bnxt[mt];
   }
 }
 
@@ -336,7 +323,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
-  float* sbias = reinterpret_cast<float*>(smem + (size_t)T * 8 * ROWS * 32);   // bpq[256] | bv2[256] | bp[256]
+  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_lds_bytes<T, MT>() - 3 * 256 * sizeof(float));   // bpq | bv2 | bp
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * ROWS;
@@ -496,20 +483,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       const int n = wave * 32 + nt * 16 + fg * 4, row = mt * 16 + fi;
       *reinterpret_cast<u16x4*>(xt + ((n >> 5) * ROWS + row) * 32 + swz_chunk(row, (n & 31) >> 3) * 8 + (n & 7)) = cvt4<BF>(o[nt][mt]);
     }
-  // residual rows for the epilogue: issue the loads now (no branches, no early values kept alive), use them after the GEMM
-  long long nat[MT];
-  float4 rres[2][MT];
-  int fi_e = fi, fg_e = fg;                      // laundered copies: keeps hipcc from hoisting the row-index arithmetic (and its
-  asm volatile("" : "+v"(fi_e), "+v"(fg_e));     // live ranges -> spills) from here up to the top of the kernel
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = (int)m0 + min(mt * 16 + fi_e, (int)(Mp - 1 - m0));
-    nat[mt] = nat_row(rm, m) * C + wave * 32 + fg_e * 4;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) rres[nt][mt] = *reinterpret_cast<const float4*>(res + nat[mt] + nt * 16);
-  }
+  AXVS_STAMP(9);
   __syncthreads();
-  // ---- out[:, 32w..32w+31] = Wp[32w.., :] . o + bp + residual ----
+  AXVS_STAMP(6);
+  // ---- out[:, 32w..32w+31] = Wp[32w.., :] . o + bp ----
   f32x4 po[2][MT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -523,24 +500,38 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
   AXVS_STAMP(7);
+  // ---- row-wise epilogue: accumulators (+bias) -> LDS fp32 tile (behind the o tile) -> whole rows: + residual -> out ----
+  float* etile = reinterpret_cast<float*>(xt + 8 * ROWS * 32);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = wave * 32 + nt * 16 + fg * 4;
     const float4 b = *reinterpret_cast<const float4*>(sbias + 2 * C + n);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (m0 + mt * 16 + fi < Mp) {
-        const float4 r = rres[nt][mt];
-        float4 v = {po[nt][mt][0] + b.x + r.x, po[nt][mt][1] + b.y + r.y, po[nt][mt][2] + b.z + r.z, po[nt][mt][3] + b.w + r.w};
-        *reinterpret_cast<float4*>(out + nat[mt] + nt * 16) = v;
-      }
+    for (int mt = 0; mt < MT; ++mt)
+      epi_put(etile, mt * 16 + fi, n, f32x4{po[nt][mt][0] + b.x, po[nt][mt][1] + b.y, po[nt][mt][2] + b.z, po[nt][mt][3] + b.w});
+  }
+  __syncthreads();
+  {
+    constexpr int RPW = ROWS / 8;                   // rows per wave
+    float4 r[RPW];
+    long long off[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wave * RPW + i;
+      const int m = (int)m0 + min(row, (int)(Mp - 1 - m0));
+      off[i] = nat_row(rm, m) * C + lane * 4;       // wave-uniform row, lane = float4 column
+      r[i] = *reinterpret_cast<const float4*>(res + off[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wave * RPW + i;
+      const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
+      if (m0 + row < Mp) *reinterpret_cast<float4*>(out + off[i]) = float4{v.x + r[i].x, v.y + r[i].y, v.z + r[i].z, v.w + r[i].w};
     }
   }
   AXVS_STAMP(8);
 }
 
-template <int T, int MT>
-constexpr size_t temporal_lds_bytes() { return (size_t)T * 8 * MT * 16 * 32 * sizeof(u16) + 3 * 256 * sizeof(float); }
 
 }  // namespace axvs
 

@@ -19,8 +19,10 @@ torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * (64 * 32))()
 raw.axvs_debug_read_stamps(buf, 64 * 32)
-a = np.array(buf, dtype=np.uint64).reshape(32, 64)[:nslots].astype(np.int64)
+a = np.array(buf, dtype=np.uint64).reshape(32, 64).astype(np.int64)
+order = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(nslots))
+a = a[order]; nslots = len(order)
 d = np.diff(a, axis=0)
 print("per-phase cycles (s_memtime ticks = shader cycles... 100MHz const clock on some parts), median over 64 waves:")
-for i in range(nslots - 1): print(f"  phase {i}->{i+1}: median {int(np.median(d[i])):8d}  min {int(d[i].min()):8d}  max {int(d[i].max()):8d}")
+for i in range(nslots - 1): print(f"  phase {order[i]}->{order[i+1]}: median {int(np.median(d[i])):8d}  min {int(d[i].min()):8d}  max {int(d[i].max()):8d}")
 print("  total", int(np.median(a[nslots-1] - a[0])))
