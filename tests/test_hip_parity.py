@@ -174,3 +174,63 @@ def test_generic_kernels_also_match_golden(name):
     assert rel_err(generic[:, ::s], t(z["out"])) < TOL_F16
     assert rel_err(fused[:, ::s], t(z["out"])) < TOL_F16
     assert rel_err(fused, generic) < TOL_F16
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 256, 12, 9, 512), (1, 2, 256, 25, 43, 1024), (2, 3, 256, 10, 16, 256),
+                                   (1, 5, 256, 8, 12, 1024)])
+def test_fused_kernels_all_frame_counts(shape):
+    """C = 256 routes through the fused kernels: cover T = 1, 2, 3, 5 (T = 4 is the metric fixture), ragged H x W
+    (incl. the VIPSeg res5 size 25 x 43), workgroups with a partial last row tile."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 21)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 21)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    out, _, _ = layer.cuda()(dev(src), dev(pos))
+    e = rel_err(out.cpu(), ref)
+    print(f"{shape}: {e:.2e}")
+    assert e < TOL_F16
+
+
+def test_ffn_tail_unit_and_determinism():
+    """axvs_ffn_fwd alone against the fp64 oracle, and 50 repeated launches bit-identical (the lgkmcnt-overflow
+    regression test: DESIGN.md section 5)."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    M, C, F = 16384 + 37, 256, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 3)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    packed = layer.cuda()._pack()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, C, generator=g) * 2 + 0.3
+    y = orc._layer_norm(x.double(), w, "norm1")
+    ref = orc._layer_norm(y + orc._linear(torch.relu(orc._linear(y, w, "linear1")), w, "linear2"), w, "norm2")
+    L = _lib.lib()
+    xs = x.cuda()
+    ws = torch.empty(L.axvs_ffn_workspace_bytes(M, C, F), dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(50):
+        out = torch.empty_like(xs)
+        _lib.check(L.axvs_ffn_fwd(xs.data_ptr(), out.data_ptr(), packed.data_ptr(), M, C, 8, F, 0, ws.data_ptr(), ws.numel(),
+                                  torch.cuda.current_stream().cuda_stream), "axvs_ffn_fwd")
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert rel_err(outs[0].cpu(), ref) < 2e-3 / 4      # unnormalised random rows: still well inside the bar
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_layer_determinism_stress():
+    import axial_vs_amd as ax
+    z, m = load("g2_axial_B1_T4_C256_H64_W64")
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    s, p = dev(src), dev(pos)
+    first = layer(s, p)[0].clone()
+    for _ in range(40):
+        assert torch.equal(layer(s, p)[0], first)
