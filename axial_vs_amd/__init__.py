@@ -7,6 +7,8 @@ from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, Tempo
                       TemporalEncoder, TemporalTrajectoryAttentionLayer, TrajectoryAttention, TubeLinkTemporalEncoder,
                       set_default_dtype)
 
-__all__ = ["TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
+from .cross_clip import CrossClipTrackingModule
+
+__all__ = ["CrossClipTrackingModule", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
            "set_default_dtype"]

@@ -30,6 +30,21 @@ class AxvsAxialLayerParams(C.Structure):
                                    "norm2_w", "norm2_b")]
 
 
+class AxvsBN(C.Structure):
+    _fields_ = [(n, _fp) for n in ("w", "b", "mean", "var")]
+
+
+class AxvsCCLayerParams(C.Structure):
+    _fields_ = [("attn", AxvsTrajParams), ("norm_w", _fp), ("norm_b", _fp), ("aspp_w", _fp * 3), ("aspp_b", _fp * 3),
+                ("aspp_proj_w", _fp), ("aspp_norm_w", _fp), ("aspp_norm_b", _fp), ("conv_norm_w", _fp), ("conv_norm_b", _fp)]
+
+
+class AxvsCCHeadParams(C.Structure):
+    _fields_ = [("class_proj_w", _fp), ("class_proj_bn", AxvsBN), ("mask_proj_w", _fp), ("mask_proj_bn", AxvsBN),
+                ("mask_head_w", _fp), ("mask_head_bn", AxvsBN), ("class_head_w", _fp), ("class_head_b", _fp),
+                ("act_head_w", _fp), ("act_head_b", _fp), ("pixel_bn", AxvsBN)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/axvs.h
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
@@ -48,6 +63,14 @@ SIGNATURES = {
     "axvs_axial_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
     "axvs_ffn_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int, C.c_int]),
     "axvs_ffn_fwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
+    "axvs_cc_layer_packed_bytes": (C.c_size_t, []),
+    "axvs_cc_layer_pack": (C.c_int, [C.POINTER(AxvsCCLayerParams), _fp, C.c_int, _fp]),
+    "axvs_cc_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "axvs_cc_layer_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, _fp, C.c_size_t, _fp]),
+    "axvs_cc_heads_packed_bytes": (C.c_size_t, [C.c_int]),
+    "axvs_cc_heads_pack": (C.c_int, [C.POINTER(AxvsCCHeadParams), _fp, C.c_int, C.c_int, _fp]),
+    "axvs_cc_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "axvs_cc_heads_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
     "axvs_pos3d": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_scaled_residual": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
 }

@@ -1,0 +1,224 @@
+"""nn.Module mirror of the cross-clip tracking module.
+
+Reference: CC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/cross_clip_tracking_module/maxtron_cross_clip_tracking_module.py
+(same classes inlined in MaXTron_Tube-Link/models/video/tube_link_vis/mask2former_video_cc_head.py:125-247).
+Same constructor, attribute names and state-dict keys as `CrossClipTrackingModule` (CC:204-331) and its parts
+(`TrajectoryAttention` CC:78-130, `TrajectoryAttentionLayer` :133-173, `ASPP` :176-201, `MaXTronCCPredictor` :30-75,
+`ConvBN` / channels-first `LayerNorm` from kmax_deeplab); forward runs in libaxvs.so.  Eval only, norm_fn='ln'
+(every shipped config), kernel sizes 3.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import _lib
+from .modules import _dev_f32, _param_key, _require_eval, _stream, _traj_struct, _workspace
+
+
+class _LayerNormCF(nn.Module):
+    """channels-first LayerNorm parameters (kmax_deeplab/modeling/backbone/convnext.py:52-81), eps 1e-6."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.eps = 1e-6
+
+
+class ConvBN(nn.Module):
+    """Parameter container with the reference's names: .conv (Conv1d), .norm (BatchNorm / channels-first LN / Identity)."""
+
+    def __init__(self, cin, cout, kernel_size=1, bias=True, norm=None, act=None):
+        super().__init__()
+        self.conv = nn.Conv1d(cin, cout, kernel_size=kernel_size, bias=bias)
+        if norm is None or norm == "none":
+            self.norm = nn.Identity()
+        elif norm == "syncbn":
+            self.norm = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01)   # same buffers/keys as nn.SyncBatchNorm
+        elif norm == "ln":
+            self.norm = _LayerNormCF(cout)
+        else:
+            raise NotImplementedError(norm)
+        self.act = nn.GELU() if act == "gelu" else nn.Identity()
+
+
+class TrajectoryAttention(nn.Module):       # CC:78-89
+    def __init__(self, d_model, nhead, attn_drop):
+        super().__init__()
+        self.num_heads = nhead
+        self.head_dim = d_model // nhead
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(d_model, d_model * 3)
+        self.proj_q = nn.Linear(d_model, d_model)
+        self.proj_kv = nn.Linear(d_model, d_model * 2)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(d_model, d_model)
+
+
+class TrajectoryAttentionLayer(nn.Module):  # CC:133-153
+    def __init__(self, d_model, nhead, dropout=0.0, attn_drop=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = TrajectoryAttention(d_model, nhead, attn_drop=attn_drop)
+        self.norm = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class ASPP(nn.Module):                       # CC:176-190
+    def __init__(self, in_channels, output_channels, kernel_sizes, atrous_rates, dropout_rate, norm_fn):
+        super().__init__()
+        if list(kernel_sizes) != [3, 3, 3]:
+            raise NotImplementedError("axial_vs_amd: ASPP kernel sizes other than [3,3,3] have no HIP path")
+        if norm_fn != "ln":
+            raise NotImplementedError("axial_vs_amd: ASPP norm_fn must be 'ln' (the shipped configuration)")
+        for i in range(3):
+            setattr(self, f"_aspp_conv{i}", nn.Conv1d(in_channels, output_channels, kernel_size=3, dilation=atrous_rates[i],
+                                                      padding="same", padding_mode="replicate"))
+        self._proj_conv_bn_act = ConvBN(output_channels * 3, output_channels, 1, bias=False, norm=norm_fn, act="gelu")
+        self._proj_drop = nn.Dropout(p=dropout_rate)
+
+
+class MaXTronCCPredictor(nn.Module):         # CC:30-43
+    def __init__(self, num_classes=133 + 1):
+        super().__init__()
+        self._transformer_mask_head = ConvBN(256, 128, 1, bias=False, norm="syncbn")
+        self._transformer_class_head = ConvBN(256, num_classes, 1, norm=None)
+        self._transformer_class_activation_head = ConvBN(256, 1, 1, norm=None)
+        self._pixel_space_mask_batch_norm = nn.BatchNorm1d(1, eps=1e-3, momentum=0.01)
+        nn.init.constant_(self._pixel_space_mask_batch_norm.weight, 0.1)
+
+
+def _bn(m) -> _lib.AxvsBN:
+    return m.weight, m.bias, m.running_mean, m.running_var
+
+
+class CrossClipTrackingModule(nn.Module):
+    def __init__(self, *, num_layers: int, num_classes: int, attn_drop: float, aspp_drop: float, kernel_sizes: List[int],
+                 atrous_rates: List[int], norm_fn: str, num_clip_frames: int, mfma_dtype: Optional[str] = None):
+        super().__init__()
+        self.kernel_sizes = kernel_sizes
+        self.atrous_rates = atrous_rates
+        self.attn_drop = attn_drop
+        self.aspp_drop = aspp_drop
+        self.norm_fn = norm_fn
+        self.num_clip_frames = num_clip_frames
+        self.num_heads = 8
+        self.num_layers = num_layers
+        self.transformer_trajectory_self_attention_layers = nn.ModuleList()
+        self.conv_short_aggregate_layers = nn.ModuleList()
+        self.conv_norms = nn.ModuleList()
+        for _ in range(num_layers):
+            self.transformer_trajectory_self_attention_layers.append(
+                TrajectoryAttentionLayer(d_model=256, nhead=8, dropout=0.0, attn_drop=attn_drop, normalize_before=False))
+            self.conv_short_aggregate_layers.append(ASPP(256, 256, kernel_sizes, atrous_rates, aspp_drop, norm_fn))
+            self.conv_norms.append(nn.LayerNorm(256))
+        self._class_embedding_projection = ConvBN(256, 256, 1, bias=False, norm="syncbn", act="gelu")
+        self._mask_embedding_projection = ConvBN(256, 256, 1, bias=False, norm="syncbn", act="gelu")
+        self._predictor = MaXTronCCPredictor(num_classes=num_classes + 1)
+        self.mfma_dtype = mfma_dtype
+        self.eval_outputs_on_cpu = True     # the reference's eval branch returns CPU tensors (CC:59,70)
+        self._packed = None
+        self._packed_key = None
+
+    # ---- packing -------------------------------------------------------------------------------------------------
+    def _dtype(self) -> str:
+        from . import modules
+        return self.mfma_dtype or modules._DEFAULT_DTYPE
+
+    def _pack(self):
+        dt = self._dtype()
+        key = _param_key(self, dt) + tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        L = _lib.lib()
+        dev = self.conv_norms[0].weight.device
+        keep: list = []
+
+        def f(t):
+            tt = _dev_f32(t.detach(), "parameter")
+            keep.append(tt)
+            return tt.data_ptr()
+
+        layers = []
+        for i in range(self.num_layers):
+            lay, asp, cn = self.transformer_trajectory_self_attention_layers[i], self.conv_short_aggregate_layers[i], self.conv_norms[i]
+            ps = _lib.AxvsCCLayerParams()
+            ps.attn = _traj_struct(lay.self_attn, keep)
+            ps.norm_w, ps.norm_b = f(lay.norm.weight), f(lay.norm.bias)
+            for k in range(3):
+                conv = getattr(asp, f"_aspp_conv{k}")
+                ps.aspp_w[k], ps.aspp_b[k] = f(conv.weight), f(conv.bias)
+            ps.aspp_proj_w = f(asp._proj_conv_bn_act.conv.weight)
+            ps.aspp_norm_w, ps.aspp_norm_b = f(asp._proj_conv_bn_act.norm.weight), f(asp._proj_conv_bn_act.norm.bias)
+            ps.conv_norm_w, ps.conv_norm_b = f(cn.weight), f(cn.bias)
+            buf = torch.empty(L.axvs_cc_layer_packed_bytes(), dtype=torch.uint8, device=dev)
+            _lib.check(L.axvs_cc_layer_pack(C.byref(ps), buf.data_ptr(), _lib.DTYPES[dt], _stream(dev)), "axvs_cc_layer_pack")
+            layers.append(buf)
+        pr = self._predictor
+        K1 = pr._transformer_class_head.conv.weight.shape[0]
+        hp = _lib.AxvsCCHeadParams()
+        hp.class_proj_w = f(self._class_embedding_projection.conv.weight)
+        hp.class_proj_bn = _lib.AxvsBN(*[f(t) for t in _bn(self._class_embedding_projection.norm)])
+        hp.mask_proj_w = f(self._mask_embedding_projection.conv.weight)
+        hp.mask_proj_bn = _lib.AxvsBN(*[f(t) for t in _bn(self._mask_embedding_projection.norm)])
+        hp.mask_head_w = f(pr._transformer_mask_head.conv.weight)
+        hp.mask_head_bn = _lib.AxvsBN(*[f(t) for t in _bn(pr._transformer_mask_head.norm)])
+        hp.class_head_w, hp.class_head_b = f(pr._transformer_class_head.conv.weight), f(pr._transformer_class_head.conv.bias)
+        hp.act_head_w = f(pr._transformer_class_activation_head.conv.weight)
+        hp.act_head_b = f(pr._transformer_class_activation_head.conv.bias)
+        hp.pixel_bn = _lib.AxvsBN(*[f(t) for t in _bn(pr._pixel_space_mask_batch_norm)])
+        hbuf = torch.empty(L.axvs_cc_heads_packed_bytes(K1), dtype=torch.uint8, device=dev)
+        _lib.check(L.axvs_cc_heads_pack(C.byref(hp), hbuf.data_ptr(), K1, _lib.DTYPES[dt], _stream(dev)), "axvs_cc_heads_pack")
+        torch.cuda.current_stream(dev).synchronize()      # `keep` (fp32 staging copies) may be released after this
+        self._packed, self._packed_key = (layers, hbuf, K1), key
+        return self._packed
+
+    # ---- forward (CC:275-322) ------------------------------------------------------------------------------------
+    def forward(self, clip_query: Tensor, panoptic_features: Tensor):
+        _require_eval(self)
+        cq = _dev_f32(clip_query, "clip_query")
+        pf = _dev_f32(panoptic_features, "panoptic_features")
+        B, Q, Tc, Cq = cq.shape
+        if Cq != 256 or pf.shape[1] != 128:
+            raise RuntimeError("clip_query must be [B,Q,T,256] and panoptic_features [B,128,T*V,H,W]")
+        V = self.num_clip_frames
+        Bp, _, TV, H, W = pf.shape
+        if Bp != B or TV != Tc * V:
+            raise RuntimeError(f"panoptic_features {tuple(pf.shape)} does not match clip_query {tuple(cq.shape)} / V={V}")
+        L = _lib.lib()
+        layers, hbuf, K1 = self._pack()
+        dt = _lib.DTYPES[self._dtype()]
+        dev, st = cq.device, _stream(cq.device)
+        ws = _workspace(dev, max(L.axvs_cc_layer_workspace_bytes(B, Q, Tc), L.axvs_cc_heads_workspace_bytes(B, Q, Tc)))
+        rates = (C.c_int * 3)(*[int(r) for r in self.atrous_rates])
+        cls_all, mask_all = [], []
+        cur = cq
+        for i in range(self.num_layers):
+            nxt = torch.empty_like(cur)
+            _lib.check(L.axvs_cc_layer_fwd(cur.data_ptr(), nxt.data_ptr(), layers[i].data_ptr(), B, Q, Tc, rates, dt, ws.data_ptr(),
+                                           ws.numel(), st), "axvs_cc_layer_fwd")
+            cur = nxt
+            logits = torch.empty(1, Q, K1, dtype=torch.float32, device=dev)
+            masks = torch.empty(B, Q, TV, H, W, dtype=torch.float32, device=dev)
+            _lib.check(L.axvs_cc_heads_fwd(cur.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), hbuf.data_ptr(), B, Q,
+                                           Tc, V, H, W, K1, dt, ws.data_ptr(), ws.numel(), st), "axvs_cc_heads_fwd")
+            cls_all.append(logits)
+            mask_all.append(masks)
+        if self.eval_outputs_on_cpu:
+            cls_all = [c.cpu() for c in cls_all]
+            mask_all = [m.cpu() for m in mask_all]
+        size = mask_all[-1].shape[-3:]
+        ac = size[-1] % 2 == 1
+        aux = [{"pred_logits": a, "pred_masks": b if b.shape[-3:] == size else F.interpolate(b, size=size, mode="trilinear", align_corners=ac)}
+               for a, b in zip(cls_all[:-1], mask_all[:-1])]
+        self.last_clip_query = cur
+        return {"pred_logits": cls_all[-1], "pred_masks": mask_all[-1], "aux_outputs": aux}

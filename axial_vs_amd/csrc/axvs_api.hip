@@ -8,6 +8,7 @@
 
 #include "../../include/axvs.h"
 #include "axvs_attn.h"
+#include "axvs_cc.h"
 #include "axvs_common.h"
 #include "axvs_fused.h"
 #include "axvs_gemm.h"
@@ -109,9 +110,10 @@ LayerPacked carve_layer(Carver& c, int C, int heads, int F) {
 }
 
 template <bool BF>
-void pack_w(const float* W, u16* out, PackDim nd, PackDim kd, hipStream_t st) {
+void pack_w(const float* W, u16* out, PackDim nd, PackDim kd, hipStream_t st, int n_off = 0, int n_total = 0) {
   long long total = (long long)nd.padded * kd.padded;
-  hipLaunchKernelGGL((pack_weight_kernel<BF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, nd, kd);
+  hipLaunchKernelGGL((pack_weight_kernel<BF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, nd, kd, n_off,
+                     n_total ? n_total : nd.padded);
 }
 void pack_b(const float* b, float* out, PackDim nd, hipStream_t st) {
   hipLaunchKernelGGL(pack_bias_kernel, dim3((nd.padded + 255) / 256), dim3(256), 0, st, b, out, nd);
@@ -380,6 +382,123 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   return last_launch_status();
 }
 
+// ---------------- cross-clip module ----------------
+struct CCLayerPacked {
+  TrajPacked t;
+  u16 *aspp[3], *aspp_proj;
+  float *aspp_b[3], *norm_w, *norm_b, *an_w, *an_b, *cn_w, *cn_b;
+};
+CCLayerPacked carve_cc_layer(Carver& c) {
+  CCLayerPacked l;
+  l.t = carve_traj(c, 256, 8);
+  for (int i = 0; i < 3; ++i) l.aspp[i] = c.take<u16>(256 * 768);
+  l.aspp_proj = c.take<u16>(256 * 768);
+  for (int i = 0; i < 3; ++i) l.aspp_b[i] = c.take<float>(256);
+  l.norm_w = c.take<float>(256); l.norm_b = c.take<float>(256);
+  l.an_w = c.take<float>(256); l.an_b = c.take<float>(256);
+  l.cn_w = c.take<float>(256); l.cn_b = c.take<float>(256);
+  return l;
+}
+struct CCHeadsPacked {
+  u16 *wemb, *wmh;                       // [512,256] (class | mask projection), [128,256]
+  float *emb_mul, *emb_add, *mh_mul, *mh_add, *wc, *bc, *wa, *ba, *pix;   // folded BN; class / activation heads fp32; pixel BN (mul, add)
+};
+CCHeadsPacked carve_cc_heads(Carver& c, int K1) {
+  CCHeadsPacked h;
+  h.wemb = c.take<u16>(512 * 256);
+  h.wmh = c.take<u16>(128 * 256);
+  h.emb_mul = c.take<float>(512); h.emb_add = c.take<float>(512);
+  h.mh_mul = c.take<float>(128); h.mh_add = c.take<float>(128);
+  h.wc = c.take<float>((size_t)K1 * 256); h.bc = c.take<float>(K1);
+  h.wa = c.take<float>(256); h.ba = c.take<float>(4);
+  h.pix = c.take<float>(4);
+  return h;
+}
+struct CCLayerWs {
+  TrajWs tw;
+  float *t1, *t2, *y;
+  u16* cat16;
+};
+CCLayerWs carve_cc_layer_ws(Carver& c, long long R, int Tc) {
+  CCLayerWs w;
+  w.tw = carve_traj_ws(c, R, Tc, 8);
+  w.t1 = c.take<float>((size_t)R * 256);
+  w.t2 = c.take<float>((size_t)R * 256);
+  w.y = c.take<float>((size_t)R * 256);
+  w.cat16 = c.take<u16>((size_t)R * 768);
+  return w;
+}
+
+void copy_f32(const float* src, float* dst, int n, hipStream_t st) {
+  PackDim d{n, n, 0, 0, 0};
+  pack_b(src, dst, d, st);
+}
+void fold_bn(const AxvsBN& bn, float* mul, float* add, int n, hipStream_t st) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bn.w, bn.b, bn.mean, bn.var, 1e-3f, mul, add, n);
+}
+
+template <bool BF>
+int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q, int Tc, const int* rates, void* ws, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  CCLayerPacked p = carve_cc_layer(pc);
+  const long long R = (long long)B * Q * Tc;
+  Carver wc(ws);
+  CCLayerWs w = carve_cc_layer_ws(wc, R, Tc);
+  g_prof_next = 0;
+  mark(st, "begin");
+  // trajectory attention over (t q) tokens of each video, read in place from [B,Q,Tc,C]:  row (b; t,q) -> b*Q*Tc + q*Tc + t
+  RowMap rm{Tc * Q, Q, 1, (long long)Q * Tc, 1, Tc, 0};
+  int rc = run_traj<BF>(x, x, x, nullptr, x, w.t1, nullptr, p.t, w.tw, rm, B, Tc, Q, 256, 8, st, 0);
+  if (rc != AXVS_OK) return rc;
+  const unsigned lnblocks = (unsigned)((R + 3) / 4);
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, w.t1, p.norm_w, p.norm_b, w.t2, (u16*)nullptr, R, 256,
+                     1e-5f);
+  mark(st, "cc.norm");
+  // temporal ASPP: three dilated 3-tap convs over the clip axis -> concat (blocked 16-bit) -> 1x1 projection
+  for (int br = 0; br < 3; ++br) {
+    ALoadShift3<BF> a{w.t2, 256, Tc, rates[br], (int)R};
+    EpiBlocked16<BF> e{w.cat16, R, p.aspp_b[br], 1.f, 0, 0};
+    e.n_off = br * 256;
+    launch_gemm<BF>(a, p.aspp[br], e, (int)R, 256, 768, st);
+  }
+  ALoadBlocked<BF> ac{w.cat16, R, (int)R, 0, 1, 1};
+  launch_gemm<BF>(ac, p.aspp_proj, EpiRowsF32{w.y, nullptr, nullptr, identity_map(R), 256, 1.f}, (int)R, 256, 768, st);
+  mark(st, "cc.aspp");
+  hipLaunchKernelGGL(cc_aspp_post_kernel, dim3(lnblocks), dim3(256), 0, st, w.y, w.t2, p.an_w, p.an_b, p.cn_w, p.cn_b, out, R);
+  mark(st, "cc.aspp_post");
+  return last_launch_status();
+}
+
+template <bool BF>
+int cc_heads_fwd_t(const float* x, const float* pf, float* logits, float* masks, const void* packed, int B, int Q, int Tc, int V, int H,
+                   int W, int K1, void* ws, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  CCHeadsPacked p = carve_cc_heads(pc, K1);
+  const long long R = (long long)B * Q * Tc, P = (long long)V * H * W;
+  Carver wc(ws);
+  float* emb = wc.take<float>((size_t)R * 512);
+  u16* kern16 = wc.take<u16>((size_t)R * 128);
+  g_prof_next = 0;
+  mark(st, "begin");
+  ALoadRowsLd<BF> ax{x, 256, 0, (int)R};
+  EpiRowsF32 ee{emb, nullptr, p.emb_add, identity_map(R), 512, 1.f};
+  ee.mul = p.emb_mul;
+  ee.gelu = 1;
+  launch_gemm<BF>(ax, p.wemb, ee, (int)R, 512, 256, st);
+  ALoadRowsLd<BF> am{emb, 512, 256, (int)R};
+  EpiBlocked16<BF> ek{kern16, R, p.mh_add, 1.f, 0, 0};
+  ek.mul = p.mh_mul;
+  launch_gemm<BF>(am, p.wmh, ek, (int)R, 128, 256, st);
+  mark(st, "cc.embeddings");
+  const float void_bias = logf((float)(K1 - 1) * 0.9f / (1.f - 0.9f));
+  hipLaunchKernelGGL(cc_class_head_kernel, dim3(Q), dim3(256), 0, st, emb, 512, p.wa, p.ba, p.wc, p.bc, logits, B, Q, Tc, K1, void_bias);
+  mark(st, "cc.class_head");
+  dim3 grid((unsigned)((P + 63) / 64), B * Tc);
+  hipLaunchKernelGGL((cc_mask_einsum_kernel<BF>), grid, dim3(256), 0, st, pf, kern16, masks, B, Q, Tc, P, R, p.pix);
+  mark(st, "cc.mask_einsum");
+  return last_launch_status();
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -541,6 +660,109 @@ int axvs_ffn_fwd(const float* x, float* out, const void* packed_layer, long long
   int rc = dtype == AXVS_BF16 ? run_ffn<true>(xin, out, p, M, C, heads, d_ffn, tmp, y16, h16, st)
                               : run_ffn<false>(xin, out, p, M, C, heads, d_ffn, tmp, y16, h16, st);
   return rc != AXVS_OK ? rc : last_launch_status();
+}
+
+size_t axvs_cc_layer_packed_bytes(void) {
+  Carver c(nullptr);
+  carve_cc_layer(c);
+  return c.off;
+}
+
+int axvs_cc_layer_pack(const AxvsCCLayerParams* p, void* packed, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  CCLayerPacked l = carve_cc_layer(c);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PackDim n256{256, 256, 0, 0, 0}, k768{768, 768, 0, 0, 0};
+  const unsigned cb = (256 * 768 + 255) / 256;
+  if (dtype == AXVS_BF16) {
+    pack_traj<true>(p->attn, l.t, 256, 8, st);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pack_conv3_kernel<true>), dim3(cb), dim3(256), 0, st, p->aspp_w[i], l.aspp[i], 256, 256);
+    pack_w<true>(p->aspp_proj_w, l.aspp_proj, n256, k768, st);
+  } else {
+    pack_traj<false>(p->attn, l.t, 256, 8, st);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pack_conv3_kernel<false>), dim3(cb), dim3(256), 0, st, p->aspp_w[i], l.aspp[i], 256, 256);
+    pack_w<false>(p->aspp_proj_w, l.aspp_proj, n256, k768, st);
+  }
+  for (int i = 0; i < 3; ++i) copy_f32(p->aspp_b[i], l.aspp_b[i], 256, st);
+  copy_f32(p->norm_w, l.norm_w, 256, st); copy_f32(p->norm_b, l.norm_b, 256, st);
+  copy_f32(p->aspp_norm_w, l.an_w, 256, st); copy_f32(p->aspp_norm_b, l.an_b, 256, st);
+  copy_f32(p->conv_norm_w, l.cn_w, 256, st); copy_f32(p->conv_norm_b, l.cn_b, 256, st);
+  return last_launch_status();
+}
+
+size_t axvs_cc_layer_workspace_bytes(int B, int Q, int Tc) {
+  Carver c(nullptr);
+  carve_cc_layer_ws(c, (long long)B * Q * Tc, Tc);
+  return c.off;
+}
+
+int axvs_cc_layer_fwd(const float* clip_query, float* out, const void* packed, int B, int Q, int Tc, const int* rates, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!clip_query || !out || !packed || !rates || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || Q <= 0 || Tc <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (clip_query == out) return fail(AXVS_ERR_ARG, "out may not alias clip_query");
+  if (workspace_bytes < axvs_cc_layer_workspace_bytes(B, Q, Tc)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return cc_layer_fwd_t<true>(clip_query, out, packed, B, Q, Tc, rates, workspace, st);
+  if (dtype == AXVS_F16) return cc_layer_fwd_t<false>(clip_query, out, packed, B, Q, Tc, rates, workspace, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+size_t axvs_cc_heads_packed_bytes(int K1) {
+  Carver c(nullptr);
+  carve_cc_heads(c, K1);
+  return c.off;
+}
+
+int axvs_cc_heads_pack(const AxvsCCHeadParams* p, void* packed, int K1, int dtype, void* stream) {
+  if (!p || !packed || K1 <= 0) return fail(AXVS_ERR_ARG, "bad argument");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  CCHeadsPacked h = carve_cc_heads(c, K1);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PackDim n256{256, 256, 0, 0, 0}, n128{128, 128, 0, 0, 0};
+  if (dtype == AXVS_BF16) {
+    pack_w<true>(p->class_proj_w, h.wemb, n256, n256, st, 0, 512);
+    pack_w<true>(p->mask_proj_w, h.wemb, n256, n256, st, 256, 512);
+    pack_w<true>(p->mask_head_w, h.wmh, n128, n256, st);
+  } else {
+    pack_w<false>(p->class_proj_w, h.wemb, n256, n256, st, 0, 512);
+    pack_w<false>(p->mask_proj_w, h.wemb, n256, n256, st, 256, 512);
+    pack_w<false>(p->mask_head_w, h.wmh, n128, n256, st);
+  }
+  fold_bn(p->class_proj_bn, h.emb_mul, h.emb_add, 256, st);
+  fold_bn(p->mask_proj_bn, h.emb_mul + 256, h.emb_add + 256, 256, st);
+  fold_bn(p->mask_head_bn, h.mh_mul, h.mh_add, 128, st);
+  fold_bn(p->pixel_bn, h.pix, h.pix + 1, 1, st);
+  copy_f32(p->class_head_w, h.wc, K1 * 256, st);
+  copy_f32(p->class_head_b, h.bc, K1, st);
+  copy_f32(p->act_head_w, h.wa, 256, st);
+  copy_f32(p->act_head_b, h.ba, 1, st);
+  return last_launch_status();
+}
+
+size_t axvs_cc_heads_workspace_bytes(int B, int Q, int Tc) {
+  Carver c(nullptr);
+  const long long R = (long long)B * Q * Tc;
+  c.take<float>((size_t)R * 512);
+  c.take<u16>((size_t)R * 128);
+  return c.off;
+}
+
+int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks,
+                      const void* packed, int B, int Q, int Tc, int V, int H, int W, int K1, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (((long long)V * H * W) % 4) return fail(AXVS_ERR_ARG, "V*H*W must be a multiple of 4");
+  if (B * Tc > 64) return fail(AXVS_ERR_ARG, "B*Tc > 64 is not supported by the class head yet");
+  if (workspace_bytes < axvs_cc_heads_workspace_bytes(B, Q, Tc)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return cc_heads_fwd_t<true>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
+  if (dtype == AXVS_F16) return cc_heads_fwd_t<false>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
 }
 
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale, void* stream) {

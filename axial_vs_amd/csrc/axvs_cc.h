@@ -1,0 +1,157 @@
+// Cross-clip tracking module kernels (CC/maxtron_cross_clip_tracking_module.py): everything that is not a plain GEMM.
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+// conv weight [Cout][Cin][3] fp32 -> blocked 16-bit [3*Cin/32][Cout][32] with k = tap*Cin + ci
+template <bool BF>
+__global__ void pack_conv3_kernel(const float* __restrict__ W, u16* __restrict__ out, int Cout, int Cin) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)Cout * Cin * 3;
+  if (idx >= total) return;
+  int kk = idx & 31;
+  long long t = idx >> 5;
+  int n = t % Cout;
+  int kb = t / Cout;
+  int k = kb * 32 + kk, tap = k / Cin, ci = k - tap * Cin;
+  out[idx] = H16<BF>::from_f32(W[((long long)n * Cin + ci) * 3 + tap]);
+}
+
+// eval-mode BatchNorm folded into a per-channel multiplier / bias:  y = (x - mean) / sqrt(var + eps) * w + b
+__global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, float* __restrict__ mul, float* __restrict__ add, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = w[i] * rsqrtf(var[i] + eps);
+  mul[i] = s;
+  add[i] = b[i] - mean[i] * s;
+}
+
+// ASPP tail + block residual (CC/...:186-201, :293-295), one wave per (bq, t) row, C = 256:
+//   z = GELU(LN_cf(y; eps 1e-6) * g_a + b_a);  out = LN(z + x; eps 1e-5) * g_n + b_n
+__global__ __launch_bounds__(256) void cc_aspp_post_kernel(const float* __restrict__ Y, const float* __restrict__ Xin,
+                                                           const float* __restrict__ ga, const float* __restrict__ ba,
+                                                           const float* __restrict__ gn, const float* __restrict__ bn,
+                                                           float* __restrict__ out, long long M) {
+  constexpr int C = 256;
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float4 y = *reinterpret_cast<const float4*>(Y + row * C + lane * 4);
+  const float4 x = *reinterpret_cast<const float4*>(Xin + row * C + lane * 4);
+  const float mu = wave_sum(y.x + y.y + y.z + y.w) * (1.f / C);
+  float d0 = y.x - mu, d1 = y.y - mu, d2 = y.z - mu, d3 = y.w - mu;
+  const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-6f);
+  const float4 g = *reinterpret_cast<const float4*>(ga + lane * 4), b = *reinterpret_cast<const float4*>(ba + lane * 4);
+  auto gelu = [](float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); };
+  const float z0 = gelu(d0 * rstd * g.x + b.x) + x.x, z1 = gelu(d1 * rstd * g.y + b.y) + x.y;
+  const float z2 = gelu(d2 * rstd * g.z + b.z) + x.z, z3 = gelu(d3 * rstd * g.w + b.w) + x.w;
+  const float mu2 = wave_sum(z0 + z1 + z2 + z3) * (1.f / C);
+  d0 = z0 - mu2; d1 = z1 - mu2; d2 = z2 - mu2; d3 = z3 - mu2;
+  const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
+  const float4 g2 = *reinterpret_cast<const float4*>(gn + lane * 4), b2 = *reinterpret_cast<const float4*>(bn + lane * 4);
+  *reinterpret_cast<float4*>(out + row * C + lane * 4) =
+      float4{d0 * rstd2 * g2.x + b2.x, d1 * rstd2 * g2.y + b2.y, d2 * rstd2 * g2.z + b2.z, d3 * rstd2 * g2.w + b2.w};
+}
+
+// Class head of MaXTronCCPredictor (CC/...:48-52): per query q, softmax over ALL (b, clip) entries of a 256->1 activation
+// head, weighted sum of the class embeddings, 256->K1 class head, void bias on the last class.
+// emb: fp32 [(b q t)][ld] (class embedding = columns 0..255); out: fp32 [Q][K1].  One workgroup (256 threads) per q.
+__global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restrict__ emb, int ld, const float* __restrict__ wa,
+                                                            const float* __restrict__ ba, const float* __restrict__ wc,
+                                                            const float* __restrict__ bc, float* __restrict__ out, int Bv, int Q,
+                                                            int Tc, int K1, float void_bias) {
+  constexpr int C = 256, MAXE = 64;
+  __shared__ float logit[MAXE], pooled[C], red[4];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int E = Bv * Tc;                              // entries the softmax runs over (dim 0 of the reference tensor)
+  const float wac = wa[tid];
+  for (int e = 0; e < E; ++e) {
+    const int b = e / Tc, t = e - b * Tc;
+    const float v = emb[(((long long)b * Q + q) * Tc + t) * ld + tid] * wac;
+    const float s = wave_sum(v);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) logit[e] = red[0] + red[1] + red[2] + red[3] + ba[0];
+    __syncthreads();
+  }
+  float mx = -INFINITY;
+  for (int e = 0; e < E; ++e) mx = fmaxf(mx, logit[e]);
+  float sum = 0.f;
+  for (int e = 0; e < E; ++e) sum += __expf(logit[e] - mx);
+  float p = 0.f;
+  for (int e = 0; e < E; ++e) {
+    const int b = e / Tc, t = e - b * Tc;
+    p += __expf(logit[e] - mx) / sum * emb[(((long long)b * Q + q) * Tc + t) * ld + tid];
+  }
+  pooled[tid] = p;
+  __syncthreads();
+  for (int k = tid; k < K1; k += 256) {
+    float acc = bc[k];
+    for (int c = 0; c < C; ++c) acc += wc[(long long)k * C + c] * pooled[c];
+    out[(long long)q * K1 + k] = acc + (k == K1 - 1 ? void_bias : 0.f);
+  }
+}
+
+// Mask logits (CC/...:61-69): for clip (b, t):  out[b, q, t*P + p] = bn( sum_c kern[(b q t), c] * pf[b, c, t*P + p] ),
+// P = V*H*W pixels of the clip, 128 channels, bn = eval BatchNorm(1) as a scalar affine.
+// Workgroup = 64 pixels of one clip (4 waves x 16 pixels) x all queries; pixels are the MFMA rows (A operand, transposed
+// into LDS from the channels-first fp32 feature), queries the columns, so a lane stores 4 consecutive pixels of one query.
+template <bool BF>
+__global__ __launch_bounds__(256) void cc_mask_einsum_kernel(const float* __restrict__ pf, const u16* __restrict__ kern16,
+                                                             float* __restrict__ out, int Bv, int Q, int Tc, long long P,
+                                                             long long Rk, const float* __restrict__ pix_bn /* {mul, add} */) {
+  constexpr int CK = 128;
+  __shared__ __attribute__((aligned(16))) u16 spx[4 * 64 * 32];      // [kb][pixel][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const int bt = blockIdx.y, b = bt / Tc, t = bt - b * Tc;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const long long TP = (long long)Tc * P;
+  const float bn_mul = pix_bn[0], bn_add = pix_bn[1];
+  // stage: thread -> (channel c, 32-pixel half); 8 float4 loads of 128 contiguous bytes
+  {
+    const int c = tid >> 1, half = tid & 1;
+    const float* src = pf + ((long long)b * CK + c) * TP + (long long)t * P + p0 + half * 32;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long p = p0 + half * 32 + i * 4;
+      v[i] = p + 3 < P ? *reinterpret_cast<const float4*>(src + i * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int kb = c >> 5, k = c & 31;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = half * 32 + i * 4 + j;
+        spx[(kb * 64 + px) * 32 + swz_chunk(px, k >> 3) * 8 + (k & 7)] = H16<BF>::from_f32(e[j]);
+      }
+      if ((i & 1) == 1) lds_fence();
+    }
+  }
+  __syncthreads();
+  u16x8 af[4];
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+    const int px = wave * 16 + fi;
+    af[kb] = *reinterpret_cast<const u16x8*>(spx + (kb * 64 + px) * 32 + swz_chunk(px, fg) * 8);
+  }
+  for (int qt = 0; qt * 16 < Q; ++qt) {
+    const int q = min(qt * 16 + fi, Q - 1);
+    const long long r = ((long long)b * Q + q) * Tc + t;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const u16x8 bf = *reinterpret_cast<const u16x8*>(kern16 + ((long long)kb * Rk + r) * 32 + fg * 8);
+      acc = H16<BF>::mfma(af[kb], bf, acc);          // D[pixel][query]
+    }
+    const long long p = p0 + wave * 16 + fg * 4;
+    if (qt * 16 + fi < Q && p + 3 < P)
+      *reinterpret_cast<float4*>(out + ((long long)b * Q + q) * TP + (long long)t * P + p) =
+          float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
+  }
+}
+
+}  // namespace axvs

@@ -33,6 +33,38 @@ struct ALoadRowsF32 {
   }
 };
 
+// fp32 rows with an explicit leading dimension / column offset (a column slice of a wider matrix), identity row order
+template <bool BF>
+struct ALoadRowsLd {
+  const float* src;
+  int ld, col0, M;
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    const float4* p = reinterpret_cast<const float4*>(src + (long long)m * ld + col0 + k);
+    float4 a = p[0], b = p[1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return cvt8<BF>(v);
+  }
+};
+
+// Dilated 3-tap Conv1d over the clip axis with replicate padding as a GEMM (CC/maxtron_cross_clip_tracking_module.py:180-182):
+// rows are (bq, t) of a [BQ, Tc, C] fp32 tensor; k = tap*C + ci reads channel ci of row (bq, clamp(t + (tap-1)*rate)).
+template <bool BF>
+struct ALoadShift3 {
+  const float* src;
+  int C, Tc, rate, M;
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    const int tap = k / C, ci = k - tap * C;
+    const int bq = m / Tc, t = m - bq * Tc;
+    const int tt = min(max(t + (tap - 1) * rate, 0), Tc - 1);
+    const float4* p = reinterpret_cast<const float4*>(src + ((long long)bq * Tc + tt) * C + ci);
+    float4 a = p[0], b = p[1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return cvt8<BF>(v);
+  }
+};
+
 template <bool BF>
 struct ALoadBlocked {
   const u16* X;       // blocked [K/32][R][32]
@@ -48,6 +80,8 @@ struct ALoadBlocked {
 };
 
 // ---------------- epilogues: 4 consecutive output channels n..n+3 of token m ----------------
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
 template <bool BF>
 struct EpiBlocked16 {
   u16* Y;             // blocked [Nout/32][R][32]
@@ -56,9 +90,16 @@ struct EpiBlocked16 {
   float scale;        // applied to channels < nscale after the bias (softmax scale folded into q)
   int nscale;
   int relu;
+  const float* mul = nullptr;   // optional per-channel multiplier applied to the accumulator before the bias (folded BN)
+  int n_off = 0;                // column offset in Y (concatenating several GEMMs along channels)
   __device__ __forceinline__ void store(int m, int n, f32x4 v) const {
+    if (mul) {
+      float4 s = *reinterpret_cast<const float4*>(mul + n);
+      v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+    }
     float4 b = *reinterpret_cast<const float4*>(bias + n);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    n += n_off;
     if (n < nscale) v *= scale;
     if (relu) {
 #pragma unroll
@@ -71,14 +112,21 @@ struct EpiBlocked16 {
 struct EpiRowsF32 {
   float* Y;           // [rows, ld] fp32, rows through rm
   const float* res;   // nullable residual, same indexing as Y
-  const float* bias;
+  const float* bias;  // nullable
   RowMap rm;
   int ld;
   float scale;
+  const float* mul = nullptr;   // optional per-channel multiplier (folded BN)
+  int gelu = 0;
   __device__ __forceinline__ void store(int m, int n, f32x4 v) const {
-    float4 b = *reinterpret_cast<const float4*>(bias + n);
+    if (mul) {
+      float4 s = *reinterpret_cast<const float4*>(mul + n);
+      v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
+    }
+    float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
     long long off = nat_row(rm, m) * ld + n;
     float4 o = {(v[0] + b.x) * scale, (v[1] + b.y) * scale, (v[2] + b.z) * scale, (v[3] + b.w) * scale};
+    if (gelu) o = float4{gelu_exact(o.x), gelu_exact(o.y), gelu_exact(o.z), gelu_exact(o.w)};
     if (res) {
       float4 r = *reinterpret_cast<const float4*>(res + off);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;

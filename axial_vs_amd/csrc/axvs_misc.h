@@ -29,8 +29,11 @@ struct PackDim {
   }
 };
 
+// n_off / n_total: the rows written are rows [n_off, n_off + nd.padded) of a wider blocked matrix with n_total rows
+// (several nn.Linear weights stacked along the output dimension).
 template <bool BF>
-__global__ void pack_weight_kernel(const float* __restrict__ W, u16* __restrict__ out, PackDim nd, PackDim kd) {
+__global__ void pack_weight_kernel(const float* __restrict__ W, u16* __restrict__ out, PackDim nd, PackDim kd, int n_off,
+                                   int n_total) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long total = (long long)nd.padded * kd.padded;
   if (idx >= total) return;
@@ -40,7 +43,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, u16* __restrict_
   int kb = t / nd.padded;
   int no = nd.to_orig(n), ko = kd.to_orig(kb * 32 + kk);
   float v = (no >= 0 && ko >= 0) ? W[(long long)no * kd.orig + ko] : 0.f;
-  out[idx] = H16<BF>::from_f32(v);
+  out[((long long)kb * n_total + n_off + n) * 32 + kk] = H16<BF>::from_f32(v);
 }
 
 __global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, PackDim nd) {

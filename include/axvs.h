@@ -103,6 +103,48 @@ size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn);
 int axvs_ffn_fwd(const float* x, float* out, const void* packed_layer, long long M, int C, int heads, int d_ffn,
                  int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
+/* =====================================================================================================
+ * Cross-clip tracking module (CC/maxtron_cross_clip_tracking_module.py), d_model = 256, 8 heads, norm_fn = 'ln'.
+ * ===================================================================================================== */
+typedef struct AxvsBN { const float *w, *b, *mean, *var; } AxvsBN;   /* eval-mode (Sync)BatchNorm, eps = 1e-3 */
+
+/* one iteration of the layer loop, CC/...:286-297 */
+typedef struct AxvsCCLayerParams {
+  AxvsTrajParams attn;                    /* TrajectoryAttention (:78-130); qkv passed as three row slices      */
+  const float *norm_w, *norm_b;           /* TrajectoryAttentionLayer.norm, LayerNorm eps 1e-5 (:140,:156-161)  */
+  const float *aspp_w[3], *aspp_b[3];     /* ASPP._aspp_conv{0,1,2}: Conv1d(256,256,3) weights [256,256,3]      */
+  const float *aspp_proj_w;               /* ASPP._proj_conv_bn_act.conv: [256,768,1], no bias                  */
+  const float *aspp_norm_w, *aspp_norm_b; /* ... .norm: channels-first LayerNorm eps 1e-6                       */
+  const float *conv_norm_w, *conv_norm_b; /* conv_norms[i]: LayerNorm eps 1e-5 (:263,:293-295)                  */
+} AxvsCCLayerParams;
+
+size_t axvs_cc_layer_packed_bytes(void);
+int axvs_cc_layer_pack(const AxvsCCLayerParams* p, void* packed, int dtype, void* stream);
+size_t axvs_cc_layer_workspace_bytes(int B, int Q, int Tc);
+/* clip_query / out: fp32 [B, Q, Tc, 256] (out may not alias clip_query); rates: the three atrous rates */
+int axvs_cc_layer_fwd(const float* clip_query, float* out, const void* packed, int B, int Q, int Tc, const int* rates,
+                      int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* embedding projections + MaXTronCCPredictor (eval branch), CC/...:45-75, :266-270, :300-309 */
+typedef struct AxvsCCHeadParams {
+  const float* class_proj_w; AxvsBN class_proj_bn;   /* _class_embedding_projection: conv [256,256,1] + BN + GELU */
+  const float* mask_proj_w;  AxvsBN mask_proj_bn;    /* _mask_embedding_projection                                */
+  const float* mask_head_w;  AxvsBN mask_head_bn;    /* _predictor._transformer_mask_head: conv [128,256,1] + BN  */
+  const float *class_head_w, *class_head_b;          /* _predictor._transformer_class_head: [K1,256,1], [K1]      */
+  const float *act_head_w, *act_head_b;              /* _predictor._transformer_class_activation_head: [1,256,1]  */
+  AxvsBN pixel_bn;                                   /* _predictor._pixel_space_mask_batch_norm (1 channel)       */
+} AxvsCCHeadParams;
+
+size_t axvs_cc_heads_packed_bytes(int K1);
+int axvs_cc_heads_pack(const AxvsCCHeadParams* p, void* packed, int K1, int dtype, void* stream);
+size_t axvs_cc_heads_workspace_bytes(int B, int Q, int Tc);
+/* clip_query fp32 [B,Q,Tc,256]; panoptic_features fp32 [B,128,Tc*V,H,W];
+ * pred_logits fp32 [1,Q,K1] (softmax pooling runs over all B*Tc entries, like the reference's dim-0 softmax);
+ * pred_masks fp32 [B,Q,Tc*V,H,W].  V*H*W must be a multiple of 4. */
+int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks,
+                      const void* packed, int B, int Q, int Tc, int V, int H, int W, int K1, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,

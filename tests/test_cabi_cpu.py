@@ -92,3 +92,19 @@ def test_no_cpu_fallback_and_forward_only():
         ax.TemporalAxialTrajectoryAttentionLayer(64, 128, activation="swish")
     enc = ax.TemporalEncoder(64, 128, temporal_attn_type="axial_trajectory")   # the reference's default-string gotcha
     assert not hasattr(enc, "temporal_layers")
+
+
+@pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2"])
+def test_cross_clip_state_dict_keys_match_reference(name):
+    import axial_vs_amd as ax
+    import axvs_oracle as orc
+    z, m = load(name)
+    mod = ax.CrossClipTrackingModule(num_layers=m["layers"], num_classes=m["num_classes"], attn_drop=0.0, aspp_drop=0.0,
+                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=m["V"])
+    ref_keys = set(m["shapes"].keys())
+    own = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
+    assert set(own.keys()) == ref_keys
+    assert all(own[k] == m["shapes"][k] for k in ref_keys)
+    sd = mod.state_dict()
+    sd.update(orc.random_weights(m["shapes"], 1))
+    mod.load_state_dict(sd, strict=True)

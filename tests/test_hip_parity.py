@@ -234,3 +234,38 @@ def test_layer_determinism_stress():
     first = layer(s, p)[0].clone()
     for _ in range(40):
         assert torch.equal(layer(s, p)[0], first)
+
+
+@pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2", "g5_cc_module_Q16_Tc4_V2_H8_L2",
+                                  "g5_cc_module_Q128_Tc4_V4_H64_L4"])
+def test_cross_clip_module_golden(name):
+    """CrossClipTrackingModule (trajectory attention over clip queries + temporal ASPP + predictor heads) against the
+    reference's outputs; the last fixture is BASELINE config 4 (4 clips x 4 frames, 64x64, 4 layers)."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w = weights(z, m)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Q"], m["Tc"], 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(m["B"], 128, m["Tc"] * m["V"], m["H"], m["W"], generator=g), dim=1)
+    mod = ax.CrossClipTrackingModule(num_layers=m["layers"], num_classes=m["num_classes"], attn_drop=0.0, aspp_drop=0.0,
+                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=m["V"]).eval()
+    sd = mod.state_dict()
+    sd.update(w)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.cuda()
+    out = mod(dev(cq), dev(pf))
+    assert out["pred_logits"].device.type == "cpu"          # the reference's eval branch hands back CPU tensors
+    e_l = rel_err(out["pred_logits"], t(z["pred_logits"]))
+    print(f"{name}: logits {e_l:.2e}")
+    assert e_l < TOL_F16
+    np.testing.assert_allclose(checks(out["pred_masks"])[1:], z["masks_checks"][1:], rtol=5e-3)
+    if "aux0_logits" in z:
+        e_m = rel_err(out["pred_masks"], t(z["pred_masks"]))
+        print(f"{name}: masks {e_m:.2e}")
+        assert e_m < TOL_F16
+        assert rel_err(out["aux_outputs"][0]["pred_logits"], t(z["aux0_logits"])) < TOL_F16
+        assert rel_err(out["aux_outputs"][0]["pred_masks"], t(z["aux0_masks"])) < TOL_F16
+    else:
+        e_m = rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]))
+        print(f"{name}: masks {e_m:.2e}")
+        assert e_m < TOL_F16

@@ -1,0 +1,23 @@
+"""Time the cross-clip module at BASELINE config 4 (tuning helper)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+import torch
+import axvs_oracle as orc
+import axial_vs_amd as ax
+from axial_vs_amd import _lib
+mod = ax.CrossClipTrackingModule(num_layers=4, num_classes=124, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
+                                 atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=4).eval()
+shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
+sd = mod.state_dict(); sd.update(orc.random_weights(shapes, 0)); mod.load_state_dict(sd)
+mod = mod.cuda(); mod.eval_outputs_on_cpu = False
+cq = torch.randn(1, 128, 4, 256, device="cuda")
+pf = torch.nn.functional.normalize(torch.randn(1, 128, 16, 64, 64, device="cuda"), dim=1)
+for _ in range(5): mod(cq, pf)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): mod(cq, pf)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 50
+print(f"cross-clip module, cfg 4 (4 layers, Q=128, 4 clips x 4 frames, 64x64): {ms*1e3:.1f} us per forward -> {16/ms*1e3:.0f} frames/s; "
+      f"mask output {4*33.5:.0f} MB -> {4*33.5e6/(ms*1e-3)/1e12:.2f} TB/s of writes")
