@@ -35,6 +35,7 @@ thread_local int g_prof_next = 0;
 constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
+thread_local int g_attn_waves = 0;   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
 inline void mark(hipStream_t st, const char* name) {
@@ -175,7 +176,8 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
       return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
     configured = true;
   }
-  const int nwaves = (N + 31) / 32 >= 8 ? 8 : (N + 31) / 32;        // 32 queries per wave, at most 8 waves
+  const int wcap = g_attn_waves > 0 ? g_attn_waves : 8;
+  const int nwaves = (N + 31) / 32 >= wcap ? wcap : (N + 31) / 32;  // 32 queries per wave, at most `wcap` waves
   dim3 grid((N + 32 * nwaves - 1) / (32 * nwaves), heads, S);
   hipLaunchKernelGGL((spatial_attn_kernel<BF, NKS>), grid, dim3(64 * nwaves), lds, st, w.q16, w.k16, w.v16, w.x16, attn, N, T, L,
                      heads, Mp);
@@ -522,6 +524,7 @@ int axvs_debug_read_stamps(unsigned long long* host, int n) {
 
 int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "generic_only")) { g_generic_only = value; return AXVS_OK; }
+  if (key && !strcmp(key, "attn_waves")) { g_attn_waves = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }

@@ -130,18 +130,25 @@ __device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shf
 
 // ---- in-kernel phase stamps: diagnostic builds only (-DAXVS_STAMPS); the shipped library contains none ----
 #ifdef AXVS_STAMPS
-__device__ unsigned long long g_stamps[64 * 32];   // [slot][wave-global id % 64]... slot-major: g_stamps[slot * 64 + id]
-__device__ __forceinline__ void stamp(int slot) {
-  __builtin_amdgcn_sched_barrier(0);
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  const int id = (blockIdx.x & 7) * 8 + (threadIdx.x >> 6);   // 8 workgroups x 8 waves
-  if (blockIdx.x < 8 && (threadIdx.x & 63) == 0) g_stamps[slot * 64 + id] = t;
-}
-#define AXVS_STAMP(slot) ::axvs::stamp(slot)
+__device__ unsigned long long g_stamps[32 * 64];   // g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]
+// Stamps stay in SGPRs until AXVS_STAMP_FLUSH at the end of the kernel: no VGPR cost where registers are tight
+// (a first version that stored each stamp immediately pushed a 250-VGPR kernel into spills and mis-measured it).
+#define AXVS_STAMP_DECL unsigned long long st_[16] = {}
+#define AXVS_STAMP(slot)                                                                      \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[slot])::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  } while (0)
+#define AXVS_STAMP_FLUSH(n)                                                                   \
+  do {                                                                                        \
+    if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)                                            \
+      for (int i_ = 0; i_ < (n); ++i_) ::axvs::g_stamps[i_ * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = st_[i_]; \
+  } while (0)
 #else
+#define AXVS_STAMP_DECL
 #define AXVS_STAMP(slot)
+#define AXVS_STAMP_FLUSH(n)
 #endif
 
 // lgkmcnt is a 4-bit counter.  hipcc (ROCm 7.2) will happily leave 16 or more LDS/SMEM operations in flight before one

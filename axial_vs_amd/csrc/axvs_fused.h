@@ -328,6 +328,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   const int fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * ROWS;
 
+  AXVS_STAMP_DECL;
   AXVS_STAMP(0);
   // first weight set: Wpq rows of my head
   u16x8 wf[2][8];
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
   AXVS_STAMP(8);
+  AXVS_STAMP_FLUSH(10);
 }
 
 

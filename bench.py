@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather every step's output across ranks (RCCL, side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (axvs_set_option)")
     args = ap.parse_args()
 
     import torch
@@ -75,6 +76,9 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import axvs_oracle as orc
 
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), "axvs_set_option")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
