@@ -35,7 +35,8 @@ thread_local int g_prof_next = 0;
 constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
-thread_local int g_attn_waves = 0;   // option "attn_waves": cap on waves per attention workgroup (tuning)
+thread_local int g_attn_waves = 0;
+thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
 inline void mark(hipStream_t st, const char* name) {
@@ -143,7 +144,7 @@ void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, h
 
 // ---------------- one trajectory attention over sequence-ordered rows ----------------
 struct TrajWs {
-  u16 *q16, *k16, *v16, *x16, *o16;
+  u16 *q16, *k16, *v16, *x16, *o16, *vt16;
   float *q2, *kv2;
 };
 
@@ -157,6 +158,7 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads) {
   w.o16 = c.take<u16>(Cp * Mp);
   w.q2 = c.take<float>(Cp * Mp);
   w.kv2 = c.take<float>(2 * Cp * Mp * T);
+  w.vt16 = c.take<u16>(2 * Cp * Mp);      // block-transposed V (frames padded to a multiple of 32 keys: at most 2x)
   return w;
 }
 
@@ -184,32 +186,46 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
   return AXVS_OK;
 }
 
-template <bool BF, int T, int MT>
+template <bool BF, int T, int MT, int NKS>
 int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
                       float scale, hipStream_t st) {
   static bool configured = false;
   constexpr size_t lds = temporal_lds_bytes<T, MT>();
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
     configured = true;
   }
   const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
-  hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp,
-                     p.bp, res, out, rm, Mp, N, L, scale);
+  hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
+                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16);
   return AXVS_OK;
 }
 
+template <bool BF, int T, int MT>
+int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
+                      int L, float scale, hipStream_t st) {
+  switch (nks) {
+    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
+    default: return fail(AXVS_ERR_ARG, "bad nks");
+  }
+}
+
+// nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel
 template <bool BF>
 int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
-                    float scale, hipStream_t st) {
+                    float scale, hipStream_t st, int nks = 0) {
   switch (T) {
-    case 1: return launch_temporal_t<BF, 1, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 2: return launch_temporal_t<BF, 2, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 3: return launch_temporal_t<BF, 3, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 4: return launch_temporal_t<BF, 4, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 5: return launch_temporal_t<BF, 5, 2>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
+    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
+    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
+    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
+    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
     default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 5");
   }
 }
@@ -220,10 +236,10 @@ template <bool BF>
 int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
              hipStream_t st, int pass = 0) {
-  static const char* const kNames[3][7] = {
-      {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused"},
-      {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused"},
-      {"w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj", "w.temporal_fused"}};
+  static const char* const kNames[3][8] = {
+      {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused", "traj_fused"},
+      {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused", "h.traj_fused"},
+      {"w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj", "w.temporal_fused", "w.traj_fused"}};
   const char* const* nm = kNames[pass];
   const int N = T * L, Cp = heads * 32, d = C / heads;
   const long long Mp = (long long)S * N;
@@ -233,6 +249,12 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const float scale = 1.0f / sqrtf((float)d);
   const float kLog2e = 1.4426950408889634f;
 
+  // Full fusion (spatial half inside the temporal kernel, x never leaves LDS) needs: the fused kernels, no attention-map
+  // output, row tiles inside one sequence, whole 16-key tiles per frame, at most 128 keys per frame.
+  const int mt_rows = T <= 4 ? 64 : 32;
+  const bool fuse_attn = !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 5 && qsrc == ksrc && vsrc == qsrc &&
+                         attn == nullptr && N % mt_rows == 0 && L % 16 == 0 && L <= 128;
+  const int nks_fused = (L + 31) / 32;
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
   if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
     static bool configured = false;
@@ -244,8 +266,12 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
     }
     // the fused kernel reads the value rows from the same tensor as the q/k rows (+ optional additive term)
     if (vsrc == qsrc) {
+      if (fuse_attn && L % 32 != 0 &&
+          hipMemsetAsync(w.vt16, 0, (size_t)(Mp / L) * nks_fused * 8 * 1024 * sizeof(u16), st) != hipSuccess)   // pad keys must be finite
+        return fail(AXVS_ERR_LAUNCH, "memset failed");
       hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3((unsigned)((Mp + 63) / 64)), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
-                         p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e);
+                         p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e,
+                         fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused);
       goto qkv_done;
     }
   }
@@ -257,6 +283,12 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   }
 qkv_done:
   mark(st, nm[0]);
+  if (fuse_attn) {
+    int rc = launch_temporal<BF>(w, p, res, out, rm, Mp, N, L, T, scale, st, nks_fused);
+    if (rc != AXVS_OK) return rc;
+    mark(st, nm[7]);
+    return AXVS_OK;
+  }
 
   // spatial half
   int nks = (L + 31) / 32, rc;
@@ -525,6 +557,7 @@ int axvs_debug_read_stamps(unsigned long long* host, int n) {
 int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "generic_only")) { g_generic_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "attn_waves")) { g_attn_waves = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }

@@ -285,7 +285,7 @@ __device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // elem
 
 // one GEMM sweep over the 8 k-blocks: acc[nt][mt] += W[slot j] . B(kb=j);  B fragments come from `bbase[mt] + kb*kbstride`
 // (per-lane LDS element offsets), one k-step of lookahead.  If REFILL, slot j is re-loaded from Wn right after its use.
-template <bool BF, int MT, bool REFILL>
+template <bool BF, int MT, bool REFILL, bool SWAP = false>   // SWAP: D[token][channel] instead of D[channel][token]
 __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], const u16* xt, const int (&bbase)[MT], int kbstride,
                                        const u16* __restrict__ Wn, int NRn, int nrow0n, int fi, int fg) {
   // B fragments run LA k-steps ahead of the MFMAs (LDS latency ~ 2 steps of 4 MFMAs); at most (LA+1)*MT <= 12 reads in flight
@@ -304,7 +304,9 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], b[j % (LA + 1)][mt], acc[nt][mt]);
+      for (int mt = 0; mt < MT; ++mt)
+        acc[nt][mt] = SWAP ? H16<BF>::mfma(b[j % (LA + 1)][mt], wf[nt][j], acc[nt][mt])
+                           : H16<BF>::mfma(wf[nt][j], b[j % (LA + 1)][mt], acc[nt][mt]);
     if (REFILL) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) wf[nt][j] = w_frag(Wn, NRn, j, nrow0n + nt * 16 + fi, fg);
@@ -313,13 +315,20 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
   }
 }
 
-template <bool BF, int T, int MT>
+// NKS = 0: the x tile is staged from global memory (X16, written by spatial_attn_kernel).
+// NKS > 0: the spatial half runs right here (32*NKS >= L keys per frame): wave w computes head w's
+//          x[q, f, :] = softmax_l(q . k[f, l]) v[f, l, :] for the 64 queries and all T frames from K / V^T fragments loaded
+//          straight from L2 (no LDS staging; V^T comes pre-blocked from qkv_fused_kernel) and writes it into the LDS x tile --
+//          the T-expanded tensor never touches HBM.  Needs the tile inside one sequence (N % (16*MT) == 0), L % 16 == 0.
+template <bool BF, int T, int MT, int NKS = 0>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
                                                              const u16* __restrict__ Wpq, const float* __restrict__ bpq,
                                                              const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
                                                              const u16* __restrict__ Wp, const float* __restrict__ bp,
                                                              const float* __restrict__ res /* required */, float* __restrict__ out,
-                                                             RowMap rm, long long Mp, int N, int L, float scale) {
+                                                             RowMap rm, long long Mp, int N, int L, float scale, const u16* __restrict__ Q16 = nullptr,
+                                                             const u16* __restrict__ K16 = nullptr,
+                                                             const u16* __restrict__ VT16 = nullptr) {
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
@@ -330,10 +339,91 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 
   AXVS_STAMP_DECL;
   AXVS_STAMP(0);
-  // first weight set: Wpq rows of my head
+  // first weight set: Wpq rows of my head (with a long in-kernel attention phase it is fetched after that phase instead,
+  // to keep 64 VGPRs free for the score tiles)
   u16x8 wf[2][8];
-  load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
+  if constexpr (NKS <= 2) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
 
+  if constexpr (NKS > 0) {
+    // ---- spatial half, head = wave (WC/temporal_attention.py:46-57) ----
+    const long long seq0 = (m0 / N) * N;                        // first row of my sequence (the tile never straddles two)
+    const u16* Qh = Q16 + (long long)wave * Mp * 32;
+    const u16* Kh = K16 + (long long)wave * Mp * 32;
+    const long long nsf = Mp / L;                               // frame slots (sequences x frames)
+    const u16* Vh = VT16 + (long long)wave * nsf * NKS * 1024;
+    u16x8 qf[MT];
+#pragma unroll
+    for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + qt * 16 + fi) * 32 + fg * 8);
+    const bool ragged = L != NKS * 32;
+#pragma unroll 1
+    for (int f = 0; f < T; ++f) {
+      const long long key0 = seq0 + (long long)f * L;
+      const long long sf = key0 / L;
+      f32x4 sc[MT][2 * NKS];
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt) {
+        const u16x8 kf = *reinterpret_cast<const u16x8*>(Kh + (key0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8);
+#pragma unroll
+        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
+      }
+      if (ragged) {
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + fg * 4 + r >= L) {
+#pragma unroll
+              for (int qt = 0; qt < MT; ++qt) sc[qt][kt][r] = -INFINITY;
+            }
+      }
+      float inv[MT];
+      u16x8 pf[MT][NKS];
+#pragma unroll
+      for (int qt = 0; qt < MT; ++qt) {
+        float mx = sc[qt][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
+        mx = groups_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sc[qt][kt][r] = __builtin_amdgcn_exp2f(sc[qt][kt][r] - mx);
+            sum += sc[qt][kt][r];
+          }
+        inv[qt] = 1.f / groups_sum(sum);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[qt][ks][j] = H16<BF>::from_f32(sc[qt][2 * ks + (j >> 2)][j & 3]);
+      }
+      f32x4 xa[MT][2];
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd) {
+#pragma unroll
+        for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const u16x8 vf = *reinterpret_cast<const u16x8*>(Vh + ((sf * NKS + ks) * 2 + nd) * 512 + fi * 32 + fg * 8);
+#pragma unroll
+          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf, pf[qt][ks], xa[qt][nd]);   // D[d][query]
+        }
+      }
+      // x tile block (frame f, k-block = my head): row = query, 16-byte chunk g holds channels in perm32 order
+#pragma unroll
+      for (int qt = 0; qt < MT; ++qt) {
+        const int row = qt * 16 + fi;
+        float v[8] = {xa[qt][0][0] * inv[qt], xa[qt][0][1] * inv[qt], xa[qt][0][2] * inv[qt], xa[qt][0][3] * inv[qt],
+                      xa[qt][1][0] * inv[qt], xa[qt][1][1] * inv[qt], xa[qt][1][2] * inv[qt], xa[qt][1][3] * inv[qt]};
+        *reinterpret_cast<u16x8*>(xt + ((f * 8 + wave) * ROWS + row) * 32 + swz_chunk(row, fg) * 8) = cvt8<BF>(v);
+      }
+    }
+    lds_fence();
+    if constexpr (NKS > 2) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
+  } else {
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
   {
     constexpr int NCH = T * 8 * ROWS * 4;                       // 16-byte chunks
@@ -356,11 +446,12 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       }
       if ((p & 7) == 7) lds_fence();
     }
-    if (tid < C) {
-      sbias[tid] = bpq[tid];
-      sbias[C + tid] = bpkv[C + tid];     // v2 half of the proj_kv bias
-      sbias[2 * C + tid] = bp[tid];
-    }
+  }
+  }
+  if (tid < C) {
+    sbias[tid] = bpq[tid];
+    sbias[C + tid] = bpkv[C + tid];       // v2 half of the proj_kv bias
+    sbias[2 * C + tid] = bp[tid];
   }
   __syncthreads();
 
@@ -551,7 +642,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                                                         const u16* __restrict__ Wv, const float* __restrict__ bq,
                                                         const float* __restrict__ bk, const float* __restrict__ bv,
                                                         u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
-                                                        long long Mp, float qscale) {
+                                                        long long Mp, float qscale, u16* __restrict__ VT16, int N, int L, int T,
+                                                        int NKS) {
   constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* tqk = smem;                       // (src + pos) tile [8][64][32]
@@ -612,7 +704,31 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
       for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (which == 0) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wk, C, wave * 32, fi, fg);
     else if (which == 1) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wv, C, wave * 32, fi, fg);
-    else sweep8<BF, MT, false>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);
+    else if (VT16 == nullptr) sweep8<BF, MT, false>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);
+    else sweep8<BF, MT, false, true>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);          // tokens on D rows
+    if (which == 2 && VT16 != nullptr) {
+      // block-transposed V^T:  VT[head][frame slot sf = m'/L][ks][nd][16 d][32 keys in perm32 order]; a lane holds channel
+      // nt*16+fi and tokens 4g..4g+3 of tile mt (one frame: L % 16 == 0) -> 8 contiguous bytes
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float b = sbias[2 * C + wave * 32 + nt * 16 + fi];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const long long mt0 = m0 + mt * 16;                 // first token of the tile
+          if (mt0 < Mp) {
+            const long long sf = mt0 / L;
+            const int l = (int)(mt0 - sf * L) + fg * 4;       // key index within the frame of the lane's first token
+            const int ks = l >> 5, pp = fg * 8 + ((l >> 4) & 1) * 4;
+            const long long heads_sf = Mp / L;                 // S*T frame slots
+            u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
+            f32x4 v = acc[nt][mt];
+            v[0] += b; v[1] += b; v[2] += b; v[3] += b;
+            *reinterpret_cast<u16x4*>(d) = cvt4<BF>(v);
+          }
+        }
+      }
+      continue;
+    }
     u16* dst = which == 0 ? Q16 : which == 1 ? K16 : V16;
     const float sc = which == 0 ? qscale : 1.f;
     const float4 b0 = *reinterpret_cast<const float4*>(sbias + which * C + wave * 32 + fg * 4);
