@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // first weight set: Wpq rows of my head (with a long in-kernel attention phase it is fetched after that phase instead,
   // to keep 64 VGPRs free for the score tiles)
   u16x8 wf[2][8];
-  if constexpr (NKS <= 2) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
+  if constexpr (NKS == 0) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
 
   if constexpr (NKS > 0) {
     // ---- spatial half, head = wave (WC/temporal_attention.py:46-57) ----
@@ -355,16 +355,31 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
     for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + qt * 16 + fi) * 32 + fg * 8);
     const bool ragged = L != NKS * 32;
+    u16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = H16<BF>::from_f32(1.f);
+    // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
+    // the L2 latency of both hides behind MFMA + softmax work
+    u16x8 kf[2 * NKS], kn[2 * NKS], vf[2][NKS];
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKS; ++kt) kf[kt] = *reinterpret_cast<const u16x8*>(Kh + (seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8);
 #pragma unroll 1
     for (int f = 0; f < T; ++f) {
       const long long key0 = seq0 + (long long)f * L;
       const long long sf = key0 / L;
+      const long long keyn = seq0 + (long long)min(f + 1, T - 1) * L;
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+          vf[nd][ks] = *reinterpret_cast<const u16x8*>(Vh + ((sf * NKS + ks) * 2 + nd) * 512 + fi * 32 + fg * 8);
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt) kn[kt] = *reinterpret_cast<const u16x8*>(Kh + (keyn + min(kt * 16 + fi, L - 1)) * 32 + fg * 8);
       f32x4 sc[MT][2 * NKS];
 #pragma unroll
       for (int kt = 0; kt < 2 * NKS; ++kt) {
-        const u16x8 kf = *reinterpret_cast<const u16x8*>(Kh + (key0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8);
 #pragma unroll
-        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
+        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
       }
       if (ragged) {
 #pragma unroll
@@ -386,19 +401,24 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
         mx = groups_max(mx);
-        float sum = 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 mx2 = {mx, mx};
 #pragma unroll
-        for (int kt = 0; kt < 2 * NKS; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            sc[qt][kt][r] = __builtin_amdgcn_exp2f(sc[qt][kt][r] - mx);
-            sum += sc[qt][kt][r];
-          }
-        inv[qt] = 1.f / groups_sum(sum);
+        for (int kt = 0; kt < 2 * NKS; ++kt) {
+          const f32x2 lo = f32x2{sc[qt][kt][0], sc[qt][kt][1]} - mx2, hi = f32x2{sc[qt][kt][2], sc[qt][kt][3]} - mx2;   // v_pk_add_f32
+          sc[qt][kt][0] = __builtin_amdgcn_exp2f(lo[0]); sc[qt][kt][1] = __builtin_amdgcn_exp2f(lo[1]);
+          sc[qt][kt][2] = __builtin_amdgcn_exp2f(hi[0]); sc[qt][kt][3] = __builtin_amdgcn_exp2f(hi[1]);
+        }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[qt][ks][j] = H16<BF>::from_f32(sc[qt][2 * ks + (j >> 2)][j & 3]);
+        // softmax denominator on the (otherwise idle) matrix pipe: ones . P^T sums the 32 keys of a step across all lanes,
+        // so every D row already holds the full row sum of its query -- no VALU adds, no cross-lane reduction
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) ssum = H16<BF>::mfma(ones, pf[qt][ks], ssum);
+        inv[qt] = 1.f / ssum[0];
       }
       f32x4 xa[MT][2];
 #pragma unroll
@@ -407,9 +427,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          const u16x8 vf = *reinterpret_cast<const u16x8*>(Vh + ((sf * NKS + ks) * 2 + nd) * 512 + fi * 32 + fg * 8);
 #pragma unroll
-          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf, pf[qt][ks], xa[qt][nd]);   // D[d][query]
+          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf[nd][ks], pf[qt][ks], xa[qt][nd]);   // D[d][query]
         }
       }
       // x tile block (frame f, k-block = my head): row = query, 16-byte chunk g holds channels in perm32 order
@@ -420,9 +439,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                       xa[qt][1][0] * inv[qt], xa[qt][1][1] * inv[qt], xa[qt][1][2] * inv[qt], xa[qt][1][3] * inv[qt]};
         *reinterpret_cast<u16x8*>(xt + ((f * 8 + wave) * ROWS + row) * 32 + swz_chunk(row, fg) * 8) = cvt8<BF>(v);
       }
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt) kf[kt] = kn[kt];
     }
     lds_fence();
-    if constexpr (NKS > 2) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
+    load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
   } else {
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
   {
