@@ -335,7 +335,17 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_lds_bytes<T, MT>() - 3 * 256 * sizeof(float));   // bpq | bv2 | bp
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * ROWS;
+  // XCD-aware tile order (speed only): blocks b and b+8 share an XCD, hence an L2.  With the spatial half in the kernel the
+  // N/ROWS row tiles of one sequence all read that sequence's K / V -- put them on the same XCD so it is fetched once.
+  long long tile = blockIdx.x;
+  if constexpr (NKS > 0) {
+    const int tps = N / ROWS;                                   // tiles per sequence
+    if (gridDim.x % (8 * tps) == 0) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      tile = ((long long)(j / tps) * 8 + xcd) * tps + (j % tps);
+    }
+  }
+  const long long m0 = tile * ROWS;
 
   AXVS_STAMP_DECL;
   AXVS_STAMP(0);
@@ -361,20 +371,28 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
     // the L2 latency of both hides behind MFMA + softmax work
     u16x8 kf[2 * NKS], kn[2 * NKS], vf[2][NKS];
+    // per-lane fragment pointers, advanced by one frame per iteration (all index math hoisted out of the loop:
+    // frame slot sf = seq0 / L + f because N = T * L)
+    const u16* kp[2 * NKS];
 #pragma unroll
-    for (int kt = 0; kt < 2 * NKS; ++kt) kf[kt] = *reinterpret_cast<const u16x8*>(Kh + (seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8);
+    for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] = Kh + (seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8;
+    const u16* vp = Vh + (seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8;
+    const int kstep = L * 32;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKS; ++kt) kf[kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
 #pragma unroll 1
     for (int f = 0; f < T; ++f) {
-      const long long key0 = seq0 + (long long)f * L;
-      const long long sf = key0 / L;
-      const long long keyn = seq0 + (long long)min(f + 1, T - 1) * L;
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-          vf[nd][ks] = *reinterpret_cast<const u16x8*>(Vh + ((sf * NKS + ks) * 2 + nd) * 512 + fi * 32 + fg * 8);
+        for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
+      vp += NKS * 1024;
+      if (f + 1 < T) {
 #pragma unroll
-      for (int kt = 0; kt < 2 * NKS; ++kt) kn[kt] = *reinterpret_cast<const u16x8*>(Kh + (keyn + min(kt * 16 + fi, L - 1)) * 32 + fg * 8);
+        for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
+      }
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt) kn[kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
       f32x4 sc[MT][2 * NKS];
 #pragma unroll
       for (int kt = 0; kt < 2 * NKS; ++kt) {
