@@ -70,20 +70,24 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ge.build()
-    import axial_vs_amd as ax
-    from axial_vs_amd import _lib
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import axvs_oracle as orc
-
-    for kv in args.opt:
-        k, v = kv.split("=")
-        _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), "axvs_set_option")
+    import torch.distributed as dist  # noqa: F811
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+    # one rank builds (a no-op when the in-tree .so is fresh), the others wait for it
+    if local_rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import axvs_oracle as orc
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), "axvs_set_option")
 
     B, T, C, H, W = (int(v) for v in args.shape.split(","))
     F = args.d_ffn
