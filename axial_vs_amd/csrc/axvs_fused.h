@@ -104,71 +104,59 @@ __device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __re
 }
 
 // =====================================================================================================
-// norm1 -> FFN -> norm2, C = 256.  X: fp32 [M][256] (the residual stream after the width pass).
-// LDS: y tile 32 KB | h tiles 2 x 32 KB | row stats.
+// norm1 -> FFN -> norm2, C = 256 (WC/temporal_attention.py:181-185, :217-218), as a workgroup-level body that both the
+// stand-alone kernel and the fused trajectory+FFN kernel run.  The 64 input rows sit in LDS as fp32 (`xtile`, row stride
+// kEpiLd) and never return to HBM: norm1 overwrites them with y (the FFN residual), the linear2 accumulators are added in
+// place, norm2 is applied per whole row on the way out.
+// LDS: xtile 65 KiB fp32 | ytile 32 KiB | htile 32 KiB (single buffer: 2 barriers per 256-unit chunk) | parameters.
 // =====================================================================================================
-template <bool BF>
-__global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict__ X, const u16* __restrict__ W1,
-                                                        const float* __restrict__ b1, const u16* __restrict__ W2,
-                                                        const float* __restrict__ b2, const float* __restrict__ g1,
-                                                        const float* __restrict__ be1, const float* __restrict__ g2,
-                                                        const float* __restrict__ be2, float* __restrict__ out,
-                                                        long long M, int F) {
-  constexpr int C = 256, KB = C / 32;
-  extern __shared__ __attribute__((aligned(16))) u16 smem[];
-  u16* ytile = smem;                                   // [8][64][32]
-  u16* htile = smem + KB * kTileElems;                 // 2 x [8][64][32]
-  float* stats = reinterpret_cast<float*>(smem + 3 * KB * kTileElems);
-  float* part = stats + 2 * kRows;                     // [8 waves][64] partial sums for norm2
-  // biases / norm parameters are staged in LDS: a global load inside the pipelined loop would have to wait (vmcnt is
-  // in-order) for every weight fragment prefetched before it
-  float* sb1 = part + 8 * kRows;                       // [F]
-  float* sb2 = sb1 + F;                                // [256] each: b2, g1, be1, g2, be2
-  float* sg1 = sb2 + C;
-  float* sbe1 = sg1 + C;
-  float* sg2 = sbe1 + C;
-  float* sbe2 = sg2 + C;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fi = lane & 15, fg = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * kRows;
-  const int nchunk = F / 256;
-  // blocks b and b+8 share an XCD (round-robin placement; speed only): give the 32 CUs of an XCD different k-block
-  // rotations and chunk orders
-  const int rot = (blockIdx.x >> 3) & 7;
-  const int crot = (blockIdx.x >> 6) % nchunk;
+struct FfnLds {
+  float* xtile;   // [64][kEpiLd] fp32
+  u16* ytile;     // [8][64][32]
+  u16* htile;     // [8][64][32]
+  float* par;     // b1[F] | b2 | g1 | be1 | g2 | be2  (256 each)
+};
 
-  // prefetch the first linear1 weight fragments while norm1 runs
-  u16x8 w1f[2][KB], w2f[2][KB];
-  load_wfrags<2, KB>(w1f, W1, F, 0, crot * 256 + wave * 32, fi, fg, rot);
-
-  for (int i = tid; i < F; i += 512) sb1[i] = b1[i];
-  if (tid < C) {
-    sb2[tid] = b2[tid];
-    sg1[tid] = g1[tid];
-    sbe1[tid] = be1[tid];
-    sg2[tid] = g2[tid];
-    sbe2[tid] = be2[tid];
+__device__ __forceinline__ void ffn_stage_params(const FfnLds& l, const float* __restrict__ b1, const float* __restrict__ b2,
+                                                 const float* __restrict__ g1, const float* __restrict__ be1,
+                                                 const float* __restrict__ g2, const float* __restrict__ be2, int F, int tid) {
+  for (int i = tid; i < F; i += 512) l.par[i] = b1[i];
+  if (tid < 256) {
+    float* q = l.par + F;
+    q[tid] = b2[tid];
+    q[256 + tid] = g1[tid];
+    q[512 + tid] = be1[tid];
+    q[768 + tid] = g2[tid];
+    q[1024 + tid] = be2[tid];
   }
-  // ---- norm1: wave handles rows 8w..8w+7, one row per pass (64 lanes x float4) ----
+}
+
+// Precondition: xtile rows 8*wave .. 8*wave+7 were written by THIS wave (or a barrier has passed), parameters staged and a
+// barrier passed since; w1f holds the linear1 fragments of chunk `crot` (rotation `rot`).
+template <bool BF>
+__device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], const u16* __restrict__ W1, const u16* __restrict__ W2,
+                                         float* __restrict__ out, long long m0, long long M, int F, int rot, int crot, int tid) {
+  constexpr int C = 256, KB = 8;
+  const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const float* sb1 = l.par;
+  const float* sb2 = l.par + F;
+  const float *sg1 = sb2 + C, *sbe1 = sb2 + 2 * C, *sg2 = sb2 + 3 * C, *sbe2 = sb2 + 4 * C;
+  const int nchunk = F / 256;
+  u16x8 w2f[2][KB];
+
+  // ---- norm1, row-wise: y (fp32) back into xtile, y (16-bit) into ytile ----
   {
-    const float4 gg = *reinterpret_cast<const float4*>(g1 + lane * 4);
-    const float4 bb = *reinterpret_cast<const float4*>(be1 + lane * 4);
-    float4 rows[8];                      // all 8 row loads in flight together
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const long long m = min(m0 + wave * 8 + rr, M - 1);
-      rows[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
-    }
+    const float4 gg = *reinterpret_cast<const float4*>(sg1 + lane * 4), bb = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr;
-      const float4 v = rows[rr];
+      const float4 v = *reinterpret_cast<const float4*>(l.xtile + r * kEpiLd + lane * 4);
       const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
       const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
       const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
-      f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
-      act_store4<BF>(ytile, lane * 4, r, y);
-      if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * r) = float2{mu, rstd};
+      const f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
+      *reinterpret_cast<float4*>(l.xtile + r * kEpiLd + lane * 4) = float4{y[0], y[1], y[2], y[3]};
+      act_store4<BF>(l.ytile, lane * 4, r, y);
       if (rr == 3) lds_fence();
     }
   }
@@ -180,19 +168,17 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // w2f of the first chunk (later ones are fetched while the previous chunk's linear2 runs... see below)
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + crot) % nchunk;                 // hidden-unit chunk handled in this iteration
     const int cn = (min(ci + 1, nchunk - 1) + crot) % nchunk;
-    u16* hbuf = htile + (ci & 1) * KB * kTileElems;
-    // ---- linear1 + ReLU: my 32 hidden units of the chunk, all 64 rows; meanwhile fetch this chunk's linear2 fragments
-    //      (rows = my 32 output channels, k-blocks = this chunk's 256 hidden units) ----
+    // ---- linear1 + ReLU: my 32 hidden units of the chunk, all 64 rows; meanwhile fetch this chunk's linear2 fragments ----
     f32x4 acc1[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_phase_pf<BF, 2, 4, KB, 2>(acc1, w1f, ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot);
+    gemm_phase_pf<BF, 2, 4, KB, 2>(acc1, w1f, l.ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot);
+    if (ci > 0) __syncthreads();                         // every wave is done reading the previous chunk's h
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int hn = c * 256 + wave * 32 + nt * 16 + fg * 4;          // global hidden index
@@ -202,46 +188,38 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
         f32x4 v = acc1[nt][mt];
         v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
         v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
-        act_store4<BF>(hbuf, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
+        act_store4<BF>(l.htile, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
       }
     }
     __syncthreads();
     // ---- linear2 partial: += W2[my 32 channels, chunk] . h ; meanwhile fetch the next chunk's linear1 fragments
     //      (unconditional: the last iteration re-loads its own chunk, which keeps the vmcnt bookkeeping branch-free) ----
-    gemm_phase_pf<BF, 2, 4, KB, 2>(acc2, w2f, hbuf, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
+    gemm_phase_pf<BF, 2, 4, KB, 2>(acc2, w2f, l.htile, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
   }
 
-  // ---- epilogue, row-wise: acc2 + b2 -> LDS fp32 tile (over the dead y/h tiles) -> each wave finishes 8 whole rows:
-  //      + y (norm1 recomputed from the row), norm2, one coalesced 1-KiB store per row ----
-  __syncthreads();                                   // every wave is done with the y / h tiles
-  float* etile = reinterpret_cast<float*>(smem);     // 64 x kEpiLd floats = 65 KiB over the (dead) y + h tiles (96 KiB)
+  // ---- xtile (= y) += acc2 + b2, in the accumulator layout; then norm2 per whole row and one 1-KiB store per row ----
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = wave * 32 + nt * 16 + fg * 4;
     const float4 b = *reinterpret_cast<const float4*>(sb2 + n);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-      epi_put(etile, mt * 16 + fi, n, f32x4{acc2[nt][mt][0] + b.x, acc2[nt][mt][1] + b.y, acc2[nt][mt][2] + b.z, acc2[nt][mt][3] + b.w});
+    for (int mt = 0; mt < 4; ++mt) {
+      float* p = l.xtile + (mt * 16 + fi) * kEpiLd + n;
+      const float4 y = *reinterpret_cast<const float4*>(p);
+      *reinterpret_cast<float4*>(p) = float4{y.x + acc2[nt][mt][0] + b.x, y.y + acc2[nt][mt][1] + b.y, y.z + acc2[nt][mt][2] + b.z,
+                                             y.w + acc2[nt][mt][3] + b.w};
+    }
+    lds_fence();
   }
   __syncthreads();
   {
-    const float4 g1v = *reinterpret_cast<const float4*>(sg1 + lane * 4), be1v = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
     const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
-    float4 xr[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const long long m = min(m0 + wave * 8 + i, M - 1);
-      xr[i] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = wave * 8 + i;
-      const float2 st = *reinterpret_cast<const float2*>(stats + 2 * r);
-      const float4 a = *reinterpret_cast<const float4*>(etile + r * kEpiLd + lane * 4);
-      const float v0 = a.x + ((xr[i].x - st.x) * st.y * g1v.x + be1v.x), v1 = a.y + ((xr[i].y - st.x) * st.y * g1v.y + be1v.y);
-      const float v2 = a.z + ((xr[i].z - st.x) * st.y * g1v.z + be1v.z), v3 = a.w + ((xr[i].w - st.x) * st.y * g1v.w + be1v.w);
-      const float mu = wave_sum(v0 + v1 + v2 + v3) * (1.f / C);
-      const float d0 = v0 - mu, d1 = v1 - mu, d2 = v2 - mu, d3 = v3 - mu;
+      const float4 v = *reinterpret_cast<const float4*>(l.xtile + r * kEpiLd + lane * 4);
+      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+      const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
       const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
       if (m0 + r < M)
         *reinterpret_cast<float4*>(out + (m0 + r) * C + lane * 4) =
@@ -251,7 +229,50 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   }
 }
 
-inline size_t ffn_lds_bytes(int F) { return 3 * 8 * kTileElems * sizeof(u16) + (2 * kRows + 8 * kRows + F + 5 * 256) * sizeof(float); }
+constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kTileElems * sizeof(u16);   // x | y | h
+inline size_t ffn_lds_bytes(int F) { return kFfnTiles + (size_t)(F + 5 * 256) * sizeof(float); }
+
+// stand-alone kernel: X fp32 [M][256] rows in, out rows out
+template <bool BF>
+__global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict__ X, const u16* __restrict__ W1,
+                                                        const float* __restrict__ b1, const u16* __restrict__ W2,
+                                                        const float* __restrict__ b2, const float* __restrict__ g1,
+                                                        const float* __restrict__ be1, const float* __restrict__ g2,
+                                                        const float* __restrict__ be2, float* __restrict__ out,
+                                                        long long M, int F) {
+  constexpr int C = 256, KB = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  FfnLds l;
+  l.xtile = reinterpret_cast<float*>(smem_c);
+  l.ytile = reinterpret_cast<u16*>(smem_c + (size_t)kRows * kEpiLd * sizeof(float));
+  l.htile = l.ytile + KB * kTileElems;
+  l.par = reinterpret_cast<float*>(l.htile + KB * kTileElems);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * kRows;
+  const int nchunk = F / 256;
+  // blocks b and b+8 share an XCD (round-robin placement; speed only): different k-block rotations / chunk orders
+  const int rot = (blockIdx.x >> 3) & 7;
+  const int crot = (blockIdx.x >> 6) % nchunk;
+  u16x8 w1f[2][KB];
+  load_wfrags<2, KB>(w1f, W1, F, 0, crot * 256 + wave * 32, fi, fg, rot);
+  ffn_stage_params(l, b1, b2, g1, be1, g2, be2, F, tid);
+  {
+    float4 rows[8];                      // my 8 rows, whole (1 KiB per wave instruction), all in flight together
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const long long m = min(m0 + wave * 8 + rr, M - 1);
+      rows[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      *reinterpret_cast<float4*>(l.xtile + (wave * 8 + rr) * kEpiLd + lane * 4) = rows[rr];
+      if (rr == 3) lds_fence();
+    }
+  }
+  __syncthreads();                       // parameters staged
+  ffn_body<BF>(l, w1f, W1, W2, out, m0, M, F, rot, crot, tid);
+}
+
 
 }  // namespace axvs
 
