@@ -36,6 +36,7 @@ constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
+thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
@@ -188,7 +189,23 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
 
 template <bool BF, int T, int MT, int NKS>
 int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                      float scale, hipStream_t st) {
+                      float scale, hipStream_t st, const FfnArgs* fa) {
+  const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
+  if constexpr (NKS > 0 && MT == 4) {
+    if (fa) {                                    // trajectory attention + FFN in one kernel
+      static bool configured_ffn = false;
+      if (!configured_ffn) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+          return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+        configured_ffn = true;
+      }
+      const size_t lds_ffn = temporal_lds_bytes<T, MT, true>(fa->F);
+      hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS, true>), dim3(grid), dim3(512), lds_ffn, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa);
+      return AXVS_OK;
+    }
+  }
+  if (fa) return fail(AXVS_ERR_ARG, "internal: FFN fusion needs the in-kernel spatial half and 64-row tiles");
   static bool configured = false;
   constexpr size_t lds = temporal_lds_bytes<T, MT>();
   if (!configured) {
@@ -197,7 +214,6 @@ int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, fl
       return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
     configured = true;
   }
-  const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
   hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
                      p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16);
   return AXVS_OK;
@@ -205,13 +221,13 @@ int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, fl
 
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st) {
+                      int L, float scale, hipStream_t st, const FfnArgs* fa) {
   switch (nks) {
-    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st);
-    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st);
+    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
     default: return fail(AXVS_ERR_ARG, "bad nks");
   }
 }
@@ -219,13 +235,13 @@ int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float
 // nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel
 template <bool BF>
 int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
-                    float scale, hipStream_t st, int nks = 0) {
+                    float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr) {
   switch (T) {
-    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
-    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
-    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
-    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
-    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st);
+    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
     default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 5");
   }
 }
@@ -235,7 +251,7 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
 template <bool BF>
 int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
-             hipStream_t st, int pass = 0) {
+             hipStream_t st, int pass = 0, const FfnArgs* ffn = nullptr, float* ffn_out = nullptr, bool* ffn_done = nullptr) {
   static const char* const kNames[3][8] = {
       {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused", "traj_fused"},
       {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused", "h.traj_fused"},
@@ -284,9 +300,12 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
 qkv_done:
   mark(st, nm[0]);
   if (fuse_attn) {
-    int rc = launch_temporal<BF>(w, p, res, out, rm, Mp, N, L, T, scale, st, nks_fused);
+    // the layer's FFN can ride along (64-row tiles, LDS budget): `out` then receives norm2(FFN(norm1(...)))
+    const bool with_ffn = ffn != nullptr && !g_no_ffn_fusion && T <= 4 && ffn->F % 256 == 0 && ffn->F <= 4096;
+    int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr);
     if (rc != AXVS_OK) return rc;
-    mark(st, nm[7]);
+    if (with_ffn) *ffn_done = true;
+    mark(st, with_ffn ? "w.traj_fused+ffn" : nm[7]);
     return AXVS_OK;
   }
 
@@ -407,8 +426,11 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   if (rc != AXVS_OK) return rc;
   // width pass: sequences (b, h), tokens (t, w)         :206-213
   RowMap rmw{T * W, W, H, sB, sT, 1, W};
-  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st, 2);
+  const FfnArgs fa{p.w1, p.w2, p.b1, p.b2, p.g1, p.be1, p.g2, p.be2, F};
+  bool ffn_done = false;
+  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st, 2, &fa, out, &ffn_done);
   if (rc != AXVS_OK) return rc;
+  if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
   // norm1 -> FFN -> norm2                               :181-185, :217-218
   int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, buf1, y16, h16, st);
@@ -558,6 +580,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "generic_only")) { g_generic_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "attn_waves")) { g_attn_waves = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }

@@ -117,10 +117,19 @@ struct FfnLds {
   float* par;     // b1[F] | b2 | g1 | be1 | g2 | be2  (256 each)
 };
 
+struct FfnArgs {   // kernel argument block of the FFN half (packed weights, fp32 parameters)
+  const u16 *W1, *W2;
+  const float *b1, *b2, *g1, *be1, *g2, *be2;
+  int F;
+};
+
 __device__ __forceinline__ void ffn_stage_params(const FfnLds& l, const float* __restrict__ b1, const float* __restrict__ b2,
                                                  const float* __restrict__ g1, const float* __restrict__ be1,
                                                  const float* __restrict__ g2, const float* __restrict__ be2, int F, int tid) {
-  for (int i = tid; i < F; i += 512) l.par[i] = b1[i];
+  for (int i = tid; i < F; i += 512) {
+    l.par[i] = b1[i];
+    lds_fence();                       // F / 512 writes: keep lgkmcnt bounded for any d_ffn
+  }
   if (tid < 256) {
     float* q = l.par + F;
     q[tid] = b2[tid];
@@ -133,9 +142,10 @@ __device__ __forceinline__ void ffn_stage_params(const FfnLds& l, const float* _
 
 // Precondition: xtile rows 8*wave .. 8*wave+7 were written by THIS wave (or a barrier has passed), parameters staged and a
 // barrier passed since; w1f holds the linear1 fragments of chunk `crot` (rotation `rot`).
-template <bool BF>
+// `row_off(r)`: element offset of tile row r in `out`, or < 0 for a row that does not exist (ragged last tile).
+template <bool BF, class RowOff>
 __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], const u16* __restrict__ W1, const u16* __restrict__ W2,
-                                         float* __restrict__ out, long long m0, long long M, int F, int rot, int crot, int tid) {
+                                         float* __restrict__ out, RowOff row_off, int F, int rot, int crot, int tid) {
   constexpr int C = 256, KB = 8;
   const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const float* sb1 = l.par;
@@ -221,8 +231,9 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
       const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
       const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
       const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
-      if (m0 + r < M)
-        *reinterpret_cast<float4*>(out + (m0 + r) * C + lane * 4) =
+      const long long off = row_off(r);
+      if (off >= 0)
+        *reinterpret_cast<float4*>(out + off + lane * 4) =
             float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
       if (i == 3) lds_fence();
     }
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
     }
   }
   __syncthreads();                       // parameters staged
-  ffn_body<BF>(l, w1f, W1, W2, out, m0, M, F, rot, crot, tid);
+  ffn_body<BF>(l, w1f, W1, W2, out, [=](int r) { return m0 + r < M ? (m0 + r) * C : -1ll; }, F, rot, crot, tid);
 }
 
 
@@ -291,12 +302,17 @@ namespace axvs {
 // Each wave streams exactly its own weight rows L2 -> VGPR (Wpq_h, Wk2_h, Wv2_h, Wp[32w..]: 64 KiB), one 64-VGPR fragment
 // set that is refilled in place, slot by slot, right after a slot's last use.
 // =====================================================================================================
-template <int T, int MT>
-constexpr size_t temporal_lds_bytes() {
-  // x tile (re-used: o tile + fp32 epilogue tile) | biases
+template <int T, int MT, bool FFN = false>
+constexpr size_t temporal_tile_bytes() {
+  // x tile, re-used as: o tile | fp32 epilogue tile [| h tile of the FFN half; its y tile takes the o tile's place]
   size_t xt = (size_t)T * 8 * MT * 16 * 32 * sizeof(u16);
   size_t epi = (size_t)8 * MT * 16 * 32 * sizeof(u16) + (size_t)MT * 16 * kEpiLd * sizeof(float);
-  return (xt > epi ? xt : epi) + 3 * 256 * sizeof(float);
+  if (FFN) epi += (size_t)8 * MT * 16 * 32 * sizeof(u16);
+  return xt > epi ? xt : epi;
+}
+template <int T, int MT, bool FFN = false>
+constexpr size_t temporal_lds_bytes(int F = 0) {   // tiles | bpq, bv2, bp | FFN parameters
+  return temporal_tile_bytes<T, MT, FFN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0);
 }
 
 template <int MT>
@@ -341,7 +357,9 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
 //          x[q, f, :] = softmax_l(q . k[f, l]) v[f, l, :] for the 64 queries and all T frames from K / V^T fragments loaded
 //          straight from L2 (no LDS staging; V^T comes pre-blocked from qkv_fused_kernel) and writes it into the LDS x tile --
 //          the T-expanded tensor never touches HBM.  Needs the tile inside one sequence (N % (16*MT) == 0), L % 16 == 0.
-template <bool BF, int T, int MT, int NKS = 0>
+// FFN: the rows do not go back to HBM after the residual; norm1 -> FFN -> norm2 (ffn_body) runs on them right here and `out`
+//      receives the layer output (MT = 4 only).
+template <bool BF, int T, int MT, int NKS = 0, bool FFN = false>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
                                                              const u16* __restrict__ Wpq, const float* __restrict__ bpq,
                                                              const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
@@ -349,11 +367,19 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const float* __restrict__ res /* required */, float* __restrict__ out,
                                                              RowMap rm, long long Mp, int N, int L, float scale, const u16* __restrict__ Q16 = nullptr,
                                                              const u16* __restrict__ K16 = nullptr,
-                                                             const u16* __restrict__ VT16 = nullptr) {
+                                                             const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{}) {
+  static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
-  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_lds_bytes<T, MT>() - 3 * 256 * sizeof(float));   // bpq | bv2 | bp
+  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN>());   // bpq | bv2 | bp
+  FfnLds fl;
+  if constexpr (FFN) {
+    fl.ytile = xt;
+    fl.xtile = reinterpret_cast<float*>(xt + 8 * ROWS * 32);
+    fl.htile = reinterpret_cast<u16*>(fl.xtile + ROWS * kEpiLd);
+    fl.par = sbias + 3 * C;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
   // XCD-aware tile order (speed only): blocks b and b+8 share an XCD, hence an L2.  With the spatial half in the kernel the
@@ -513,6 +539,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     sbias[C + tid] = bpkv[C + tid];       // v2 half of the proj_kv bias
     sbias[2 * C + tid] = bp[tid];
   }
+  if constexpr (FFN) lds_fence();
+  if constexpr (FFN) ffn_stage_params(fl, fa.b1, fa.b2, fa.g1, fa.be1, fa.g2, fa.be2, fa.F, tid);
   __syncthreads();
 
   AXVS_STAMP(1);
@@ -650,7 +678,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const int row = mt * 16 + fi;
     bo[mt] = row * 32 + swz_chunk(row, fg) * 8;
   }
-  sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
+  // with the FFN half following, the sweep leaves the first linear1 fragment set behind
+  const int crot = FFN ? (int)((blockIdx.x >> 6) % (fa.F / 256)) : 0;
+  if constexpr (FFN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, fa.W1, fa.F, crot * 256 + wave * 32, fi, fg);
+  else sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
   AXVS_STAMP(7);
   // ---- row-wise epilogue: accumulators (+bias) -> LDS fp32 tile (behind the o tile) -> whole rows: + residual -> out ----
   float* etile = reinterpret_cast<float*>(xt + 8 * ROWS * 32);
@@ -678,8 +709,15 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int i = 0; i < RPW; ++i) {
       const int row = wave * RPW + i;
       const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
-      if (m0 + row < Mp) *reinterpret_cast<float4*>(out + off[i]) = float4{v.x + r[i].x, v.y + r[i].y, v.z + r[i].z, v.w + r[i].w};
+      const float4 y = float4{v.x + r[i].x, v.y + r[i].y, v.z + r[i].z, v.w + r[i].w};
+      if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
+      else if (m0 + row < Mp) *reinterpret_cast<float4*>(out + off[i]) = y;
     }
+  }
+  if constexpr (FFN) {
+    lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
+    ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
+                 [=](int row) { return m0 + row < Mp ? nat_row(rm, (int)m0 + row) * C : -1ll; }, fa.F, 0, crot, tid);
   }
   AXVS_STAMP(8);
   AXVS_STAMP_FLUSH(10);
