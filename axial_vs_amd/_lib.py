@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaxvs.so")
+# AXVS_LIB_PATH: diagnostic builds of the same library (tools/ only: -DAXVS_STAMPS, ablations)
+LIB_PATH = os.environ.get("AXVS_LIB_PATH") or os.path.join(_HERE, "libaxvs.so")
 
 AXVS_F16 = 0
 AXVS_BF16 = 1

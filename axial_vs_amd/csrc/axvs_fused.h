@@ -24,6 +24,9 @@ __device__ __forceinline__ u16x8 act_frag(const u16* tile, int kb, int mt, int f
 
 // A-operand fragment (weights) straight from the blocked global layout [K/32][NR][32]
 __device__ __forceinline__ u16x8 w_frag(const u16* __restrict__ W, int NR, int kb, int nrow, int fg) {
+#ifdef AXVS_ABL_W   // diagnostic: every fragment load hits the same 1 KiB (L1-resident) -- results are wrong on purpose
+  return *reinterpret_cast<const u16x8*>(W + (nrow & 15) * 32 + fg * 8);
+#endif
   return *reinterpret_cast<const u16x8*>(W + ((long long)kb * NR + nrow) * 32 + fg * 8);
 }
 
@@ -714,13 +717,14 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       else if (m0 + row < Mp) *reinterpret_cast<float4*>(out + off[i]) = y;
     }
   }
+  AXVS_STAMP(8);
   if constexpr (FFN) {
     lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
     ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
                  [=](int row) { return m0 + row < Mp ? nat_row(rm, (int)m0 + row) * C : -1ll; }, fa.F, 0, crot, tid);
   }
-  AXVS_STAMP(8);
-  AXVS_STAMP_FLUSH(10);
+  AXVS_STAMP(10);
+  AXVS_STAMP_FLUSH(11);
 }
 
 

@@ -188,9 +188,17 @@ def main():
         names = [L.axvs_profile_stage_name(i).decode() for i in range(nrun)]
         kernels = {names[i]: round(stage_ms[i] * 1e3, 2) for i in range(1, nrun)}
         dom = max(kernels, key=kernels.get)
+        # HBM traffic per layer forward from the TCC counters: collected by tools/pmc_traffic.sh (rocprofv3 --pmc passes of this
+        # very command cannot run inside the timed process); reported only for the workload it was measured on
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
+        if os.path.exists(tpath) and (B, T, C, H, W, F, args.dtype) == (1, 4, 256, 64, 64, 1024, "f16") and not args.opt:
+            tj = json.load(open(tpath))
+            traffic, traffic_src = int(tj["layer_total_MB"] * 1e6), "profiles/hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per layer forward",
+            "traffic_source": traffic_src,
             "kernel": "axial layer forward (all launches of one step)", "launch_us": round(fwd_ms * 1e3, 2),
             "algorithmic_gflop": round(flops / 1e9, 2), "algorithmic_mbytes": round(layer_bytes(B, T, H, W, C, F) / 1e6, 2),
             "hbm_frac_if_memory_bound": round(layer_bytes(B, T, H, W, C, F) / (fwd_ms * 1e-3) / 8e12, 4),

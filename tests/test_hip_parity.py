@@ -153,9 +153,11 @@ def test_workspace_and_alias_errors():
     assert rc == -2 and b"workspace" in L.axvs_last_error()
 
 
+@pytest.mark.parametrize("option", ["generic_only", "no_attn_fusion", "no_ffn_fusion"])
 @pytest.mark.parametrize("name", ["g2_axial_B1_T4_C256_H64_W64"])
-def test_generic_kernels_also_match_golden(name):
-    """The shape-generic (v1) kernels stay selectable and parity-green next to the fused C=256 path."""
+def test_generic_kernels_also_match_golden(name, option):
+    """Every kernel tier stays selectable and parity-green at the metric shape: the shape-generic (v1) kernels, the fused
+    C=256 kernels with the spatial half in its own kernel, and with the FFN in its own kernel."""
     import axial_vs_amd as ax
     from axial_vs_amd import _lib
     z, m = load(name)
@@ -165,11 +167,11 @@ def test_generic_kernels_also_match_golden(name):
     layer.load_state_dict(w, strict=True)
     layer = layer.cuda()
     fused = layer(dev(src), dev(pos))[0].cpu()
-    assert _lib.lib().axvs_set_option(b"generic_only", 1) == 0
+    assert _lib.lib().axvs_set_option(option.encode(), 1) == 0
     try:
         generic = layer(dev(src), dev(pos))[0].cpu()
     finally:
-        _lib.lib().axvs_set_option(b"generic_only", 0)
+        _lib.lib().axvs_set_option(option.encode(), 0)
     s = m["stride"]
     assert rel_err(generic[:, ::s], t(z["out"])) < TOL_F16
     assert rel_err(fused[:, ::s], t(z["out"])) < TOL_F16
@@ -177,7 +179,11 @@ def test_generic_kernels_also_match_golden(name):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 256, 12, 9, 512), (1, 2, 256, 25, 43, 1024), (2, 3, 256, 10, 16, 256),
-                                   (1, 5, 256, 8, 12, 1024)])
+                                   (1, 5, 256, 8, 12, 1024),
+                                   # whole 16-key tiles per frame: spatial half inside the trajectory kernel, 1..4 key steps,
+                                   # ragged last key step (L = 16, 48), FFN riding on the width pass (T <= 4), T = 5 without
+                                   (1, 1, 256, 64, 128, 1024), (1, 2, 256, 32, 96, 512), (1, 3, 256, 64, 64, 1024),
+                                   (2, 4, 256, 16, 48, 2048), (1, 5, 256, 32, 64, 1024)])
 def test_fused_kernels_all_frame_counts(shape):
     """C = 256 routes through the fused kernels: cover T = 1, 2, 3, 5 (T = 4 is the metric fixture), ragged H x W
     (incl. the VIPSeg res5 size 25 x 43), workgroups with a partial last row tile."""

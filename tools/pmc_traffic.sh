@@ -16,19 +16,21 @@ for f in sorted(glob.glob("$OUT/*/*/*counter_collection.csv")):
         k = r["Kernel_Name"].split("(")[0].replace("void axvs::", "")
         if "at::" in k or "rocclr" in k or "pack" in k: continue
         a = agg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
-launches = {"qkv_fused_kernel": 2, "temporal_fused_kernel": 2, "spatial_attn_kernel": 2, "ffn_fused_kernel": 1}
+# launches per layer forward: every forward launches qkv_fused_kernel exactly twice
+nq = max((max(c[1] for c in cs.values()) for k, cs in agg.items() if "qkv_fused_kernel" in k), default=2)
 tot_r = tot_w = 0.0
 rows = {}
 for k, cs in agg.items():
     fs = cs.get("FETCH_SIZE", [0, 1]); ws = cs.get("WRITE_SIZE", [0, 1])
     rd = fs[0] / max(fs[1], 1) * 1024 * 2      # KB -> bytes, x2 gfx950 correction for wide coalesced reads
     wr = ws[0] / max(ws[1], 1) * 1024
-    n = next((v for kk, v in launches.items() if kk in k), 1)
+    n = round(2 * max(c[1] for c in cs.values()) / nq)
     rows[k[:60]] = {"read_MB_per_launch": round(rd / 1e6, 2), "write_MB_per_launch": round(wr / 1e6, 2), "launches_per_layer": n}
     tot_r += rd * n; tot_w += wr * n
 res = {"per_kernel": rows, "layer_read_MB": round(tot_r / 1e6, 1), "layer_write_MB": round(tot_w / 1e6, 1),
        "layer_total_MB": round((tot_r + tot_w) / 1e6, 1),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B)"}
 print(json.dumps(res, indent=1))
+res["workload"] = "axial layer fwd B=1 T=4 C=256 H=W=64 d_ffn=1024 f16"
 json.dump(res, open("$OUT/traffic.json", "w"), indent=1)
 PY
