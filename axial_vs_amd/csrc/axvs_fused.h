@@ -486,7 +486,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) ssum = H16<BF>::mfma(ones, pf[qt][ks], ssum);
-        inv[qt] = 1.f / ssum[0];
+        inv[qt] = __builtin_amdgcn_rcpf(ssum[0]);   // 1 ulp; the result is rounded to 16 bits right after
       }
       f32x4 xa[MT][2];
 #pragma unroll
@@ -681,6 +681,17 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const int row = mt * 16 + fi;
     bo[mt] = row * 32 + swz_chunk(row, fg) * 8;
   }
+  // residual rows of the row-wise epilogue: requested before the sweep, so their HBM latency hides behind it
+  constexpr int RPW = ROWS / 8;                     // rows per wave
+  float4 rres[RPW];
+  long long roff[RPW];
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int row = wave * RPW + i;
+    const int m = (int)m0 + min(row, (int)(Mp - 1 - m0));
+    roff[i] = nat_row(rm, m) * C + lane * 4;        // wave-uniform row, lane = float4 column
+    rres[i] = *reinterpret_cast<const float4*>(res + roff[i]);
+  }
   // with the FFN half following, the sweep leaves the first linear1 fragment set behind
   const int crot = FFN ? (int)((blockIdx.x >> 6) % (fa.F / 256)) : 0;
   if constexpr (FFN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, fa.W1, fa.F, crot * 256 + wave * 32, fi, fg);
@@ -697,25 +708,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       epi_put(etile, mt * 16 + fi, n, f32x4{po[nt][mt][0] + b.x, po[nt][mt][1] + b.y, po[nt][mt][2] + b.z, po[nt][mt][3] + b.w});
   }
   __syncthreads();
-  {
-    constexpr int RPW = ROWS / 8;                   // rows per wave
-    float4 r[RPW];
-    long long off[RPW];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int row = wave * RPW + i;
-      const int m = (int)m0 + min(row, (int)(Mp - 1 - m0));
-      off[i] = nat_row(rm, m) * C + lane * 4;       // wave-uniform row, lane = float4 column
-      r[i] = *reinterpret_cast<const float4*>(res + off[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int row = wave * RPW + i;
-      const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
-      const float4 y = float4{v.x + r[i].x, v.y + r[i].y, v.z + r[i].z, v.w + r[i].w};
-      if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
-      else if (m0 + row < Mp) *reinterpret_cast<float4*>(out + off[i]) = y;
-    }
+  for (int i = 0; i < RPW; ++i) {
+    const int row = wave * RPW + i;
+    const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
+    const float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
+    if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
+    else if (m0 + row < Mp) *reinterpret_cast<float4*>(out + roff[i]) = y;
   }
   AXVS_STAMP(8);
   if constexpr (FFN) {
@@ -724,12 +723,24 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                  [=](int row) { return m0 + row < Mp ? nat_row(rm, (int)m0 + row) * C : -1ll; }, fa.F, 0, crot, tid);
   }
   AXVS_STAMP(10);
+#ifndef AXVS_STAMPS_QKV
   AXVS_STAMP_FLUSH(11);
+#endif
 }
 
 
 }  // namespace axvs
 
+// diagnostic builds: -DAXVS_STAMPS plus -DAXVS_STAMPS_QKV stamps the QKV kernel instead of the trajectory kernel
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_QKV)
+#define QSTAMP_DECL AXVS_STAMP_DECL
+#define QSTAMP(s) AXVS_STAMP(s)
+#define QSTAMP_FLUSH(n) AXVS_STAMP_FLUSH(n)
+#else
+#define QSTAMP_DECL
+#define QSTAMP(s)
+#define QSTAMP_FLUSH(n)
+#endif
 namespace axvs {
 
 // =====================================================================================================
@@ -755,6 +766,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
   const int fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * ROWS;
 
+  QSTAMP_DECL;
+  QSTAMP(0);
   u16x8 wf[2][8];
   load_wfrags<2, 8>(wf, Wq, C, 0, wave * 32, fi, fg);
 
@@ -788,7 +801,9 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
       sbias[2 * C + tid] = bv[tid];
     }
   }
+  QSTAMP(1);
   __syncthreads();
+  QSTAMP(2);
 
   int bb[MT];
 #pragma unroll
@@ -808,9 +823,32 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
     else if (which == 1) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wv, C, wave * 32, fi, fg);
     else if (VT16 == nullptr) sweep8<BF, MT, false>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);
     else sweep8<BF, MT, false, true>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);          // tokens on D rows
+    if (which == 0) QSTAMP(3);
+    if (which == 1) QSTAMP(5);
+    if (which == 2) QSTAMP(7);
     if (which == 2 && VT16 != nullptr) {
       // block-transposed V^T:  VT[head][frame slot sf = m'/L][ks][nd][16 d][32 keys in perm32 order]; a lane holds channel
       // nt*16+fi and tokens 4g..4g+3 of tile mt (one frame: L % 16 == 0) -> 8 contiguous bytes
+      const long long heads_sf = Mp / L;                     // S*T frame slots
+      if (L % 32 == 0) {
+        // tile pairs (mt, mt+1) are the two 16-key halves of one 32-key step: 16 contiguous bytes per lane
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const float b = sbias[2 * C + wave * 32 + nt * 16 + fi];
+#pragma unroll
+          for (int mp = 0; mp < MT; mp += 2) {
+            const long long mt0 = m0 + mp * 16;
+            if (mt0 < Mp) {
+              const long long sf = mt0 / L;
+              const int ks = (int)(mt0 - sf * L) >> 5;
+              u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + fg * 8;
+              float v[8] = {acc[nt][mp][0] + b, acc[nt][mp][1] + b, acc[nt][mp][2] + b, acc[nt][mp][3] + b,
+                            acc[nt][mp + 1][0] + b, acc[nt][mp + 1][1] + b, acc[nt][mp + 1][2] + b, acc[nt][mp + 1][3] + b};
+              *reinterpret_cast<u16x8*>(d) = cvt8<BF>(v);
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const float b = sbias[2 * C + wave * 32 + nt * 16 + fi];
@@ -821,7 +859,6 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
             const long long sf = mt0 / L;
             const int l = (int)(mt0 - sf * L) + fg * 4;       // key index within the frame of the lane's first token
             const int ks = l >> 5, pp = fg * 8 + ((l >> 4) & 1) * 4;
-            const long long heads_sf = Mp / L;                 // S*T frame slots
             u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
             f32x4 v = acc[nt][mt];
             v[0] += b; v[1] += b; v[2] += b; v[3] += b;
@@ -829,6 +866,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
           }
         }
       }
+      }
+      QSTAMP(8);
       continue;
     }
     u16* dst = which == 0 ? Q16 : which == 1 ? K16 : V16;
@@ -855,7 +894,10 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
         }
       }
     }
+    if (which == 0) QSTAMP(4);
+    if (which == 1) QSTAMP(6);
   }
+  QSTAMP_FLUSH(9);
 }
 
 constexpr size_t kQkvLdsBytes = 16 * 64 * 32 * sizeof(u16) + 3 * 256 * sizeof(float);
