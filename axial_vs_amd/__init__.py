@@ -7,8 +7,8 @@ from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, Tempo
                       TemporalEncoder, TemporalTrajectoryAttentionLayer, TrajectoryAttention, TubeLinkTemporalEncoder,
                       set_default_dtype)
 
-from .cross_clip import CrossClipTrackingModule
+from .cross_clip import CrossClipTrackingModule, TubeLinkCrossClipHead
 
-__all__ = ["CrossClipTrackingModule", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
+__all__ = ["CrossClipTrackingModule", "TubeLinkCrossClipHead", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
            "set_default_dtype"]

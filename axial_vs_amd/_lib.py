@@ -46,6 +46,11 @@ class AxvsCCHeadParams(C.Structure):
                 ("act_head_w", _fp), ("act_head_b", _fp), ("pixel_bn", AxvsBN)]
 
 
+class AxvsTLHeadParams(C.Structure):
+    _fields_ = [(n, _fp) for n in ("post_norm_w", "post_norm_b", "activation_proj_w", "activation_proj_b", "cls_embed_w",
+                                   "cls_embed_b")] + [("mask_embed_w", _fp * 3), ("mask_embed_b", _fp * 3)]
+
+
 # name -> (restype, argtypes); must list every symbol of include/axvs.h
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
@@ -72,6 +77,10 @@ SIGNATURES = {
     "axvs_cc_heads_pack": (C.c_int, [C.POINTER(AxvsCCHeadParams), _fp, C.c_int, C.c_int, _fp]),
     "axvs_cc_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "axvs_cc_heads_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_tl_heads_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "axvs_tl_heads_pack": (C.c_int, [C.POINTER(AxvsTLHeadParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "axvs_tl_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "axvs_tl_heads_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_pos3d": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_scaled_residual": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
 }

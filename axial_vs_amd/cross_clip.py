@@ -101,6 +101,27 @@ def _bn(m) -> _lib.AxvsBN:
     return m.weight, m.bias, m.running_mean, m.running_var
 
 
+def _pack_cc_layers(mod, num_layers, f, keep, dt, dev):
+    """axvs_cc_layer_pack for every (trajectory layer, ASPP, LayerNorm) triple of `mod` -> list of packed device buffers."""
+    L = _lib.lib()
+    layers = []
+    for i in range(num_layers):
+        lay, asp, cn = mod.transformer_trajectory_self_attention_layers[i], mod.conv_short_aggregate_layers[i], mod.conv_norms[i]
+        ps = _lib.AxvsCCLayerParams()
+        ps.attn = _traj_struct(lay.self_attn, keep)
+        ps.norm_w, ps.norm_b = f(lay.norm.weight), f(lay.norm.bias)
+        for k in range(3):
+            conv = getattr(asp, f"_aspp_conv{k}")
+            ps.aspp_w[k], ps.aspp_b[k] = f(conv.weight), f(conv.bias)
+        ps.aspp_proj_w = f(asp._proj_conv_bn_act.conv.weight)
+        ps.aspp_norm_w, ps.aspp_norm_b = f(asp._proj_conv_bn_act.norm.weight), f(asp._proj_conv_bn_act.norm.bias)
+        ps.conv_norm_w, ps.conv_norm_b = f(cn.weight), f(cn.bias)
+        buf = torch.empty(L.axvs_cc_layer_packed_bytes(), dtype=torch.uint8, device=dev)
+        _lib.check(L.axvs_cc_layer_pack(C.byref(ps), buf.data_ptr(), _lib.DTYPES[dt], _stream(dev)), "axvs_cc_layer_pack")
+        layers.append(buf)
+    return layers
+
+
 class CrossClipTrackingModule(nn.Module):
     def __init__(self, *, num_layers: int, num_classes: int, attn_drop: float, aspp_drop: float, kernel_sizes: List[int],
                  atrous_rates: List[int], norm_fn: str, num_clip_frames: int, mfma_dtype: Optional[str] = None):
@@ -148,21 +169,7 @@ class CrossClipTrackingModule(nn.Module):
             keep.append(tt)
             return tt.data_ptr()
 
-        layers = []
-        for i in range(self.num_layers):
-            lay, asp, cn = self.transformer_trajectory_self_attention_layers[i], self.conv_short_aggregate_layers[i], self.conv_norms[i]
-            ps = _lib.AxvsCCLayerParams()
-            ps.attn = _traj_struct(lay.self_attn, keep)
-            ps.norm_w, ps.norm_b = f(lay.norm.weight), f(lay.norm.bias)
-            for k in range(3):
-                conv = getattr(asp, f"_aspp_conv{k}")
-                ps.aspp_w[k], ps.aspp_b[k] = f(conv.weight), f(conv.bias)
-            ps.aspp_proj_w = f(asp._proj_conv_bn_act.conv.weight)
-            ps.aspp_norm_w, ps.aspp_norm_b = f(asp._proj_conv_bn_act.norm.weight), f(asp._proj_conv_bn_act.norm.bias)
-            ps.conv_norm_w, ps.conv_norm_b = f(cn.weight), f(cn.bias)
-            buf = torch.empty(L.axvs_cc_layer_packed_bytes(), dtype=torch.uint8, device=dev)
-            _lib.check(L.axvs_cc_layer_pack(C.byref(ps), buf.data_ptr(), _lib.DTYPES[dt], _stream(dev)), "axvs_cc_layer_pack")
-            layers.append(buf)
+        layers = _pack_cc_layers(self, self.num_layers, f, keep, dt, dev)
         pr = self._predictor
         K1 = pr._transformer_class_head.conv.weight.shape[0]
         hp = _lib.AxvsCCHeadParams()
@@ -222,3 +229,105 @@ class CrossClipTrackingModule(nn.Module):
                for a, b in zip(cls_all[:-1], mask_all[:-1])]
         self.last_clip_query = cur
         return {"pred_logits": cls_all[-1], "pred_masks": mask_all[-1], "aux_outputs": aux}
+
+
+class TubeLinkCrossClipHead(nn.Module):
+    """The cross-clip members of Tube-Link's `Mask2FormerVideoCCHeadTube` (TLCC = MaXTron_Tube-Link/models/video/tube_link_vis/
+    mask2former_video_cc_head.py:365-394) under their own names -- a checkpoint of the head loads with strict=False and fills
+    every parameter here -- and the cross-clip part of its forward: the layer loop (TLCC:925-946), `forward_head_clips`
+    (:761-781) and `pred_class` (:783-797).  Keyword names follow the head's constructor (:283-330).
+
+    forward(clip_query [B,Tc,Q,256] (the matched clip queries, TLCC:919), mask_features [B,T,Cm,h,w], T = Tc*frames_per_clip)
+        -> (tuple of class logits [B,Q,K+1] per layer, tuple of mask logits [B,T,Q,h,w] per layer)
+    """
+
+    def __init__(self, *, num_classes: int, feat_channels: int = 256, out_channels: int = 256, num_cc_layers: int = 6,
+                 trajectory_drop_out: float = 0.0, kernel_sizes=(3, 3, 3), atrous_rates=(1, 2, 3), drop_path_prob: float = 0.1,
+                 aspp_norm_fn: Optional[str] = "ln", mfma_dtype: Optional[str] = None):
+        super().__init__()
+        if feat_channels != 256:
+            raise NotImplementedError("axial_vs_amd: the cross-clip kernels are built for feat_channels = 256")
+        if out_channels not in (128, 256):
+            raise NotImplementedError("axial_vs_amd: mask feature channels must be 128 or 256")
+        self.num_classes, self.num_cc_layers = num_classes, num_cc_layers
+        self.kernel_sizes, self.atrous_rates = kernel_sizes, atrous_rates
+        self.transformer_decoder = nn.Module()
+        self.transformer_decoder.post_norm = nn.LayerNorm(feat_channels)
+        self.cls_embed = nn.Linear(feat_channels, num_classes + 1)
+        self.mask_embed = nn.Sequential(nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+                                        nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+                                        nn.Linear(feat_channels, out_channels))
+        self.transformer_trajectory_self_attention_layers = nn.ModuleList()
+        self.conv_short_aggregate_layers = nn.ModuleList()
+        self.conv_norms = nn.ModuleList()
+        for _ in range(num_cc_layers):
+            self.transformer_trajectory_self_attention_layers.append(
+                TrajectoryAttentionLayer(d_model=256, nhead=8, dropout=0.0, attn_drop=trajectory_drop_out, normalize_before=False))
+            self.conv_short_aggregate_layers.append(ASPP(256, 256, list(kernel_sizes), list(atrous_rates), drop_path_prob, aspp_norm_fn))
+            self.conv_norms.append(nn.LayerNorm(256))
+        self.activation_proj = nn.Linear(256, 1)
+        self.mfma_dtype = mfma_dtype
+        self._packed = None
+        self._packed_key = None
+
+    def _dtype(self) -> str:
+        from . import modules
+        return self.mfma_dtype or modules._DEFAULT_DTYPE
+
+    def _pack(self):
+        dt = self._dtype()
+        key = _param_key(self, dt)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        L = _lib.lib()
+        dev = self.activation_proj.weight.device
+        keep: list = []
+
+        def f(t):
+            tt = _dev_f32(t.detach(), "parameter")
+            keep.append(tt)
+            return tt.data_ptr()
+
+        layers = _pack_cc_layers(self, self.num_cc_layers, f, keep, dt, dev)
+        K1, Cm = self.cls_embed.weight.shape[0], self.mask_embed[4].weight.shape[0]
+        hp = _lib.AxvsTLHeadParams()
+        pn = self.transformer_decoder.post_norm
+        hp.post_norm_w, hp.post_norm_b = f(pn.weight), f(pn.bias)
+        hp.activation_proj_w, hp.activation_proj_b = f(self.activation_proj.weight), f(self.activation_proj.bias)
+        hp.cls_embed_w, hp.cls_embed_b = f(self.cls_embed.weight), f(self.cls_embed.bias)
+        for k, idx in enumerate((0, 2, 4)):
+            hp.mask_embed_w[k], hp.mask_embed_b[k] = f(self.mask_embed[idx].weight), f(self.mask_embed[idx].bias)
+        hbuf = torch.empty(L.axvs_tl_heads_packed_bytes(K1, Cm), dtype=torch.uint8, device=dev)
+        _lib.check(L.axvs_tl_heads_pack(C.byref(hp), hbuf.data_ptr(), K1, Cm, _lib.DTYPES[dt], _stream(dev)), "axvs_tl_heads_pack")
+        torch.cuda.current_stream(dev).synchronize()
+        self._packed, self._packed_key = (layers, hbuf, K1, Cm), key
+        return self._packed
+
+    def forward(self, clip_query: Tensor, mask_features: Tensor):
+        _require_eval(self)
+        cq = _dev_f32(clip_query, "clip_query")
+        mf = _dev_f32(mask_features, "mask_features")
+        B, Tc, Q, Cq = cq.shape
+        layers, hbuf, K1, Cm = self._pack()
+        if Cq != 256 or mf.dim() != 5 or mf.shape[0] != B or mf.shape[2] != Cm or mf.shape[1] % Tc:
+            raise RuntimeError(f"clip_query must be [B,Tc,Q,256] and mask_features [B,Tc*f,{Cm},h,w]; got {tuple(cq.shape)}, {tuple(mf.shape)}")
+        T, h, w = mf.shape[1], mf.shape[3], mf.shape[4]
+        L = _lib.lib()
+        dt = _lib.DTYPES[self._dtype()]
+        dev, st = cq.device, _stream(cq.device)
+        ws = _workspace(dev, max(L.axvs_cc_layer_workspace_bytes(B, Q, Tc), L.axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm)))
+        rates = (C.c_int * 3)(*[int(r) for r in self.atrous_rates])
+        cur = cq.permute(0, 2, 1, 3).contiguous()          # [B,Q,Tc,C]: the token order of 'b c t q -> b (t q) c' (TLCC:931)
+        cls_all, mask_all = [], []
+        for i in range(self.num_cc_layers):
+            nxt = torch.empty_like(cur)
+            _lib.check(L.axvs_cc_layer_fwd(cur.data_ptr(), nxt.data_ptr(), layers[i].data_ptr(), B, Q, Tc, rates, dt, ws.data_ptr(),
+                                           ws.numel(), st), "axvs_cc_layer_fwd")
+            cur = nxt
+            logits = torch.empty(B, Q, K1, dtype=torch.float32, device=dev)
+            masks = torch.empty(B, T, Q, h, w, dtype=torch.float32, device=dev)
+            _lib.check(L.axvs_tl_heads_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), hbuf.data_ptr(), B, Q, Tc,
+                                           T // Tc, h, w, K1, Cm, dt, ws.data_ptr(), ws.numel(), st), "axvs_tl_heads_fwd")
+            cls_all.append(logits)
+            mask_all.append(masks)
+        return tuple(cls_all), tuple(mask_all)

@@ -550,8 +550,56 @@ int cc_heads_fwd_t(const float* x, const float* pf, float* logits, float* masks,
   hipLaunchKernelGGL(cc_class_head_kernel, dim3(Q), dim3(256), 0, st, emb, 512, p.wa, p.ba, p.wc, p.bc, logits, B, Q, Tc, K1, void_bias);
   mark(st, "cc.class_head");
   dim3 grid((unsigned)((P + 63) / 64), B * Tc);
-  hipLaunchKernelGGL((cc_mask_einsum_kernel<BF>), grid, dim3(256), 0, st, pf, kern16, masks, B, Q, Tc, P, R, p.pix);
+  const long long TP = (long long)Tc * P;
+  const EinsumMap mp{128 * TP, P, TP, (long long)Q * TP, P, TP, Tc, 1};
+  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix);
   mark(st, "cc.mask_einsum");
+  return last_launch_status();
+}
+
+// ---------------- Tube-Link cross-clip heads ----------------
+struct TLHeadsPacked {
+  u16 *w0, *w1, *w2;                                     // mask_embed MLP [256,256], [256,256], [Cm,256]
+  float *b0, *b1, *b2, *pn_w, *pn_b, *wa, *ba, *wc, *bc;  // biases, post_norm, activation_proj, cls_embed (fp32)
+};
+TLHeadsPacked carve_tl_heads(Carver& c, int K1, int Cm) {
+  TLHeadsPacked h;
+  h.w0 = c.take<u16>(256 * 256); h.w1 = c.take<u16>(256 * 256); h.w2 = c.take<u16>((size_t)Cm * 256);
+  h.b0 = c.take<float>(256); h.b1 = c.take<float>(256); h.b2 = c.take<float>(Cm);
+  h.pn_w = c.take<float>(256); h.pn_b = c.take<float>(256);
+  h.wa = c.take<float>(256); h.ba = c.take<float>(1);
+  h.wc = c.take<float>((size_t)K1 * 256); h.bc = c.take<float>(K1);
+  return h;
+}
+
+template <bool BF>
+int tl_heads_fwd_t(const float* x, const float* mf, float* logits, float* masks, const void* packed, int B, int Q, int Tc, int fpc,
+                   int h, int w, int K1, int Cm, void* ws, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  TLHeadsPacked p = carve_tl_heads(pc, K1, Cm);
+  const long long R = (long long)B * Q * Tc, P = (long long)h * w;
+  const int T = Tc * fpc;
+  Carver wc(ws);
+  float* xn = wc.take<float>((size_t)R * 256);
+  u16* xn16 = wc.take<u16>((size_t)R * 256);
+  u16* h1 = wc.take<u16>((size_t)R * 256);
+  u16* h2 = wc.take<u16>((size_t)R * 256);
+  u16* kern16 = wc.take<u16>((size_t)R * Cm);
+  g_prof_next = 0;
+  mark(st, "begin");
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, p.pn_w, p.pn_b, xn, xn16, R, 256, 1e-5f);
+  mark(st, "tl.post_norm");
+  hipLaunchKernelGGL(tl_class_head_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, st, xn, p.wa, p.ba, p.wc, p.bc, logits, Tc, K1);
+  mark(st, "tl.class_head");
+  launch_gemm<BF>(ALoadBlocked<BF>{xn16, R, (int)R, 0, 1, 1}, p.w0, EpiBlocked16<BF>{h1, R, p.b0, 1.f, 0, 1}, (int)R, 256, 256, st);
+  launch_gemm<BF>(ALoadBlocked<BF>{h1, R, (int)R, 0, 1, 1}, p.w1, EpiBlocked16<BF>{h2, R, p.b1, 1.f, 0, 1}, (int)R, 256, 256, st);
+  launch_gemm<BF>(ALoadBlocked<BF>{h2, R, (int)R, 0, 1, 1}, p.w2, EpiBlocked16<BF>{kern16, R, p.b2, 1.f, 0, 0}, (int)R, Cm, 256, st);
+  mark(st, "tl.mask_embed");
+  dim3 grid((unsigned)((P + 63) / 64), B * T);
+  const EinsumMap mp{(long long)T * Cm * P, (long long)Cm * P, P, (long long)T * Q * P, (long long)Q * P, P, T, fpc};
+  if (Cm == 128) hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr);
+  else hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr);
+  mark(st, "tl.mask_einsum");
   return last_launch_status();
 }
 
@@ -821,6 +869,67 @@ int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, f
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == AXVS_BF16) return cc_heads_fwd_t<true>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
   if (dtype == AXVS_F16) return cc_heads_fwd_t<false>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+size_t axvs_tl_heads_packed_bytes(int K1, int Cm) {
+  Carver c(nullptr);
+  carve_tl_heads(c, K1, Cm);
+  return c.off;
+}
+
+int axvs_tl_heads_pack(const AxvsTLHeadParams* p, void* packed, int K1, int Cm, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (K1 <= 0 || (Cm != 128 && Cm != 256)) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  TLHeadsPacked h = carve_tl_heads(c, K1, Cm);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PackDim n256{256, 256, 0, 0, 0}, ncm{Cm, Cm, 0, 0, 0};
+  if (dtype == AXVS_BF16) {
+    pack_w<true>(p->mask_embed_w[0], h.w0, n256, n256, st);
+    pack_w<true>(p->mask_embed_w[1], h.w1, n256, n256, st);
+    pack_w<true>(p->mask_embed_w[2], h.w2, ncm, n256, st);
+  } else {
+    pack_w<false>(p->mask_embed_w[0], h.w0, n256, n256, st);
+    pack_w<false>(p->mask_embed_w[1], h.w1, n256, n256, st);
+    pack_w<false>(p->mask_embed_w[2], h.w2, ncm, n256, st);
+  }
+  copy_f32(p->mask_embed_b[0], h.b0, 256, st);
+  copy_f32(p->mask_embed_b[1], h.b1, 256, st);
+  copy_f32(p->mask_embed_b[2], h.b2, Cm, st);
+  copy_f32(p->post_norm_w, h.pn_w, 256, st);
+  copy_f32(p->post_norm_b, h.pn_b, 256, st);
+  copy_f32(p->activation_proj_w, h.wa, 256, st);
+  copy_f32(p->activation_proj_b, h.ba, 1, st);
+  copy_f32(p->cls_embed_w, h.wc, (size_t)K1 * 256, st);
+  copy_f32(p->cls_embed_b, h.bc, K1, st);
+  return last_launch_status();
+}
+
+size_t axvs_tl_heads_workspace_bytes(int B, int Q, int Tc, int Cm) {
+  Carver c(nullptr);
+  const long long R = (long long)B * Q * Tc;
+  c.take<float>((size_t)R * 256);
+  c.take<u16>((size_t)R * 256);
+  c.take<u16>((size_t)R * 256);
+  c.take<u16>((size_t)R * 256);
+  c.take<u16>((size_t)R * Cm);
+  return c.off;
+}
+
+int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float* cls_logits, float* mask_logits,
+                      const void* packed, int B, int Q, int Tc, int frames_per_clip, int h, int w, int K1, int Cm, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!clip_query || !mask_feature || !cls_logits || !mask_logits || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (Cm != 128 && Cm != 256) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
+  if (((long long)h * w) % 4) return fail(AXVS_ERR_ARG, "h*w must be a multiple of 4");
+  if (Tc > 64) return fail(AXVS_ERR_ARG, "more than 64 clips are not supported by the class head yet");
+  if (workspace_bytes < axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return tl_heads_fwd_t<true>(clip_query, mask_feature, cls_logits, mask_logits, packed, B, Q, Tc, frames_per_clip, h, w, K1, Cm, workspace, st);
+  if (dtype == AXVS_F16) return tl_heads_fwd_t<false>(clip_query, mask_feature, cls_logits, mask_logits, packed, B, Q, Tc, frames_per_clip, h, w, K1, Cm, workspace, st);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
 }
 

@@ -94,25 +94,34 @@ __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restr
   }
 }
 
-// Mask logits (CC/...:61-69): for clip (b, t):  out[b, q, t*P + p] = bn( sum_c kern[(b q t), c] * pf[b, c, t*P + p] ),
-// P = V*H*W pixels of the clip, 128 channels, bn = eval BatchNorm(1) as a scalar affine.
-// Workgroup = 64 pixels of one clip (4 waves x 16 pixels) x all queries; pixels are the MFMA rows (A operand, transposed
+// Mask logits as a strided batched contraction over channels, shared by the two heads:
+//   out[b, q, unit u, p] = mul * sum_c kern[(b q clip(u)), c] * feat[b, u, c, p] + add,        p = 0..P-1 pixels of a unit
+// Video-kMaX (CC/...:61-69): unit = clip, P = V*H*W, feat = panoptic_features [B,CK,(Tc P)], out [B,Q,(Tc P)], clip(u) = u,
+//   mul/add = eval BatchNorm(1).   Tube-Link (TLCC:774-778): unit = frame, P = h*w, feat = mask_feature [B,T,CK,P],
+//   out [B,T,Q,P], clip(u) = u / frames_per_clip, mul/add = 1/0.
+// Workgroup = 64 pixels of one unit (4 waves x 16 pixels) x all queries; pixels are the MFMA rows (A operand, transposed
 // into LDS from the channels-first fp32 feature), queries the columns, so a lane stores 4 consecutive pixels of one query.
-template <bool BF>
-__global__ __launch_bounds__(256) void cc_mask_einsum_kernel(const float* __restrict__ pf, const u16* __restrict__ kern16,
-                                                             float* __restrict__ out, int Bv, int Q, int Tc, long long P,
-                                                             long long Rk, const float* __restrict__ pix_bn /* {mul, add} */) {
-  constexpr int CK = 128;
-  __shared__ __attribute__((aligned(16))) u16 spx[4 * 64 * 32];      // [kb][pixel][32]
+struct EinsumMap {
+  long long f_b, f_u, f_c;     // feature strides (elements): batch, unit, channel
+  long long o_b, o_u, o_q;     // output strides: batch, unit, query
+  int units, upc;              // units per batch entry; units per clip
+};
+
+template <bool BF, int CK>
+__global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restrict__ pf, const u16* __restrict__ kern16,
+                                                          float* __restrict__ out, int Q, int Tc, long long P, long long Rk,
+                                                          EinsumMap mp, const float* __restrict__ pix_bn /* {mul, add} or null */) {
+  constexpr int KB = CK / 32;
+  __shared__ __attribute__((aligned(16))) u16 spx[KB * 64 * 32];      // [kb][pixel][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
-  const int bt = blockIdx.y, b = bt / Tc, t = bt - b * Tc;
+  const int bu = blockIdx.y, b = bu / mp.units, u = bu - b * mp.units, clip = u / mp.upc;
   const long long p0 = (long long)blockIdx.x * 64;
-  const long long TP = (long long)Tc * P;
-  const float bn_mul = pix_bn[0], bn_add = pix_bn[1];
+  const float bn_mul = pix_bn ? pix_bn[0] : 1.f, bn_add = pix_bn ? pix_bn[1] : 0.f;
   // stage: thread -> (channel c, 32-pixel half); 8 float4 loads of 128 contiguous bytes
-  {
-    const int c = tid >> 1, half = tid & 1;
-    const float* src = pf + ((long long)b * CK + c) * TP + (long long)t * P + p0 + half * 32;
+#pragma unroll
+  for (int cp = 0; cp < CK / 128; ++cp) {
+    const int c = cp * 128 + (tid >> 1), half = tid & 1;
+    const float* src = pf + b * mp.f_b + u * mp.f_u + c * mp.f_c + p0 + half * 32;
     float4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -132,25 +141,58 @@ __global__ __launch_bounds__(256) void cc_mask_einsum_kernel(const float* __rest
     }
   }
   __syncthreads();
-  u16x8 af[4];
+  u16x8 af[KB];
 #pragma unroll
-  for (int kb = 0; kb < 4; ++kb) {
+  for (int kb = 0; kb < KB; ++kb) {
     const int px = wave * 16 + fi;
     af[kb] = *reinterpret_cast<const u16x8*>(spx + (kb * 64 + px) * 32 + swz_chunk(px, fg) * 8);
   }
   for (int qt = 0; qt * 16 < Q; ++qt) {
     const int q = min(qt * 16 + fi, Q - 1);
-    const long long r = ((long long)b * Q + q) * Tc + t;
+    const long long r = ((long long)b * Q + q) * Tc + clip;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int kb = 0; kb < KB; ++kb) {
       const u16x8 bf = *reinterpret_cast<const u16x8*>(kern16 + ((long long)kb * Rk + r) * 32 + fg * 8);
       acc = H16<BF>::mfma(af[kb], bf, acc);          // D[pixel][query]
     }
     const long long p = p0 + wave * 16 + fg * 4;
     if (qt * 16 + fi < Q && p + 3 < P)
-      *reinterpret_cast<float4*>(out + ((long long)b * Q + q) * TP + (long long)t * P + p) =
+      *reinterpret_cast<float4*>(out + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) =
           float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
+  }
+}
+
+// Tube-Link class head (TLCC:783-797), one workgroup (256 threads = channels) per (b, q):
+//   a_t = softmax_t(w_a . x[b,q,t,:] + b_a);  pooled = sum_t a_t x[b,q,t,:];  logits = W_c pooled + b_c.
+// x: fp32 [(b q t)][256] (post-normed); out: fp32 [(b q)][K1].
+__global__ __launch_bounds__(256) void tl_class_head_kernel(const float* __restrict__ x, const float* __restrict__ wa,
+                                                            const float* __restrict__ ba, const float* __restrict__ wc,
+                                                            const float* __restrict__ bc, float* __restrict__ out, int Tc, int K1) {
+  constexpr int C = 256, MAXT = 64;
+  __shared__ float logit[MAXT], pooled[C], red[4];
+  const int bq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (long long)bq * Tc * C;
+  const float wac = wa[tid];
+  for (int t = 0; t < Tc; ++t) {
+    const float s = wave_sum(xr[t * C + tid] * wac);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) logit[t] = red[0] + red[1] + red[2] + red[3] + ba[0];
+    __syncthreads();
+  }
+  float mx = -INFINITY;
+  for (int t = 0; t < Tc; ++t) mx = fmaxf(mx, logit[t]);
+  float sum = 0.f;
+  for (int t = 0; t < Tc; ++t) sum += __expf(logit[t] - mx);
+  float p = 0.f;
+  for (int t = 0; t < Tc; ++t) p += __expf(logit[t] - mx) / sum * xr[t * C + tid];
+  pooled[tid] = p;
+  __syncthreads();
+  for (int k = tid; k < K1; k += 256) {
+    float acc = bc[k];
+    for (int c = 0; c < C; ++c) acc += wc[(long long)k * C + c] * pooled[c];
+    out[(long long)bq * K1 + k] = acc;
   }
 }
 

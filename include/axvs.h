@@ -145,6 +145,26 @@ int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, f
                       const void* packed, int B, int Q, int Tc, int V, int H, int W, int K1, int dtype, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* ---- Tube-Link flavour of the cross-clip heads.  The cross-clip layers themselves are axvs_cc_layer_*:
+ *      TL/models/video/tube_link_vis/mask2former_video_cc_head.py:927-946 is the same computation as CC/...:286-297.
+ *      Replaces forward_head_clips (:761-781) + pred_class (:783-797) for ONE decoder layer's output. */
+typedef struct AxvsTLHeadParams {
+  const float *post_norm_w, *post_norm_b;               /* transformer_decoder.post_norm: LayerNorm(256), eps 1e-5 (:767) */
+  const float *activation_proj_w, *activation_proj_b;   /* Linear(256,1) (:394, :791)                                      */
+  const float *cls_embed_w, *cls_embed_b;               /* Linear(256,K1) (:365, :796)                                     */
+  const float* mask_embed_w[3];                         /* Linear(256,256), Linear(256,256), Linear(256,Cm) (:368-371)     */
+  const float* mask_embed_b[3];
+} AxvsTLHeadParams;
+
+size_t axvs_tl_heads_packed_bytes(int K1, int Cm);
+int axvs_tl_heads_pack(const AxvsTLHeadParams* p, void* packed, int K1, int Cm, int dtype, void* stream);
+size_t axvs_tl_heads_workspace_bytes(int B, int Q, int Tc, int Cm);
+/* clip_query fp32 [B,Q,Tc,256] (a cross-clip layer's output, axvs_cc_layer_fwd layout); mask_feature fp32 [B,Tc*fpc,Cm,h,w];
+ * cls_logits fp32 [B,Q,K1]; mask_logits fp32 [B,Tc*fpc,Q,h,w].  Cm in {128,256}; h*w must be a multiple of 4. */
+int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float* cls_logits, float* mask_logits,
+                      const void* packed, int B, int Q, int Tc, int frames_per_clip, int h, int w, int K1, int Cm, int dtype,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,

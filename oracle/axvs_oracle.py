@@ -330,6 +330,48 @@ def cross_clip_module(clip_query: Tensor, panoptic_features: Tensor, w: Weights,
 
 
 # --------------------------------------------------------------------------------------
+# Tube-Link flavour of the cross-clip module: the same trajectory-attention / ASPP core, different heads.
+# TLCC = MaXTron_Tube-Link/models/video/tube_link_vis/mask2former_video_cc_head.py
+# --------------------------------------------------------------------------------------
+def tl_pred_class(x: Tensor, w: Weights) -> Tensor:
+    """TLCC:783-797 for one decoder layer.  x [B,Tc,Q,C] (already post-normed) -> class logits [B,Q,K+1]:
+    Linear(C,1) activation, softmax over the clips, weighted sum of the queries over clips, Linear(C,K+1)."""
+    act = torch.softmax(_linear(x, w, "activation_proj"), dim=1)     # [B,Tc,Q,1], softmax over clips
+    pooled = (x * act).sum(dim=1)                                      # [B,Q,C]
+    return _linear(pooled, w, "cls_embed")
+
+
+def tl_forward_head_clips(x: Tensor, mask_feature: Tensor, w: Weights) -> Tuple[Tensor, Tensor]:
+    """TLCC:761-781 for one decoder layer.  x [B,Q,Tc,C] (output of a cross-clip layer), mask_feature [B,T,Cm,h,w] with
+    T = Tc * frames_per_clip  ->  (class logits [B,Q,K+1], mask logits [B,T,Q,h,w])."""
+    B, Q, Tc, C = x.shape
+    T = mask_feature.shape[1]
+    fpc = T // Tc
+    xn = _layer_norm(x, w, "transformer_decoder.post_norm").permute(0, 2, 1, 3)        # [B,Tc,Q,C]   :768-769
+    cls = tl_pred_class(xn, w)
+    me = _linear(torch.relu(_linear(torch.relu(_linear(xn, w, "mask_embed.0")), w, "mask_embed.2")), w, "mask_embed.4")
+    masks = []
+    for c in range(Tc):                                                                 # :774-778
+        mf = mask_feature[:, fpc * c:fpc * (c + 1)]                                     # [B,fpc,Cm,h,w]
+        masks.append(torch.einsum("bqc,btchw->btqhw", me[:, c], mf))
+    return cls, torch.cat(masks, dim=1)
+
+
+def tl_cross_clip_head(clip_query: Tensor, mask_features: Tensor, w: Weights, num_layers: int, kernel_sizes=(3, 3, 3),
+                       atrous_rates=(1, 2, 3), norm_fn: str = "ln", heads: int = 8):
+    """TLCC:925-950: clip_query [B,Tc,Q,C] (matched clip queries), mask_features [B,T,Cm,h,w] ->
+    (list of class logits [B,Q,K+1] per layer, list of mask logits [B,T,Q,h,w] per layer)."""
+    x = clip_query.permute(0, 2, 1, 3)                                 # carried here as [B,Q,Tc,C] (same tokens as 'b c t q')
+    cls_all, mask_all = [], []
+    for i in range(num_layers):
+        x = cc_layer(x, w, i, kernel_sizes, atrous_rates, norm_fn, heads)
+        c, m = tl_forward_head_clips(x, mask_features, w)
+        cls_all.append(c)
+        mask_all.append(m)
+    return cls_all, mask_all
+
+
+# --------------------------------------------------------------------------------------
 # synthetic inputs / weights shared by tests, smoke and bench (SURVEY.md 8d recipe)
 # --------------------------------------------------------------------------------------
 def axial_layer_param_shapes(C: int, d_ffn: int) -> Dict[str, Tuple[int, ...]]:

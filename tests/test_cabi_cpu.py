@@ -108,3 +108,18 @@ def test_cross_clip_state_dict_keys_match_reference(name):
     sd = mod.state_dict()
     sd.update(orc.random_weights(m["shapes"], 1))
     mod.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("name", ["g6_tl_cc_head_Tc3_Q16_f2_L2"])
+def test_tube_link_head_state_dict_keys_match_reference(name):
+    """TubeLinkCrossClipHead exposes the cross-clip members of the reference head under the reference's key names."""
+    import axial_vs_amd as ax
+    import axvs_oracle as orc
+    z, m = load(name)
+    mod = ax.TubeLinkCrossClipHead(num_classes=m["num_classes"], out_channels=m["Cm"], num_cc_layers=m["layers"])
+    own = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
+    assert set(own.keys()) == set(m["shapes"].keys())
+    assert all(own[k] == tuple(m["shapes"][k]) for k in own)
+    mod.load_state_dict(orc.random_weights(m["shapes"], 1), strict=True)
+    with pytest.raises(RuntimeError):
+        mod.eval()(torch.zeros(1, 3, 16, 256), torch.zeros(1, 6, m["Cm"], 8, 12))      # CPU tensors: no fallback

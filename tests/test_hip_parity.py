@@ -275,3 +275,30 @@ def test_cross_clip_module_golden(name):
         e_m = rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]))
         print(f"{name}: masks {e_m:.2e}")
         assert e_m < TOL_F16
+
+
+@pytest.mark.parametrize("name", ["g6_tl_cc_head_Tc3_Q16_f2_L2", "g6_tl_cc_head_Tc2_Q20_f1_L1", "g6_tl_cc_head_Tc4_Q100_f2_L4"])
+def test_tube_link_cross_clip_head_golden(name):
+    """Tube-Link flavour of the cross-clip module: layer loop + forward_head_clips + pred_class against the
+    reference's outputs (Cm = 256 and 128, 1 and 2 frames per clip, Q = 100 at a 48 x 80 mask feature)."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w = weights(z, m)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Tc"], m["Q"], 256, generator=g)
+    mf = torch.nn.functional.normalize(torch.randn(m["B"], m["Tc"] * m["fpc"], m["Cm"], m["h"], m["w"], generator=g), dim=2)
+    mod = ax.TubeLinkCrossClipHead(num_classes=m["num_classes"], out_channels=m["Cm"], num_cc_layers=m["layers"]).eval()
+    mod.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    cls, masks = mod(dev(cq), dev(mf))
+    assert len(cls) == m["layers"] and masks[-1].shape == (m["B"], m["Tc"] * m["fpc"], m["Q"], m["h"], m["w"])
+    e_c, e_c0 = rel_err(cls[-1].cpu(), t(z["cls_last"])), rel_err(cls[0].cpu(), t(z["cls_first"]))
+    print(f"{name}: cls {e_c:.2e} / first layer {e_c0:.2e}")
+    assert e_c < TOL_F16 and e_c0 < TOL_F16
+    np.testing.assert_allclose(checks(masks[-1].cpu())[1:], z["masks_checks"][1:], rtol=5e-3)
+    if "masks_first" in z:
+        e_m, e_m0 = rel_err(masks[-1].cpu(), t(z["masks_last"])), rel_err(masks[0].cpu(), t(z["masks_first"]))
+    else:
+        e_m, e_m0 = rel_err(masks[-1].cpu()[:, :, ::5, ::6, ::8], t(z["masks_last"])), 0.0
+    print(f"{name}: masks {e_m:.2e} / first layer {e_m0:.2e}")
+    assert e_m < TOL_F16 and e_m0 < TOL_F16

@@ -96,3 +96,30 @@ def test_cc_module(name):
         assert rel_err(out["aux_outputs"][0]["pred_masks"], t(z["aux0_masks"])) < 5e-5
     else:
         assert rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"])) < 5e-5
+
+
+TL_HEAD = ["g6_tl_cc_head_Tc3_Q16_f2_L2", "g6_tl_cc_head_Tc2_Q20_f1_L1", "g6_tl_cc_head_Tc4_Q100_f2_L4"]
+
+
+def tl_inputs(m):
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Tc"], m["Q"], 256, generator=g)
+    mf = torch.nn.functional.normalize(torch.randn(m["B"], m["Tc"] * m["fpc"], m["Cm"], m["h"], m["w"], generator=g), dim=2)
+    return cq, mf
+
+
+@pytest.mark.parametrize("name", TL_HEAD)
+def test_tl_cross_clip_head(name):
+    """Tube-Link flavour of the cross-clip module against the reference's own layers + head methods."""
+    z, m = load(name)
+    w = weights(z, m)
+    cq, mf = tl_inputs(m)
+    cls, masks = orc.tl_cross_clip_head(cq, mf, w, m["layers"])
+    assert rel_err(cls[-1], t(z["cls_last"])) < 5e-5
+    assert rel_err(cls[0], t(z["cls_first"])) < 5e-5
+    np.testing.assert_allclose(checks(masks[-1])[1:], z["masks_checks"][1:], rtol=1e-4)
+    if "masks_first" in z:
+        assert rel_err(masks[-1], t(z["masks_last"])) < 5e-5
+        assert rel_err(masks[0], t(z["masks_first"])) < 5e-5
+    else:
+        assert rel_err(masks[-1][:, :, ::5, ::6, ::8], t(z["masks_last"])) < 5e-5
