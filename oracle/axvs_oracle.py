@@ -372,6 +372,63 @@ def tl_cross_clip_head(clip_query: Tensor, mask_features: Tensor, w: Weights, nu
 
 
 # --------------------------------------------------------------------------------------
+# Multi-scale deformable attention.  OPS = MaXTron_Video-kMaX/maxtron_deeplab/modeling/
+# within_clip_tracking_module/ops
+# --------------------------------------------------------------------------------------
+def msda_core(value: Tensor, spatial_shapes, sampling_locations: Tensor, attention_weights: Tensor) -> Tensor:
+    """OPS/functions/ms_deform_attn_func.py:55-77 (and the CUDA op OPS/src/cuda/ms_deform_attn_im2col_cuda.cuh, which
+    samples at (loc*size - 0.5) with zero padding) restated with explicit bilinear gathers -- no grid_sample.
+    value [N,S,M,D]; spatial_shapes [(H,W)]*L; sampling_locations [N,Lq,M,L,P,2] (x,y in [0,1]); attention_weights
+    [N,Lq,M,L,P] -> [N,Lq,M*D]."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    out = value.new_zeros(N, Lq, M, D)
+    start = 0
+    n_idx = torch.arange(N).view(N, 1, 1, 1).expand(N, Lq, M, P)
+    m_idx = torch.arange(M).view(1, 1, M, 1).expand(N, Lq, M, P)
+    for lvl, (H, W) in enumerate(spatial_shapes):
+        H, W = int(H), int(W)
+        loc = sampling_locations[:, :, :, lvl]                        # [N,Lq,M,P,2]
+        x = loc[..., 0] * W - 0.5
+        y = loc[..., 1] * H - 0.5
+        x0, y0 = torch.floor(x), torch.floor(y)
+        fx, fy = x - x0, y - y0
+        aw = attention_weights[:, :, :, lvl]                          # [N,Lq,M,P]
+        for dy, wy in ((0, 1 - fy), (1, fy)):
+            for dx, wx in ((0, 1 - fx), (1, fx)):
+                xi, yi = (x0 + dx).long(), (y0 + dy).long()
+                ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+                idx = start + yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)
+                v = value[n_idx, idx, m_idx]                          # [N,Lq,M,P,D]
+                out = out + (v * (wy * wx * aw * ok.to(value.dtype)).unsqueeze(-1)).sum(3)
+        start += H * W
+    return out.reshape(N, Lq, M * D)
+
+
+def msda_module(query: Tensor, reference_points: Tensor, input_flatten: Tensor, spatial_shapes, w: Weights, n_heads: int,
+                n_levels: int, n_points: int, input_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """MSDeformAttn.forward, OPS/modules/ms_deform_attn.py:81-125 (level_start_index follows from spatial_shapes)."""
+    N, Lq, C = query.shape
+    S = input_flatten.shape[1]
+    value = _linear(input_flatten, w, "value_proj")
+    if input_padding_mask is not None:
+        value = value.masked_fill(input_padding_mask[..., None], 0.0)
+    value = value.reshape(N, S, n_heads, C // n_heads)
+    off = _linear(query, w, "sampling_offsets").reshape(N, Lq, n_heads, n_levels, n_points, 2)
+    aw = torch.softmax(_linear(query, w, "attention_weights").reshape(N, Lq, n_heads, n_levels * n_points), -1)
+    aw = aw.reshape(N, Lq, n_heads, n_levels, n_points)
+    shp = torch.as_tensor([[int(h), int(ww)] for h, ww in spatial_shapes], dtype=query.dtype)
+    if reference_points.shape[-1] == 2:
+        normalizer = torch.stack([shp[:, 1], shp[:, 0]], -1)          # (W, H) per level
+        loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    elif reference_points.shape[-1] == 4:
+        loc = reference_points[:, :, None, :, None, :2] + off / n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+    else:
+        raise ValueError("Last dim of reference_points must be 2 or 4")
+    return _linear(msda_core(value, spatial_shapes, loc, aw), w, "output_proj")
+
+
+# --------------------------------------------------------------------------------------
 # synthetic inputs / weights shared by tests, smoke and bench (SURVEY.md 8d recipe)
 # --------------------------------------------------------------------------------------
 def axial_layer_param_shapes(C: int, d_ffn: int) -> Dict[str, Tuple[int, ...]]:

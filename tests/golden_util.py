@@ -13,7 +13,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(bytes(z["meta"]).decode())
-    meta["shapes"] = {k: tuple(v) for k, v in meta["shapes"].items()}
+    if isinstance(meta.get("shapes"), dict):        # parameter shape table (G7 fixtures keep spatial shapes under this key)
+        meta["shapes"] = {k: tuple(v) for k, v in meta["shapes"].items()}
     return z, meta
 
 
@@ -59,3 +60,46 @@ def axial_inputs(meta):
 AXIAL = ["g2_axial_B1_T2_C128_H32_W32", "g2_axial_B2_T3_C64_H5_W7", "g2_axial_B1_T5_C64_H6_W4",
          "g2_axial_B1_T1_C64_H4_W5", "g2_axial_B1_T4_C256_H64_W64"]
 TRAJ = ["g1_traj_S3_T2_L7_C64", "g1_traj_S2_T5_L6_C64", "g1_traj_S2_T1_L9_C64", "g1_traj_S4_T4_L16_C256"]
+
+
+MSDA_CORE = ["g7_msda_core_N1_M2_D2_Lq2_L2_P2", "g7_msda_core_N2_M8_D32_Lq50_L3_P4", "g7_msda_core_N1_M4_D30_Lq33_L2_P3"]
+MSDA_MODULE = ["g7_msda_module_N2_C256_L3_S252", "g7_msda_module_N1_C64_L2_S39", "g7_msda_module_N4_C256_L3_S5376"]
+
+
+def msda_core_inputs(m):
+    """The reference test's input recipe (ops/test.py:36-41), seeded; `spread` pushes locations outside [0,1]."""
+    g = torch.Generator().manual_seed(m["seed"])
+    shapes, N, M, D, Lq, P, spread = m["shapes"], m["N"], m["M"], m["D"], m["Lq"], m["P"], m["spread"]
+    L, S = len(shapes), sum(h * w for h, w in shapes)
+    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * (1 + 2 * spread) - spread
+    aw = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    aw = aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    return value, loc, aw
+
+
+def msda_module_case(z, m):
+    """weights + inputs of a G7b fixture: (state dict, query, reference_points, src, padding mask or None)."""
+    import axvs_oracle as orc
+    w = orc.random_weights({k: tuple(v) for k, v in m["wshapes"].items()}, m["seed"])
+    for k in z.files:
+        if k.startswith("w."):
+            w[k[2:]] = torch.from_numpy(z[k])
+    shapes, N, C = m["shapes"], m["N"], m["C"]
+    L, S = len(shapes), sum(h * ww for h, ww in shapes)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    for k in ("sampling_offsets.weight", "attention_weights.weight", "attention_weights.bias"):   # the generator's draw order
+        torch.rand(w[k].shape, generator=g)
+    src = torch.randn(N, S, C, generator=g)
+    pos = torch.randn(N, S, C, generator=g) * 0.5
+    refs = []
+    for (h, ww) in shapes:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, ww - 0.5, ww) / ww, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(N, S, L, 2).contiguous()
+    pm = None
+    if m["mask"]:
+        pm = torch.zeros(N, S, dtype=torch.bool)
+        pm[0, 5:40] = True
+        pm[1, -7:] = True
+    return w, src + pos, ref, src, pm

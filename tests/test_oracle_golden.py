@@ -123,3 +123,30 @@ def test_tl_cross_clip_head(name):
         assert rel_err(masks[0], t(z["masks_first"])) < 5e-5
     else:
         assert rel_err(masks[-1][:, :, ::5, ::6, ::8], t(z["masks_last"])) < 5e-5
+
+
+from golden_util import MSDA_CORE, MSDA_MODULE, msda_core_inputs, msda_module_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", MSDA_CORE)
+def test_msda_core(name):
+    """Explicit-bilinear restatement vs the reference's ms_deform_attn_core_pytorch (first case = the reference's own
+    test configuration, ops/test.py:24-28), fp32 and fp64."""
+    z, m = load(name)
+    value, loc, aw = msda_core_inputs(m)
+    out = orc.msda_core(value, m["shapes"], loc, aw)
+    assert rel_err(out, t(z["out"])) < TOL
+    out64 = orc.msda_core(value.double(), m["shapes"], loc.double(), aw.double())
+    assert rel_err(out64, torch.from_numpy(z["out64"])) < 1e-12
+
+
+@pytest.mark.parametrize("name", MSDA_MODULE)
+def test_msda_module(name):
+    z, m = load(name)
+    w, query, ref, src, pm = msda_module_case(z, m)
+    assert abs(sum(v.double().sum().item() for v in w.values()) - float(z["wsum"])) < 1e-6 * max(1.0, abs(float(z["wsum"])))
+    out = orc.msda_module(query, ref, src, m["shapes"], w, m["M"], len(m["shapes"]), m["P"], pm)
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
+    ref_out = t(z["out"])
+    got = out if ref_out.shape == out.shape else out[:, ::29, ::3]
+    assert rel_err(got, ref_out) < 5e-5
