@@ -51,6 +51,11 @@ class AxvsTLHeadParams(C.Structure):
                                    "cls_embed_b")] + [("mask_embed_w", _fp * 3), ("mask_embed_b", _fp * 3)]
 
 
+class AxvsMsdaParams(C.Structure):
+    _fields_ = [(n, _fp) for n in ("value_proj_w", "value_proj_b", "sampling_offsets_w", "sampling_offsets_b",
+                                   "attention_weights_w", "attention_weights_b", "output_proj_w", "output_proj_b")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/axvs.h
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
@@ -77,6 +82,11 @@ SIGNATURES = {
     "axvs_cc_heads_pack": (C.c_int, [C.POINTER(AxvsCCHeadParams), _fp, C.c_int, C.c_int, _fp]),
     "axvs_cc_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "axvs_cc_heads_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_msda_packed_bytes": (C.c_size_t, [C.c_int] * 4),
+    "axvs_msda_pack": (C.c_int, [C.POINTER(AxvsMsdaParams), _fp] + [C.c_int] * 5 + [_fp]),
+    "axvs_msda_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "axvs_msda_fwd": (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_msda_core_fwd": (C.c_int, [_fp, C.POINTER(C.c_int), _fp, _fp, _fp] + [C.c_int] * 7 + [_fp]),
     "axvs_tl_heads_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_tl_heads_pack": (C.c_int, [C.POINTER(AxvsTLHeadParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "axvs_tl_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

@@ -9,6 +9,7 @@
 #include "../../include/axvs.h"
 #include "axvs_attn.h"
 #include "axvs_cc.h"
+#include "axvs_msda.h"
 #include "axvs_common.h"
 #include "axvs_fused.h"
 #include "axvs_gemm.h"
@@ -116,6 +117,12 @@ template <bool BF>
 void pack_w(const float* W, u16* out, PackDim nd, PackDim kd, hipStream_t st, int n_off = 0, int n_total = 0) {
   long long total = (long long)nd.padded * kd.padded;
   hipLaunchKernelGGL((pack_weight_kernel<BF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, nd, kd, n_off,
+                     n_total ? n_total : nd.padded);
+}
+template <bool BF>
+void pack_w3(const float* W, u16* out, PackDim nd, PackDim kd, hipStream_t st, int n_off = 0, int n_total = 0) {   // split precision
+  long long total = (long long)nd.padded * kd.padded;
+  hipLaunchKernelGGL((pack_weight_split3_kernel<BF>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, nd, kd, n_off,
                      n_total ? n_total : nd.padded);
 }
 void pack_b(const float* b, float* out, PackDim nd, hipStream_t st) {
@@ -603,6 +610,69 @@ int tl_heads_fwd_t(const float* x, const float* mf, float* logits, float* masks,
   return last_launch_status();
 }
 
+// ---------------- multi-scale deformable attention ----------------
+struct MsdaPacked {
+  u16 *wv, *wq, *wo;            // value_proj [Cp,C] (head blocks), sampling_offsets|attention_weights [3MLP,C], output_proj [C,Cp]
+  float *bv, *bq, *bo;
+};
+MsdaPacked carve_msda(Carver& c, int C, int heads, int L, int P) {
+  const size_t Cp = (size_t)heads * 32, nq = (size_t)3 * heads * L * P;
+  MsdaPacked m;
+  m.wv = c.take<u16>(3 * Cp * C);          // split precision: (hi | lo | hi) along K
+  m.wq = c.take<u16>(3 * nq * C);
+  m.wo = c.take<u16>(3 * (size_t)C * Cp);
+  m.bv = c.take<float>(Cp);
+  m.bq = c.take<float>(nq);
+  m.bo = c.take<float>(C);
+  return m;
+}
+
+int msda_levels(const int* shapes, int L, int S, MsdaLevels* lv) {
+  if (L <= 0 || L > kMsdaMaxLevels) return fail(AXVS_ERR_ARG, "n_levels=%d must be in 1..%d", L, kMsdaMaxLevels);
+  long long start = 0;
+  lv->L = L;
+  for (int l = 0; l < L; ++l) {
+    if (shapes[2 * l] <= 0 || shapes[2 * l + 1] <= 0) return fail(AXVS_ERR_ARG, "empty level %d", l);
+    lv->H[l] = shapes[2 * l];
+    lv->W[l] = shapes[2 * l + 1];
+    lv->start[l] = (int)start;
+    start += (long long)shapes[2 * l] * shapes[2 * l + 1];
+  }
+  if (start != S) return fail(AXVS_ERR_ARG, "spatial shapes cover %lld tokens, input has %d", start, S);   // modules/ms_deform_attn.py:96
+  return AXVS_OK;
+}
+
+template <bool BF>
+int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* input, const unsigned char* mask, const MsdaLevels& lv,
+               float* out, const void* packed, int N, int Lq, int S, int C, int heads, int P, void* ws, hipStream_t st) {
+  const int L = lv.L, Cp = heads * 32, nq = 3 * heads * L * P;
+  Carver pc(const_cast<void*>(packed));
+  MsdaPacked p = carve_msda(pc, C, heads, L, P);
+  const long long Rv = (long long)N * S, Rq = (long long)N * Lq;
+  Carver wc(ws);
+  u16* value16 = wc.take<u16>((size_t)Rv * Cp);
+  float* qproj = wc.take<float>((size_t)Rq * nq);
+  u16* o16 = wc.take<u16>(2 * (size_t)Rq * Cp);
+  g_prof_next = 0;
+  mark(st, "begin");
+  // value_proj and output_proj feed the module output directly (no residual / norm inside the module): split precision
+  EpiBlocked16<BF> ev{value16, Rv, p.bv, 1.f, 0, 0};
+  ev.zero_rows = mask;
+  launch_gemm<BF>(ALoadRowsF32Split3<BF>{input, (int)Rv, C}, p.wv, ev, (int)Rv, Cp, 3 * C, st);
+  mark(st, "msda.value_proj");
+  launch_gemm<BF>(ALoadRowsF32Split3<BF>{query, (int)Rq, C}, p.wq, EpiRowsF32{qproj, nullptr, p.bq, identity_map(Rq), nq, 1.f}, (int)Rq, nq,
+                  3 * C, st);
+  mark(st, "msda.offsets+weights");
+  const long long groups = Rq * heads;
+  hipLaunchKernelGGL((msda_gather_kernel<BF>), dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, st, value16, qproj, refp, ref_dim, lv,
+                     o16, N, S, Lq, heads, P);
+  mark(st, "msda.gather");
+  launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, nullptr, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
+                  C, 3 * Cp, st);
+  mark(st, "msda.output_proj");
+  return last_launch_status();
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -931,6 +1001,80 @@ int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float*
   if (dtype == AXVS_BF16) return tl_heads_fwd_t<true>(clip_query, mask_feature, cls_logits, mask_logits, packed, B, Q, Tc, frames_per_clip, h, w, K1, Cm, workspace, st);
   if (dtype == AXVS_F16) return tl_heads_fwd_t<false>(clip_query, mask_feature, cls_logits, mask_logits, packed, B, Q, Tc, frames_per_clip, h, w, K1, Cm, workspace, st);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+size_t axvs_msda_packed_bytes(int C, int heads, int L, int P) {
+  Carver c(nullptr);
+  carve_msda(c, C, heads, L, P);
+  return c.off;
+}
+
+int axvs_msda_pack(const AxvsMsdaParams* p, void* packed, int C, int heads, int L, int P, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (L <= 0 || L > kMsdaMaxLevels || P <= 0 || L * P > 64) return fail(AXVS_ERR_ARG, "unsupported n_levels=%d / n_points=%d", L, P);
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  MsdaPacked m = carve_msda(c, C, heads, L, P);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int d = C / heads, Cp = heads * 32, mlp = heads * L * P;
+  PackDim plainC{C, C, 0, 0, 0}, headC{C, Cp, heads, d, 0}, off{2 * mlp, 2 * mlp, 0, 0, 0}, lg{mlp, mlp, 0, 0, 0};
+  if (dtype == AXVS_BF16) {
+    pack_w3<true>(p->value_proj_w, m.wv, headC, plainC, st);
+    pack_w3<true>(p->sampling_offsets_w, m.wq, off, plainC, st, 0, 3 * mlp);
+    pack_w3<true>(p->attention_weights_w, m.wq, lg, plainC, st, 2 * mlp, 3 * mlp);
+    pack_w3<true>(p->output_proj_w, m.wo, plainC, headC, st);
+  } else {
+    pack_w3<false>(p->value_proj_w, m.wv, headC, plainC, st);
+    pack_w3<false>(p->sampling_offsets_w, m.wq, off, plainC, st, 0, 3 * mlp);
+    pack_w3<false>(p->attention_weights_w, m.wq, lg, plainC, st, 2 * mlp, 3 * mlp);
+    pack_w3<false>(p->output_proj_w, m.wo, plainC, headC, st);
+  }
+  pack_b(p->value_proj_b, m.bv, headC, st);
+  copy_f32(p->sampling_offsets_b, m.bq, 2 * mlp, st);
+  copy_f32(p->attention_weights_b, m.bq + 2 * mlp, mlp, st);
+  copy_f32(p->output_proj_b, m.bo, C, st);
+  return last_launch_status();
+}
+
+size_t axvs_msda_workspace_bytes(int N, int Lq, int S, int C, int heads, int L, int P) {
+  Carver c(nullptr);
+  const size_t Cp = (size_t)heads * 32;
+  c.take<u16>((size_t)N * S * Cp);
+  c.take<float>((size_t)N * Lq * 3 * heads * L * P);
+  c.take<u16>(2 * (size_t)N * Lq * Cp);
+  (void)C;
+  return c.off;
+}
+
+int axvs_msda_fwd(const float* query, const float* reference_points, int ref_dim, const float* input_flatten,
+                  const unsigned char* padding_mask, const int* spatial_shapes, float* out, const void* packed, int N, int Lq, int S,
+                  int C, int heads, int L, int P, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!query || !reference_points || !input_flatten || !spatial_shapes || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || Lq <= 0 || S <= 0 || P <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (ref_dim != 2 && ref_dim != 4) return fail(AXVS_ERR_ARG, "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+  if (L * P > 64) return fail(AXVS_ERR_ARG, "n_levels * n_points > 64 is not supported");
+  if ((long long)N * S > 2147483647LL / 64 || (long long)N * Lq > 2147483647LL / 64) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
+  MsdaLevels lv;
+  if (int rc = msda_levels(spatial_shapes, L, S, &lv)) return rc;
+  if (workspace_bytes < axvs_msda_workspace_bytes(N, Lq, S, C, heads, L, P)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return msda_fwd_t<true>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, packed, N, Lq, S, C, heads, P, workspace, st);
+  if (dtype == AXVS_F16) return msda_fwd_t<false>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, packed, N, Lq, S, C, heads, P, workspace, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight, float* out,
+                       int N, int S, int M, int D, int Lq, int L, int P, void* stream) {
+  if (!value || !spatial_shapes || !sampling_loc || !attn_weight || !out) return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || Lq <= 0 || P <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  MsdaLevels lv;
+  if (int rc = msda_levels(spatial_shapes, L, S, &lv)) return rc;
+  const long long total = (long long)N * Lq * M * D;
+  hipLaunchKernelGGL(msda_core_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), value, lv,
+                     sampling_loc, attn_weight, out, N, S, M, D, Lq, P);
+  return last_launch_status();
 }
 
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale, void* stream) {

@@ -626,15 +626,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int f = 0; f < T; ++f) lg[f][mt] *= inv;
   }
 
-  // L2 prefetch of the residual rows the row-wise epilogue will read (HBM latency under load is ~2 us, more than the
-  // projection sweep covers): one 4-byte load per 128-byte line of my 8 rows, result discarded
-  if constexpr (MT == 4) {
-    const int prow = wave * 8 + (lane >> 3);
-    const int pm = (int)m0 + min(prow, (int)(Mp - 1 - m0));
-    const float* pp = res + nat_row(rm, pm) * C + (lane & 7) * 32;
-    int sink;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(pp) : "memory");
-  }
   // ---- pass 2: o = sum_f a_f * (Wv2_h x_f) + bv2_h; the last sweep refills the set with Wp[32w..32w+31] ----
   f32x4 o[2][MT];
 #pragma unroll

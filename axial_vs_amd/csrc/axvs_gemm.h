@@ -79,6 +79,40 @@ struct ALoadBlocked {
   }
 };
 
+// ---- split-precision operands: x = hi + lo (both 16-bit), W = hi + lo  =>  x.W ~ hi.hi + hi.lo + lo.hi as ONE GEMM over a
+//      3x longer K:  activations (hi | hi | lo)  against weights packed as (hi | lo | hi) (pack_weight_split3_kernel).  Used
+//      where a raw projection output (no residual / norm behind it) has to hold the 1e-3 bar: ~16 mantissa bits for 3x the
+//      MFMA work of a small GEMM. ----
+template <bool BF>
+struct ALoadRowsF32Split3 {
+  const float* src;   // [M, K] fp32 rows
+  int M, K;
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    const int part = k / K, kk = k - part * K;
+    const float4* p = reinterpret_cast<const float4*>(src + (long long)m * K + kk);
+    const float4 a = p[0], b = p[1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u16x8 hi = cvt8<BF>(v);
+    if (part < 2) return hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] -= H16<BF>::to_f32(hi[i]);
+    return cvt8<BF>(v);
+  }
+};
+
+template <bool BF>
+struct ALoadBlockedSplit3 {
+  const u16* X;       // blocked [2*Kp/32][R][32]: hi blocks, then lo blocks
+  long long R;
+  int M, Kp;
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    const int part = k / Kp, kk = k - part * Kp;
+    return *reinterpret_cast<const u16x8*>(X + blk_off(R, m, (part == 2 ? Kp : 0) + kk));
+  }
+};
+
 // ---------------- epilogues: 4 consecutive output channels n..n+3 of token m ----------------
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
@@ -92,6 +126,7 @@ struct EpiBlocked16 {
   int relu;
   const float* mul = nullptr;   // optional per-channel multiplier applied to the accumulator before the bias (folded BN)
   int n_off = 0;                // column offset in Y (concatenating several GEMMs along channels)
+  const unsigned char* zero_rows = nullptr;   // optional: rows with a non-zero flag are written as zeros (padding masks)
   __device__ __forceinline__ void store(int m, int n, f32x4 v) const {
     if (mul) {
       float4 s = *reinterpret_cast<const float4*>(mul + n);
@@ -105,6 +140,7 @@ struct EpiBlocked16 {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
     }
+    if (zero_rows && zero_rows[m]) v = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<u16x4*>(Y + blk_off(R, m, n)) = cvt4<BF>(v);
   }
 };

@@ -46,6 +46,28 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, u16* __restrict_
   out[((long long)kb * n_total + n_off + n) * 32 + kk] = H16<BF>::from_f32(v);
 }
 
+// split-precision weights for the (hi | hi | lo) activations of ALoad*Split3: out blocked [3*Kp/32][N][32], K parts (hi | lo | hi)
+template <bool BF>
+__global__ void pack_weight_split3_kernel(const float* __restrict__ W, u16* __restrict__ out, PackDim nd, PackDim kd, int n_off,
+                                          int n_total) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)nd.padded * kd.padded;
+  if (idx >= total) return;
+  int kk = idx & 31;
+  long long t = idx >> 5;
+  int n = t % nd.padded;
+  int kb = t / nd.padded;
+  int no = nd.to_orig(n), ko = kd.to_orig(kb * 32 + kk);
+  float v = (no >= 0 && ko >= 0) ? W[(long long)no * kd.orig + ko] : 0.f;
+  const u16 hi = H16<BF>::from_f32(v);
+  const u16 lo = H16<BF>::from_f32(v - H16<BF>::to_f32(hi));
+  const long long part = (long long)(kd.padded / 32) * n_total * 32;
+  const long long o = ((long long)kb * n_total + n_off + n) * 32 + kk;
+  out[o] = hi;
+  out[part + o] = lo;
+  out[2 * part + o] = hi;
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, PackDim nd) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nd.padded) return;

@@ -1,0 +1,126 @@
+// Multi-scale deformable attention forward.
+// Reference: OPS = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module/ops
+//   module  OPS/modules/ms_deform_attn.py:81-125, core  OPS/functions/ms_deform_attn_func.py:55-77,
+//   native op OPS/src/cuda/ms_deform_attn_cuda.cu:21-86 (im2col kernel: sample at loc*size - 0.5, zero outside).
+// The op is a gather: per (query, head) L*P bilinear samples of a D-channel value row, so it is bound by L2/TA request
+// rate, not by arithmetic; the layouts below make every sample corner one contiguous 64-byte (16-bit) segment.
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+constexpr int kMsdaMaxLevels = 8;
+struct MsdaLevels {
+  int H[kMsdaMaxLevels], W[kMsdaMaxLevels], start[kMsdaMaxLevels];
+  int L;
+};
+
+// ---- compatibility core op: fp32 value [N,S,M,D] exactly as the reference extension takes it; one thread per output
+//      element (n, q, m, d), d fastest (the D channels of a sample corner are D*4 contiguous bytes) ----
+__global__ __launch_bounds__(256) void msda_core_kernel(const float* __restrict__ value, MsdaLevels lv,
+                                                        const float* __restrict__ loc, const float* __restrict__ aw,
+                                                        float* __restrict__ out, int N, int S, int M, int D, int Lq, int P) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Lq * M * D;
+  if (idx >= total) return;
+  const int d = (int)(idx % D);
+  long long r = idx / D;
+  const int m = (int)(r % M);
+  r /= M;                                                   // r = n*Lq + q
+  const int n = (int)(r / Lq);
+  const float* lp = loc + (r * M + m) * lv.L * P * 2;
+  const float* ap = aw + (r * M + m) * lv.L * P;
+  const float* vb = value + ((long long)n * S * M + m) * D + d;
+  float acc = 0.f;
+  for (int l = 0; l < lv.L; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    const float* vl = vb + (long long)lv.start[l] * M * D;
+    for (int p = 0; p < P; ++p) {
+      const float x = lp[(l * P + p) * 2] * W - 0.5f, y = lp[(l * P + p) * 2 + 1] * H - 0.5f;
+      const float a = ap[l * P + p];
+      if (y > -1.f && x > -1.f && y < H && x < W) {
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float fx = x - xf, fy = y - yf;
+        float s = 0.f;
+        if (y0 >= 0 && x0 >= 0) s += (1.f - fy) * (1.f - fx) * vl[((long long)y0 * W + x0) * M * D];
+        if (y0 >= 0 && x0 + 1 < W) s += (1.f - fy) * fx * vl[((long long)y0 * W + x0 + 1) * M * D];
+        if (y0 + 1 < H && x0 >= 0) s += fy * (1.f - fx) * vl[((long long)(y0 + 1) * W + x0) * M * D];
+        if (y0 + 1 < H && x0 + 1 < W) s += fy * fx * vl[((long long)(y0 + 1) * W + x0 + 1) * M * D];
+        acc += a * s;
+      }
+    }
+  }
+  out[idx] = acc;
+}
+
+// ---- module path: softmax over the L*P logits, sampling locations from the reference points, bilinear gather, weighted
+//      sum.  value16: blocked 16-bit [M][N*S][32] (head blocks, written by the value_proj GEMM epilogue);
+//      qproj: fp32 [N*Lq][3*M*L*P] = sampling offsets (M,L,P,2) | attention logits (M,L,P) (one GEMM on the query);
+//      o16: blocked 16-bit [2M][N*Lq][32] for the output_proj GEMM: hi blocks then lo blocks (o = hi + lo, split precision).
+//      8 lanes per (query, head): lane j owns channels 4j..4j+3, so a sample corner is one 64-byte segment per group. ----
+template <bool BF>
+__global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict__ value16, const float* __restrict__ qproj,
+                                                          const float* __restrict__ refp, int ref_dim, MsdaLevels lv,
+                                                          u16* __restrict__ o16, int N, int S, int Lq, int M, int P) {
+  const long long gid = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);        // (row, head) group
+  const int j = threadIdx.x & 7;
+  const long long R = (long long)N * Lq;
+  const bool valid = gid < R * M;
+  const long long g = valid ? gid : R * M - 1;
+  const int m = (int)(g % M);
+  const long long row = g / M;
+  const int n = (int)(row / Lq);
+  const int L = lv.L, LP = L * P, MLP = M * LP;
+  const float* offs = qproj + row * 3 * MLP + (long long)m * LP * 2;
+  const float* logit = qproj + row * 3 * MLP + 2 * MLP + (long long)m * LP;
+  float mx = -INFINITY;
+  for (int i = 0; i < LP; ++i) mx = fmaxf(mx, logit[i]);
+  float den = 0.f;
+  for (int i = 0; i < LP; ++i) den += __expf(logit[i] - mx);
+  const float inv = 1.f / den;
+  const u16* vbase = value16 + ((long long)m * N * S + (long long)n * S) * 32 + j * 4;
+  const float* rp = refp + row * L * ref_dim;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    const u16* vl = vbase + (long long)lv.start[l] * 32;
+    const float rx = rp[l * ref_dim], ry = rp[l * ref_dim + 1];
+    float sx, sy;                                                    // offset scale (modules/ms_deform_attn.py:107-113)
+    if (ref_dim == 2) { sx = 1.f / W; sy = 1.f / H; }
+    else { sx = rp[l * ref_dim + 2] * 0.5f / P; sy = rp[l * ref_dim + 3] * 0.5f / P; }
+#pragma unroll 4
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      const float a = __expf(logit[i] - mx) * inv;
+      const float x = (rx + offs[i * 2] * sx) * W - 0.5f, y = (ry + offs[i * 2 + 1] * sy) * H - 0.5f;
+      if (y > -1.f && x > -1.f && y < H && x < W) {
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float fx = x - xf, fy = y - yf;
+        const bool t = y0 >= 0, b = y0 + 1 < H, lft = x0 >= 0, rgt = x0 + 1 < W;
+        const int yc0 = max(y0, 0), yc1 = min(y0 + 1, H - 1), xc0 = max(x0, 0), xc1 = min(x0 + 1, W - 1);
+        const u16x4 v00 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc0 * W + xc0) * 32);
+        const u16x4 v01 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc0 * W + xc1) * 32);
+        const u16x4 v10 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc1 * W + xc0) * 32);
+        const u16x4 v11 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc1 * W + xc1) * 32);
+        const float w00 = (t && lft) ? a * (1.f - fy) * (1.f - fx) : 0.f, w01 = (t && rgt) ? a * (1.f - fy) * fx : 0.f;
+        const float w10 = (b && lft) ? a * fy * (1.f - fx) : 0.f, w11 = (b && rgt) ? a * fy * fx : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[c] += w00 * H16<BF>::to_f32(v00[c]) + w01 * H16<BF>::to_f32(v01[c]) + w10 * H16<BF>::to_f32(v10[c]) +
+                    w11 * H16<BF>::to_f32(v11[c]);
+      }
+    }
+  }
+  if (valid) {
+    const u16x4 hi = cvt4<BF>(acc);
+    f32x4 lo;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lo[c] = acc[c] - H16<BF>::to_f32(hi[c]);
+    *reinterpret_cast<u16x4*>(o16 + ((long long)m * R + row) * 32 + j * 4) = hi;
+    *reinterpret_cast<u16x4*>(o16 + ((long long)(M + m) * R + row) * 32 + j * 4) = cvt4<BF>(lo);
+  }
+}
+
+}  // namespace axvs

@@ -1,0 +1,148 @@
+"""nn.Module mirror of the multi-scale deformable attention of the within-clip pixel decoder.
+
+Reference: OPS = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module/ops
+  `MSDeformAttn` (OPS/modules/ms_deform_attn.py:35-125; Tube-Link uses mmcv's MultiScaleDeformableAttention with the same
+  math), `MSDeformAttnFunction` / `ms_deform_attn_core_pytorch` (OPS/functions/ms_deform_attn_func.py:33-77).
+Same constructor, parameter names (state-dict keys), initialisation and forward signature; forward runs in libaxvs.so.
+Forward only (the reference's backward kernel is SURVEY 8f-4), GPU only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+from .modules import _dev_f32, _param_key, _require_eval, _stream, _workspace
+
+
+def _shapes_host(spatial_shapes) -> list:
+    """(n_levels, 2) tensor / list of (H, W) -> host ints.  A device tensor costs one sync, like the reference's own
+    `assert (...).sum() == Len_in` (OPS/modules/ms_deform_attn.py:96)."""
+    if isinstance(spatial_shapes, Tensor):
+        spatial_shapes = spatial_shapes.tolist()
+    return [(int(h), int(w)) for h, w in spatial_shapes]
+
+
+def ms_deform_attn_forward(value: Tensor, value_spatial_shapes, value_level_start_index, sampling_locations: Tensor,
+                           attention_weights: Tensor, im2col_step: int = 64) -> Tensor:
+    """Drop-in for `MSDA.ms_deform_attn_forward` / `MSDeformAttnFunction.apply` (forward):
+    value [N,S,M,D], sampling_locations [N,Lq,M,L,P,2], attention_weights [N,Lq,M,L,P] -> [N,Lq,M*D].
+    `value_level_start_index` and `im2col_step` are accepted for signature parity and not needed."""
+    v = _dev_f32(value, "value")
+    loc = _dev_f32(sampling_locations, "sampling_locations")
+    aw = _dev_f32(attention_weights, "attention_weights")
+    N, S, M, D = v.shape
+    _, Lq, _, L, P, _ = loc.shape
+    shp = _shapes_host(value_spatial_shapes)
+    arr = (C.c_int * (2 * L))(*[x for hw in shp for x in hw])
+    out = torch.empty(N, Lq, M * D, dtype=torch.float32, device=v.device)
+    _lib.check(_lib.lib().axvs_msda_core_fwd(v.data_ptr(), arr, loc.data_ptr(), aw.data_ptr(), out.data_ptr(), N, S, M, D, Lq, L, P,
+                                             _stream(v.device)), "axvs_msda_core_fwd")
+    return out
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, mfma_dtype: Optional[str] = None):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError('d_model must be divisible by n_heads, but got {} and {}'.format(d_model, n_heads))
+        d = d_model // n_heads
+        if d & (d - 1):
+            warnings.warn("d_model / n_heads is not a power of 2 (the reference warns about this too)")
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self.mfma_dtype = mfma_dtype
+        self._packed = None
+        self._packed_key = None
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        """OPS/modules/ms_deform_attn.py:66-79: zero offset/attention weights, offsets biased along n_heads directions with
+        radius growing with the point index, xavier value/output projections."""
+        nn.init.constant_(self.sampling_offsets.weight.data, 0.)
+        ang = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        dirs = torch.stack([ang.cos(), ang.sin()], -1)
+        dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]
+        grid = dirs.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        grid = grid * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, self.n_points, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.reshape(-1))
+        nn.init.constant_(self.attention_weights.weight.data, 0.)
+        nn.init.constant_(self.attention_weights.bias.data, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight.data)
+        nn.init.constant_(self.value_proj.bias.data, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight.data)
+        nn.init.constant_(self.output_proj.bias.data, 0.)
+
+    def _dtype(self) -> str:
+        from . import modules
+        return self.mfma_dtype or modules._DEFAULT_DTYPE
+
+    def _pack(self):
+        dt = self._dtype()
+        key = _param_key(self, dt)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        L = _lib.lib()
+        dev = self.value_proj.weight.device
+        keep = []
+
+        def f(t):
+            tt = _dev_f32(t.detach(), "parameter")
+            keep.append(tt)
+            return tt.data_ptr()
+
+        ps = _lib.AxvsMsdaParams()
+        for name in ("value_proj", "sampling_offsets", "attention_weights", "output_proj"):
+            lin = getattr(self, name)
+            setattr(ps, name + "_w", f(lin.weight))
+            setattr(ps, name + "_b", f(lin.bias))
+        buf = torch.empty(L.axvs_msda_packed_bytes(self.d_model, self.n_heads, self.n_levels, self.n_points), dtype=torch.uint8, device=dev)
+        _lib.check(L.axvs_msda_pack(C.byref(ps), buf.data_ptr(), self.d_model, self.n_heads, self.n_levels, self.n_points,
+                                    _lib.DTYPES[dt], _stream(dev)), "axvs_msda_pack")
+        torch.cuda.current_stream(dev).synchronize()
+        self._packed, self._packed_key = buf, key
+        return buf
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index=None,
+                input_padding_mask=None):
+        """query (N, Len_q, C); reference_points (N, Len_q, n_levels, 2 | 4) in [0,1]; input_flatten (N, sum H_l W_l, C);
+        input_spatial_shapes (n_levels, 2) = (H_l, W_l); input_padding_mask (N, sum H_l W_l) True = padding -> (N, Len_q, C)"""
+        _require_eval(self)
+        q = _dev_f32(query, "query")
+        x = _dev_f32(input_flatten, "input_flatten")
+        ref = _dev_f32(reference_points, "reference_points")
+        N, Lq, Cq = q.shape
+        S = x.shape[1]
+        shp = _shapes_host(input_spatial_shapes)
+        if sum(h * w for h, w in shp) != S:
+            raise AssertionError("input_spatial_shapes do not cover input_flatten")          # reference: assert, :96
+        if ref.shape[-1] not in (2, 4):
+            raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(ref.shape[-1]))
+        if Cq != self.d_model or len(shp) != self.n_levels or ref.shape[:3] != (N, Lq, self.n_levels):
+            raise RuntimeError(f"shape mismatch: query {tuple(q.shape)}, reference_points {tuple(ref.shape)}, levels {len(shp)}")
+        mask = None
+        if input_padding_mask is not None:
+            if not input_padding_mask.is_cuda:
+                raise RuntimeError("axial_vs_amd: input_padding_mask must be a CUDA tensor (no CPU fallback)")
+            mask = input_padding_mask.to(torch.uint8).contiguous()
+        L = _lib.lib()
+        packed = self._pack()
+        dev = q.device
+        ws = _workspace(dev, L.axvs_msda_workspace_bytes(N, Lq, S, self.d_model, self.n_heads, self.n_levels, self.n_points))
+        arr = (C.c_int * (2 * self.n_levels))(*[v for hw in shp for v in hw])
+        out = torch.empty(N, Lq, self.d_model, dtype=torch.float32, device=dev)
+        _lib.check(L.axvs_msda_fwd(q.data_ptr(), ref.data_ptr(), ref.shape[-1], x.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                   arr, out.data_ptr(), packed.data_ptr(), N, Lq, S, self.d_model, self.n_heads, self.n_levels,
+                                   self.n_points, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(), _stream(dev)), "axvs_msda_fwd")
+        return out

@@ -165,6 +165,33 @@ int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float*
                       const void* packed, int B, int Q, int Tc, int frames_per_clip, int h, int w, int K1, int Cm, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- Multi-scale deformable attention forward.
+ *      OPS = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module/ops
+ *      axvs_msda_fwd  replaces MSDeformAttn.forward (OPS/modules/ms_deform_attn.py:81-125): value_proj (+ padding mask),
+ *      sampling_offsets, attention_weights + softmax, sampling locations, the gather, output_proj.
+ *      axvs_msda_core_fwd replaces the native op ms_deform_attn_forward (OPS/src/ms_deform_attn.h:24-47,
+ *      OPS/src/cuda/ms_deform_attn_cuda.cu:21-86) with its fp32 tensors as they are; level_start_index follows from
+ *      spatial_shapes and im2col_step has no meaning here. */
+typedef struct AxvsMsdaParams {        /* fp32 device pointers, nn.Linear layout [out,in] (OPS/modules/ms_deform_attn.py:59-62) */
+  const float *value_proj_w, *value_proj_b;                 /* [C,C], [C]                  */
+  const float *sampling_offsets_w, *sampling_offsets_b;     /* [heads*L*P*2, C], [..]      */
+  const float *attention_weights_w, *attention_weights_b;   /* [heads*L*P, C], [..]        */
+  const float *output_proj_w, *output_proj_b;               /* [C,C], [C]                  */
+} AxvsMsdaParams;
+
+size_t axvs_msda_packed_bytes(int C, int heads, int L, int P);
+int axvs_msda_pack(const AxvsMsdaParams* p, void* packed, int C, int heads, int L, int P, int dtype, void* stream);
+size_t axvs_msda_workspace_bytes(int N, int Lq, int S, int C, int heads, int L, int P);
+/* query fp32 [N,Lq,C]; reference_points fp32 [N,Lq,L,ref_dim], ref_dim 2 or 4; input_flatten fp32 [N,S,C];
+ * padding_mask: NULL or bytes [N,S], non-zero = padding (value rows zeroed); spatial_shapes: HOST ints [L][2] = (H_l, W_l),
+ * sum H_l*W_l == S; out fp32 [N,Lq,C]. */
+int axvs_msda_fwd(const float* query, const float* reference_points, int ref_dim, const float* input_flatten,
+                  const unsigned char* padding_mask, const int* spatial_shapes, float* out, const void* packed, int N, int Lq,
+                  int S, int C, int heads, int L, int P, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* value fp32 [N,S,M,D]; sampling_loc fp32 [N,Lq,M,L,P,2]; attn_weight fp32 [N,Lq,M,L,P]; out fp32 [N,Lq,M*D] */
+int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight,
+                       float* out, int N, int S, int M, int D, int Lq, int L, int P, void* stream);
+
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,

@@ -302,3 +302,70 @@ def test_tube_link_cross_clip_head_golden(name):
         e_m, e_m0 = rel_err(masks[-1].cpu()[:, :, ::5, ::6, ::8], t(z["masks_last"])), 0.0
     print(f"{name}: masks {e_m:.2e} / first layer {e_m0:.2e}")
     assert e_m < TOL_F16 and e_m0 < TOL_F16
+
+
+from golden_util import MSDA_CORE, MSDA_MODULE, msda_core_inputs, msda_module_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", MSDA_CORE)
+def test_msda_core_golden(name):
+    """axvs_msda_core_fwd (the reference extension's forward op, fp32 throughout) against the reference's
+    ms_deform_attn_core_pytorch; the first case is the reference's own test configuration (ops/test.py:24-28), checked with
+    its own allclose bounds, the others at 1e-5 relative; locations outside [0,1] exercise the zero-padding branch."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    value, loc, aw = msda_core_inputs(m)
+    shapes = torch.as_tensor(m["shapes"], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    out = ax.ms_deform_attn_forward(dev(value), shapes.cuda(), lsi.cuda(), dev(loc), dev(aw), 2).cpu()
+    assert torch.allclose(out, t(z["out"]), rtol=1e-2, atol=1e-3)                 # the reference's float check
+    e = rel_err(out, torch.from_numpy(z["out64"]))
+    print(f"{name}: {e:.2e}")
+    assert e < 1e-5
+
+
+@pytest.mark.parametrize("name", MSDA_MODULE)
+def test_msda_module_golden(name):
+    """MSDeformAttn.forward (projections + gather) against the reference module: padding mask, C = 64 (head dim 8),
+    and the cfg-3-sized case N=4, 64x64 + 32x32 + 16x16."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w, query, ref, src, pm = msda_module_case(z, m)
+    mod = ax.MSDeformAttn(d_model=m["C"], n_levels=len(m["shapes"]), n_heads=m["M"], n_points=m["P"]).eval()
+    mod.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    shapes = torch.as_tensor(m["shapes"], dtype=torch.long, device="cuda")
+    out = mod(dev(query), dev(ref), dev(src), shapes, None, pm.cuda() if pm is not None else None).cpu()
+    ref_out = t(z["out"])
+    got = out if ref_out.shape == out.shape else out[:, ::29, ::3]
+    e = rel_err(got, ref_out)
+    print(f"{name}: {e:.2e}")
+    assert e < TOL_F16
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=5e-3)
+
+
+def test_msda_reference_boxes_and_errors():
+    """4-d reference points (boxes) against the fp64 oracle; the reference's error for any other last dim."""
+    import axial_vs_amd as ax
+    shapes = [(12, 10), (6, 5)]
+    z, m = load(MSDA_MODULE[0])
+    g = torch.Generator().manual_seed(77)
+    mod = ax.MSDeformAttn(d_model=256, n_levels=2, n_heads=8, n_points=4).eval()
+    with torch.no_grad():
+        mod.sampling_offsets.weight.copy_((torch.rand(mod.sampling_offsets.weight.shape, generator=g) - 0.5) * 0.2)
+        mod.attention_weights.weight.copy_((torch.rand(mod.attention_weights.weight.shape, generator=g) - 0.5) * 0.5)
+    w = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    S, Lq = 150, 37
+    src = torch.randn(2, S, 256, generator=g)
+    q = torch.randn(2, Lq, 256, generator=g)
+    ref = torch.rand(2, Lq, 2, 4, generator=g) * torch.tensor([1.0, 1.0, 0.3, 0.3])
+    want = orc.msda_module(q.double(), ref.double(), src.double(), shapes, {k: v.double() for k, v in w.items()}, 8, 2, 4)
+    mod = mod.cuda()
+    out = mod(dev(q), dev(ref), dev(src), shapes).cpu()
+    e = rel_err(out, want)
+    print(f"boxes: {e:.2e}")
+    assert e < TOL_F16
+    with pytest.raises(ValueError):
+        mod(dev(q), dev(ref[..., :3]), dev(src), shapes)
+    with pytest.raises(AssertionError):
+        mod(dev(q), dev(ref), dev(src[:, :-1]), shapes)
