@@ -664,8 +664,9 @@ int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* 
                   3 * C, st);
   mark(st, "msda.offsets+weights");
   const long long groups = Rq * heads;
-  hipLaunchKernelGGL((msda_gather_kernel<BF>), dim3((unsigned)((groups + 31) / 32)), dim3(256), 0, st, value16, qproj, refp, ref_dim, lv,
-                     o16, N, S, Lq, heads, P);
+  const dim3 ggrid((unsigned)((groups + 63) / 64));
+  if (P == 4) hipLaunchKernelGGL((msda_gather_kernel<BF, 4>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P);
+  else hipLaunchKernelGGL((msda_gather_kernel<BF, 0>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P);
   mark(st, "msda.gather");
   launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, nullptr, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
                   C, 3 * Cp, st);

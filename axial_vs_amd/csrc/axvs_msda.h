@@ -58,13 +58,14 @@ __global__ __launch_bounds__(256) void msda_core_kernel(const float* __restrict_
 //      sum.  value16: blocked 16-bit [M][N*S][32] (head blocks, written by the value_proj GEMM epilogue);
 //      qproj: fp32 [N*Lq][3*M*L*P] = sampling offsets (M,L,P,2) | attention logits (M,L,P) (one GEMM on the query);
 //      o16: blocked 16-bit [2M][N*Lq][32] for the output_proj GEMM: hi blocks then lo blocks (o = hi + lo, split precision).
-//      8 lanes per (query, head): lane j owns channels 4j..4j+3, so a sample corner is one 64-byte segment per group. ----
-template <bool BF>
+//      4 lanes per (query, head): lane j owns channels 8j..8j+7 (16-byte loads), a sample corner is one 64-byte segment. ----
+template <bool BF, int PT>   // PT > 0: n_points known at compile time (all 4*PT corner loads of a level in flight together)
 __global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict__ value16, const float* __restrict__ qproj,
                                                           const float* __restrict__ refp, int ref_dim, MsdaLevels lv,
-                                                          u16* __restrict__ o16, int N, int S, int Lq, int M, int P) {
-  const long long gid = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);        // (row, head) group
-  const int j = threadIdx.x & 7;
+                                                          u16* __restrict__ o16, int N, int S, int Lq, int M, int Prt) {
+  const int P = PT > 0 ? PT : Prt;
+  const long long gid = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);        // (row, head) group
+  const int j = threadIdx.x & 3;
   const long long R = (long long)N * Lq;
   const bool valid = gid < R * M;
   const long long g = valid ? gid : R * M - 1;
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict_
   float den = 0.f;
   for (int i = 0; i < LP; ++i) den += __expf(logit[i] - mx);
   const float inv = 1.f / den;
-  const u16* vbase = value16 + ((long long)m * N * S + (long long)n * S) * 32 + j * 4;
+  const u16* vbase = value16 + ((long long)m * N * S + (long long)n * S) * 32 + j * 8;
   const float* rp = refp + row * L * ref_dim;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < L; ++l) {
     const int H = lv.H[l], W = lv.W[l];
     const u16* vl = vbase + (long long)lv.start[l] * 32;
@@ -89,37 +90,37 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict_
     float sx, sy;                                                    // offset scale (modules/ms_deform_attn.py:107-113)
     if (ref_dim == 2) { sx = 1.f / W; sy = 1.f / H; }
     else { sx = rp[l * ref_dim + 2] * 0.5f / P; sy = rp[l * ref_dim + 3] * 0.5f / P; }
-#pragma unroll 4
-    for (int p = 0; p < P; ++p) {
+#pragma unroll
+    for (int p = 0; p < (PT > 0 ? PT : P); ++p) {
       const int i = l * P + p;
       const float a = __expf(logit[i] - mx) * inv;
       const float x = (rx + offs[i * 2] * sx) * W - 0.5f, y = (ry + offs[i * 2 + 1] * sy) * H - 0.5f;
-      if (y > -1.f && x > -1.f && y < H && x < W) {
-        const float xf = floorf(x), yf = floorf(y);
-        const int x0 = (int)xf, y0 = (int)yf;
-        const float fx = x - xf, fy = y - yf;
-        const bool t = y0 >= 0, b = y0 + 1 < H, lft = x0 >= 0, rgt = x0 + 1 < W;
-        const int yc0 = max(y0, 0), yc1 = min(y0 + 1, H - 1), xc0 = max(x0, 0), xc1 = min(x0 + 1, W - 1);
-        const u16x4 v00 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc0 * W + xc0) * 32);
-        const u16x4 v01 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc0 * W + xc1) * 32);
-        const u16x4 v10 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc1 * W + xc0) * 32);
-        const u16x4 v11 = *reinterpret_cast<const u16x4*>(vl + ((long long)yc1 * W + xc1) * 32);
-        const float w00 = (t && lft) ? a * (1.f - fy) * (1.f - fx) : 0.f, w01 = (t && rgt) ? a * (1.f - fy) * fx : 0.f;
-        const float w10 = (b && lft) ? a * fy * (1.f - fx) : 0.f, w11 = (b && rgt) ? a * fy * fx : 0.f;
+      // branch-free: corners outside the map get weight 0 and a clamped (valid) address, so every load of the level can be
+      // in flight at once
+      const float xf = floorf(x), yf = floorf(y);
+      const float fx = x - xf, fy = y - yf;
+      const int x0 = (int)fmaxf(fminf(xf, (float)W), -2.f), y0 = (int)fmaxf(fminf(yf, (float)H), -2.f);
+      const bool t = y0 >= 0 && y0 < H, b = y0 + 1 >= 0 && y0 + 1 < H, lft = x0 >= 0 && x0 < W, rgt = x0 + 1 >= 0 && x0 + 1 < W;
+      const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1), xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+      const u16x8 v00 = *reinterpret_cast<const u16x8*>(vl + ((long long)yc0 * W + xc0) * 32);
+      const u16x8 v01 = *reinterpret_cast<const u16x8*>(vl + ((long long)yc0 * W + xc1) * 32);
+      const u16x8 v10 = *reinterpret_cast<const u16x8*>(vl + ((long long)yc1 * W + xc0) * 32);
+      const u16x8 v11 = *reinterpret_cast<const u16x8*>(vl + ((long long)yc1 * W + xc1) * 32);
+      const float w00 = (t && lft) ? a * (1.f - fy) * (1.f - fx) : 0.f, w01 = (t && rgt) ? a * (1.f - fy) * fx : 0.f;
+      const float w10 = (b && lft) ? a * fy * (1.f - fx) : 0.f, w11 = (b && rgt) ? a * fy * fx : 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          acc[c] += w00 * H16<BF>::to_f32(v00[c]) + w01 * H16<BF>::to_f32(v01[c]) + w10 * H16<BF>::to_f32(v10[c]) +
-                    w11 * H16<BF>::to_f32(v11[c]);
-      }
+      for (int c = 0; c < 8; ++c)
+        acc[c] += w00 * H16<BF>::to_f32(v00[c]) + w01 * H16<BF>::to_f32(v01[c]) + w10 * H16<BF>::to_f32(v10[c]) +
+                  w11 * H16<BF>::to_f32(v11[c]);
     }
   }
   if (valid) {
-    const u16x4 hi = cvt4<BF>(acc);
-    f32x4 lo;
+    const u16x8 hi = cvt8<BF>(acc);
+    float lo[8];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) lo[c] = acc[c] - H16<BF>::to_f32(hi[c]);
-    *reinterpret_cast<u16x4*>(o16 + ((long long)m * R + row) * 32 + j * 4) = hi;
-    *reinterpret_cast<u16x4*>(o16 + ((long long)(M + m) * R + row) * 32 + j * 4) = cvt4<BF>(lo);
+    for (int c = 0; c < 8; ++c) lo[c] = acc[c] - H16<BF>::to_f32(hi[c]);
+    *reinterpret_cast<u16x8*>(o16 + ((long long)m * R + row) * 32 + j * 8) = hi;
+    *reinterpret_cast<u16x8*>(o16 + ((long long)(M + m) * R + row) * 32 + j * 8) = cvt8<BF>(lo);
   }
 }
 

@@ -123,3 +123,20 @@ def test_tube_link_head_state_dict_keys_match_reference(name):
     mod.load_state_dict(orc.random_weights(m["shapes"], 1), strict=True)
     with pytest.raises(RuntimeError):
         mod.eval()(torch.zeros(1, 3, 16, 256), torch.zeros(1, 6, m["Cm"], 8, 12))      # CPU tensors: no fallback
+
+
+def test_msda_module_surface_matches_reference():
+    """MSDeformAttn keeps the reference's parameter names / shapes / init (ops/modules/ms_deform_attn.py:59-79) and refuses
+    CPU tensors (no fallback to a PyTorch sampling path)."""
+    import axial_vs_amd as ax
+    from golden_util import MSDA_MODULE
+    z, m = load(MSDA_MODULE[0])
+    mod = ax.MSDeformAttn(d_model=m["C"], n_levels=len(m["shapes"]), n_heads=m["M"], n_points=m["P"])
+    own = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    assert own == {k: tuple(v) for k, v in m["wshapes"].items()}
+    assert float(mod.sampling_offsets.weight.abs().max()) == 0.0 and float(mod.attention_weights.bias.abs().max()) == 0.0
+    b = mod.sampling_offsets.bias.view(m["M"], len(m["shapes"]), m["P"], 2)
+    assert torch.allclose(b[0, 0, :, 0], torch.arange(1, m["P"] + 1, dtype=torch.float32))     # head 0 points along +x, radius 1..P
+    assert torch.allclose(b[:, :, 1], 2 * b[:, :, 0])
+    with pytest.raises(RuntimeError):
+        mod.eval()(torch.zeros(1, 4, m["C"]), torch.zeros(1, 4, len(m["shapes"]), 2), torch.zeros(1, 252, m["C"]), m["shapes"])
