@@ -8,8 +8,8 @@ from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, Tempo
                       set_default_dtype)
 
 from .cross_clip import CrossClipTrackingModule, TubeLinkCrossClipHead
-from .msda import MSDeformAttn, ms_deform_attn_forward
+from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer, ms_deform_attn_forward
 
-__all__ = ["CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
+__all__ = ["CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
            "set_default_dtype"]

@@ -56,6 +56,11 @@ class AxvsMsdaParams(C.Structure):
                                    "attention_weights_w", "attention_weights_b", "output_proj_w", "output_proj_b")]
 
 
+class AxvsMsdaLayerParams(C.Structure):
+    _fields_ = [("self_attn", AxvsMsdaParams)] + [(n, _fp) for n in ("norm1_w", "norm1_b", "linear1_w", "linear1_b", "linear2_w",
+                                                                      "linear2_b", "norm2_w", "norm2_b")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/axvs.h
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
@@ -86,6 +91,10 @@ SIGNATURES = {
     "axvs_msda_pack": (C.c_int, [C.POINTER(AxvsMsdaParams), _fp] + [C.c_int] * 5 + [_fp]),
     "axvs_msda_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_msda_fwd": (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_msda_layer_packed_bytes": (C.c_size_t, [C.c_int] * 5),
+    "axvs_msda_layer_pack": (C.c_int, [C.POINTER(AxvsMsdaLayerParams), _fp] + [C.c_int] * 6 + [_fp]),
+    "axvs_msda_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "axvs_msda_layer_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
     "axvs_msda_core_fwd": (C.c_int, [_fp, C.POINTER(C.c_int), _fp, _fp, _fp] + [C.c_int] * 7 + [_fp]),
     "axvs_tl_heads_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_tl_heads_pack": (C.c_int, [C.POINTER(AxvsTLHeadParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),

@@ -98,6 +98,19 @@ struct LayerPacked {
   float *b1, *b2, *g1, *be1, *g2, *be2;
 };
 
+LayerPacked carve_ffn(Carver& c, int C, int F) {   // norm1 / linear1 / linear2 / norm2 only (th, tw unused)
+  LayerPacked l{};
+  l.w1 = c.take<u16>((size_t)F * C);
+  l.w2 = c.take<u16>((size_t)F * C);
+  l.b1 = c.take<float>(F);
+  l.b2 = c.take<float>(C);
+  l.g1 = c.take<float>(C);
+  l.be1 = c.take<float>(C);
+  l.g2 = c.take<float>(C);
+  l.be2 = c.take<float>(C);
+  return l;
+}
+
 LayerPacked carve_layer(Carver& c, int C, int heads, int F) {
   LayerPacked l;
   l.th = carve_traj(c, C, heads);
@@ -127,6 +140,20 @@ void pack_w3(const float* W, u16* out, PackDim nd, PackDim kd, hipStream_t st, i
 }
 void pack_b(const float* b, float* out, PackDim nd, hipStream_t st) {
   hipLaunchKernelGGL(pack_bias_kernel, dim3((nd.padded + 255) / 256), dim3(256), 0, st, b, out, nd);
+}
+
+template <bool BF>
+void pack_ffn(const float* n1w, const float* n1b, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
+              const float* n2w, const float* n2b, const LayerPacked& l, int C, int F, hipStream_t st) {
+  PackDim plainC{C, C, 0, 0, 0}, plainF{F, F, 0, 0, 0};
+  pack_w<BF>(l1w, l.w1, plainF, plainC, st);
+  pack_w<BF>(l2w, l.w2, plainC, plainF, st);
+  pack_b(l1b, l.b1, plainF, st);
+  pack_b(l2b, l.b2, plainC, st);
+  pack_b(n1w, l.g1, plainC, st);
+  pack_b(n1b, l.be1, plainC, st);
+  pack_b(n2w, l.g2, plainC, st);
+  pack_b(n2b, l.be2, plainC, st);
 }
 
 template <bool BF>
@@ -644,10 +671,9 @@ int msda_levels(const int* shapes, int L, int S, MsdaLevels* lv) {
 
 template <bool BF>
 int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* input, const unsigned char* mask, const MsdaLevels& lv,
-               float* out, const void* packed, int N, int Lq, int S, int C, int heads, int P, void* ws, hipStream_t st) {
+               float* out, const MsdaPacked& p, int N, int Lq, int S, int C, int heads, int P, void* ws, hipStream_t st,
+               const float* qadd = nullptr, const float* residual = nullptr) {
   const int L = lv.L, Cp = heads * 32, nq = 3 * heads * L * P;
-  Carver pc(const_cast<void*>(packed));
-  MsdaPacked p = carve_msda(pc, C, heads, L, P);
   const long long Rv = (long long)N * S, Rq = (long long)N * Lq;
   Carver wc(ws);
   u16* value16 = wc.take<u16>((size_t)Rv * Cp);
@@ -660,15 +686,15 @@ int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* 
   ev.zero_rows = mask;
   launch_gemm<BF>(ALoadRowsF32Split3<BF>{input, (int)Rv, C}, p.wv, ev, (int)Rv, Cp, 3 * C, st);
   mark(st, "msda.value_proj");
-  launch_gemm<BF>(ALoadRowsF32Split3<BF>{query, (int)Rq, C}, p.wq, EpiRowsF32{qproj, nullptr, p.bq, identity_map(Rq), nq, 1.f}, (int)Rq, nq,
-                  3 * C, st);
+  launch_gemm<BF>(ALoadRowsF32Split3<BF>{query, (int)Rq, C, qadd}, p.wq, EpiRowsF32{qproj, nullptr, p.bq, identity_map(Rq), nq, 1.f}, (int)Rq,
+                  nq, 3 * C, st);
   mark(st, "msda.offsets+weights");
   const long long groups = Rq * heads;
   const dim3 ggrid((unsigned)((groups + 63) / 64));
   if (P == 4) hipLaunchKernelGGL((msda_gather_kernel<BF, 4>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P);
   else hipLaunchKernelGGL((msda_gather_kernel<BF, 0>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P);
   mark(st, "msda.gather");
-  launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, nullptr, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
+  launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, residual, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
                   C, 3 * Cp, st);
   mark(st, "msda.output_proj");
   return last_launch_status();
@@ -1061,9 +1087,77 @@ int axvs_msda_fwd(const float* query, const float* reference_points, int ref_dim
   if (int rc = msda_levels(spatial_shapes, L, S, &lv)) return rc;
   if (workspace_bytes < axvs_msda_workspace_bytes(N, Lq, S, C, heads, L, P)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dtype == AXVS_BF16) return msda_fwd_t<true>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, packed, N, Lq, S, C, heads, P, workspace, st);
-  if (dtype == AXVS_F16) return msda_fwd_t<false>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, packed, N, Lq, S, C, heads, P, workspace, st);
+  Carver pc(const_cast<void*>(packed));
+  const MsdaPacked mp = carve_msda(pc, C, heads, L, P);
+  if (dtype == AXVS_BF16) return msda_fwd_t<true>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, mp, N, Lq, S, C, heads, P, workspace, st);
+  if (dtype == AXVS_F16) return msda_fwd_t<false>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, mp, N, Lq, S, C, heads, P, workspace, st);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+// ---- MSDeformAttnTransformerEncoderLayer (WC/msdeformattn.py:177-216): self-attention + residual, norm1, FFN, norm2 ----
+size_t axvs_msda_layer_packed_bytes(int C, int heads, int L, int P, int d_ffn) {
+  Carver c(nullptr);
+  carve_msda(c, C, heads, L, P);
+  carve_ffn(c, C, d_ffn);
+  return c.off;
+}
+
+int axvs_msda_layer_pack(const AxvsMsdaLayerParams* p, void* packed, int C, int heads, int L, int P, int d_ffn, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (int rc = axvs_msda_pack(&p->self_attn, packed, C, heads, L, P, dtype, stream)) return rc;
+  Carver c(packed);
+  carve_msda(c, C, heads, L, P);
+  LayerPacked l = carve_ffn(c, C, d_ffn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) pack_ffn<true>(p->norm1_w, p->norm1_b, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w, p->norm2_b, l, C, d_ffn, st);
+  else pack_ffn<false>(p->norm1_w, p->norm1_b, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w, p->norm2_b, l, C, d_ffn, st);
+  return last_launch_status();
+}
+
+size_t axvs_msda_layer_workspace_bytes(int N, int S, int C, int heads, int L, int P, int d_ffn) {
+  Carver c(nullptr);
+  c.take<char>(axvs_msda_workspace_bytes(N, S, S, C, heads, L, P));
+  const size_t M = (size_t)N * S;
+  c.take<float>(M * C);            // x = src + attention
+  c.take<float>(M * C);            // generic FFN path scratch
+  c.take<u16>(M * C);
+  c.take<u16>(M * d_ffn);
+  return c.off;
+}
+
+int axvs_msda_layer_fwd(const float* src, const float* pos, const float* reference_points, int ref_dim, const unsigned char* padding_mask,
+                        const int* spatial_shapes, float* out, const void* packed, int N, int S, int C, int heads, int L, int P,
+                        int d_ffn, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!src || !reference_points || !spatial_shapes || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || S <= 0 || P <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (ref_dim != 2 && ref_dim != 4) return fail(AXVS_ERR_ARG, "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+  if (L * P > 64) return fail(AXVS_ERR_ARG, "n_levels * n_points > 64 is not supported");
+  if (out == src) return fail(AXVS_ERR_ARG, "out must not alias src");
+  if ((long long)N * S > 2147483647LL / 64) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
+  MsdaLevels lv;
+  if (int rc = msda_levels(spatial_shapes, L, S, &lv)) return rc;
+  if (workspace_bytes < axvs_msda_layer_workspace_bytes(N, S, C, heads, L, P, d_ffn)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Carver pc(const_cast<void*>(packed));
+  const MsdaPacked mp = carve_msda(pc, C, heads, L, P);
+  const LayerPacked lp = carve_ffn(pc, C, d_ffn);
+  Carver wc(workspace);
+  void* mws = wc.take<char>(axvs_msda_workspace_bytes(N, S, S, C, heads, L, P));
+  const long long M = (long long)N * S;
+  float* x = wc.take<float>((size_t)M * C);
+  float* tmp = wc.take<float>((size_t)M * C);
+  u16* y16 = wc.take<u16>((size_t)M * C);
+  u16* h16 = wc.take<u16>((size_t)M * d_ffn);
+  int rc = dtype == AXVS_BF16
+               ? msda_fwd_t<true>(src, reference_points, ref_dim, src, padding_mask, lv, x, mp, N, S, S, C, heads, P, mws, st, pos, src)
+               : msda_fwd_t<false>(src, reference_points, ref_dim, src, padding_mask, lv, x, mp, N, S, S, C, heads, P, mws, st, pos, src);
+  if (rc != AXVS_OK) return rc;
+  rc = dtype == AXVS_BF16 ? run_ffn<true>(x, out, lp, M, C, heads, d_ffn, tmp, y16, h16, st)
+                          : run_ffn<false>(x, out, lp, M, C, heads, d_ffn, tmp, y16, h16, st);
+  return rc != AXVS_OK ? rc : last_launch_status();
 }
 
 int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight, float* out,

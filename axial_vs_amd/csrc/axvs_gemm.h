@@ -87,11 +87,18 @@ template <bool BF>
 struct ALoadRowsF32Split3 {
   const float* src;   // [M, K] fp32 rows
   int M, K;
+  const float* add = nullptr;   // optional [M, K], added element-wise (positional embedding)
   __device__ __forceinline__ u16x8 load(int m, int k) const {
     m = min(m, M - 1);
     const int part = k / K, kk = k - part * K;
     const float4* p = reinterpret_cast<const float4*>(src + (long long)m * K + kk);
-    const float4 a = p[0], b = p[1];
+    float4 a = p[0], b = p[1];
+    if (add) {
+      const float4* q = reinterpret_cast<const float4*>(add + (long long)m * K + kk);
+      const float4 c = q[0], d = q[1];
+      a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+      b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+    }
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     u16x8 hi = cvt8<BF>(v);
     if (part < 2) return hi;

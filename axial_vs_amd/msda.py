@@ -146,3 +146,99 @@ class MSDeformAttn(nn.Module):
                                    arr, out.data_ptr(), packed.data_ptr(), N, Lq, S, self.d_model, self.n_heads, self.n_levels,
                                    self.n_points, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(), _stream(dev)), "axvs_msda_fwd")
         return out
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    """Mirror of WC/msdeformattn.py:177-216 (the spatial layer of every within-clip stage): deformable self-attention +
+    residual, norm1, FFN, norm2 -- one C-ABI call (`axvs_msda_layer_fwd`); the FFN half is the axial layer's fused kernel."""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4,
+                 mfma_dtype: Optional[str] = None):
+        super().__init__()
+        if activation != "relu":
+            if activation in ("gelu", "glu"):
+                raise NotImplementedError("axial_vs_amd: only activation='relu' (every shipped config) has a HIP path")
+            raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.d_model, self.d_ffn = d_model, d_ffn
+        self.mfma_dtype = mfma_dtype
+        self._packed = None
+        self._packed_key = None
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def _dtype(self) -> str:
+        from . import modules
+        return self.mfma_dtype or modules._DEFAULT_DTYPE
+
+    def _pack(self):
+        dt = self._dtype()
+        key = _param_key(self, dt)
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        L = _lib.lib()
+        a = self.self_attn
+        dev = self.norm1.weight.device
+        keep = []
+
+        def f(t):
+            tt = _dev_f32(t.detach(), "parameter")
+            keep.append(tt)
+            return tt.data_ptr()
+
+        ps = _lib.AxvsMsdaLayerParams()
+        for name in ("value_proj", "sampling_offsets", "attention_weights", "output_proj"):
+            lin = getattr(a, name)
+            setattr(ps.self_attn, name + "_w", f(lin.weight))
+            setattr(ps.self_attn, name + "_b", f(lin.bias))
+        for name in ("norm1", "linear1", "linear2", "norm2"):
+            mod = getattr(self, name)
+            setattr(ps, name + "_w", f(mod.weight))
+            setattr(ps, name + "_b", f(mod.bias))
+        buf = torch.empty(L.axvs_msda_layer_packed_bytes(self.d_model, a.n_heads, a.n_levels, a.n_points, self.d_ffn), dtype=torch.uint8,
+                          device=dev)
+        _lib.check(L.axvs_msda_layer_pack(C.byref(ps), buf.data_ptr(), self.d_model, a.n_heads, a.n_levels, a.n_points, self.d_ffn,
+                                          _lib.DTYPES[dt], _stream(dev)), "axvs_msda_layer_pack")
+        torch.cuda.current_stream(dev).synchronize()
+        self._packed, self._packed_key = buf, key
+        return buf
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index=None, padding_mask=None):
+        _require_eval(self)
+        x = _dev_f32(src, "src")
+        p = _dev_f32(pos, "pos") if pos is not None else None
+        ref = _dev_f32(reference_points, "reference_points")
+        a = self.self_attn
+        N, S, Cq = x.shape
+        shp = _shapes_host(spatial_shapes)
+        if sum(h * w for h, w in shp) != S:
+            raise AssertionError("spatial_shapes do not cover src")
+        if ref.shape[-1] not in (2, 4):
+            raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(ref.shape[-1]))
+        if Cq != self.d_model or len(shp) != a.n_levels or ref.shape[:3] != (N, S, a.n_levels) or (p is not None and p.shape != x.shape):
+            raise RuntimeError(f"shape mismatch: src {tuple(x.shape)}, reference_points {tuple(ref.shape)}, levels {len(shp)}")
+        mask = None
+        if padding_mask is not None:
+            if not padding_mask.is_cuda:
+                raise RuntimeError("axial_vs_amd: padding_mask must be a CUDA tensor (no CPU fallback)")
+            mask = padding_mask.to(torch.uint8).contiguous()
+        L = _lib.lib()
+        packed = self._pack()
+        dev = x.device
+        ws = _workspace(dev, L.axvs_msda_layer_workspace_bytes(N, S, self.d_model, a.n_heads, a.n_levels, a.n_points, self.d_ffn))
+        arr = (C.c_int * (2 * a.n_levels))(*[v for hw in shp for v in hw])
+        out = torch.empty_like(x)
+        _lib.check(L.axvs_msda_layer_fwd(x.data_ptr(), p.data_ptr() if p is not None else None, ref.data_ptr(), ref.shape[-1],
+                                         mask.data_ptr() if mask is not None else None, arr, out.data_ptr(), packed.data_ptr(), N, S,
+                                         self.d_model, a.n_heads, a.n_levels, a.n_points, self.d_ffn, _lib.DTYPES[self._dtype()],
+                                         ws.data_ptr(), ws.numel(), _stream(dev)), "axvs_msda_layer_fwd")
+        return out

@@ -188,6 +188,21 @@ size_t axvs_msda_workspace_bytes(int N, int Lq, int S, int C, int heads, int L, 
 int axvs_msda_fwd(const float* query, const float* reference_points, int ref_dim, const float* input_flatten,
                   const unsigned char* padding_mask, const int* spatial_shapes, float* out, const void* packed, int N, int Lq,
                   int S, int C, int heads, int L, int P, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* MSDeformAttnTransformerEncoderLayer.forward (WC/msdeformattn.py:177-216), eval:
+ *   x = norm1(src + MSDeformAttn(src + pos, reference_points, src, ...));  out = norm2(x + linear2(relu(linear1(x)))) */
+typedef struct AxvsMsdaLayerParams {
+  AxvsMsdaParams self_attn;
+  const float *norm1_w, *norm1_b, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
+} AxvsMsdaLayerParams;
+size_t axvs_msda_layer_packed_bytes(int C, int heads, int L, int P, int d_ffn);
+int axvs_msda_layer_pack(const AxvsMsdaLayerParams* p, void* packed, int C, int heads, int L, int P, int d_ffn, int dtype,
+                         void* stream);
+size_t axvs_msda_layer_workspace_bytes(int N, int S, int C, int heads, int L, int P, int d_ffn);
+/* src / out fp32 [N,S,C] (out must not alias src); pos fp32 [N,S,C] or NULL; reference_points fp32 [N,S,L,ref_dim] */
+int axvs_msda_layer_fwd(const float* src, const float* pos, const float* reference_points, int ref_dim,
+                        const unsigned char* padding_mask, const int* spatial_shapes, float* out, const void* packed, int N,
+                        int S, int C, int heads, int L, int P, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
+                        void* stream);
 /* value fp32 [N,S,M,D]; sampling_loc fp32 [N,Lq,M,L,P,2]; attn_weight fp32 [N,Lq,M,L,P]; out fp32 [N,Lq,M*D] */
 int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight,
                        float* out, int N, int S, int M, int D, int Lq, int L, int P, void* stream);

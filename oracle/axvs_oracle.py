@@ -428,6 +428,15 @@ def msda_module(query: Tensor, reference_points: Tensor, input_flatten: Tensor, 
     return _linear(msda_core(value, spatial_shapes, loc, aw), w, "output_proj")
 
 
+def msda_encoder_layer(src: Tensor, pos: Optional[Tensor], reference_points: Tensor, spatial_shapes, w: Weights, n_heads: int,
+                       n_levels: int, n_points: int, padding_mask: Optional[Tensor] = None) -> Tensor:
+    """MSDeformAttnTransformerEncoderLayer.forward, WC/msdeformattn.py:207-216 (eval: dropouts are identities)."""
+    q = src if pos is None else src + pos
+    x = src + msda_module(q, reference_points, src, spatial_shapes, _sub(w, "self_attn"), n_heads, n_levels, n_points, padding_mask)
+    x = _layer_norm(x, w, "norm1")
+    return _layer_norm(x + _linear(torch.relu(_linear(x, w, "linear1")), w, "linear2"), w, "norm2")
+
+
 # --------------------------------------------------------------------------------------
 # synthetic inputs / weights shared by tests, smoke and bench (SURVEY.md 8d recipe)
 # --------------------------------------------------------------------------------------

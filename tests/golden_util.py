@@ -103,3 +103,33 @@ def msda_module_case(z, m):
         pm[0, 5:40] = True
         pm[1, -7:] = True
     return w, src + pos, ref, src, pm
+
+
+MSDA_ENCLAYER = ["g7_msda_enclayer_N2_C256_L3_S252", "g7_msda_enclayer_N1_C64_L2_S39"]
+
+
+def msda_enclayer_case(z, m):
+    """weights + inputs of a G7c fixture: (state dict, src, pos, reference_points, padding mask or None)."""
+    import axvs_oracle as orc
+    w = orc.random_weights({k: tuple(v) for k, v in m["wshapes"].items()}, m["seed"])
+    for k in z.files:
+        if k.startswith("w."):
+            w[k[2:]] = torch.from_numpy(z[k])
+    shapes, N, C = m["shapes"], m["N"], m["C"]
+    L, S = len(shapes), sum(h * ww for h, ww in shapes)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    for k in ("self_attn.sampling_offsets.weight", "self_attn.attention_weights.weight", "self_attn.attention_weights.bias"):
+        torch.rand(w[k].shape, generator=g)
+    src = torch.randn(N, S, C, generator=g)
+    pos = torch.randn(N, S, C, generator=g) * 0.5
+    refs = []
+    for (h, ww) in shapes:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, ww - 0.5, ww) / ww, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(N, S, L, 2).contiguous()
+    pm = None
+    if m["mask"]:
+        pm = torch.zeros(N, S, dtype=torch.bool)
+        pm[0, 5:40] = True
+        pm[1, -7:] = True
+    return w, src, pos, ref, pm

@@ -369,3 +369,23 @@ def test_msda_reference_boxes_and_errors():
         mod(dev(q), dev(ref[..., :3]), dev(src), shapes)
     with pytest.raises(AssertionError):
         mod(dev(q), dev(ref), dev(src[:, :-1]), shapes)
+
+
+from golden_util import MSDA_ENCLAYER, msda_enclayer_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", MSDA_ENCLAYER)
+def test_msda_encoder_layer_golden(name):
+    """MSDeformAttnTransformerEncoderLayer (deformable self-attention + residual + norm1 + FFN + norm2) against the reference
+    class: padding mask, pos embedding folded into the query loader, C = 256 (fused FFN kernel) and C = 64 (generic kernels)."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w, src, pos, ref, pm = msda_enclayer_case(z, m)
+    mod = ax.MSDeformAttnTransformerEncoderLayer(d_model=m["C"], d_ffn=m["d_ffn"], dropout=0.0, n_levels=len(m["shapes"]),
+                                                 n_heads=m["M"], n_points=m["P"]).eval()
+    mod.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    out = mod(dev(src), dev(pos), dev(ref), m["shapes"], None, pm.cuda() if pm is not None else None).cpu()
+    e = rel_err(out, t(z["out"]))
+    print(f"{name}: {e:.2e}")
+    assert e < TOL_F16

@@ -150,3 +150,15 @@ def test_msda_module(name):
     ref_out = t(z["out"])
     got = out if ref_out.shape == out.shape else out[:, ::29, ::3]
     assert rel_err(got, ref_out) < 5e-5
+
+
+from golden_util import MSDA_ENCLAYER, msda_enclayer_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", MSDA_ENCLAYER)
+def test_msda_encoder_layer(name):
+    z, m = load(name)
+    w, src, pos, ref, pm = msda_enclayer_case(z, m)
+    assert abs(sum(v.double().sum().item() for v in w.values()) - float(z["wsum"])) < 1e-6 * max(1.0, abs(float(z["wsum"])))
+    out = orc.msda_encoder_layer(src, pos, ref, m["shapes"], w, m["M"], len(m["shapes"]), m["P"], pm)
+    assert rel_err(out, t(z["out"])) < 5e-5
