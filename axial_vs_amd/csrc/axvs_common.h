@@ -113,6 +113,12 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 // all-reduce across the four 16-lane groups (same lane&15)
+// max of three without the NaN-quieting v_max_f32 x,x canonicalisations hipcc puts in front of fmaxf chains
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ float groups_sum(float v) {
   v += lane_xor16(v);
   v += lane_xor32(v);

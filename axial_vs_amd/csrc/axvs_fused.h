@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int j = 0; j < 8; ++j) ones[j] = H16<BF>::from_f32(1.f);
     // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
     // the L2 latency of both hides behind MFMA + softmax work
-    u16x8 kf[2 * NKS], kn[2 * NKS], vf[2][NKS];
+    u16x8 kb[2][2 * NKS], vf[2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
     // per-lane fragment pointers, advanced by one frame per iteration (all index math hoisted out of the loop:
     // frame slot sf = seq0 / L + f because N = T * L)
     const u16* kp[2 * NKS];
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const u16* vp = Vh + (seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8;
     const int kstep = L * 32;
 #pragma unroll
-    for (int kt = 0; kt < 2 * NKS; ++kt) kf[kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
-#pragma unroll 1
+    for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+#pragma unroll 2
     for (int f = 0; f < T; ++f) {
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd)
@@ -442,12 +442,12 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
       }
 #pragma unroll
-      for (int kt = 0; kt < 2 * NKS; ++kt) kn[kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+      for (int kt = 0; kt < 2 * NKS; ++kt) kb[(f + 1) & 1][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
       f32x4 sc[MT][2 * NKS];
 #pragma unroll
       for (int kt = 0; kt < 2 * NKS; ++kt) {
 #pragma unroll
-        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
+        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kb[f & 1][kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
       }
       if (ragged) {
 #pragma unroll
@@ -507,10 +507,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                       xa[qt][1][0] * inv[qt], xa[qt][1][1] * inv[qt], xa[qt][1][2] * inv[qt], xa[qt][1][3] * inv[qt]};
         *reinterpret_cast<u16x8*>(xt + ((f * 8 + wave) * ROWS + row) * 32 + swz_chunk(row, fg) * 8) = cvt8<BF>(v);
       }
-#pragma unroll
-      for (int kt = 0; kt < 2 * NKS; ++kt) kf[kt] = kn[kt];
+      lds_fence();                       // per frame: the LDS stores of several frames must never pile up (4-bit lgkmcnt)
     }
-    lds_fence();
     load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
   } else {
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
