@@ -4,12 +4,12 @@ Python host mirroring the reference nn.Module surface; all compute runs in hand-
 behind the C-ABI of libaxvs.so (include/axvs.h).
 """
 from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, TemporalAxialTrajectoryAttentionLayer,
-                      TemporalEncoder, TemporalTrajectoryAttentionLayer, TrajectoryAttention, TubeLinkTemporalEncoder,
-                      set_default_dtype)
+                      GraphedForward, TemporalEncoder, TemporalTrajectoryAttentionLayer, TrajectoryAttention,
+                      TubeLinkTemporalEncoder, set_default_dtype)
 
 from .cross_clip import CrossClipTrackingModule, TubeLinkCrossClipHead
 from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer, ms_deform_attn_forward
 
 __all__ = ["CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
-           "set_default_dtype"]
+           "set_default_dtype", "GraphedForward"]

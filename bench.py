@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--d-ffn", type=int, default=1024)
     ap.add_argument("--gather", action="store_true", help="all-gather every step's output across ranks (RCCL, side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay a captured HIP graph per step instead of launching from Python")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (axvs_set_option)")
     args = ap.parse_args()
@@ -106,8 +107,14 @@ def main():
         gathered = torch.empty(world * B * T, H * W, C, device=dev)
         side = torch.cuda.Stream(dev)
 
+    # one step = one layer forward on the resident clip.  --graph replays the 4 launches from a captured HIP graph
+    # (axial_vs_amd.GraphedForward); measured on MI355X / ROCm 7.2 it is NOT faster at this size (137.7 vs 133.5 us per step: the
+    # Python launch path already keeps ahead of 130 us of GPU work and a graph launch costs more than 4 kernel launches), so the
+    # default stays the plain path.
+    graphed = ax.GraphedForward(layer, src, pos) if args.graph else None
+
     def step():
-        out = layer(src, pos)[0]
+        out = graphed()[0] if graphed is not None else layer(src, pos)[0]
         if gathered is not None:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -147,7 +154,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"TemporalAxialTrajectoryAttentionLayer fwd, [B={B},T={T},C={C},H={H},W={W}] per GPU, "
                                f"heads={heads}, d_ffn={F}, fp32 in/out, {args.dtype} MFMA operands",
-                   "shape_per_gpu": [B, T, C, H, W], "parallelism": f"dp{world} (clips sharded over ranks"
+                   "shape_per_gpu": [B, T, C, H, W], "launch": "python per step" if graphed is None else "hipGraph replay (4 kernels)",
+                   "parallelism": f"dp{world} (clips sharded over ranks"
                    + (", RCCL all-gather of outputs overlapped)" if gathered is not None else ", no collective)")},
     }
 
@@ -178,7 +186,7 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.steps):
-            layer(src, pos)
+            step()
         e1.record()
         torch.cuda.synchronize(dev)
         fwd_ms = e0.elapsed_time(e1) / args.steps

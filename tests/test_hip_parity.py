@@ -389,3 +389,20 @@ def test_msda_encoder_layer_golden(name):
     e = rel_err(out, t(z["out"]))
     print(f"{name}: {e:.2e}")
     assert e < TOL_F16
+
+
+def test_graphed_forward_matches_eager():
+    """The whole forward is capturable into a HIP graph (no allocation / sync inside the library): replay == eager, bitwise,
+    also after the inputs change."""
+    import axial_vs_amd as ax
+    C, F = 256, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 9)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    src, pos = orc.synthetic_clip(1, 2, C, 32, 32, 9)
+    src2, _ = orc.synthetic_clip(1, 2, C, 32, 32, 10)
+    g = ax.GraphedForward(layer, dev(src), dev(pos))
+    assert torch.equal(g()[0], layer(dev(src), dev(pos))[0])
+    out2 = g(dev(src2), dev(pos))[0].clone()
+    assert torch.equal(out2, layer(dev(src2), dev(pos))[0])
