@@ -8,8 +8,11 @@ from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, Tempo
                       TubeLinkTemporalEncoder, set_default_dtype)
 
 from .cross_clip import CrossClipTrackingModule, TubeLinkCrossClipHead
+from .pixel_decoder import (MSDeformAttnPixelDecoder, MSDeformAttnTransformerEncoder, MSDeformAttnTransformerEncoderOnly,
+                            PositionEmbeddingSine, WithinClipTrackingModule)
 from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer, ms_deform_attn_forward
 
-__all__ = ["CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
+__all__ = ["WithinClipTrackingModule", "MSDeformAttnPixelDecoder", "MSDeformAttnTransformerEncoder", "MSDeformAttnTransformerEncoderOnly",
+           "PositionEmbeddingSine", "CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
            "set_default_dtype", "GraphedForward"]

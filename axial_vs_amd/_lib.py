@@ -61,6 +61,10 @@ class AxvsMsdaLayerParams(C.Structure):
                                                                       "linear2_b", "norm2_w", "norm2_b")]
 
 
+class AxvsConvGnParams(C.Structure):
+    _fields_ = [(n, _fp) for n in ("conv_w", "conv_b", "gn_w", "gn_b")]
+
+
 # name -> (restype, argtypes); must list every symbol of include/axvs.h
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
@@ -87,6 +91,13 @@ SIGNATURES = {
     "axvs_cc_heads_pack": (C.c_int, [C.POINTER(AxvsCCHeadParams), _fp, C.c_int, C.c_int, _fp]),
     "axvs_cc_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "axvs_cc_heads_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_conv1x1_gn_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "axvs_conv1x1_gn_pack": (C.c_int, [C.POINTER(AxvsConvGnParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "axvs_conv1x1_gn_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "axvs_conv1x1_gn_fwd": (C.c_int, [_fp, C.c_int, C.c_longlong, C.c_longlong, _fp, C.c_int, C.c_longlong, C.c_longlong, _fp] +
+                            [C.c_int] * 5 + [C.c_float, C.c_int, _fp, C.c_size_t, _fp]),
+    "axvs_add_channel_vector": (C.c_int, [_fp, _fp, C.c_size_t, C.c_int, _fp]),
+    "axvs_pos2d": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [C.c_longlong, C.c_longlong, C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_msda_packed_bytes": (C.c_size_t, [C.c_int] * 4),
     "axvs_msda_pack": (C.c_int, [C.POINTER(AxvsMsdaParams), _fp] + [C.c_int] * 5 + [_fp]),
     "axvs_msda_workspace_bytes": (C.c_size_t, [C.c_int] * 7),

@@ -10,6 +10,7 @@
 #include "axvs_attn.h"
 #include "axvs_cc.h"
 #include "axvs_msda.h"
+#include "axvs_glue.h"
 #include "axvs_common.h"
 #include "axvs_fused.h"
 #include "axvs_gemm.h"
@@ -1169,6 +1170,96 @@ int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const floa
   const long long total = (long long)N * Lq * M * D;
   hipLaunchKernelGGL(msda_core_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), value, lv,
                      sampling_loc, attn_weight, out, N, S, M, D, Lq, P);
+  return last_launch_status();
+}
+
+// ---- pixel-decoder glue ----
+size_t axvs_conv1x1_gn_packed_bytes(int Cin, int Cout) {
+  Carver c(nullptr);
+  c.take<u16>(3 * (size_t)Cin * Cout);
+  c.take<float>(Cout); c.take<float>(Cout); c.take<float>(Cout);
+  return c.off;
+}
+
+int axvs_conv1x1_gn_pack(const AxvsConvGnParams* p, void* packed, int Cin, int Cout, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 4) return fail(AXVS_ERR_ARG, "Cin=%d must be a multiple of 32, Cout=%d of 4", Cin, Cout);
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  u16* w = c.take<u16>(3 * (size_t)Cin * Cout);
+  float* b = c.take<float>(Cout); float* g = c.take<float>(Cout); float* be = c.take<float>(Cout);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PackDim nd{Cout, Cout, 0, 0, 0}, kd{Cin, Cin, 0, 0, 0};
+  if (dtype == AXVS_BF16) pack_w3<true>(p->conv_w, w, nd, kd, st);
+  else pack_w3<false>(p->conv_w, w, nd, kd, st);
+  copy_f32(p->conv_b, b, Cout, st);
+  copy_f32(p->gn_w, g, Cout, st);
+  copy_f32(p->gn_b, be, Cout, st);
+  return last_launch_status();
+}
+
+size_t axvs_conv1x1_gn_workspace_bytes(int N, int HW, int Cout, int groups) {
+  Carver c(nullptr);
+  c.take<float>((size_t)N * HW * Cout);
+  c.take<float>((size_t)N * groups * 2);
+  c.take<float>((size_t)N * ((HW + 63) / 64) * groups * 2);
+  return c.off;
+}
+
+int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride, long long in_ld, float* out, int out_layout,
+                        long long out_batch_stride, long long out_ld, const void* packed, int N, int HW, int Cin, int Cout, int groups,
+                        float eps, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || HW <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (Cin % 32 || Cout % 4 || groups <= 0 || Cout % groups || groups > 256) return fail(AXVS_ERR_ARG, "unsupported channels/groups %d/%d/%d", Cin, Cout, groups);
+  if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return fail(AXVS_ERR_ARG, "layout must be 0 (NCHW) or 1 (token rows)");
+  if ((long long)N * HW > 2147483647LL / 64) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
+  if (workspace_bytes < axvs_conv1x1_gn_workspace_bytes(N, HW, Cout, groups)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Carver pc(const_cast<void*>(packed));
+  const u16* w = pc.take<u16>(3 * (size_t)Cin * Cout);
+  const float* b = pc.take<float>(Cout); const float* g = pc.take<float>(Cout); const float* be = pc.take<float>(Cout);
+  Carver wc(workspace);
+  const long long M = (long long)N * HW;
+  float* y = wc.take<float>((size_t)M * Cout);
+  float* stats = wc.take<float>((size_t)N * groups * 2);
+  const int nblk = (HW + 63) / 64;
+  float* partial = wc.take<float>((size_t)N * nblk * groups * 2);
+  if (Cout > 8192) return fail(AXVS_ERR_ARG, "Cout=%d too large for the GroupNorm statistics kernel", Cout);
+  g_prof_next = 0;
+  mark(st, "begin");
+  const EpiRowsF32 ey{y, nullptr, b, identity_map(M), Cout, 1.f};
+  if (dtype == AXVS_BF16) {
+    if (in_layout == 0) launch_gemm<true>(ALoadNCHWSplit3<true>{x, (int)M, Cin, HW}, w, ey, (int)M, Cout, 3 * Cin, st);
+    else launch_gemm<true>(ALoadTokensSplit3<true>{x, (int)M, Cin, HW, in_batch_stride, in_ld}, w, ey, (int)M, Cout, 3 * Cin, st);
+  } else {
+    if (in_layout == 0) launch_gemm<false>(ALoadNCHWSplit3<false>{x, (int)M, Cin, HW}, w, ey, (int)M, Cout, 3 * Cin, st);
+    else launch_gemm<false>(ALoadTokensSplit3<false>{x, (int)M, Cin, HW, in_batch_stride, in_ld}, w, ey, (int)M, Cout, 3 * Cin, st);
+  }
+  mark(st, "glue.conv1x1");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nblk, N), dim3(256), 2 * (size_t)Cout * sizeof(float), st, y, partial, HW, Cout, groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((N * groups + 255) / 256)), dim3(256), 0, st, partial, stats, nblk, groups, N * groups);
+  const dim3 ag((unsigned)((HW + 63) / 64), (unsigned)((Cout + 63) / 64), N);
+  if (out_layout == 0) hipLaunchKernelGGL((gn_apply_kernel<true>), ag, dim3(256), 0, st, y, stats, g, be, out, HW, Cout, groups, eps, (long long)0, (long long)Cout * HW);
+  else hipLaunchKernelGGL((gn_apply_kernel<false>), ag, dim3(256), 0, st, y, stats, g, be, out, HW, Cout, groups, eps, out_ld, out_batch_stride);
+  mark(st, "glue.group_norm");
+  return last_launch_status();
+}
+
+int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long long S, long long row0, float temperature, int normalize,
+               float scale, void* stream) {
+  if (!pos) return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 2 || row0 < 0 || row0 + (long long)H * W > S) return fail(AXVS_ERR_ARG, "bad shape");
+  const long long total = (long long)H * W * C;
+  hipLaunchKernelGGL(pos2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pos, add, N, H, W,
+                     C, S, row0, temperature, normalize, scale);
+  return last_launch_status();
+}
+
+int axvs_add_channel_vector(float* x, const float* v, size_t n, int C, void* stream) {
+  if (!x || !v || C <= 0) return fail(AXVS_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(add_channel_vector_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, v, n, C);
   return last_launch_status();
 }
 

@@ -1,0 +1,168 @@
+// Pixel-decoder glue around the within-clip stages: 1x1 conv + GroupNorm projections between backbone NCHW maps and
+// token rows, 2-D sine position embedding.  Reference: WC/msdeformattn.py:349-375 (input_proj / output_proj), :404-435
+// (forward_features), WC/pos_embeddings.py:12-53 (PositionEmbeddingSine).
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+
+// A-operand loader for a 1x1 convolution that reads the backbone map where it lies: x [N][Cin][HW] fp32 (NCHW), row m = n*HW + p,
+// k = input channel.  Lanes of a wave hold consecutive m, so each of the 8 strided loads is coalesced across the wave.
+// Split precision (hi | hi | lo along a 3x longer K, see ALoadRowsF32Split3): the projection output feeds a GroupNorm directly.
+template <bool BF>
+struct ALoadNCHWSplit3 {
+  const float* x;
+  int M, K, HW;          // M = N*HW rows, K = Cin
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    const int part = k / K, kk = k - part * K;
+    const int n = m / HW, p = m - n * HW;
+    const float* s = x + ((long long)n * K + kk) * HW + p;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = s[(long long)i * HW];
+    u16x8 hi = cvt8<BF>(v);
+    if (part < 2) return hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] -= H16<BF>::to_f32(hi[i]);
+    return cvt8<BF>(v);
+  }
+};
+
+// token rows that may be a slice of a wider buffer: row (n, p) at x + n*batch_stride + p*ld  (split precision as above)
+template <bool BF>
+struct ALoadTokensSplit3 {
+  const float* x;
+  int M, K, HW;
+  long long batch_stride, ld;
+  __device__ __forceinline__ u16x8 load(int m, int k) const {
+    m = min(m, M - 1);
+    const int part = k / K, kk = k - part * K;
+    const int n = m / HW, p = m - n * HW;
+    const float4* s = reinterpret_cast<const float4*>(x + n * batch_stride + p * ld + kk);
+    const float4 a = s[0], b = s[1];
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    u16x8 hi = cvt8<BF>(v);
+    if (part < 2) return hi;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] -= H16<BF>::to_f32(hi[i]);
+    return cvt8<BF>(v);
+  }
+};
+
+// GroupNorm statistics over token rows y [N*HW][C], deterministic (no atomics: a 1-ulp change of a statistic flips 16-bit
+// roundings downstream and shows up as run-to-run differences of whole f16 ulps).  Stage 1: one workgroup = 64 rows of one
+// sample, thread = 4 consecutive channels -> per-channel sums in LDS -> per-group partials [N][nblk][G][2] in channel order.
+// Stage 2 (gn_finalize_kernel): partials summed in block order -> stats [N][G][2] = (sum, sum of squares).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int HW, int C, int G) {
+  extern __shared__ float chs[];                        // [C] sums | [C] sums of squares
+  float* chq = chs + C;
+  const int n = blockIdx.y, r0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int rows = min(64, HW - r0);
+  for (int c = tid * 4; c < C; c += 1024) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < rows; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(y + ((long long)n * HW + r0 + r) * C + c);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { chs[c + i] = s[i]; chq[c + i] = q[i]; }
+  }
+  __syncthreads();
+  const int cg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += chs[c]; q += chq[c]; }
+    float* o = partial + (((long long)n * gridDim.x + blockIdx.x) * G + g) * 2;
+    o[0] = s; o[1] = q;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int G, int NG) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (n, g)
+  if (i >= NG) return;
+  const int n = i / G, g = i - n * G;
+  float s = 0.f, q = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    const float* p = partial + (((long long)n * nblk + b) * G + g) * 2;
+    s += p[0]; q += p[1];
+  }
+  stats[(long long)i * 2] = s;
+  stats[(long long)i * 2 + 1] = q;
+}
+
+// GroupNorm apply: out = (y - mean_g) * rstd_g * gamma_c + beta_c; token rows in, token rows (in place allowed) or NCHW out.
+// Workgroup = 64 pixels x 64 channels of one sample, transposed through LDS for the NCHW store.
+template <bool OUT_NCHW>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int HW, int C, int G, float eps, long long out_ld,
+                                                       long long out_batch_stride) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int cg = C / G;
+  const float cnt = (float)HW * cg;
+  // read: thread -> (pixel row, 16 channels) as float4 x 4: 64 rows x 16 float4
+  for (int i = tid; i < 64 * 16; i += 256) {
+    const int r = i >> 4, c4 = (i & 15) * 4;
+    const int p = p0 + r, c = c0 + c4;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p < HW && c < C) {
+      v = *reinterpret_cast<const float4*>(y + ((long long)n * HW + p) * C + c);
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int g = (c + k) / cg;
+        const float mu = stats[((long long)n * G + g) * 2] / cnt;
+        const float var = fmaxf(stats[((long long)n * G + g) * 2 + 1] / cnt - mu * mu, 0.f);
+        o[k] = (o[k] - mu) * rsqrtf(var + eps) * gamma[c + k] + beta[c + k];
+      }
+      v = float4{o[0], o[1], o[2], o[3]};
+      if (!OUT_NCHW) *reinterpret_cast<float4*>(out + (long long)n * out_batch_stride + (long long)p * out_ld + c) = v;
+    }
+    if (OUT_NCHW) {
+      tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+  }
+  if (OUT_NCHW) {
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int cc = i >> 6, r = i & 63;
+      if (p0 + r < HW && c0 + cc < C) out[(long long)n * out_batch_stride + (long long)(c0 + cc) * HW + p0 + r] = tile[r][cc];
+    }
+  }
+}
+
+// PositionEmbeddingSine(num_pos_feats = C/2, normalize, mask = None) in token form, plus an optional per-channel vector (the
+// level embedding, WC/msdeformattn.py:113-114): pos[n][row0 + y*W + x][c], rows of a level inside a [N][S][C] buffer.
+__global__ void pos2d_kernel(float* __restrict__ pos, const float* __restrict__ add, int N, int H, int W, int C, long long S, long long row0,
+                             float temperature, int normalize, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)H * W * C;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long r = idx / C;
+  const int x = (int)(r % W), y = (int)(r / W);
+  const int n = C / 2;
+  float ye = (float)(y + 1), xe = (float)(x + 1);
+  if (normalize) {
+    const float eps = 1e-6f;
+    ye = ye / ((float)H + eps) * scale;
+    xe = xe / ((float)W + eps) * scale;
+  }
+  const int cc = c < n ? c : c - n;                       // first half: y, second half: x (pos_embeddings.py:52)
+  const float dim_t = powf(temperature, 2.f * (float)(cc / 2) / (float)n);
+  const float a = (c < n ? ye : xe) / dim_t;
+  float v = (cc & 1) ? cosf(a) : sinf(a);
+  if (add) v += add[c];
+  for (int b = 0; b < N; ++b) pos[((long long)b * S + row0 + r) * C + c] = v;
+}
+
+// x[i] += v[i % C]  (level embedding added to a channels-last position embedding, WC/msdeformattn.py:117-118)
+__global__ void add_channel_vector_kernel(float* __restrict__ x, const float* __restrict__ v, size_t n, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += v[i % C];
+}
+
+}  // namespace axvs

@@ -1,0 +1,288 @@
+"""nn.Module mirrors of the within-clip pixel decoder around the stages (SURVEY 8f-2, 8b registry hook).
+
+Reference: WC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module
+  `PositionEmbeddingSine` (WC/pos_embeddings.py:12-53), `MSDeformAttnTransformerEncoder` (WC/msdeformattn.py:219-275),
+  `MSDeformAttnTransformerEncoderOnly` (:34-174), `MSDeformAttnPixelDecoder` (:293-437),
+  `WithinClipTrackingModule` (WC/maxtron_within_clip_tracking_module.py:14-69).
+Same constructor keywords, attribute names and state-dict keys (a reference checkpoint loads with strict=True); every
+tensor op of `forward_features` runs in libaxvs.so (1x1 conv + GroupNorm projections straight from / to the backbone's NCHW
+maps, sine embeddings, deformable spatial layers, axial-trajectory temporal layers); PyTorch only slices and concatenates
+token buffers.  Eval only; configurations with spatial layers (with or without temporal layers), like every shipped config.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _lib
+from .modules import PositionEmbeddingSine3D, TemporalEncoder, _dev_f32, _param_key, _require_eval, _stream, _workspace
+from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class PositionEmbeddingSine(nn.Module):
+    """WC/pos_embeddings.py:12-53 (mask=None): returns [N, 2*num_pos_feats, H, W] like the reference."""
+
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def tokens_into(self, pos: Tensor, add: Optional[Tensor], N: int, H: int, W: int, row0: int) -> None:
+        """pos[n, row0 + y*W + x, :] (+ add) for a level inside a [N, S, C] fp32 CUDA buffer."""
+        Cc = 2 * self.num_pos_feats
+        _lib.check(_lib.lib().axvs_pos2d(pos.data_ptr(), add.data_ptr() if add is not None else None, N, H, W, Cc, pos.shape[1], row0,
+                                         float(self.temperature), int(self.normalize), float(self.scale), _stream(pos.device)), "axvs_pos2d")
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("axial_vs_amd: PositionEmbeddingSine supports mask=None (the within-clip module's only use)")
+        if not x.is_cuda:
+            raise RuntimeError("axial_vs_amd: CUDA tensors only (no CPU fallback)")
+        N, _, H, W = x.shape
+        pos = torch.empty(N, H * W, 2 * self.num_pos_feats, dtype=torch.float32, device=x.device)
+        self.tokens_into(pos, None, N, H, W, 0)
+        return pos.view(N, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _conv_gn(in_channels: int, out_channels: int) -> nn.Sequential:
+    """Parameter holder with the reference's names (`.0` conv, `.1` GroupNorm(32)); the computation is axvs_conv1x1_gn_fwd."""
+    return nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1), nn.GroupNorm(32, out_channels))
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, spatial_layer, num_stages, transformer_num_spatial_feature_levels, transformer_num_temporal_feature_levels=0,
+                 temporal_layer=None):
+        super().__init__()
+        self.spatial_layers = _get_clones(spatial_layer, num_stages)
+        self.transformer_num_spatial_feature_levels = transformer_num_spatial_feature_levels
+        self.transformer_num_temporal_feature_levels = transformer_num_temporal_feature_levels
+        if transformer_num_temporal_feature_levels > 0:
+            self.temporal_layers = _get_clones(temporal_layer, num_stages)
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """WC/msdeformattn.py:229-242 with all-valid masks (valid ratios = 1): pixel centres, repeated for every level."""
+        refs = []
+        for (H_, W_) in spatial_shapes:
+            ys = (torch.arange(H_, dtype=torch.float32, device=device) + 0.5) / H_
+            xs = (torch.arange(W_, dtype=torch.float32, device=device) + 0.5) / W_
+            refs.append(torch.stack((xs.view(1, W_).expand(H_, W_).reshape(-1), ys.view(H_, 1).expand(H_, W_).reshape(-1)), -1))
+        ref = torch.cat(refs, 0)
+        return ref[None, :, None, :].expand(valid_ratios, -1, len(spatial_shapes), 2).contiguous()
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos, padding_mask, pos_3d=None):
+        """src / pos [BT, S, C]; spatial_shapes: list of (H, W); valid_ratios: BT (all maps valid); pos_3d: list of [B,T,H,W,C]."""
+        output = src
+        key = (tuple(spatial_shapes), src.shape[0], src.device)
+        if getattr(self, "_ref_key", None) != key:
+            self._ref, self._ref_key = self.get_reference_points(spatial_shapes, src.shape[0], src.device), key
+        sizes = [h * w for h, w in spatial_shapes]
+        h_attn = w_attn = None
+        for i, spatial_layer in enumerate(self.spatial_layers):
+            output = spatial_layer(output, pos, self._ref, spatial_shapes, level_start_index, padding_mask)
+            if self.transformer_num_temporal_feature_levels > 0:
+                parts = list(torch.split(output, sizes, dim=1))
+                for j in range(self.transformer_num_temporal_feature_levels):
+                    parts[j], h_attn, w_attn = self.temporal_layers[i](src=parts[j].contiguous(), pos=pos_3d[j])
+                output = torch.cat(parts, dim=1)
+        return output, h_attn, w_attn
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_stages=2, num_spatial_layers=2, num_temporal_layers=4,
+                 temporal_attn_type="axial_trajectory", dim_feedforward=1024, dropout=0.1, attn_drop=0.1, activation="relu",
+                 enc_n_points=4, num_spatial_feature_levels=3, num_temporal_feature_levels=2):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.num_spatial_layers, self.num_temporal_layers = num_spatial_layers, num_temporal_layers
+        assert num_spatial_layers + num_temporal_layers > 0, "number of layers should be greater than 0"
+        if num_spatial_layers == 0:
+            raise NotImplementedError("axial_vs_amd: temporal-only decoders (TemporalTransformerEncoder) are not built")
+        assert num_spatial_layers == num_stages, "number of spatial layers should be equal to number of stages"
+        spatial_layer = MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation, num_spatial_feature_levels,
+                                                            nhead, enc_n_points)
+        if num_temporal_layers > 0:
+            temporal_layer = TemporalEncoder(d_model, dim_feedforward, dropout, attn_drop, activation, nhead, temporal_attn_type,
+                                             num_temporal_layers // num_stages)
+            self.encoder = MSDeformAttnTransformerEncoder(spatial_layer, num_spatial_layers, num_spatial_feature_levels,
+                                                          num_temporal_feature_levels, temporal_layer)
+        else:
+            self.encoder = MSDeformAttnTransformerEncoder(spatial_layer, num_spatial_layers, num_spatial_feature_levels)
+        self.level_embed_2d = nn.Parameter(torch.Tensor(num_spatial_feature_levels, d_model))
+        if num_temporal_layers > 0:
+            self.level_embed_3d = nn.Parameter(torch.Tensor(num_temporal_feature_levels, d_model))
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.normal_(self.level_embed_2d)
+        if self.num_temporal_layers > 0:
+            nn.init.normal_(self.level_embed_3d)
+
+
+class MSDeformAttnPixelDecoder(nn.Module):
+    def __init__(self, input_shape: Dict[str, object], *, transformer_dropout: float, transformer_attn_drop: float,
+                 transformer_nheads: int, transformer_dim_feedforward: int, transformer_num_stages: int,
+                 transformer_spatial_layers: int, transformer_temporal_layers: int, transformer_temporal_attn_type: str,
+                 conv_dims: int, transformer_spatial_in_features: List[str], transformer_temporal_in_features: List[str],
+                 num_clip_frames: int, cross_clip_training: bool, mfma_dtype: Optional[str] = None):
+        super().__init__()
+        self.transformer_temporal_layers = transformer_temporal_layers
+        self.num_clip_frames = num_clip_frames
+        sp = sorted(((k, v) for k, v in input_shape.items() if k in transformer_spatial_in_features), key=lambda kv: kv[1].stride)
+        tp = sorted(((k, v) for k, v in input_shape.items() if k in transformer_temporal_in_features), key=lambda kv: kv[1].stride)
+        self.transformer_spatial_in_features = [k for k, _ in sp]
+        self.transformer_temporal_in_features = [k for k, _ in tp]
+        chans = [v.channels for _, v in sp]
+        self.transformer_num_spatial_feature_levels = len(sp)
+        self.transformer_num_temporal_feature_levels = len(tp)
+        ins = chans[::-1] if len(sp) > 1 else [chans[-1]]            # from low to high resolution (res5 -> res3)
+        self.input_proj = nn.ModuleList([_conv_gn(c, conv_dims) for c in ins])
+        self.output_proj = nn.ModuleList([_conv_gn(conv_dims, c) for c in ins])
+        for proj in list(self.input_proj) + list(self.output_proj):
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(
+            d_model=conv_dims, dropout=transformer_dropout, attn_drop=transformer_attn_drop, nhead=transformer_nheads,
+            dim_feedforward=transformer_dim_feedforward, num_stages=transformer_num_stages,
+            num_spatial_layers=transformer_spatial_layers, num_temporal_layers=transformer_temporal_layers,
+            temporal_attn_type=transformer_temporal_attn_type, num_spatial_feature_levels=self.transformer_num_spatial_feature_levels,
+            num_temporal_feature_levels=self.transformer_num_temporal_feature_levels)
+        self.pe_layer = PositionEmbeddingSine(conv_dims // 2, normalize=True)
+        self.pe_layer_3d = PositionEmbeddingSine3D(conv_dims // 2, normalize=True)
+        self.cross_clip_training = cross_clip_training
+        self.conv_dims = conv_dims
+        self.mfma_dtype = mfma_dtype
+        self._packed = None
+        self._packed_key = None
+
+    def _dtype(self) -> str:
+        from . import modules
+        return self.mfma_dtype or modules._DEFAULT_DTYPE
+
+    def _pack_projs(self):
+        dt = self._dtype()
+        projs = list(self.input_proj) + list(self.output_proj)
+        key = (dt,) + tuple((p.data_ptr(), p._version) for m in projs for p in m.parameters())
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        L = _lib.lib()
+        dev = self.input_proj[0][0].weight.device
+        keep, bufs = [], []
+
+        def f(t):
+            tt = _dev_f32(t.detach(), "parameter")
+            keep.append(tt)
+            return tt.data_ptr()
+
+        for m in projs:
+            cout, cin = m[0].weight.shape[:2]
+            ps = _lib.AxvsConvGnParams(f(m[0].weight), f(m[0].bias), f(m[1].weight), f(m[1].bias))
+            buf = torch.empty(L.axvs_conv1x1_gn_packed_bytes(cin, cout), dtype=torch.uint8, device=dev)
+            _lib.check(L.axvs_conv1x1_gn_pack(C.byref(ps), buf.data_ptr(), cin, cout, _lib.DTYPES[dt], _stream(dev)), "axvs_conv1x1_gn_pack")
+            bufs.append(buf)
+        torch.cuda.current_stream(dev).synchronize()
+        n = len(self.input_proj)
+        self._packed, self._packed_key = (bufs[:n], bufs[n:]), key
+        return self._packed
+
+    def forward_features(self, features):
+        _require_eval(self)
+        order = self.transformer_spatial_in_features[::-1]          # low -> high resolution (WC/msdeformattn.py:411)
+        xs = [_dev_f32(features[f], f) for f in order]
+        BT = xs[0].shape[0]
+        B = BT // self.num_clip_frames if self.cross_clip_training else 1
+        T = BT // B
+        Cd = self.conv_dims
+        dev = xs[0].device
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in xs]
+        sizes = [h * w for h, w in shapes]
+        S = sum(sizes)
+        L = _lib.lib()
+        dt = _lib.DTYPES[self._dtype()]
+        st = _stream(dev)
+        pin, pout = self._pack_projs()
+        src = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev)
+        pos = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev)
+        wsb = max(L.axvs_conv1x1_gn_workspace_bytes(BT, hw, max(Cd, x.shape[1]), 32) for hw, x in zip(sizes, xs))
+        ws = _workspace(dev, wsb)
+        lvl2d = _dev_f32(self.transformer.level_embed_2d.detach(), "level_embed_2d")
+        pos_3d = []
+        row0 = 0
+        for idx, (f, x) in enumerate(zip(order, xs)):
+            H, W = shapes[idx]
+            _lib.check(L.axvs_conv1x1_gn_fwd(x.data_ptr(), 0, 0, 0, src.data_ptr() + row0 * Cd * 4, 1, S * Cd, Cd, pin[idx].data_ptr(), BT,
+                                             H * W, x.shape[1], Cd, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
+            self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
+            if self.transformer_temporal_layers > 0 and f in self.transformer_temporal_in_features:
+                p3 = self.pe_layer_3d.channels_last(B, T, H, W, dev)
+                lvl3d = _dev_f32(self.transformer.level_embed_3d.detach(), "level_embed_3d")
+                _lib.check(L.axvs_add_channel_vector(p3.data_ptr(), lvl3d[len(pos_3d)].data_ptr(), p3.numel(), Cd, st), "axvs_add_channel_vector")
+                pos_3d.append(p3)
+            row0 += H * W
+        y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, pos, None, pos_3d)
+        out = {}
+        row0 = 0
+        for i, f in enumerate(order):
+            H, W = shapes[i]
+            cin = xs[i].shape[1]
+            o = torch.empty(BT, cin, H, W, dtype=torch.float32, device=dev)
+            _lib.check(L.axvs_conv1x1_gn_fwd(y.data_ptr() + row0 * Cd * 4, 1, S * Cd, Cd, o.data_ptr(), 0, 0, 0, pout[i].data_ptr(), BT, H * W,
+                                             Cd, cin, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
+            out[f] = o
+            row0 += H * W
+        return out, h_attn, w_attn
+
+
+class WithinClipTrackingModule(nn.Module):
+    """WC/maxtron_within_clip_tracking_module.py:14-69 without the detectron2 decorators (register it with
+    `SEM_SEG_HEADS_REGISTRY.register()(WithinClipTrackingModule)` where detectron2 is present; `from_config` reads the same keys)."""
+
+    def __init__(self, input_shape, *, transformer_dropout: float, transformer_attn_drop: float, transformer_nheads: int,
+                 transformer_dim_feedforward: int, transformer_num_stages: int, transformer_spatial_layers: int,
+                 transformer_temporal_layers: int, transformer_temporal_attn_type: str, transformer_conv_dims: int,
+                 transformer_spatial_in_features: List[str], transformer_temporal_in_features: List[str], num_clip_frames: int,
+                 cross_clip_training: bool):
+        super().__init__()
+        self.within_clip_tracking_module = MSDeformAttnPixelDecoder(
+            input_shape=input_shape, transformer_dropout=transformer_dropout, transformer_attn_drop=transformer_attn_drop,
+            transformer_nheads=transformer_nheads, transformer_dim_feedforward=transformer_dim_feedforward,
+            transformer_spatial_layers=transformer_spatial_layers, transformer_temporal_layers=transformer_temporal_layers,
+            transformer_temporal_attn_type=transformer_temporal_attn_type, conv_dims=transformer_conv_dims,
+            transformer_spatial_in_features=transformer_spatial_in_features,
+            transformer_temporal_in_features=transformer_temporal_in_features, transformer_num_stages=transformer_num_stages,
+            num_clip_frames=num_clip_frames, cross_clip_training=cross_clip_training)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        m = cfg.MODEL.MAXTRON.WITHIN_CLIP_TRACKING_MODULE
+        return dict(input_shape={k: v for k, v in input_shape.items() if k in m.SPATIAL_IN_FEATURES},
+                    transformer_dropout=m.DROPOUT, transformer_attn_drop=m.ATTN_DROP, transformer_nheads=m.NHEADS,
+                    transformer_dim_feedforward=m.DIM_FEEDFORWARD, transformer_num_stages=m.NUM_STAGES,
+                    transformer_spatial_layers=m.SPATIAL_LAYERS, transformer_temporal_layers=m.TEMPORAL_LAYERS,
+                    transformer_temporal_attn_type=m.TEMPORAL_ATTN_TYPE, transformer_conv_dims=m.CONV_DIMS,
+                    transformer_spatial_in_features=m.SPATIAL_IN_FEATURES, transformer_temporal_in_features=m.TEMPORAL_IN_FEATURES,
+                    num_clip_frames=cfg.INPUT.NUM_CLIP_FRAMES, cross_clip_training=cfg.MODEL.MAXTRON.CROSS_CLIP_TRACKING_MODULE.ENABLE)
+
+    def forward_features(self, features):
+        within_clip_features, axial_height_attn, axial_width_attn = self.within_clip_tracking_module.forward_features(features)
+        for k in within_clip_features:
+            features[k] = within_clip_features[k]
+        return features, axial_height_attn, axial_width_attn

@@ -207,6 +207,27 @@ int axvs_msda_layer_fwd(const float* src, const float* pos, const float* referen
 int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight,
                        float* out, int N, int S, int M, int D, int Lq, int L, int P, void* stream);
 
+/* ---- Pixel-decoder glue: nn.Sequential(Conv2d(k=1), GroupNorm) between backbone NCHW maps and token rows
+ *      (WC/msdeformattn.py:349-375 input_proj / output_proj; used at :412 and :434), PositionEmbeddingSine
+ *      (WC/pos_embeddings.py:12-53) in token form. */
+typedef struct AxvsConvGnParams {
+  const float *conv_w, *conv_b;   /* Conv2d weight [Cout,Cin,1,1], bias [Cout] */
+  const float *gn_w, *gn_b;       /* GroupNorm affine [Cout]                    */
+} AxvsConvGnParams;
+size_t axvs_conv1x1_gn_packed_bytes(int Cin, int Cout);
+int axvs_conv1x1_gn_pack(const AxvsConvGnParams* p, void* packed, int Cin, int Cout, int dtype, void* stream);
+size_t axvs_conv1x1_gn_workspace_bytes(int N, int HW, int Cout, int groups);
+/* layouts: 0 = NCHW fp32 [N,C,H*W] (contiguous; strides ignored), 1 = token rows: row (n,p) at base + n*batch_stride + p*ld
+ * (elements), so a level slice of a concatenated [N,S,C] buffer can be read / written in place. */
+int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride, long long in_ld, float* out, int out_layout,
+                        long long out_batch_stride, long long out_ld, const void* packed, int N, int HW, int Cin, int Cout,
+                        int groups, float eps, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* x[i] += v[i % C] in place (level_embed_3d on a channels-last position embedding, WC/msdeformattn.py:117-118) */
+int axvs_add_channel_vector(float* x, const float* v, size_t n, int C, void* stream);
+/* pos[n][row0 + y*W + x][c] (+ add[c] if add != NULL) inside a fp32 [N][S][C] buffer */
+int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long long S, long long row0, float temperature,
+               int normalize, float scale, void* stream);
+
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,

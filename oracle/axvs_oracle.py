@@ -438,6 +438,88 @@ def msda_encoder_layer(src: Tensor, pos: Optional[Tensor], reference_points: Ten
 
 
 # --------------------------------------------------------------------------------------
+# Within-clip pixel decoder around the stages: WC/msdeformattn.py:34-174 (encoder-only transformer),
+# :219-275 (stage loop), :293-437 (MSDeformAttnPixelDecoder), WC/pos_embeddings.py:12-53 (2-D sine embedding)
+# --------------------------------------------------------------------------------------
+def pos_embed_sine_2d(N: int, H: int, W: int, num_pos_feats: int, temperature: float = 10000.0, normalize: bool = True,
+                      scale: float = 2 * math.pi, dtype=torch.float32) -> Tensor:
+    """WC/pos_embeddings.py:29-53 with mask=None -> channels-last [N,H,W,2*num_pos_feats] (y half, then x half)."""
+    ye = torch.arange(1, H + 1, dtype=dtype).view(H, 1).expand(H, W)
+    xe = torch.arange(1, W + 1, dtype=dtype).view(1, W).expand(H, W)
+    if normalize:
+        eps = 1e-6
+        ye = ye / (H + eps) * scale
+        xe = xe / (W + eps) * scale
+    i = torch.arange(num_pos_feats, dtype=dtype)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="trunc") / num_pos_feats)
+
+    def enc(e):
+        a = e[..., None] / dim_t
+        return torch.stack((a[..., 0::2].sin(), a[..., 1::2].cos()), dim=-1).flatten(-2)
+
+    return torch.cat((enc(ye), enc(xe)), dim=-1)[None].expand(N, H, W, 2 * num_pos_feats)
+
+
+def conv1x1_group_norm(x: Tensor, w: Weights, name: str, groups: int = 32, eps: float = 1e-5) -> Tensor:
+    """nn.Sequential(Conv2d(k=1), GroupNorm(32, C)) (WC/msdeformattn.py:355-362) on NCHW x."""
+    wt, b = w[name + ".0.weight"], w[name + ".0.bias"]
+    y = torch.einsum("nchw,oc->nohw", x, wt.reshape(wt.shape[0], wt.shape[1])) + b.view(1, -1, 1, 1)
+    N, C, H, W = y.shape
+    yg = y.reshape(N, groups, C // groups * H * W)
+    mu = yg.mean(-1, keepdim=True)
+    var = ((yg - mu) ** 2).mean(-1, keepdim=True)
+    yn = ((yg - mu) / torch.sqrt(var + eps)).reshape(N, C, H, W)
+    return yn * w[name + ".1.weight"].view(1, -1, 1, 1) + w[name + ".1.bias"].view(1, -1, 1, 1)
+
+
+def pixel_decoder(features: Dict[str, Tensor], w: Weights, spatial_in: Sequence[str], temporal_in: Sequence[str], num_stages: int,
+                  temporal_layers_per_stage: int, heads: int = 8, n_points: int = 4, num_clip_frames: int = 1,
+                  B: int = 1) -> Dict[str, Tensor]:
+    """MSDeformAttnPixelDecoder.forward_features (WC/msdeformattn.py:404-437) with spatial and temporal layers in every stage.
+    `spatial_in` / `temporal_in`: feature names sorted by stride (high resolution first), as the constructor sorts them (:344-349).
+    features[name]: [(B T), C_l, H_l, W_l].  Returns {name: [(B T), C_l, H_l, W_l]}."""
+    order = list(spatial_in)[::-1]                                    # low -> high resolution (:411)
+    L, Lt = len(order), len(temporal_in)
+    BT = features[order[0]].shape[0]
+    T = BT // B
+    C = w["input_proj.0.0.weight"].shape[0]
+    srcs, poss, pos3d, shapes = [], [], [], []
+    for idx, f in enumerate(order):
+        x = features[f]
+        y = conv1x1_group_norm(x, w, f"input_proj.{idx}")
+        _, _, H, W = y.shape
+        shapes.append((H, W))
+        srcs.append(y.flatten(2).transpose(1, 2))                     # [(B T), HW, C]
+        poss.append(pos_embed_sine_2d(BT, H, W, C // 2, dtype=x.dtype).reshape(BT, H * W, C)
+                    + w["transformer.level_embed_2d"][idx].view(1, 1, -1))
+        if f in temporal_in:
+            pos3d.append(pos_embed_sine_3d(B, T, H, W, C // 2, dtype=x.dtype) + w["transformer.level_embed_3d"][len(pos3d)].view(1, 1, 1, 1, -1))
+    src = torch.cat(srcs, 1)
+    pos = torch.cat(poss, 1)
+    refs = []
+    for (H, W) in shapes:                                             # get_reference_points, valid ratios = 1 (:229-242)
+        ys = (torch.arange(H, dtype=src.dtype) + 0.5) / H
+        xs = (torch.arange(W, dtype=src.dtype) + 0.5) / W
+        refs.append(torch.stack((xs.view(1, W).expand(H, W).reshape(-1), ys.view(H, 1).expand(H, W).reshape(-1)), -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(BT, -1, L, 2)
+    sizes = [h * ww for h, ww in shapes]
+    out = src
+    for s_i in range(num_stages):                                     # :247-266
+        out = msda_encoder_layer(out, pos, ref, shapes, _sub(w, f"transformer.encoder.spatial_layers.{s_i}"), heads, L, n_points)
+        parts = list(torch.split(out, sizes, dim=1))
+        for i in range(Lt):
+            parts[i], _, _ = temporal_encoder(parts[i], pos3d[i], _sub(w, f"transformer.encoder.temporal_layers.{s_i}"),
+                                              temporal_layers_per_stage, heads, want_attn=False)
+        out = torch.cat(parts, 1)
+    res = {}
+    for i, z in enumerate(torch.split(out, sizes, dim=1)):            # :426-435
+        H, W = shapes[i]
+        zz = z.transpose(1, 2).reshape(BT, C, H, W)
+        res[order[i]] = conv1x1_group_norm(zz, w, f"output_proj.{i}")
+    return res
+
+
+# --------------------------------------------------------------------------------------
 # synthetic inputs / weights shared by tests, smoke and bench (SURVEY.md 8d recipe)
 # --------------------------------------------------------------------------------------
 def axial_layer_param_shapes(C: int, d_ffn: int) -> Dict[str, Tuple[int, ...]]:

@@ -140,3 +140,33 @@ def test_msda_module_surface_matches_reference():
     assert torch.allclose(b[:, :, 1], 2 * b[:, :, 0])
     with pytest.raises(RuntimeError):
         mod.eval()(torch.zeros(1, 4, m["C"]), torch.zeros(1, 4, len(m["shapes"]), 2), torch.zeros(1, 252, m["C"]), m["shapes"])
+
+
+def _decoder_from_meta(m):
+    import axial_vs_amd as ax
+
+    class Shape:
+        def __init__(self, c, s):
+            self.channels, self.stride = c, s
+
+    strides = {"res3": 8, "res4": 16, "res5": 32}
+    return ax.WithinClipTrackingModule(
+        {k: Shape(c, strides[k]) for k, c in m["chans"].items()}, transformer_dropout=0.0, transformer_attn_drop=0.0,
+        transformer_nheads=8, transformer_dim_feedforward=m["d_ffn"], transformer_num_stages=m["stages"],
+        transformer_spatial_layers=m["stages"], transformer_temporal_layers=m["stages"] * m["temporal_per_stage"],
+        transformer_temporal_attn_type="axial-trajectory", transformer_conv_dims=256,
+        transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
+        num_clip_frames=m["T"], cross_clip_training=False)
+
+
+def test_within_clip_module_state_dict_matches_reference():
+    """WithinClipTrackingModule (pixel decoder: input/output projections, level embeddings, spatial + temporal stages) has the
+    reference MSDeformAttnPixelDecoder's parameter names and shapes; CPU inputs raise."""
+    import axvs_oracle as orc
+    z, m = load("g8_pixel_decoder_T2_S2")
+    mod = _decoder_from_meta(m)
+    own = {k: tuple(v.shape) for k, v in mod.within_clip_tracking_module.state_dict().items()}
+    assert own == {k: tuple(v) for k, v in m["shapes"].items()}
+    mod.within_clip_tracking_module.load_state_dict(orc.random_weights(m["shapes"], 1), strict=True)
+    with pytest.raises(RuntimeError):
+        mod.eval().forward_features({k: torch.zeros(m["T"], c, *m["sizes"][k]) for k, c in m["chans"].items()})

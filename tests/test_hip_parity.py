@@ -406,3 +406,27 @@ def test_graphed_forward_matches_eager():
     assert torch.equal(g()[0], layer(dev(src), dev(pos))[0])
     out2 = g(dev(src2), dev(pos))[0].clone()
     assert torch.equal(out2, layer(dev(src2), dev(pos))[0])
+
+
+@pytest.mark.parametrize("name", ["g8_pixel_decoder_T2_S2", "g8_pixel_decoder_T3_S1"])
+def test_within_clip_module_golden(name):
+    """WithinClipTrackingModule.forward_features (the registry hook of SURVEY 8b): NCHW backbone maps -> 1x1 conv + GroupNorm ->
+    stages of deformable spatial layer + axial-trajectory temporal layers -> 1x1 conv + GroupNorm -> NCHW maps, against the
+    reference MSDeformAttnPixelDecoder (2 stages x 2 temporal layers; T = 3 with non-square 12x20 / 6x10 / 3x5 maps)."""
+    from test_cabi_cpu import _decoder_from_meta
+    z, m = load(name)
+    w = weights(z, m)
+    mod = _decoder_from_meta(m).eval()
+    mod.within_clip_tracking_module.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    feats = {k: torch.randn(m["B"] * m["T"], m["chans"][k], *m["sizes"][k], generator=g) for k in m["chans"]}
+    out, _, _ = mod.forward_features({k: v.cuda() for k, v in feats.items()})
+    # Tolerance: every layer of the stack holds the 1e-3 per-layer bar on its own fixtures (axial layer, MSDA encoder layer,
+    # projections); here 2 + 4 (resp. 1 + 2) of them run back to back on the temporal levels, each LayerNorm re-normalising
+    # the stream, so the independent 16-bit operand roundings add in quadrature: measured 5e-4 on res3 (spatial layers only),
+    # 1.1e-3 .. 2.1e-3 on res4 / res5.  3e-3 is the stated bound for the whole decoder.
+    for k in m["chans"]:
+        e = rel_err(out[k].cpu(), t(z["out_" + k]))
+        print(f"{name} {k}: {e:.2e}")
+        assert e < (TOL_F16 if k == "res3" else 3e-3), k

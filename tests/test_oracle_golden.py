@@ -162,3 +162,23 @@ def test_msda_encoder_layer(name):
     assert abs(sum(v.double().sum().item() for v in w.values()) - float(z["wsum"])) < 1e-6 * max(1.0, abs(float(z["wsum"])))
     out = orc.msda_encoder_layer(src, pos, ref, m["shapes"], w, m["M"], len(m["shapes"]), m["P"], pm)
     assert rel_err(out, t(z["out"])) < 5e-5
+
+
+PIXEL_DECODER = ["g8_pixel_decoder_T2_S2", "g8_pixel_decoder_T3_S1"]
+
+
+def decoder_inputs(m):
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    return {k: torch.randn(m["B"] * m["T"], m["chans"][k], *m["sizes"][k], generator=g) for k in m["chans"]}
+
+
+@pytest.mark.parametrize("name", PIXEL_DECODER)
+def test_pixel_decoder(name):
+    """input_proj (1x1 conv + GroupNorm) -> 2-D / 3-D sine embeddings + level embeddings -> stages of (deformable spatial layer,
+    axial-trajectory temporal layers on the two coarsest levels) -> output_proj, against the reference MSDeformAttnPixelDecoder."""
+    z, m = load(name)
+    w = weights(z, m)
+    out = orc.pixel_decoder(decoder_inputs(m), w, ["res3", "res4", "res5"], ["res4", "res5"], m["stages"], m["temporal_per_stage"],
+                            B=m["B"])
+    for k in m["chans"]:
+        assert rel_err(out[k], t(z["out_" + k])) < 2e-4, k
