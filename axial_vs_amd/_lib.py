@@ -96,6 +96,9 @@ SIGNATURES = {
     "axvs_conv1x1_gn_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "axvs_conv1x1_gn_fwd": (C.c_int, [_fp, C.c_int, C.c_longlong, C.c_longlong, _fp, C.c_int, C.c_longlong, C.c_longlong, _fp] +
                             [C.c_int] * 5 + [C.c_float, C.c_int, _fp, C.c_size_t, _fp]),
+    "axvs_linear_sum_assignment": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
+    "axvs_match_embds_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "axvs_match_embds": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_add_channel_vector": (C.c_int, [_fp, _fp, C.c_size_t, C.c_int, _fp]),
     "axvs_pos2d": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [C.c_longlong, C.c_longlong, C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_msda_packed_bytes": (C.c_size_t, [C.c_int] * 4),

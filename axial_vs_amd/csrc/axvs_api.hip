@@ -11,6 +11,7 @@
 #include "axvs_cc.h"
 #include "axvs_msda.h"
 #include "axvs_glue.h"
+#include "axvs_lsap.h"
 #include "axvs_common.h"
 #include "axvs_fused.h"
 #include "axvs_gemm.h"
@@ -1254,6 +1255,30 @@ int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long lo
   const long long total = (long long)H * W * C;
   hipLaunchKernelGGL(pos2d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pos, add, N, H, W,
                      C, S, row0, temperature, normalize, scale);
+  return last_launch_status();
+}
+
+// ---- clip-to-clip query alignment ----
+int axvs_linear_sum_assignment(const float* cost, long long* col4row, int batch, int n, void* stream) {
+  if (!cost || !col4row) return fail(AXVS_ERR_ARG, "null pointer");
+  if (batch <= 0 || n <= 0 || n > kLsapMax) return fail(AXVS_ERR_ARG, "n=%d must be in 1..%d", n, kLsapMax);
+  hipLaunchKernelGGL(lsap_kernel, dim3(batch), dim3(64), 0, static_cast<hipStream_t>(stream), cost, col4row, n);
+  return last_launch_status();
+}
+
+size_t axvs_match_embds_workspace_bytes(int Q, int C) { return ((size_t)Q * Q + 2 * (size_t)Q * C) * sizeof(float); }
+
+int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* indices, int Q, int C, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (!tgt_embds || !cur_embds || !indices || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (Q <= 0 || Q > kLsapMax || C <= 0) return fail(AXVS_ERR_ARG, "Q=%d must be in 1..%d", Q, kLsapMax);
+  if (workspace_bytes < axvs_match_embds_workspace_bytes(Q, C)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* cost = static_cast<float*>(workspace);
+  float* nrm = cost + (size_t)Q * Q;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((2 * Q + 3) / 4)), dim3(256), 0, st, tgt_embds, cur_embds, nrm, Q, C);
+  hipLaunchKernelGGL(cosine_cost_kernel, dim3((unsigned)((Q * Q + 255) / 256)), dim3(256), 0, st, nrm, cost, Q, C);
+  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(64), 0, st, cost, indices, Q);
   return last_launch_status();
 }
 

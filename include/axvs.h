@@ -228,6 +228,16 @@ int axvs_add_channel_vector(float* x, const float* v, size_t n, int C, void* str
 int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long long S, long long row0, float temperature,
                int normalize, float scale, void* stream);
 
+/* ---- Clip-to-clip query alignment, maxtron_cc_model.py:360-369 `match_from_embds` without the host round trip.
+ *      axvs_linear_sum_assignment: `batch` square problems, cost fp32 [batch][n][n] -> col4row int64 [batch][n] (the column
+ *      assigned to every row) = scipy.optimize.linear_sum_assignment(cost)[1]; n <= 512.
+ *      axvs_match_embds: tgt/cur fp32 [Q,C] -> indices int64 [Q] such that cur[indices] aligns with tgt
+ *      (cost = 1 - cosine similarity, rows = target queries). */
+int axvs_linear_sum_assignment(const float* cost, long long* col4row, int batch, int n, void* stream);
+size_t axvs_match_embds_workspace_bytes(int Q, int C);
+int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* indices, int Q, int C, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,
