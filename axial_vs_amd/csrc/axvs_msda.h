@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict_
     float sx, sy;                                                    // offset scale (modules/ms_deform_attn.py:107-113)
     if (ref_dim == 2) { sx = 1.f / W; sy = 1.f / H; }
     else { sx = rp[l * ref_dim + 2] * 0.5f / P; sy = rp[l * ref_dim + 3] * 0.5f / P; }
-#pragma unroll
+#pragma unroll 4
     for (int p = 0; p < (PT > 0 ? PT : P); ++p) {
       const int i = l * P + p;
       const float a = __expf(logit[i] - mx) * inv;
