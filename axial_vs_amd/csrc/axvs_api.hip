@@ -72,7 +72,7 @@ int check_cfg(int C, int heads) {
 
 // ---------------- packed weights ----------------
 struct TrajPacked {  // pointers into the packed blob
-  u16 *wq, *wk, *wv, *wpq, *wpkv, *wp;
+  u16 *wq, *wk, *wv, *wpq, *wpkv, *wp, *wk2t;     // wk2t: transposed k half of proj_kv (fused temporal kernel, C = 256)
   float *bq, *bk, *bv, *bpq, *bpkv, *bp;
 };
 
@@ -84,6 +84,7 @@ TrajPacked carve_traj(Carver& c, int C, int heads) {
   t.wv = c.take<u16>(Cp * C);
   t.wpq = c.take<u16>(Cp * Cp);
   t.wpkv = c.take<u16>(2 * Cp * Cp);
+  t.wk2t = c.take<u16>(Cp * Cp);
   t.wp = c.take<u16>((size_t)C * Cp);
   t.bq = c.take<float>(Cp);
   t.bk = c.take<float>(Cp);
@@ -170,6 +171,7 @@ void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, h
   pack_w<BF>(p.v_w, t.wv, headC, plainC, st);
   pack_w<BF>(p.proj_q_w, t.wpq, headC, headCp, st);
   pack_w<BF>(p.proj_kv_w, t.wpkv, head2C, headCp, st);
+  if (d == 32) hipLaunchKernelGGL((pack_wk2t_kernel<BF>), dim3((unsigned)(((long long)heads * C * 32 + 255) / 256)), dim3(256), 0, st, p.proj_kv_w, t.wk2t, C, heads);
   pack_w<BF>(p.proj_w, t.wp, plainC, headC, st);
   pack_b(p.q_b, t.bq, headC, st);
   pack_b(p.k_b, t.bk, headC, st);
@@ -237,7 +239,7 @@ int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, fl
         configured_ffn = true;
       }
       const size_t lds_ffn = temporal_lds_bytes<T, MT, true>(fa->F);
-      hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS, true>), dim3(grid), dim3(512), lds_ffn, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa);
+      hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS, true>), dim3(grid), dim3(512), lds_ffn, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa, p.wk2t);
       return AXVS_OK;
     }
   }
@@ -251,7 +253,7 @@ int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, fl
     configured = true;
   }
   hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
-                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16);
+                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t);
   return AXVS_OK;
 }
 

@@ -39,6 +39,48 @@ struct H16<true> {
   }
 };
 
+// ---- 16-bit VALU helpers for the reassociated temporal half (axvs_fused.h): fp32 accumulate dot of 8 element pairs, and
+//      acc += a * x on 8 packed elements.  fp16: v_dot2_f32_f16 / v_pk_fma_f16; bf16 (non-default operand type): fp32 math.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+struct H2x4 { h16x2 v[4]; };
+
+template <bool BF>
+__device__ __forceinline__ float dot8_acc(f32x4 a_lo, f32x4 a_hi, u16x8 x, float acc) {
+  if constexpr (!BF) {
+    const H2x4 xs = __builtin_bit_cast(H2x4, x);
+    const h16x2 a0 = {(_Float16)a_lo[0], (_Float16)a_lo[1]}, a1 = {(_Float16)a_lo[2], (_Float16)a_lo[3]};
+    const h16x2 a2 = {(_Float16)a_hi[0], (_Float16)a_hi[1]}, a3 = {(_Float16)a_hi[2], (_Float16)a_hi[3]};
+    acc = __builtin_amdgcn_fdot2(a0, xs.v[0], acc, false);
+    acc = __builtin_amdgcn_fdot2(a1, xs.v[1], acc, false);
+    acc = __builtin_amdgcn_fdot2(a2, xs.v[2], acc, false);
+    acc = __builtin_amdgcn_fdot2(a3, xs.v[3], acc, false);
+    return acc;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc += a_lo[i] * H16<BF>::to_f32(x[i]) + a_hi[i] * H16<BF>::to_f32(x[4 + i]);
+    return acc;
+  }
+}
+
+// acc (8 packed 16-bit values) += a * x.  fp16: four v_pk_fma_f16 (running sum kept in fp16: the result is an MFMA operand and
+// would be rounded to 16 bits anyway; T <= 5 terms).  bf16: fp32 math, rounded per call.
+template <bool BF>
+__device__ __forceinline__ u16x8 axpy8(float a, u16x8 x, u16x8 acc) {
+  if constexpr (!BF) {
+    const H2x4 xs = __builtin_bit_cast(H2x4, x);
+    H2x4 as = __builtin_bit_cast(H2x4, acc);
+    const h16x2 a2 = {(_Float16)a, (_Float16)a};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) as.v[i] = xs.v[i] * a2 + as.v[i];
+    return __builtin_bit_cast(u16x8, as);
+  } else {
+    u16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = H16<BF>::from_f32(H16<BF>::to_f32(acc[i]) + a * H16<BF>::to_f32(x[i]));
+    return r;
+  }
+}
+
 template <bool BF>
 __device__ __forceinline__ u16x8 cvt8(const float (&v)[8]) {
   u16x8 r;

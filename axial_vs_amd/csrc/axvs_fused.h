@@ -370,7 +370,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const float* __restrict__ res /* required */, float* __restrict__ out,
                                                              RowMap rm, long long Mp, int N, int L, float scale, const u16* __restrict__ Q16 = nullptr,
                                                              const u16* __restrict__ K16 = nullptr,
-                                                             const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{}) {
+                                                             const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
+                                                             const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < MT; ++b) q2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  sweep8<BF, MT, true>(q2, wf, xt, bown, KBS, Wpkv, 2 * C, wave * 32, fi, fg);
+  sweep8<BF, MT, true>(q2, wf, xt, bown, KBS, Wk2T, 32, wave * C, fi, fg);      // refill: slot (nt, j) <- Wk2_h^T rows of channel block j
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const float4 b = *reinterpret_cast<const float4*>(sbias + wave * 32 + nt * 16 + fg * 4);
@@ -576,36 +577,57 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
 
   AXVS_STAMP(2);
-  // ---- pass 1: logits over frames.  The row tiles are swept in halves (HM at a time) against the same fragment set:
-  //      same MFMAs and LDS reads, half the accumulator / B-fragment registers ----
-  constexpr int HM = MT >= 2 ? MT / 2 : 1, NH = MT / HM;
+  // ---- temporal logits and weighted values, REASSOCIATED so that proj_kv is applied once instead of once per frame:
+  //        logit_f = q2 . (Wk2_h x_f) = (Wk2_h^T q2) . x_f            o = sum_f a_f (Wv2_h x_f) = Wv2_h (sum_f a_f x_f)
+  //      (the reference computes k2, v2 = proj_kv(x) for all T slots, WC/temporal_attention.py:66-73: 4 T C^2 MACs per token;
+  //      here 2 C^2 plus 2 T C dot / axpy work on the x tile).  Both rely on the x tile's perm32 channel order: an MFMA D tile
+  //      pair (channels of block kb) and a B fragment of that block hold the same 8 channels in the same lane.
+  //      The k2 bias still drops out of the softmax over f, the v2 bias is added once.
+  //      x fragments are read one (channel block, row tile) group of T at a time, one group ahead (<= 2T LDS reads in flight).
+  u16x8 q2f[MT];                                            // q2 as the B operand (K = head dim, perm32 order)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float v[8] = {q2[0][mt][0], q2[0][mt][1], q2[0][mt][2], q2[0][mt][3], q2[1][mt][0], q2[1][mt][1], q2[1][mt][2], q2[1][mt][3]};
+    q2f[mt] = cvt8<BF>(v);
+  }
   float lg[T][MT];
 #pragma unroll
-  for (int f = 0; f < T; ++f) {
+  for (int f = 0; f < T; ++f)
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-      f32x4 k2[2][HM];
+    for (int mt = 0; mt < MT; ++mt) lg[f][mt] = 0.f;
+  {
+    u16x8 xc[T], xn[T];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int f = 0; f < T; ++f) xc[f] = *reinterpret_cast<const u16x8*>(xt + bfr[0] + f * FS);
 #pragma unroll
-        for (int b = 0; b < HM; ++b) k2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      int bb[HM];
+    for (int kb = 0; kb < 8; ++kb) {
+      f32x4 qk[2][MT];                                      // (Wk2_h^T q2)[channels of block kb][token]
 #pragma unroll
-      for (int b = 0; b < HM; ++b) bb[b] = bfr[hh * HM + b] + f * FS;
-      if (f == T - 1 && hh == NH - 1) sweep8<BF, HM, true>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, C + wave * 32, fi, fg);   // -> Wv2_h
-      else sweep8<BF, HM, false>(k2, wf, xt, bb, KBS, Wpkv, 2 * C, 0, fi, fg);
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int b = 0; b < HM; ++b) {
-        const int mt = hh * HM + b;
-        float p = 0.f;
+        for (int mt = 0; mt < MT; ++mt) qk[nt][mt] = H16<BF>::mfma(wf[nt][kb], q2f[mt], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt) wf[nt][kb] = w_frag(Wpkv, 2 * C, kb, C + wave * 32 + nt * 16 + fi, fg);      // -> Wv2_h
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p += q2[nt][mt][r] * k2[nt][b][r];
-        lg[f][mt] = groups_sum(p);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int g = kb * MT + mt + 1;                     // next group
+        if (g < 8 * MT) {
+#pragma unroll
+          for (int f = 0; f < T; ++f) xn[f] = *reinterpret_cast<const u16x8*>(xt + bfr[g % MT] + f * FS + (g / MT) * KBS);
+        }
+#pragma unroll
+        for (int f = 0; f < T; ++f) lg[f][mt] = dot8_acc<BF>(qk[0][mt], qk[1][mt], xc[f], lg[f][mt]);
+#pragma unroll
+        for (int f = 0; f < T; ++f) xc[f] = xn[f];
+        __builtin_amdgcn_sched_barrier(0);                  // keeps the LDS reads of later groups from being hoisted (lgkmcnt)
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+#pragma unroll
+  for (int f = 0; f < T; ++f)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) lg[f][mt] = groups_sum(lg[f][mt]);
   AXVS_STAMP(3);
   // softmax over frames
 #pragma unroll
@@ -624,7 +646,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int f = 0; f < T; ++f) lg[f][mt] *= inv;
   }
 
-  // ---- pass 2: o = sum_f a_f * (Wv2_h x_f) + bv2_h; the last sweep refills the set with Wp[32w..32w+31] ----
+  // ---- o = Wv2_h (sum_f a_f x_f) + bv2_h; every slot is refilled with Wp[32w..32w+31] right after its use ----
   f32x4 o[2][MT];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -632,24 +654,35 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) o[nt][mt] = f32x4{b.x, b.y, b.z, b.w};
   }
+  {
+    u16x8 xc[T], xn[T];
 #pragma unroll
-  for (int f = 0; f < T; ++f) {
+    for (int f = 0; f < T; ++f) xc[f] = *reinterpret_cast<const u16x8*>(xt + bfr[0] + f * FS);
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-      f32x4 v2[2][HM];
+    for (int kb = 0; kb < 8; ++kb) {
+      u16x8 xb[MT];                                         // sum_f a_f x_f, block kb, as the B operand
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int g = kb * MT + mt + 1;
+        if (g < 8 * MT) {
 #pragma unroll
-        for (int b = 0; b < HM; ++b) v2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      int bb[HM];
+          for (int f = 0; f < T; ++f) xn[f] = *reinterpret_cast<const u16x8*>(xt + bfr[g % MT] + f * FS + (g / MT) * KBS);
+        }
+        u16x8 acc = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int b = 0; b < HM; ++b) bb[b] = bfr[hh * HM + b] + f * FS;
-      if (f == T - 1 && hh == NH - 1) sweep8<BF, HM, true>(v2, wf, xt, bb, KBS, Wp, C, wave * 32, fi, fg);
-      else sweep8<BF, HM, false>(v2, wf, xt, bb, KBS, Wp, C, 0, fi, fg);
+        for (int f = 0; f < T; ++f) acc = axpy8<BF>(lg[f][mt], xc[f], acc);
+        xb[mt] = acc;
+#pragma unroll
+        for (int f = 0; f < T; ++f) xc[f] = xn[f];
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int b = 0; b < HM; ++b) o[nt][hh * HM + b] += lg[f][hh * HM + b] * v2[nt][b];
+        for (int mt = 0; mt < MT; ++mt) o[nt][mt] = H16<BF>::mfma(wf[nt][kb], xb[mt], o[nt][mt]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[nt][kb] = w_frag(Wp, C, kb, wave * 32 + nt * 16 + fi, fg);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

@@ -68,6 +68,19 @@ __global__ void pack_weight_split3_kernel(const float* __restrict__ W, u16* __re
   out[2 * part + o] = hi;
 }
 
+// Transposed k-half of proj_kv for the reassociated temporal logits (axvs_fused.h):  qk_h = Wk2_h^T q2_h.
+// W: proj_kv weight [2C][C] fp32 (rows 0..C-1 = the k half), C = heads*32.  out: blocked [1][heads*C][32]:
+// row h*C + c (c = input channel), position p = Wk2[h*32 + perm32(p)][c]  (K = head dim in the order of an MFMA D tile pair).
+template <bool BF>
+__global__ void pack_wk2t_kernel(const float* __restrict__ W, u16* __restrict__ out, int C, int heads) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)heads * C * 32) return;
+  const int p = idx & 31;
+  const long long r = idx >> 5;
+  const int c = (int)(r % C), h = (int)(r / C);
+  out[idx] = H16<BF>::from_f32(W[(long long)(h * 32 + perm32(p)) * C + c]);
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, PackDim nd) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nd.padded) return;
