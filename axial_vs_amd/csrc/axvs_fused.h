@@ -596,9 +596,12 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) lg[f][mt] = 0.f;
   {
-    u16x8 xc[T], xn[T];
+    constexpr int PD = T <= 4 ? 2 : 1;                      // groups of x fragments in flight ahead of their use
+    u16x8 xg[PD + 1][T];                                    // x fragments of group g live in xg[g % (PD + 1)] (no copies)
 #pragma unroll
-    for (int f = 0; f < T; ++f) xc[f] = *reinterpret_cast<const u16x8*>(xt + bfr[0] + f * FS);
+    for (int g0 = 0; g0 < PD; ++g0)
+#pragma unroll
+      for (int f = 0; f < T; ++f) xg[g0][f] = *reinterpret_cast<const u16x8*>(xt + bfr[g0 % MT] + f * FS + (g0 / MT) * KBS);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       f32x4 qk[2][MT];                                      // (Wk2_h^T q2)[channels of block kb][token]
@@ -610,18 +613,16 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       for (int nt = 0; nt < 2; ++nt) wf[nt][kb] = w_frag(Wpkv, 2 * C, kb, C + wave * 32 + nt * 16 + fi, fg);      // -> Wv2_h
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int g = kb * MT + mt + 1;                     // next group
-        if (g < 8 * MT) {
+        const int g = kb * MT + mt;
+        if (g + PD < 8 * MT) {
 #pragma unroll
-          for (int f = 0; f < T; ++f) xn[f] = *reinterpret_cast<const u16x8*>(xt + bfr[g % MT] + f * FS + (g / MT) * KBS);
+          for (int f = 0; f < T; ++f)
+            xg[(g + PD) % (PD + 1)][f] = *reinterpret_cast<const u16x8*>(xt + bfr[(g + PD) % MT] + f * FS + ((g + PD) / MT) * KBS);
         }
 #pragma unroll
-        for (int f = 0; f < T; ++f) lg[f][mt] = dot8_acc<BF>(qk[0][mt], qk[1][mt], xc[f], lg[f][mt]);
-#pragma unroll
-        for (int f = 0; f < T; ++f) xc[f] = xn[f];
+        for (int f = 0; f < T; ++f) lg[f][mt] = dot8_acc<BF>(qk[0][mt], qk[1][mt], xg[g % (PD + 1)][f], lg[f][mt]);
         __builtin_amdgcn_sched_barrier(0);                  // keeps the LDS reads of later groups from being hoisted (lgkmcnt)
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -655,25 +656,27 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int mt = 0; mt < MT; ++mt) o[nt][mt] = f32x4{b.x, b.y, b.z, b.w};
   }
   {
-    u16x8 xc[T], xn[T];
+    constexpr int PD = T <= 4 ? 2 : 1;
+    u16x8 xg[PD + 1][T];
 #pragma unroll
-    for (int f = 0; f < T; ++f) xc[f] = *reinterpret_cast<const u16x8*>(xt + bfr[0] + f * FS);
+    for (int g0 = 0; g0 < PD; ++g0)
+#pragma unroll
+      for (int f = 0; f < T; ++f) xg[g0][f] = *reinterpret_cast<const u16x8*>(xt + bfr[g0 % MT] + f * FS + (g0 / MT) * KBS);
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       u16x8 xb[MT];                                         // sum_f a_f x_f, block kb, as the B operand
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int g = kb * MT + mt + 1;
-        if (g < 8 * MT) {
+        const int g = kb * MT + mt;
+        if (g + PD < 8 * MT) {
 #pragma unroll
-          for (int f = 0; f < T; ++f) xn[f] = *reinterpret_cast<const u16x8*>(xt + bfr[g % MT] + f * FS + (g / MT) * KBS);
+          for (int f = 0; f < T; ++f)
+            xg[(g + PD) % (PD + 1)][f] = *reinterpret_cast<const u16x8*>(xt + bfr[(g + PD) % MT] + f * FS + ((g + PD) / MT) * KBS);
         }
         u16x8 acc = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int f = 0; f < T; ++f) acc = axpy8<BF>(lg[f][mt], xc[f], acc);
+        for (int f = 0; f < T; ++f) acc = axpy8<BF>(lg[f][mt], xg[g % (PD + 1)][f], acc);
         xb[mt] = acc;
-#pragma unroll
-        for (int f = 0; f < T; ++f) xc[f] = xn[f];
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
