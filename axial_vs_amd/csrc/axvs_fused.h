@@ -719,12 +719,19 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   constexpr int RPW = ROWS / 8;                     // rows per wave
   float4 rres[RPW];
   long long roff[RPW];
+  // RowMap arithmetic (integer divisions) once per wave, lane i computing row i of the wave's RPW rows, then broadcast with
+  // v_readlane -- instead of RPW unrolled copies of the same ~75-instruction sequence
+  {
+    const int myrow = wave * RPW + (lane % RPW);
+    const int mym = (int)m0 + min(myrow, (int)(Mp - 1 - m0));
+    const long long myoff = nat_row(rm, mym) * C;
+    const int lo = (int)(myoff & 0xffffffffll), hi = (int)(myoff >> 32);
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int row = wave * RPW + i;
-    const int m = (int)m0 + min(row, (int)(Mp - 1 - m0));
-    roff[i] = nat_row(rm, m) * C + lane * 4;        // wave-uniform row, lane = float4 column
-    rres[i] = *reinterpret_cast<const float4*>(res + roff[i]);
+    for (int i = 0; i < RPW; ++i) {
+      const long long o = ((long long)__builtin_amdgcn_readlane(hi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, i);
+      roff[i] = o + lane * 4;                       // wave-uniform row, lane = float4 column
+      rres[i] = *reinterpret_cast<const float4*>(res + roff[i]);
+    }
   }
   // with the FFN half following, the sweep leaves the first linear1 fragment set behind
   const int crot = FFN ? (int)((blockIdx.x >> 6) % (fa.F / 256)) : 0;
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   if constexpr (FFN) {
     lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
     ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
-                 [=](int row) { return m0 + row < Mp ? nat_row(rm, (int)m0 + row) * C : -1ll; }, fa.F, 0, crot, tid);
+                 [=](int row) { return m0 + row < Mp ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid);   // rows of this wave
   }
   AXVS_STAMP(10);
 #ifndef AXVS_STAMPS_QKV
