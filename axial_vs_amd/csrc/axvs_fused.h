@@ -815,14 +815,22 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
   // ---- gather + convert the 64 token rows: thread -> (row, float4 column), 64 consecutive threads cover one row ----
   {
     const int c4 = tid & 63;             // float4 index within the row
+    // RowMap arithmetic once per wave: lane k computes the k-th of the wave's 8 rows (rows wave + 8k), v_readlane broadcasts
+    int off_lo, off_hi;
+    {
+      const int myrow = (tid >> 6) + 8 * (lane & 7);
+      const long long mym = min(m0 + myrow, Mp - 1);
+      const long long myoff = nat_row(rm, (int)mym) * C;
+      off_lo = (int)(myoff & 0xffffffffll);
+      off_hi = (int)(myoff >> 32);
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float4 a[4], p[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 6) + 8 * (half * 4 + i);
-        const long long m = min(m0 + row, Mp - 1);
-        const long long off = nat_row(rm, (int)m) * C + c4 * 4;
+        const int k = half * 4 + i;
+        const long long off = (((long long)__builtin_amdgcn_readlane(off_hi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(off_lo, k)) + c4 * 4;
         a[i] = *reinterpret_cast<const float4*>(src + off);
         p[i] = pos ? *reinterpret_cast<const float4*>(pos + off) : float4{0.f, 0.f, 0.f, 0.f};
       }
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
     if (which == 2 && VT16 != nullptr) {
       // block-transposed V^T:  VT[head][frame slot sf = m'/L][ks][nd][16 d][32 keys in perm32 order]; a lane holds channel
       // nt*16+fi and tokens 4g..4g+3 of tile mt (one frame: L % 16 == 0) -> 8 contiguous bytes
-      const long long heads_sf = Mp / L;                     // S*T frame slots
+      const long long heads_sf = (unsigned)Mp / (unsigned)L;  // S*T frame slots
       if (L % 32 == 0) {
         // tile pairs (mt, mt+1) are the two 16-key halves of one 32-key step: 16 contiguous bytes per lane
 #pragma unroll
@@ -878,9 +886,9 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
           const float b = sbias[2 * C + wave * 32 + nt * 16 + fi];
 #pragma unroll
           for (int mp = 0; mp < MT; mp += 2) {
-            const long long mt0 = m0 + mp * 16;
-            if (mt0 < Mp) {
-              const long long sf = mt0 / L;
+            const unsigned mt0 = (unsigned)m0 + mp * 16;         // row indices fit 32 bits (checked by the host)
+            if (mt0 < (unsigned)Mp) {
+              const unsigned sf = mt0 / (unsigned)L;
               const int ks = (int)(mt0 - sf * L) >> 5;
               u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + fg * 8;
               float v[8] = {acc[nt][mp][0] + b, acc[nt][mp][1] + b, acc[nt][mp][2] + b, acc[nt][mp][3] + b,
@@ -895,9 +903,9 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
         const float b = sbias[2 * C + wave * 32 + nt * 16 + fi];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const long long mt0 = m0 + mt * 16;                 // first token of the tile
-          if (mt0 < Mp) {
-            const long long sf = mt0 / L;
+          const unsigned mt0 = (unsigned)m0 + mt * 16;        // first token of the tile
+          if (mt0 < (unsigned)Mp) {
+            const unsigned sf = mt0 / (unsigned)L;
             const int l = (int)(mt0 - sf * L) + fg * 4;       // key index within the frame of the lane's first token
             const int ks = l >> 5, pp = fg * 8 + ((l >> 4) & 1) * 4;
             u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
