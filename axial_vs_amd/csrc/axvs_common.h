@@ -161,15 +161,20 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// v_permlane16_swap(a, b) exchanges the odd rows of a with the even rows of b: with a = b = v it returns
+// (v of the even row of my row pair, v of the odd row) in every lane -- both halves of the butterfly step at once, so a
+// reduction needs no select.  v_permlane32_swap likewise returns (lower 32 lanes, upper 32 lanes).
 __device__ __forceinline__ float groups_sum(float v) {
-  v += lane_xor16(v);
-  v += lane_xor32(v);
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float groups_max(float v) {
-  v = fmaxf(v, lane_xor16(v));
-  v = fmaxf(v, lane_xor32(v));
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float wave_sum(float v) { return groups_sum(row16_sum(v)); }
 

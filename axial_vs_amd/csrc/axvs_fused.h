@@ -493,11 +493,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) {
 #pragma unroll
-        for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf[nd][0], pf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f});   // D[d][query]
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
+        for (int ks = 1; ks < NKS; ++ks) {
 #pragma unroll
-          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf[nd][ks], pf[qt][ks], xa[qt][nd]);   // D[d][query]
+          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf[nd][ks], pf[qt][ks], xa[qt][nd]);
         }
       }
       // x tile block (frame f, k-block = my head): row = query, 16-byte chunk g holds channels in perm32 order
