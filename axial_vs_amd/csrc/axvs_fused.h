@@ -548,13 +548,18 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   AXVS_STAMP(1);
   // per-lane query bookkeeping
   int bown[MT], bfr[MT];                  // element offsets of my B fragment rows: own-frame slot / frame 0
+  {
+    // own frame of every tile row: lane l computes it for row l (two integer divisions, once), ds_bpermute hands lane
+    // (fi, fg) the value of row mt*16 + fi
+    const int mrow = (int)m0 + min(lane, (int)(Mp - 1 - m0));
+    const int fown_l = (int)(((unsigned)mrow % (unsigned)N) / (unsigned)L);
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = mt * 16 + fi;
-    const int m = (int)m0 + min(row, (int)(Mp - 1 - m0));
-    const int fown = (m % N) / L;
-    bown[mt] = xt_off<MT>(fown, 0, row, fg);
-    bfr[mt] = xt_off<MT>(0, 0, row, fg);
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row = mt * 16 + fi;
+      const int fown = __builtin_amdgcn_ds_bpermute(row * 4, fown_l);
+      bown[mt] = xt_off<MT>(fown, 0, row, fg);
+      bfr[mt] = xt_off<MT>(0, 0, row, fg);
+    }
   }
   constexpr int KBS = ROWS * 32;          // k-block stride (elements)
   constexpr int FS = 8 * ROWS * 32;       // frame stride
