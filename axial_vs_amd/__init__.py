@@ -5,7 +5,7 @@ behind the C-ABI of libaxvs.so (include/axvs.h).
 """
 from .modules import (AxialTrajectoryAttention5D, PositionEmbeddingSine3D, TemporalAxialTrajectoryAttentionLayer,
                       GraphedForward, TemporalEncoder, TemporalTrajectoryAttentionLayer, TrajectoryAttention,
-                      TubeLinkTemporalEncoder, set_default_dtype)
+                      TubeLinkTemporalEncoder, invalidate_pack, set_default_dtype)
 
 from .cross_clip import CrossClipTrackingModule, TubeLinkCrossClipHead
 from .pixel_decoder import (MSDeformAttnPixelDecoder, MSDeformAttnTransformerEncoder, MSDeformAttnTransformerEncoderOnly,
@@ -16,4 +16,4 @@ from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer, ms_deform_a
 __all__ = ["linear_sum_assignment", "match_from_embds", "match_clips", "WithinClipTrackingModule", "MSDeformAttnPixelDecoder", "MSDeformAttnTransformerEncoder", "MSDeformAttnTransformerEncoderOnly",
            "PositionEmbeddingSine", "CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
-           "set_default_dtype", "GraphedForward"]
+           "set_default_dtype", "GraphedForward", "invalidate_pack"]

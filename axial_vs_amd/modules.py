@@ -72,7 +72,26 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 
 
 def _param_key(mod: nn.Module, dtype: str):
-    return (dtype,) + tuple((p.data_ptr(), p._version, str(p.device)) for p in mod.parameters())
+    """Cheap change detector for the packed-weight caches: (storage pointer, version counter) of every parameter.
+    The parameter list is cached on the module (walking `mod.parameters()` costs ~75 us for a layer, more than half of the
+    GPU time of a forward); `.to()` / `.cuda()` / `load_state_dict` keep the Parameter objects, so the list stays valid, and
+    it is re-walked every 256 calls to catch a Parameter that was replaced by assignment."""
+    d = mod.__dict__
+    pl = d.get("_axvs_plist")
+    n = d.get("_axvs_pcalls", 0)
+    if pl is None or (n & 255) == 255:
+        pl = list(mod.parameters())
+        d["_axvs_plist"] = pl
+    d["_axvs_pcalls"] = n + 1
+    return (dtype,) + tuple((p.data_ptr(), p._version) for p in pl)
+
+
+def invalidate_pack(mod: nn.Module) -> None:
+    """Forget cached parameter lists / packed weights of `mod` and its children (after replacing Parameter objects)."""
+    for m in mod.modules():
+        m.__dict__.pop("_axvs_plist", None)
+        if "_packed" in m.__dict__:
+            m.__dict__["_packed"] = None
 
 
 def _traj_struct(m: "TrajectoryAttention", keep: list) -> _lib.AxvsTrajParams:
