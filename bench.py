@@ -214,7 +214,7 @@ def main():
         }
 
         # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would just wait)
             ncpu = os.cpu_count() or 1
             fwd = lambda: orc.axial_layer(src_cpu, pos_cpu, w, heads, want_attn=False)
             with torch.no_grad():
