@@ -13,6 +13,7 @@ namespace axvs {
 // ---------------- loaders: 8 consecutive k of token row m, converted to the 16-bit operand type ----------------
 template <bool BF>
 struct ALoadRowsF32 {
+  static constexpr int kPrefetch = 3;
   const float* src;   // [rows, K] fp32
   const float* add;   // nullable: added element-wise (positional embedding)
   RowMap rm;
@@ -36,6 +37,7 @@ struct ALoadRowsF32 {
 // fp32 rows with an explicit leading dimension / column offset (a column slice of a wider matrix), identity row order
 template <bool BF>
 struct ALoadRowsLd {
+  static constexpr int kPrefetch = 3;
   const float* src;
   int ld, col0, M;
   __device__ __forceinline__ u16x8 load(int m, int k) const {
@@ -51,6 +53,7 @@ struct ALoadRowsLd {
 // rows are (bq, t) of a [BQ, Tc, C] fp32 tensor; k = tap*C + ci reads channel ci of row (bq, clamp(t + (tap-1)*rate)).
 template <bool BF>
 struct ALoadShift3 {
+  static constexpr int kPrefetch = 3;
   const float* src;
   int C, Tc, rate, M;
   __device__ __forceinline__ u16x8 load(int m, int k) const {
@@ -67,6 +70,7 @@ struct ALoadShift3 {
 
 template <bool BF>
 struct ALoadBlocked {
+  static constexpr int kPrefetch = 3;
   const u16* X;       // blocked [K/32][R][32]
   long long R;
   int M;
@@ -85,6 +89,7 @@ struct ALoadBlocked {
 //      MFMA work of a small GEMM. ----
 template <bool BF>
 struct ALoadRowsF32Split3 {
+  static constexpr int kPrefetch = 1;
   const float* src;   // [M, K] fp32 rows
   int M, K;
   const float* add = nullptr;   // optional [M, K], added element-wise (positional embedding)
@@ -110,6 +115,7 @@ struct ALoadRowsF32Split3 {
 
 template <bool BF>
 struct ALoadBlockedSplit3 {
+  static constexpr int kPrefetch = 1;
   const u16* X;       // blocked [2*Kp/32][R][32]: hi blocks, then lo blocks
   long long R;
   int M, Kp;
@@ -181,8 +187,8 @@ struct EpiRowsF32 {
 // ---------------- v1 kernel: 64x64 tile, 4 waves (2x2), both operands staged through LDS ----------------
 template <bool BF, class ALoad, class Epi>
 __global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
-  __shared__ __attribute__((aligned(16))) u16 sX[64 * 32];
-  __shared__ __attribute__((aligned(16))) u16 sW[64 * 32];
+  __shared__ __attribute__((aligned(16))) u16 sX[2][64 * 32];      // two buffers, used alternately: one barrier per k-step
+  __shared__ __attribute__((aligned(16))) u16 sW[2][64 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
@@ -198,29 +204,46 @@ __global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __rest
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkb = K >> 5;
-  u16x8 rx = al.load(m0 + lrow, lg * 8);
-  u16x8 rw = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, lg * 8));
-  for (int kb = 0; kb < nkb; ++kb) {
-    *reinterpret_cast<u16x8*>(sX + st_off) = rx;
-    *reinterpret_cast<u16x8*>(sW + st_off) = rw;
-    __syncthreads();
-    if (kb + 1 < nkb) {
-      rx = al.load(m0 + lrow, (kb + 1) * 32 + lg * 8);
-      rw = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, (kb + 1) * 32 + lg * 8));
+  // global -> register prefetch depth in k-steps: 3 hides the L2 latency of the small, latency-bound GEMMs (cross-clip
+  // module: -12 %); loaders that do split-precision arithmetic on fp32 rows are throughput-bound on big grids and lose
+  // occupancy to the extra registers, they declare kPrefetch = 1
+  constexpr int PF = ALoad::kPrefetch;
+  u16x8 rx[PF], rw[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int k = min(u, nkb - 1) * 32 + lg * 8;
+    rx[u] = al.load(m0 + lrow, k);
+    rw[u] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, k));
+  }
+  for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int kb = kb0 + u;
+      if (kb < nkb) {                       // uniform
+        u16* bx = sX[kb & 1];
+        u16* bw = sW[kb & 1];
+        *reinterpret_cast<u16x8*>(bx + st_off) = rx[u];
+        *reinterpret_cast<u16x8*>(bw + st_off) = rw[u];
+        __syncthreads();                    // also orders these writes after the reads of this buffer two steps ago
+        {
+          const int k = min(kb + PF, nkb - 1) * 32 + lg * 8;   // unconditional (clamped) prefetch keeps vmcnt bookkeeping simple
+          rx[u] = al.load(m0 + lrow, k);
+          rw[u] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, k));
+        }
+        u16x8 fx[2], fw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int r = wm * 32 + i * 16 + fi;
+          fx[i] = *reinterpret_cast<const u16x8*>(bx + r * 32 + swz_chunk(r, fg) * 8);
+          int c = wn * 32 + i * 16 + fi;
+          fw[i] = *reinterpret_cast<const u16x8*>(bw + c * 32 + swz_chunk(c, fg) * 8);
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = H16<BF>::mfma(fw[ni], fx[mi], acc[ni][mi]);
+      }
     }
-    u16x8 fx[2], fw[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int r = wm * 32 + i * 16 + fi;
-      fx[i] = *reinterpret_cast<const u16x8*>(sX + r * 32 + swz_chunk(r, fg) * 8);
-      int c = wn * 32 + i * 16 + fi;
-      fw[i] = *reinterpret_cast<const u16x8*>(sW + c * 32 + swz_chunk(c, fg) * 8);
-    }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = H16<BF>::mfma(fw[ni], fx[mi], acc[ni][mi]);
-    __syncthreads();
   }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)

@@ -11,6 +11,7 @@ namespace axvs {
 // Split precision (hi | hi | lo along a 3x longer K, see ALoadRowsF32Split3): the projection output feeds a GroupNorm directly.
 template <bool BF>
 struct ALoadNCHWSplit3 {
+  static constexpr int kPrefetch = 1;
   const float* x;
   int M, K, HW;          // M = N*HW rows, K = Cin
   __device__ __forceinline__ u16x8 load(int m, int k) const {
@@ -32,6 +33,7 @@ struct ALoadNCHWSplit3 {
 // token rows that may be a slice of a wider buffer: row (n, p) at x + n*batch_stride + p*ld  (split precision as above)
 template <bool BF>
 struct ALoadTokensSplit3 {
+  static constexpr int kPrefetch = 1;
   const float* x;
   int M, K, HW;
   long long batch_stride, ld;
