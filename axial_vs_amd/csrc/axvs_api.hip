@@ -1261,11 +1261,26 @@ int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long lo
 }
 
 // ---- clip-to-clip query alignment ----
+static int launch_lsap(const float* cost, long long* col4row, int batch, int n, hipStream_t st) {
+  const size_t bytes = (size_t)n * n * sizeof(float);
+  if (bytes <= 128 * 1024) {
+    static bool configured = false;
+    if (!configured) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lsap_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+        return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+      configured = true;
+    }
+    hipLaunchKernelGGL((lsap_kernel<true>), dim3(batch), dim3(64), bytes, st, cost, col4row, n);
+  } else {
+    hipLaunchKernelGGL((lsap_kernel<false>), dim3(batch), dim3(64), 0, st, cost, col4row, n);
+  }
+  return last_launch_status();
+}
+
 int axvs_linear_sum_assignment(const float* cost, long long* col4row, int batch, int n, void* stream) {
   if (!cost || !col4row) return fail(AXVS_ERR_ARG, "null pointer");
   if (batch <= 0 || n <= 0 || n > kLsapMax) return fail(AXVS_ERR_ARG, "n=%d must be in 1..%d", n, kLsapMax);
-  hipLaunchKernelGGL(lsap_kernel, dim3(batch), dim3(64), 0, static_cast<hipStream_t>(stream), cost, col4row, n);
-  return last_launch_status();
+  return launch_lsap(cost, col4row, batch, n, static_cast<hipStream_t>(stream));
 }
 
 size_t axvs_match_embds_workspace_bytes(int Q, int C) { return ((size_t)Q * Q + 2 * (size_t)Q * C) * sizeof(float); }
@@ -1280,8 +1295,7 @@ int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* 
   float* nrm = cost + (size_t)Q * Q;
   hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((2 * Q + 3) / 4)), dim3(256), 0, st, tgt_embds, cur_embds, nrm, Q, C);
   hipLaunchKernelGGL(cosine_cost_kernel, dim3((unsigned)((Q * Q + 255) / 256)), dim3(256), 0, st, nrm, cost, Q, C);
-  hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(64), 0, st, cost, indices, Q);
-  return last_launch_status();
+  return launch_lsap(cost, indices, 1, Q, st);
 }
 
 int axvs_add_channel_vector(float* x, const float* v, size_t n, int C, void* stream) {

@@ -36,29 +36,73 @@ __global__ __launch_bounds__(256) void cosine_cost_kernel(const float* __restric
   cost[idx] = 1.f - dot;
 }
 
-// candidate of the column scan: (shortest path cost, column unassigned?, position in `remaining`)
+// candidate of the column scan: (shortest path cost, tie key).  The sequential rule
+// `if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1))` scanned in increasing position `it` picks the lowest value;
+// among equals the LAST unassigned column if there is one, otherwise the FIRST column.  As a total order with "smaller wins":
+// tie key = -1 - it for an unassigned column (always beats an assigned one, later position beats earlier), it for an assigned one.
 struct LsapCand {
   double v;
-  int unassigned, it;
+  int k2;
 };
-// the sequential rule `if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1))` scanned in increasing `it` picks: the
-// lowest value; among equals the LAST unassigned column if there is one, otherwise the FIRST column.
+__device__ __forceinline__ int lsap_key(bool unassigned, int it) { return unassigned ? -1 - it : it; }
 __device__ __forceinline__ bool lsap_better(const LsapCand& a, const LsapCand& b) {   // a wins over b
-  if (a.v != b.v) return a.v < b.v;
-  if (a.unassigned != b.unassigned) return a.unassigned > b.unassigned;
-  return a.unassigned ? a.it > b.it : a.it < b.it;
+  return a.v < b.v || (a.v == b.v && a.k2 < b.k2);
+}
+// wave-wide arg-min on the VALU (DPP within rows of 16, v_permlane*_swap across rows): no LDS crossbar round trips
+template <int CTRL>
+__device__ __forceinline__ LsapCand lsap_dpp(const LsapCand& c) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, c.v);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)b, CTRL, 0xF, 0xF, true);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  LsapCand o;
+  o.v = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  o.k2 = (int)__builtin_amdgcn_update_dpp(0u, (unsigned)c.k2, CTRL, 0xF, 0xF, true);
+  return o;
+}
+__device__ __forceinline__ LsapCand lsap_wave_best(LsapCand best) {
+  LsapCand o = lsap_dpp<0xB1>(best);  if (lsap_better(o, best)) best = o;      // lane ^ 1
+  o = lsap_dpp<0x4E>(best);           if (lsap_better(o, best)) best = o;      // lane ^ 2
+  o = lsap_dpp<0x141>(best);          if (lsap_better(o, best)) best = o;      // row_half_mirror (stands in for ^ 4)
+  o = lsap_dpp<0x140>(best);          if (lsap_better(o, best)) best = o;      // row_mirror      (stands in for ^ 8)
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, best.v);
+  {
+    auto rl = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+    auto rk = __builtin_amdgcn_permlane16_swap((unsigned)best.k2, (unsigned)best.k2, false, false);
+    LsapCand c0{__builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]), (int)rk[0]};
+    LsapCand c1{__builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]), (int)rk[1]};
+    best = lsap_better(c1, c0) ? c1 : c0;
+  }
+  const unsigned long long b2 = __builtin_bit_cast(unsigned long long, best.v);
+  {
+    auto rl = __builtin_amdgcn_permlane32_swap((unsigned)b2, (unsigned)b2, false, false);
+    auto rh = __builtin_amdgcn_permlane32_swap((unsigned)(b2 >> 32), (unsigned)(b2 >> 32), false, false);
+    auto rk = __builtin_amdgcn_permlane32_swap((unsigned)best.k2, (unsigned)best.k2, false, false);
+    LsapCand c0{__builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]), (int)rk[0]};
+    LsapCand c1{__builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]), (int)rk[1]};
+    best = lsap_better(c1, c0) ? c1 : c0;
+  }
+  return best;
 }
 
 // One wave per assignment problem (blockIdx.x = problem), n x n costs (fp32 -> double), n <= kLsapMax.
 // out[t] = column assigned to row t (int64, like the reference's indices[1]).
 constexpr int kLsapMax = 512;
+// LDS_COST: the cost matrix is copied into dynamic LDS first (n*n*4 bytes <= 128 KiB): every augmenting step reads one row of
+// it, and an L2 round trip per step dominated the run time.
+template <bool LDS_COST>
 __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost_all, long long* __restrict__ out_all, int n) {
+  extern __shared__ float scost[];
   __shared__ double u[kLsapMax], v[kLsapMax], spc[kLsapMax];
   __shared__ int path[kLsapMax], row4col[kLsapMax], col4row[kLsapMax], remaining[kLsapMax];
   __shared__ unsigned char SR[kLsapMax], SC[kLsapMax];
   const int lane = threadIdx.x;
-  const float* cost = cost_all + (long long)blockIdx.x * n * n;
+  const float* gcost = cost_all + (long long)blockIdx.x * n * n;
   long long* out = out_all + (long long)blockIdx.x * n;
+  if (LDS_COST) {
+    for (int i = lane; i < n * n; i += 64) scost[i] = gcost[i];
+  }
+  const float* cost = LDS_COST ? scost : gcost;
   for (int i = lane; i < n; i += 64) { u[i] = 0.0; v[i] = 0.0; row4col[i] = -1; col4row[i] = -1; path[i] = -1; }
   __syncthreads();
   const double INF = __builtin_huge_val();
@@ -72,27 +116,18 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     while (sink == -1) {
       if (lane == 0) SR[i] = 1;
       const double ui = u[i];
-      LsapCand best{INF, 0, 0x7fffffff};
-      bool have = false;
+      LsapCand best{INF, 0x7fffffff};
       for (int it = lane; it < num_remaining; it += 64) {
         const int j = remaining[it];
         const double r = minVal + (double)cost[(long long)i * n + j] - ui - v[j];
         if (r < spc[j]) { path[j] = i; spc[j] = r; }
-        const LsapCand c{spc[j], row4col[j] == -1 ? 1 : 0, it};
-        if (!have || lsap_better(c, best)) { best = c; have = true; }
+        const LsapCand c{spc[j], lsap_key(row4col[j] == -1, it)};
+        if (lsap_better(c, best)) best = c;
       }
-      if (!have) best = LsapCand{INF, 0, 0x7fffffff};
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) {
-        LsapCand o;
-        o.v = __shfl_xor(best.v, m, 64);
-        o.unassigned = __shfl_xor(best.unassigned, m, 64);
-        o.it = __shfl_xor(best.it, m, 64);
-        if (lsap_better(o, best)) best = o;
-      }
+      best = lsap_wave_best(best);
       minVal = best.v;
       if (minVal == INF) { sink = -2; break; }                 // infeasible (cannot happen with finite costs)
-      const int index = best.it;
+      const int index = best.k2 < 0 ? -1 - best.k2 : best.k2;
       const int j = remaining[index];
       __syncthreads();                                          // every lane has read remaining[index]
       if (row4col[j] == -1) sink = j; else i = row4col[j];
