@@ -196,6 +196,17 @@ def main():
         names = [L.axvs_profile_stage_name(i).decode() for i in range(nrun)]
         kernels = {names[i]: round(stage_ms[i] * 1e3, 2) for i in range(1, nrun)}
         dom = max(kernels, key=kernels.get)
+        # algorithmic FLOPs per launch (SURVEY 8d terms) -> per-kernel fraction of the MFMA peak, from the same HIP events
+        def f_qkv(S, L):
+            return S * T * L * C * C * 6
+        def f_traj(S, L):
+            N = T * L
+            return S * (N * C * C * (4 + 4 * T) + 4 * N * N * C + 4 * N * T * C)
+        f_ffn = 4 * B * T * H * W * C * F
+        stage_flops = {"h.qkv_proj": f_qkv(B * W, H), "w.qkv_proj": f_qkv(B * H, W), "h.traj_fused": f_traj(B * W, H),
+                       "w.traj_fused": f_traj(B * H, W), "w.traj_fused+ffn": f_traj(B * H, W) + f_ffn, "norm1+ffn+norm2": f_ffn}
+        stage_frac = {k: round(stage_flops[k] / (v * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) for k, v in kernels.items()
+                      if k in stage_flops and v > 0}
         # HBM traffic per layer forward from the TCC counters: collected by tools/pmc_traffic.sh (rocprofv3 --pmc passes of this
         # very command cannot run inside the timed process); reported only for the workload it was measured on
         traffic, traffic_src = None, None
@@ -210,7 +221,7 @@ def main():
             "kernel": "axial layer forward (all launches of one step)", "launch_us": round(fwd_ms * 1e3, 2),
             "algorithmic_gflop": round(flops / 1e9, 2), "algorithmic_mbytes": round(layer_bytes(B, T, H, W, C, F) / 1e6, 2),
             "hbm_frac_if_memory_bound": round(layer_bytes(B, T, H, W, C, F) / (fwd_ms * 1e-3) / 8e12, 4),
-            "stage_us": kernels, "dominant_stage": dom,
+            "stage_us": kernels, "stage_frac": stage_frac, "dominant_stage": dom,
         }
 
         # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
