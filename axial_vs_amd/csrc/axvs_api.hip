@@ -2,11 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
-#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 
-#include "../../include/axvs.h"
+#include "axvs_host.h"
 #include "axvs_attn.h"
 #include "axvs_cc.h"
 #include "axvs_msda.h"
@@ -20,16 +19,6 @@
 using namespace axvs;
 
 namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
 
 // optional per-stage event recording (bench.py / tuning): events[i] is recorded on the stream after stage i
 thread_local hipEvent_t* g_prof_events = nullptr;
@@ -71,11 +60,6 @@ int check_cfg(int C, int heads) {
 }
 
 // ---------------- packed weights ----------------
-struct TrajPacked {  // pointers into the packed blob
-  u16 *wq, *wk, *wv, *wpq, *wpkv, *wp, *wk2t;     // wk2t: transposed k half of proj_kv (fused temporal kernel, C = 256)
-  float *bq, *bk, *bv, *bpq, *bpkv, *bp;
-};
-
 TrajPacked carve_traj(Carver& c, int C, int heads) {
   const size_t Cp = (size_t)heads * 32;
   TrajPacked t;
@@ -182,11 +166,6 @@ void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, h
 }
 
 // ---------------- one trajectory attention over sequence-ordered rows ----------------
-struct TrajWs {
-  u16 *q16, *k16, *v16, *x16, *o16, *vt16;
-  float *q2, *kv2;
-};
-
 TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads) {
   const size_t Cp = (size_t)heads * 32;
   TrajWs w;
@@ -208,66 +187,15 @@ RowMap identity_map(long long rows) {
 
 template <bool BF, int NKS>
 int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int heads, long long Mp, hipStream_t st) {
-  static bool configured = false;
   const size_t lds = (size_t)T * NKS * 32 * 32 * 2 * sizeof(u16);
   if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "sequence too long for the LDS-resident K/V (T=%d, L=%d)", T, L);
-  if (!configured || lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_attn_kernel<BF, NKS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
-    configured = true;
-  }
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&spatial_attn_kernel<BF, NKS>))) return rc;
   const int wcap = g_attn_waves > 0 ? g_attn_waves : 8;
   const int nwaves = (N + 31) / 32 >= wcap ? wcap : (N + 31) / 32;  // 32 queries per wave, at most `wcap` waves
   dim3 grid((N + 32 * nwaves - 1) / (32 * nwaves), heads, S);
   hipLaunchKernelGGL((spatial_attn_kernel<BF, NKS>), grid, dim3(64 * nwaves), lds, st, w.q16, w.k16, w.v16, w.x16, attn, N, T, L,
                      heads, Mp);
   return AXVS_OK;
-}
-
-template <bool BF, int T, int MT, int NKS>
-int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                      float scale, hipStream_t st, const FfnArgs* fa) {
-  const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
-  if constexpr (NKS > 0 && MT == 4) {
-    if (fa) {                                    // trajectory attention + FFN in one kernel
-      static bool configured_ffn = false;
-      if (!configured_ffn) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-          return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
-        configured_ffn = true;
-      }
-      const size_t lds_ffn = temporal_lds_bytes<T, MT, true>(fa->F);
-      hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS, true>), dim3(grid), dim3(512), lds_ffn, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa, p.wk2t);
-      return AXVS_OK;
-    }
-  }
-  if (fa) return fail(AXVS_ERR_ARG, "internal: FFN fusion needs the in-kernel spatial half and 64-row tiles");
-  static bool configured = false;
-  constexpr size_t lds = temporal_lds_bytes<T, MT>();
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
-    configured = true;
-  }
-  hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
-                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t);
-  return AXVS_OK;
-}
-
-template <bool BF, int T, int MT>
-int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa) {
-  switch (nks) {
-    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    default: return fail(AXVS_ERR_ARG, "bad nks");
-  }
 }
 
 // nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel
@@ -311,13 +239,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const int nks_fused = (L + 31) / 32;
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
   if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
-    static bool configured = false;
-    if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_fused_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess)
-        return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
-      configured = true;
-    }
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&qkv_fused_kernel<BF>))) return rc;
     // the fused kernel reads the value rows from the same tensor as the q/k rows (+ optional additive term)
     if (vsrc == qsrc) {
       if (fuse_attn && L % 32 != 0 &&
@@ -393,15 +315,9 @@ template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
             hipStream_t st) {
   if (!g_generic_only && C == 256 && heads == 8 && F % 256 == 0) {
-    static bool configured = false;
     const size_t lds = ffn_lds_bytes(F);
     if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "d_ffn=%d too large for the fused FFN kernel", F);
-    if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024) != hipSuccess)
-        return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
-      configured = true;
-    }
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>))) return rc;
     hipLaunchKernelGGL((ffn_fused_kernel<BF>), dim3((unsigned)((M + kRows - 1) / kRows)), dim3(512), lds, st, X, p.w1, p.b1,
                        p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
     mark(st, "norm1+ffn+norm2");
@@ -1264,12 +1180,7 @@ int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long lo
 static int launch_lsap(const float* cost, long long* col4row, int batch, int n, hipStream_t st) {
   const size_t bytes = (size_t)n * n * sizeof(float);
   if (bytes <= 128 * 1024) {
-    static bool configured = false;
-    if (!configured) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lsap_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-        return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
-      configured = true;
-    }
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<true>))) return rc;
     hipLaunchKernelGGL((lsap_kernel<true>), dim3(batch), dim3(64), bytes, st, cost, col4row, n);
   } else {
     hipLaunchKernelGGL((lsap_kernel<false>), dim3(batch), dim3(64), 0, st, cost, col4row, n);

@@ -1,0 +1,60 @@
+// Host-side plumbing shared by the translation units of libaxvs.so: error string, per-device kernel attributes, the
+// packed-weight / workspace views of one trajectory attention, and the launcher of the fused trajectory kernels (whose
+// instantiations are compiled one (operand type, frame count) pair per translation unit: axvs_temporal_inst.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/axvs.h"
+#include "axvs_common.h"
+
+namespace axvs {
+
+inline thread_local char g_err[512] = "";
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember (device, kernel) pairs that have
+// been raised to the full 160 KiB so a second device in the same process is configured too.
+inline int ensure_max_lds(const void* fn) {
+  constexpr int kCap = 256;
+  struct Entry { int dev; const void* fn; };
+  static thread_local Entry seen[kCap];
+  static thread_local int nseen = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipGetDevice failed");
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i].fn == fn && seen[i].dev == dev) return AXVS_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
+  if (nseen < kCap) seen[nseen++] = Entry{dev, fn};
+  return AXVS_OK;
+}
+
+struct TrajPacked {  // pointers into the packed blob
+  u16 *wq, *wk, *wv, *wpq, *wpkv, *wp, *wk2t;     // wk2t: transposed k half of proj_kv (fused temporal kernel, C = 256)
+  float *bq, *bk, *bv, *bpq, *bpkv, *bp;
+};
+
+struct TrajWs {
+  u16 *q16, *k16, *v16, *x16, *o16, *vt16;
+  float *q2, *kv2;
+};
+
+struct FfnArgs;   // axvs_fused.h
+
+// nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel.  `fa` non-null: the
+// layer's FFN rides along (needs nks > 0 and 64-row tiles).
+template <bool BF, int T, int MT>
+int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
+                      int L, float scale, hipStream_t st, const FfnArgs* fa);
+
+}  // namespace axvs
