@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import _lib
-from .modules import _dev_f32, _param_key, _require_eval, _stream, _traj_struct, _workspace
+from .modules import _dev_f32, _param_key, _require_eval, _stream, _traj_struct, _workspace, _guarded
 
 
 class _LayerNormCF(nn.Module):
@@ -190,6 +190,7 @@ class CrossClipTrackingModule(nn.Module):
         return self._packed
 
     # ---- forward (CC:275-322) ------------------------------------------------------------------------------------
+    @_guarded
     def forward(self, clip_query: Tensor, panoptic_features: Tensor):
         _require_eval(self)
         cq = _dev_f32(clip_query, "clip_query")
@@ -303,6 +304,7 @@ class TubeLinkCrossClipHead(nn.Module):
         self._packed, self._packed_key = (layers, hbuf, K1, Cm), key
         return self._packed
 
+    @_guarded
     def forward(self, clip_query: Tensor, mask_features: Tensor):
         _require_eval(self)
         cq = _dev_f32(clip_query, "clip_query")

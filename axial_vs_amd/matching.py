@@ -11,9 +11,10 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from .modules import _dev_f32, _stream, _workspace
+from .modules import _dev_f32, _stream, _workspace, _guarded
 
 
+@_guarded
 def linear_sum_assignment(cost: Tensor) -> Tensor:
     """cost fp32 [n,n] or [batch,n,n] (CUDA) -> int64 column index per row = scipy.optimize.linear_sum_assignment(cost)[1]."""
     c = _dev_f32(cost, "cost")
@@ -28,6 +29,7 @@ def linear_sum_assignment(cost: Tensor) -> Tensor:
     return out[0] if squeeze else out
 
 
+@_guarded
 def match_from_embds(tgt_embds: Tensor, cur_embds: Tensor) -> Tensor:
     """maxtron_cc_model.py:360-369: permutation (int64, on the device) that makes `cur_embds` align with `tgt_embds`."""
     t = _dev_f32(tgt_embds, "tgt_embds")
@@ -43,6 +45,7 @@ def match_from_embds(tgt_embds: Tensor, cur_embds: Tensor) -> Tensor:
     return idx
 
 
+@_guarded
 def match_clips(pred_mask_embeddings: Tensor, pred_cluster_centers: Tensor) -> Tensor:
     """maxtron_cc_model.py:280-301: per video, align the queries of clip i to the already aligned clip i-1 by their mask
     embeddings and carry the cluster centres along.  pred_mask_embeddings / pred_cluster_centers [B, Tc, Q, C*] ->

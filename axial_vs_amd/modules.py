@@ -14,6 +14,7 @@ SURVEY.md section 8f).  There is no CPU fallback -- tensors must live on the GPU
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from typing import Dict, Optional, Tuple
 
@@ -73,25 +74,71 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
 
 def _param_key(mod: nn.Module, dtype: str):
     """Cheap change detector for the packed-weight caches: (storage pointer, version counter) of every parameter.
-    The parameter list is cached on the module (walking `mod.parameters()` costs ~75 us for a layer, more than half of the
-    GPU time of a forward); `.to()` / `.cuda()` / `load_state_dict` keep the Parameter objects, so the list stays valid, and
-    it is re-walked every 256 calls to catch a Parameter that was replaced by assignment."""
+    Walking `mod.modules()` / `mod.parameters()` costs ~75 us for a layer (more than half of the GPU time of a forward), so the
+    walk is cached as references INTO the owners' dictionaries: (owner._parameters, name) pairs are re-read on every call --
+    a Parameter replaced by assignment (`lin.bias = nn.Parameter(...)`, parametrizations, `.to()` with
+    overwrite_module_params_on_conversion) is seen at once -- and (parent._modules, name, id(child)) triples detect a replaced
+    submodule, which triggers a fresh walk."""
     d = mod.__dict__
-    pl = d.get("_axvs_plist")
-    n = d.get("_axvs_pcalls", 0)
-    if pl is None or (n & 255) == 255:
-        pl = list(mod.parameters())
-        d["_axvs_plist"] = pl
-    d["_axvs_pcalls"] = n + 1
-    return (dtype,) + tuple((p.data_ptr(), p._version) for p in pl)
+    cache = d.get("_axvs_refs")
+    if cache is not None:
+        for md, name, ident in cache[0]:
+            if id(md.get(name)) != ident:
+                cache = None
+                break
+    if cache is None:
+        mods, prefs = [], []
+        for m in mod.modules():
+            for name, child in m._modules.items():
+                mods.append((m._modules, name, id(child)))
+            for name in m._parameters:
+                prefs.append((m._parameters, name))
+        cache = (mods, prefs)
+        d["_axvs_refs"] = cache
+    key = [dtype]
+    for pd, name in cache[1]:
+        p = pd.get(name)
+        key.append(None if p is None else (p.data_ptr(), p._version))
+    return tuple(key)
 
 
 def invalidate_pack(mod: nn.Module) -> None:
-    """Forget cached parameter lists / packed weights of `mod` and its children (after replacing Parameter objects)."""
+    """Forget cached parameter references / packed weights of `mod` and its children."""
     for m in mod.modules():
-        m.__dict__.pop("_axvs_plist", None)
+        m.__dict__.pop("_axvs_refs", None)
         if "_packed" in m.__dict__:
             m.__dict__["_packed"] = None
+
+
+class _on:
+    """Make `device` current around a library call when it is not already (the library launches on the current HIP device)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def _guarded(fn):
+    """Run `fn` with the device of its first CUDA tensor argument current (libaxvs launches on the current HIP device and its
+    streams / per-device kernel attributes belong to it): tensors on cuda:1 while cuda:0 is current must not launch on 0."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in args:
+            if isinstance(a, Tensor) and a.is_cuda:
+                with _on(a.device):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapper
 
 
 def _traj_struct(m: "TrajectoryAttention", keep: list) -> _lib.AxvsTrajParams:
@@ -150,6 +197,7 @@ class TrajectoryAttention(nn.Module):
             self._packed, self._packed_key = buf, key
         return self._packed
 
+    @_guarded
     def forward(self, query, key, value, num_frames=2):
         """query/key/value: [S, num_frames*L, C] -> (x [S, N, C], space_attn [(S h), N, T, L] or None)."""
         _require_eval(self)
@@ -233,6 +281,7 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             self._packed, self._packed_key = buf, key
         return self._packed
 
+    @_guarded
     def forward(self, src: Tensor, pos: Tensor):
         """
         :param src: tensor of shape [B*T, H*W, C]
@@ -343,8 +392,9 @@ class PositionEmbeddingSine3D(nn.Module):
         """[B,T,H,W,C] fp32 -- the layout the trajectory layers consume."""
         Cc = 2 * self.num_pos_feats
         pos = torch.empty(B, T, H, W, Cc, dtype=torch.float32, device=device)
-        _lib.check(_lib.lib().axvs_pos3d(pos.data_ptr(), B, T, H, W, Cc, float(self.temperature), int(self.normalize),
-                                         float(self.scale), _stream(pos.device)), "axvs_pos3d")
+        with _on(pos.device):
+            _lib.check(_lib.lib().axvs_pos3d(pos.data_ptr(), B, T, H, W, Cc, float(self.temperature), int(self.normalize),
+                                             float(self.scale), _stream(pos.device)), "axvs_pos3d")
         return pos
 
     @torch.no_grad()

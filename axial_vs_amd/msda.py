@@ -18,7 +18,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import _lib
-from .modules import _dev_f32, _param_key, _require_eval, _stream, _workspace
+from .modules import _dev_f32, _param_key, _require_eval, _stream, _workspace, _guarded
 
 
 def _shapes_host(spatial_shapes) -> list:
@@ -29,6 +29,7 @@ def _shapes_host(spatial_shapes) -> list:
     return [(int(h), int(w)) for h, w in spatial_shapes]
 
 
+@_guarded
 def ms_deform_attn_forward(value: Tensor, value_spatial_shapes, value_level_start_index, sampling_locations: Tensor,
                            attention_weights: Tensor, im2col_step: int = 64) -> Tensor:
     """Drop-in for `MSDA.ms_deform_attn_forward` / `MSDeformAttnFunction.apply` (forward):
@@ -114,6 +115,7 @@ class MSDeformAttn(nn.Module):
         self._packed, self._packed_key = buf, key
         return buf
 
+    @_guarded
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index=None,
                 input_padding_mask=None):
         """query (N, Len_q, C); reference_points (N, Len_q, n_levels, 2 | 4) in [0,1]; input_flatten (N, sum H_l W_l, C);
@@ -212,6 +214,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self._packed, self._packed_key = buf, key
         return buf
 
+    @_guarded
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index=None, padding_mask=None):
         _require_eval(self)
         x = _dev_f32(src, "src")

@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import _lib
-from .modules import PositionEmbeddingSine3D, TemporalEncoder, _dev_f32, _param_key, _require_eval, _stream, _workspace
+from .modules import PositionEmbeddingSine3D, TemporalEncoder, _dev_f32, _param_key, _require_eval, _stream, _workspace, _guarded
 from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer
 
 
@@ -82,6 +82,7 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         ref = torch.cat(refs, 0)
         return ref[None, :, None, :].expand(valid_ratios, -1, len(spatial_shapes), 2).contiguous()
 
+    @_guarded
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos, padding_mask, pos_3d=None):
         """src / pos [BT, S, C]; spatial_shapes: list of (H, W); valid_ratios: BT (all maps valid); pos_3d: list of [B,T,H,W,C]."""
         output = src
@@ -204,6 +205,11 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return self._packed
 
     def forward_features(self, features):
+        from .modules import _on
+        with _on(next(iter(features.values())).device):
+            return self._forward_features(features)
+
+    def _forward_features(self, features):
         _require_eval(self)
         order = self.transformer_spatial_in_features[::-1]          # low -> high resolution (WC/msdeformattn.py:411)
         xs = [_dev_f32(features[f], f) for f in order]

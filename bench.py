@@ -60,18 +60,30 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (axvs_set_option)")
     args = ap.parse_args()
 
+    import __graft_entry__ as ge
+    if "RANK" not in os.environ and args.gpus > 1:
+        # Invoked as `python bench.py --gpus N`: become the launcher.  This process has made no GPU call (torch is not even
+        # imported yet); it compiles the library if needed, starts one worker per GPU under torch.distributed.run as a CHILD
+        # process and relays its output and exit code (never exec: see the gpurun notes on re-exec after GPU initialisation).
+        import socket
+        import subprocess
+        ge.build(load=False)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
 
-    import __graft_entry__ as ge
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    import torch.distributed as dist  # noqa: F811
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -170,3 +170,25 @@ def test_within_clip_module_state_dict_matches_reference():
     mod.within_clip_tracking_module.load_state_dict(orc.random_weights(m["shapes"], 1), strict=True)
     with pytest.raises(RuntimeError):
         mod.eval().forward_features({k: torch.zeros(m["T"], c, *m["sizes"][k]) for k, c in m["chans"].items()})
+
+
+def test_packed_weight_key_sees_replaced_parameters_and_modules():
+    """The packed-weight cache key must change at once when a Parameter object is replaced by assignment, when it is updated
+    in place, and when a whole submodule is replaced (the old key re-walked the module only every 256 calls)."""
+    import axial_vs_amd as ax
+    from axial_vs_amd.modules import _param_key
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(64, 128, n_heads=8)
+    k0 = _param_key(layer, "f16")
+    assert _param_key(layer, "f16") == k0 and _param_key(layer, "bf16") != k0
+    layer.linear1.bias = torch.nn.Parameter(torch.zeros(128))                 # replaced Parameter object
+    k1 = _param_key(layer, "f16")
+    assert k1 != k0
+    with torch.no_grad():
+        layer.height_attn.q.weight.add_(1.0)                                  # in-place update (version counter)
+    k2 = _param_key(layer, "f16")
+    assert k2 != k1
+    layer.norm2 = torch.nn.LayerNorm(64)                                      # replaced submodule
+    k3 = _param_key(layer, "f16")
+    assert k3 != k2 and _param_key(layer, "f16") == k3
+    layer.load_state_dict(layer.state_dict())                                 # copy_ into the same Parameters
+    assert _param_key(layer, "f16") != k3
