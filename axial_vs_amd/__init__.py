@@ -11,9 +11,10 @@ from .cross_clip import CrossClipTrackingModule, TubeLinkCrossClipHead
 from .pixel_decoder import (MSDeformAttnPixelDecoder, MSDeformAttnTransformerEncoder, MSDeformAttnTransformerEncoderOnly,
                             PositionEmbeddingSine, WithinClipTrackingModule)
 from .matching import linear_sum_assignment, match_clips, match_from_embds
+from .tube_link import MultiScaleDeformableAxialTrajectoryAttention
 from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer, ms_deform_attn_forward
 
-__all__ = ["linear_sum_assignment", "match_from_embds", "match_clips", "WithinClipTrackingModule", "MSDeformAttnPixelDecoder", "MSDeformAttnTransformerEncoder", "MSDeformAttnTransformerEncoderOnly",
+__all__ = ["MultiScaleDeformableAxialTrajectoryAttention", "linear_sum_assignment", "match_from_embds", "match_clips", "WithinClipTrackingModule", "MSDeformAttnPixelDecoder", "MSDeformAttnTransformerEncoder", "MSDeformAttnTransformerEncoderOnly",
            "PositionEmbeddingSine", "CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
            "set_default_dtype", "GraphedForward", "invalidate_pack"]

@@ -105,6 +105,8 @@ SIGNATURES = {
     "axvs_msda_pack": (C.c_int, [C.POINTER(AxvsMsdaParams), _fp] + [C.c_int] * 5 + [_fp]),
     "axvs_msda_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_msda_fwd": (C.c_int, [_fp, _fp, C.c_int, _fp, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_msda_sample_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
+    "axvs_msda_output_proj_fwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_longlong] + [C.c_int] * 5 + [_fp]),
     "axvs_msda_layer_packed_bytes": (C.c_size_t, [C.c_int] * 5),
     "axvs_msda_layer_pack": (C.c_int, [C.POINTER(AxvsMsdaLayerParams), _fp] + [C.c_int] * 6 + [_fp]),
     "axvs_msda_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),

@@ -589,10 +589,12 @@ int msda_levels(const int* shapes, int L, int S, MsdaLevels* lv) {
   return AXVS_OK;
 }
 
+// what: 0 = whole module (value_proj, offsets | logits, gather, output_proj), 1 = up to the gather with fp32 rows out
+// (`out` = sampled [N*Lq][C], no output_proj)
 template <bool BF>
 int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* input, const unsigned char* mask, const MsdaLevels& lv,
                float* out, const MsdaPacked& p, int N, int Lq, int S, int C, int heads, int P, void* ws, hipStream_t st,
-               const float* qadd = nullptr, const float* residual = nullptr) {
+               const float* qadd = nullptr, const float* residual = nullptr, int what = 0) {
   const int L = lv.L, Cp = heads * 32, nq = 3 * heads * L * P;
   const long long Rv = (long long)N * S, Rq = (long long)N * Lq;
   Carver wc(ws);
@@ -611,9 +613,11 @@ int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* 
   mark(st, "msda.offsets+weights");
   const long long groups = Rq * heads;
   const dim3 ggrid((unsigned)((groups + 63) / 64));
-  if (P == 4) hipLaunchKernelGGL((msda_gather_kernel<BF, 4>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P);
-  else hipLaunchKernelGGL((msda_gather_kernel<BF, 0>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P);
+  float* of32 = what == 1 ? out : nullptr;
+  if (P == 4) hipLaunchKernelGGL((msda_gather_kernel<BF, 4>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P, of32, C / heads);
+  else hipLaunchKernelGGL((msda_gather_kernel<BF, 0>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P, of32, C / heads);
   mark(st, "msda.gather");
+  if (what == 1) return last_launch_status();
   launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, residual, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
                   C, 3 * Cp, st);
   mark(st, "msda.output_proj");
@@ -1012,6 +1016,45 @@ int axvs_msda_fwd(const float* query, const float* reference_points, int ref_dim
   if (dtype == AXVS_BF16) return msda_fwd_t<true>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, mp, N, Lq, S, C, heads, P, workspace, st);
   if (dtype == AXVS_F16) return msda_fwd_t<false>(query, reference_points, ref_dim, input_flatten, padding_mask, lv, out, mp, N, Lq, S, C, heads, P, workspace, st);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+// ---- the two halves of the module for callers that work on the sampled rows before output_proj (Tube-Link plugin) ----
+int axvs_msda_sample_fwd(const float* query, const float* query_pos, const float* reference_points, int ref_dim, const float* value,
+                         const unsigned char* padding_mask, const int* spatial_shapes, float* sampled, const void* packed, int N, int Lq,
+                         int S, int C, int heads, int L, int P, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!query || !reference_points || !value || !spatial_shapes || !sampled || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || Lq <= 0 || S <= 0 || P <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if ((C / heads) % 8) return fail(AXVS_ERR_ARG, "head_dim=%d must be a multiple of 8", C / heads);
+  if (ref_dim != 2 && ref_dim != 4) return fail(AXVS_ERR_ARG, "Last dim of reference_points must be 2 or 4, but get %d instead.", ref_dim);
+  if (L * P > 64) return fail(AXVS_ERR_ARG, "n_levels * n_points > 64 is not supported");
+  if ((long long)N * S > 2147483647LL / 64 || (long long)N * Lq > 2147483647LL / 64) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
+  MsdaLevels lv;
+  if (int rc = msda_levels(spatial_shapes, L, S, &lv)) return rc;
+  if (workspace_bytes < axvs_msda_workspace_bytes(N, Lq, S, C, heads, L, P)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Carver pc(const_cast<void*>(packed));
+  const MsdaPacked mp = carve_msda(pc, C, heads, L, P);
+  if (dtype == AXVS_BF16) return msda_fwd_t<true>(query, reference_points, ref_dim, value, padding_mask, lv, sampled, mp, N, Lq, S, C, heads, P, workspace, st, query_pos, nullptr, 1);
+  if (dtype == AXVS_F16) return msda_fwd_t<false>(query, reference_points, ref_dim, value, padding_mask, lv, sampled, mp, N, Lq, S, C, heads, P, workspace, st, query_pos, nullptr, 1);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int axvs_msda_output_proj_fwd(const float* x, const float* identity, float* out, const void* packed, long long rows, int C, int heads,
+                              int L, int P, int dtype, void* stream) {
+  if (!x || !out || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (rows <= 0 || rows > 2147483647LL / 64) return fail(AXVS_ERR_ARG, "bad row count");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (C / heads != 32) return fail(AXVS_ERR_ARG, "axvs_msda_output_proj_fwd needs head_dim 32 (got %d)", C / heads);
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Carver pc(const_cast<void*>(packed));
+  const MsdaPacked mp = carve_msda(pc, C, heads, L, P);
+  const EpiRowsF32 e{out, identity, mp.bo, identity_map(rows), C, 1.f};
+  // split-precision operands as in the module path (the projection output has no norm behind it)
+  if (dtype == AXVS_BF16) launch_gemm<true>(ALoadRowsF32Split3<true>{x, (int)rows, C}, mp.wo, e, (int)rows, C, 3 * C, st);
+  else launch_gemm<false>(ALoadRowsF32Split3<false>{x, (int)rows, C}, mp.wo, e, (int)rows, C, 3 * C, st);
+  return last_launch_status();
 }
 
 // ---- MSDeformAttnTransformerEncoderLayer (WC/msdeformattn.py:177-216): self-attention + residual, norm1, FFN, norm2 ----

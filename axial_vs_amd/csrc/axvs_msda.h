@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256) void msda_core_kernel(const float* __restrict_
 template <bool BF, int PT>   // PT > 0: n_points known at compile time (all 4*PT corner loads of a level in flight together)
 __global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict__ value16, const float* __restrict__ qproj,
                                                           const float* __restrict__ refp, int ref_dim, MsdaLevels lv,
-                                                          u16* __restrict__ o16, int N, int S, int Lq, int M, int Prt) {
+                                                          u16* __restrict__ o16, int N, int S, int Lq, int M, int Prt,
+                                                          float* __restrict__ of32 = nullptr, int d = 32) {
+  // of32 != nullptr: the sampled rows go out as fp32 [N*Lq][M*d] (natural channel order) instead of the split 16-bit blocks
+  // -- the Tube-Link plugin runs its temporal encoder on them before output_proj (TL ...pixel_decoder.py:613-633).
   const int P = PT > 0 ? PT : Prt;
   const long long gid = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);        // (row, head) group
   const int j = threadIdx.x & 3;
@@ -114,7 +117,13 @@ __global__ __launch_bounds__(256) void msda_gather_kernel(const u16* __restrict_
                   w11 * H16<BF>::to_f32(v11[c]);
     }
   }
-  if (valid) {
+  if (valid && of32) {
+    if (j * 8 < d) {
+      float* o = of32 + row * (long long)(M * d) + m * d + j * 8;
+      *reinterpret_cast<float4*>(o) = float4{acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<float4*>(o + 4) = float4{acc[4], acc[5], acc[6], acc[7]};
+    }
+  } else if (valid) {
     const u16x8 hi = cvt8<BF>(acc);
     float lo[8];
 #pragma unroll

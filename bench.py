@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured HIP graph per step instead of launching from Python")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + AXVS_BENCH_SHARE_GPU=1 runs N ranks on ONE GPU (launcher smoke test only)")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (axvs_set_option)")
     args = ap.parse_args()
 
@@ -84,11 +86,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    share = os.environ.get("AXVS_BENCH_SHARE_GPU") == "1" and args.backend == "gloo"
+    dev = torch.device("cuda", 0 if share else local_rank)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     # one rank builds (a no-op when the in-tree .so is fresh), the others wait for it
     if local_rank == 0:
         ge.build()
@@ -150,7 +156,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(out).all()

@@ -188,6 +188,19 @@ size_t axvs_msda_workspace_bytes(int N, int Lq, int S, int C, int heads, int L, 
 int axvs_msda_fwd(const float* query, const float* reference_points, int ref_dim, const float* input_flatten,
                   const unsigned char* padding_mask, const int* spatial_shapes, float* out, const void* packed, int N, int Lq,
                   int S, int C, int heads, int L, int P, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The module in two halves, for the Tube-Link plugin MultiScaleDeformableAxialTrajectoryAttention.forward
+ * (TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:566-638), which runs its temporal encoder on the sampled rows of the
+ * coarsest levels BEFORE output_proj (:613-633):
+ *   axvs_msda_sample_fwd       :594-611  value_proj(value) (+ key_padding_mask), sampling_offsets / attention_weights of
+ *                                        (query + query_pos), softmax, bilinear gather -> sampled fp32 [N,Lq,C]
+ *   axvs_msda_output_proj_fwd  :633-638  out = output_proj(x) + identity (identity may be NULL); head_dim 32 only.
+ * query_pos: NULL or fp32 [N,Lq,C].  Workspace: axvs_msda_workspace_bytes. */
+int axvs_msda_sample_fwd(const float* query, const float* query_pos, const float* reference_points, int ref_dim,
+                         const float* value, const unsigned char* padding_mask, const int* spatial_shapes, float* sampled,
+                         const void* packed, int N, int Lq, int S, int C, int heads, int L, int P, int dtype, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int axvs_msda_output_proj_fwd(const float* x, const float* identity, float* out, const void* packed, long long rows, int C,
+                              int heads, int L, int P, int dtype, void* stream);
 /* MSDeformAttnTransformerEncoderLayer.forward (WC/msdeformattn.py:177-216), eval:
  *   x = norm1(src + MSDeformAttn(src + pos, reference_points, src, ...));  out = norm2(x + linear2(relu(linear1(x)))) */
 typedef struct AxvsMsdaLayerParams {

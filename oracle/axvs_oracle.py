@@ -428,6 +428,41 @@ def msda_module(query: Tensor, reference_points: Tensor, input_flatten: Tensor, 
     return _linear(msda_core(value, spatial_shapes, loc, aw), w, "output_proj")
 
 
+def tl_plugin_attention(query: Tensor, query_pos: Optional[Tensor], pos3d, reference_points: Tensor, spatial_shapes, w: Weights,
+                        n_heads: int, n_points: int, num_temporal_levels: int, num_temporal_layers: int, skip_connect: bool = True,
+                        key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """MultiScaleDeformableAxialTrajectoryAttention.forward (TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:566-638), batch-first
+    tensors [bs, num_query, C], value = identity = query, eval (dropout = identity):
+    value_proj / offsets / softmaxed weights / bilinear sampling (:589-611) -> per temporal level `f + gamma * encoder(f, pos3d[i])`
+    (:613-630) -> output_proj + identity (:633-638)."""
+    N, Lq, C = query.shape
+    n_levels = len(spatial_shapes)
+    q = query if query_pos is None else query + query_pos
+    value = _linear(query, w, "value_proj")
+    if key_padding_mask is not None:
+        value = value.masked_fill(key_padding_mask[..., None], 0.0)
+    value = value.reshape(N, Lq, n_heads, C // n_heads)
+    off = _linear(q, w, "sampling_offsets").reshape(N, Lq, n_heads, n_levels, n_points, 2)
+    aw = torch.softmax(_linear(q, w, "attention_weights").reshape(N, Lq, n_heads, n_levels * n_points), -1)
+    aw = aw.reshape(N, Lq, n_heads, n_levels, n_points)
+    shp = torch.as_tensor([[int(h), int(ww)] for h, ww in spatial_shapes], dtype=query.dtype)
+    if reference_points.shape[-1] == 2:
+        normalizer = torch.stack([shp[:, 1], shp[:, 0]], -1)
+        loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+    else:
+        loc = reference_points[:, :, None, :, None, :2] + off / n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+    sampled = msda_core(value, spatial_shapes, loc, aw)
+    outs, start = [], 0
+    for i, (h, ww) in enumerate(spatial_shapes):
+        f = sampled[:, start:start + h * ww]
+        start += h * ww
+        if i < num_temporal_levels:
+            y, _, _ = temporal_encoder(f, pos3d[i], _sub(w, "temporal_layer"), num_temporal_layers, n_heads, want_attn=False)
+            f = f + w["gamma"].to(f.dtype) * y if skip_connect else y
+        outs.append(f)
+    return _linear(torch.cat(outs, 1), w, "output_proj") + query
+
+
 def msda_encoder_layer(src: Tensor, pos: Optional[Tensor], reference_points: Tensor, spatial_shapes, w: Weights, n_heads: int,
                        n_levels: int, n_points: int, padding_mask: Optional[Tensor] = None) -> Tensor:
     """MSDeformAttnTransformerEncoderLayer.forward, WC/msdeformattn.py:207-216 (eval: dropouts are identities)."""

@@ -133,3 +133,31 @@ def msda_enclayer_case(z, m):
         pm[0, 5:40] = True
         pm[1, -7:] = True
     return w, src, pos, ref, pm
+
+
+TL_PLUGIN = ["g9_tl_plugin_T2_L3_l1", "g9_tl_plugin_T3_L3_l2", "g9_tl_plugin_T4_L2_l1"]
+
+
+def tl_plugin_case(z, m, C=256):
+    """weights + inputs of a G9 fixture (same recipe as oracle/gen_golden_tl_plugin.py:plugin_case / scale_gamma), batch-first:
+    (state dict, query, query_pos, pos3d list, reference_points, key_padding_mask or None)."""
+    import axvs_oracle as orc
+    w = orc.random_weights({k: tuple(v) for k, v in m["wshapes"].items()}, m["seed"])
+    if "gamma" in w:
+        w["gamma"] = w["gamma"] * 10.0 + 1.0
+    assert abs(sum(v.double().sum().item() for v in w.values()) - float(z["wsum"])) < 1e-6 * max(1.0, abs(float(z["wsum"])))
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    B, T, shapes = m["B"], m["T"], [tuple(s) for s in m["shapes"]]
+    bs, nq = B * T, sum(h * ww for h, ww in shapes)
+    query = torch.randn(bs, nq, C, generator=g)
+    query_pos = torch.randn(bs, nq, C, generator=g) * 0.5
+    lvl3d = torch.randn(m["temporal_levels"], C, generator=g) * 0.3
+    pos3d = [orc.pos_embed_sine_3d(B, T, h, ww, C // 2) + lvl3d[i].view(1, 1, 1, 1, -1)
+             for i, (h, ww) in enumerate(shapes[:m["temporal_levels"]])]
+    refs = []
+    for (h, ww) in shapes:
+        ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(ww) + 0.5) / ww, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)[None, :, None].repeat(bs, 1, len(shapes), 1)
+    mask = (torch.rand(bs, nq, generator=g) < 0.1) if m["mask"] else None
+    return w, query, query_pos, pos3d, ref, mask

@@ -391,6 +391,33 @@ def test_msda_encoder_layer_golden(name):
     assert e < TOL_F16
 
 
+from golden_util import TL_PLUGIN, tl_plugin_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", TL_PLUGIN)
+def test_tube_link_plugin_golden(name):
+    """MultiScaleDeformableAxialTrajectoryAttention (TL ...pixel_decoder.py:393-638) against the reference class:
+    (num_query, bs, C) and batch-first layouts, padding mask, 1 and 2 temporal layers, gamma of O(1), skip_connect off."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w, q, qp, pos3d, ref, km = tl_plugin_case(z, m)
+    shapes = [tuple(s) for s in m["shapes"]]
+    mod = ax.MultiScaleDeformableAxialTrajectoryAttention(
+        embed_dims=256, num_heads=8, num_levels=len(shapes), num_temporal_levels=m["temporal_levels"], num_temporal_layers=m["layers"],
+        num_temporal_dim=m["d_ffn"], num_points=4, dropout=0.0, batch_first=m["batch_first"], skip_connect=m["skip_connect"]).eval()
+    mod.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    perm = (lambda x: x) if m["batch_first"] else (lambda x: x.permute(1, 0, 2))
+    ss = torch.as_tensor(shapes, dtype=torch.long, device="cuda")
+    out = mod(query=perm(dev(q)), query_pos=perm(dev(qp)), query_pos3d=[dev(p) for p in pos3d],
+              key_padding_mask=km.cuda() if km is not None else None, reference_points=dev(ref), spatial_shapes=ss)
+    out = perm(out).cpu() if not m["batch_first"] else out.cpu()
+    e, e2 = rel_err(out[:, ::m["stride"]], t(z["out"])), rel_l2(out[:, ::m["stride"]], t(z["out"]))
+    print(f"{name}: max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < TOL_F16 and e2 < TOL_F16
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=2e-3)
+
+
 def test_graphed_forward_matches_eager():
     """The whole forward is capturable into a HIP graph (no allocation / sync inside the library): replay == eager, bitwise,
     also after the inputs change."""

@@ -182,3 +182,18 @@ def test_pixel_decoder(name):
                             B=m["B"])
     for k in m["chans"]:
         assert rel_err(out[k], t(z["out_" + k])) < 2e-4, k
+
+
+from golden_util import TL_PLUGIN, tl_plugin_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", TL_PLUGIN)
+def test_tl_plugin_attention(name):
+    """Tube-Link trajectory-attention plugin: deformable sampling -> f + gamma * TemporalEncoder(f) on the coarsest
+    levels -> output_proj + identity, against the reference class (batch_first on and off, padding mask, skip_connect off)."""
+    z, m = load(name)
+    w, q, qp, pos3d, ref, km = tl_plugin_case(z, m)
+    out = orc.tl_plugin_attention(q, qp, pos3d, ref, [tuple(s) for s in m["shapes"]], w, 8, 4, m["temporal_levels"], m["layers"],
+                                  m["skip_connect"], km)
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
+    assert rel_err(out[:, ::m["stride"]], t(z["out"])) < 5e-5
