@@ -31,6 +31,10 @@ class AxvsAxialLayerParams(C.Structure):
                                    "norm2_w", "norm2_b")]
 
 
+class AxvsSinePos3D(C.Structure):
+    _fields_ = [("temperature", C.c_float), ("normalize", C.c_int), ("scale", C.c_float), ("level_embed", _fp)]
+
+
 class AxvsBN(C.Structure):
     _fields_ = [(n, _fp) for n in ("w", "b", "mean", "var")]
 
@@ -81,6 +85,8 @@ SIGNATURES = {
     "axvs_traj_attn_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [C.c_int] * 6 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_axial_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
+    "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "axvs_axial_layer_fwd_sine3d": (C.c_int, [_fp, C.POINTER(AxvsSinePos3D), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
     "axvs_ffn_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int, C.c_int]),
     "axvs_ffn_fwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_cc_layer_packed_bytes": (C.c_size_t, []),

@@ -217,7 +217,8 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
 template <bool BF>
 int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
-             hipStream_t st, int pass = 0, const FfnArgs* ffn = nullptr, float* ffn_out = nullptr, bool* ffn_done = nullptr) {
+             hipStream_t st, int pass = 0, const FfnArgs* ffn = nullptr, float* ffn_out = nullptr, bool* ffn_done = nullptr,
+             const PosGen* posgen = nullptr) {
   static const char* const kNames[3][8] = {
       {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused", "traj_fused"},
       {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused", "h.traj_fused"},
@@ -247,11 +248,12 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
         return fail(AXVS_ERR_LAUNCH, "memset failed");
       hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3((unsigned)((Mp + 63) / 64)), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
                          p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e,
-                         fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused);
+                         fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{});
       goto qkv_done;
     }
   }
   {
+    if (posgen) return fail(AXVS_ERR_ARG, "internal: generated positions need the fused QKV kernel");
     ALoadRowsF32<BF> aq{qsrc, qk_add, rm, M, C}, ak{ksrc, qk_add, rm, M, C}, av{vsrc, nullptr, rm, M, C};
     launch_gemm<BF>(aq, p.wq, EpiBlocked16<BF>{w.q16, Mp, p.bq, scale * kLog2e, Cp, 0}, M, Cp, C, st);
     launch_gemm<BF>(ak, p.wk, EpiBlocked16<BF>{w.k16, Mp, p.bk, 1.f, 0, 0}, M, Cp, C, st);
@@ -358,9 +360,26 @@ int traj_attn_fwd_t(const float* query, const float* key, const float* value, fl
   return rc != AXVS_OK ? rc : last_launch_status();
 }
 
+bool sine_in_kernel(int C, int heads) { return !g_generic_only && C == 256 && heads == 8; }
+
+PosGen make_posgen(const AxvsSinePos3D& sp, int T, int H, int W, int C, int l_is_h) {
+  PosGen pg{};
+  pg.mode = 1;
+  pg.l_is_h = l_is_h;
+  const float eps = 1e-6f;
+  pg.zs = sp.normalize ? sp.scale / ((float)T + eps) : 1.f;
+  pg.ys = sp.normalize ? sp.scale / ((float)H + eps) : 1.f;
+  pg.xs = sp.normalize ? sp.scale / ((float)W + eps) : 1.f;
+  pg.n = C / 2;
+  pg.ke_yx = -log2f(sp.temperature) * 2.f / (float)pg.n;
+  pg.ke_z = -log2f(sp.temperature) * 2.f / (float)C;
+  pg.level = sp.level_embed;
+  return pg;
+}
+
 template <bool BF>
 int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W, int C,
-                      int heads, int F, void* ws, float* h_attn, float* w_attn, hipStream_t st) {
+                      int heads, int F, void* ws, float* h_attn, float* w_attn, hipStream_t st, const AxvsSinePos3D* sine = nullptr) {
   Carver pc(const_cast<void*>(packed));
   LayerPacked p = carve_layer(pc, C, heads, F);
   const long long M = (long long)B * T * H * W;
@@ -374,15 +393,37 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
 
   g_prof_next = 0;
   mark(st, "begin");
+  // positions given as a PositionEmbeddingSine3D specification: the fused QKV kernel evaluates them (no HBM read); the other
+  // tiers get them materialised into the workspace first
+  PosGen pgh{}, pgw{};
+  const PosGen *ph = nullptr, *pw = nullptr;
+  if (sine) {
+    if (sine_in_kernel(C, heads)) {
+      pgh = make_posgen(*sine, T, H, W, C, 1);
+      pgw = make_posgen(*sine, T, H, W, C, 0);
+      ph = &pgh;
+      pw = &pgw;
+    } else {
+      float* pbuf = wc.take<float>((size_t)M * C);
+      const long long total = (long long)T * H * W * C;
+      hipLaunchKernelGGL(pos3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pbuf, B, T, H, W, C, sine->temperature,
+                         sine->normalize, sine->scale);
+      if (sine->level_embed)
+        hipLaunchKernelGGL(add_channel_vector_kernel, dim3((unsigned)(((size_t)M * C + 255) / 256)), dim3(256), 0, st, pbuf, sine->level_embed,
+                           (size_t)M * C, C);
+      pos = pbuf;
+      mark(st, "pos3d");
+    }
+  }
   // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
   RowMap rmh{T * H, H, W, sB, sT, W, 1};
-  int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1);
+  int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1, nullptr, nullptr, nullptr, ph);
   if (rc != AXVS_OK) return rc;
   // width pass: sequences (b, h), tokens (t, w)         :206-213
   RowMap rmw{T * W, W, H, sB, sT, 1, W};
   const FfnArgs fa{p.w1, p.w2, p.b1, p.b2, p.g1, p.be1, p.g2, p.be2, F};
   bool ffn_done = false;
-  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st, 2, &fa, out, &ffn_done);
+  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st, 2, &fa, out, &ffn_done, pw);
   if (rc != AXVS_OK) return rc;
   if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
@@ -639,7 +680,7 @@ int axvs_profile_stages(void** events, int capacity) {
 int axvs_profile_stage_count(void) { return g_prof_next < kMaxStages ? g_prof_next : kMaxStages; }
 const char* axvs_profile_stage_name(int i) { return (i >= 0 && i < kMaxStages && g_stage_names[i]) ? g_stage_names[i] : ""; }
 
-#ifdef AXVS_STAMPS
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_QKV)   // the QKV kernel lives in this unit; the trajectory kernels: axvs_temporal_inst.hip
 int axvs_debug_read_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(axvs::g_stamps), sizeof(unsigned long long) * n);
 }
@@ -740,23 +781,42 @@ size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int h
   return c.off;
 }
 
-int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W,
-                         int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, float* h_attn,
-                         float* w_attn, void* stream) {
-  if (!src || !pos || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+static int axial_layer_entry(const float* src, const float* pos, const AxvsSinePos3D* sine, float* out, const void* packed, int B, int T,
+                             int H, int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, float* h_attn,
+                             float* w_attn, void* stream) {
+  if (!src || (!pos && !sine) || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
   if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return fail(AXVS_ERR_ARG, "empty shape B=%d T=%d H=%d W=%d", B, T, H, W);
   if (src == out) return fail(AXVS_ERR_ARG, "out may not alias src");
   if (int rc = check_cfg(C, heads)) return rc;
   if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
-  if (workspace_bytes < axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn))
-    return fail(AXVS_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes,
-                axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn));
+  if (sine && (T > 255 || H > 4095 || W > 4095)) return fail(AXVS_ERR_ARG, "grid too large for generated positions");
+  const size_t need = sine ? axvs_axial_layer_sine3d_workspace_bytes(B, T, H, W, C, heads, d_ffn) : axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn);
+  if (workspace_bytes < need) return fail(AXVS_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == AXVS_BF16)
-    return axial_layer_fwd_t<true>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st);
+    return axial_layer_fwd_t<true>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st, sine);
   if (dtype == AXVS_F16)
-    return axial_layer_fwd_t<false>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st);
+    return axial_layer_fwd_t<false>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, h_attn, w_attn, st, sine);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W,
+                         int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, float* h_attn,
+                         float* w_attn, void* stream) {
+  if (!pos) return fail(AXVS_ERR_ARG, "null pointer");
+  return axial_layer_entry(src, pos, nullptr, out, packed, B, T, H, W, C, heads, d_ffn, dtype, workspace, workspace_bytes, h_attn, w_attn, stream);
+}
+
+size_t axvs_axial_layer_sine3d_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
+  return axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn) + align_up((size_t)B * T * H * W * C * sizeof(float));
+}
+
+int axvs_axial_layer_fwd_sine3d(const float* src, const AxvsSinePos3D* pos, float* out, const void* packed, int B, int T, int H, int W,
+                                int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, float* h_attn,
+                                float* w_attn, void* stream) {
+  if (!pos) return fail(AXVS_ERR_ARG, "null pointer");
+  if (!(pos->temperature > 0.f)) return fail(AXVS_ERR_ARG, "temperature must be positive");
+  return axial_layer_entry(src, nullptr, pos, out, packed, B, T, H, W, C, heads, d_ffn, dtype, workspace, workspace_bytes, h_attn, w_attn, stream);
 }
 
 size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn) {
@@ -1223,7 +1283,7 @@ int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long lo
 static int launch_lsap(const float* cost, long long* col4row, int batch, int n, hipStream_t st) {
   const size_t bytes = (size_t)n * n * sizeof(float);
   if (bytes <= 128 * 1024) {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<true>), 128 * 1024)   /* + static state arrays */) return rc;
     hipLaunchKernelGGL((lsap_kernel<true>), dim3(batch), dim3(64), bytes, st, cost, col4row, n);
   } else {
     hipLaunchKernelGGL((lsap_kernel<false>), dim3(batch), dim3(64), 0, st, cost, col4row, n);

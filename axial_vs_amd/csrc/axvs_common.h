@@ -114,6 +114,60 @@ __device__ __forceinline__ long long nat_row(const RowMap& rm, int mp) {
   return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
 }
 
+// Same decomposition, also returning the (t, h, w) grid coordinates packed as t | h << 8 | w << 20 (T <= 255, H, W <= 4095):
+// what an in-kernel positional embedding needs.  l_is_h: the on-axis coordinate l is the image row (height pass).
+__device__ __forceinline__ long long nat_row_coords(const RowMap& rm, int mp, int l_is_h, int* packed) {
+  int s = mp / rm.N, n = mp - s * rm.N;
+  int b = s / rm.Loff, o = s - b * rm.Loff;
+  int t = n / rm.L, l = n - t * rm.L;
+  *packed = t | ((l_is_h ? l : o) << 8) | ((l_is_h ? o : l) << 20);
+  return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
+}
+
+// PositionEmbeddingSine3D (WC/pos_embeddings.py:86-130, mask = None) evaluated inside a loader instead of read from HBM:
+//   pos[t,h,w,c] = (c < n ? sincos(y_h / dim_t(c)) : sincos(x_w / dim_t(c - n))) + sincos(z_t / dim_tz(c)) [+ level[c]],  n = C/2,
+//   dim_t(i) = temperature^(2 floor(i/2) / n), dim_tz(i) = temperature^(2 floor(i/2) / C), sin for even channels, cos for odd ones,
+//   coordinates 1..L, scaled by scale / (L + 1e-6) when normalised.
+struct PosGen {
+  int mode;               // 0: read the pos tensor, 1: generate
+  int l_is_h;             // RowMap's on-axis coordinate is the image row
+  float zs, ys, xs;       // coordinate scale factors (1 when not normalised)
+  float ke_yx, ke_z;      // -log2(temperature) * 2 / n  and  -log2(temperature) * 2 / C
+  int n;                  // C / 2
+  const float* level;     // nullable fp32 [C]
+};
+
+// the 4 consecutive channels c0..c0+3 (c0 % 4 == 0) of one token
+struct PosGenLane {
+  float f0, f1, g0, g1;   // yx / z frequencies of the two channel pairs, in revolutions per coordinate unit
+  float lv[4];
+  int xside;
+  __device__ __forceinline__ void init(const PosGen& pg, int c0) {
+    const float inv2pi = 0.15915494309189535f;
+    xside = c0 >= pg.n;
+    const int cc = c0 - (xside ? pg.n : 0);
+    f0 = __builtin_amdgcn_exp2f(pg.ke_yx * (float)(cc >> 1)) * inv2pi;
+    f1 = __builtin_amdgcn_exp2f(pg.ke_yx * (float)((cc >> 1) + 1)) * inv2pi;
+    g0 = __builtin_amdgcn_exp2f(pg.ke_z * (float)(c0 >> 1)) * inv2pi;
+    g1 = __builtin_amdgcn_exp2f(pg.ke_z * (float)((c0 >> 1) + 1)) * inv2pi;
+    if (pg.level) {
+      const float4 l = *reinterpret_cast<const float4*>(pg.level + c0);
+      lv[0] = l.x; lv[1] = l.y; lv[2] = l.z; lv[3] = l.w;
+    } else {
+      lv[0] = lv[1] = lv[2] = lv[3] = 0.f;
+    }
+  }
+  // v_sin_f32 / v_cos_f32 take revolutions and need a bounded argument: reduce with v_fract_f32 first
+  __device__ __forceinline__ float4 eval(const PosGen& pg, int packed) const {
+    const float z = (float)((packed & 255) + 1) * pg.zs;
+    const float u = xside ? (float)(((packed >> 20) & 4095) + 1) * pg.xs : (float)(((packed >> 8) & 4095) + 1) * pg.ys;
+    const float a0 = __builtin_amdgcn_fractf(u * f0), a1 = __builtin_amdgcn_fractf(u * f1);
+    const float b0 = __builtin_amdgcn_fractf(z * g0), b1 = __builtin_amdgcn_fractf(z * g1);
+    return float4{__builtin_amdgcn_sinf(a0) + __builtin_amdgcn_sinf(b0) + lv[0], __builtin_amdgcn_cosf(a0) + __builtin_amdgcn_cosf(b0) + lv[1],
+                  __builtin_amdgcn_sinf(a1) + __builtin_amdgcn_sinf(b1) + lv[2], __builtin_amdgcn_cosf(a1) + __builtin_amdgcn_cosf(b1) + lv[3]};
+  }
+};
+
 // Blocked 16-bit matrix [K/32][R][32]: element (row r, col k).
 __device__ __forceinline__ long long blk_off(long long R, long long r, int k) {
   return ((long long)(k >> 5) * R + r) * kBlk + (k & 31);
@@ -183,7 +237,7 @@ __device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shf
 
 // ---- in-kernel phase stamps: diagnostic builds only (-DAXVS_STAMPS); the shipped library contains none ----
 #ifdef AXVS_STAMPS
-__device__ unsigned long long g_stamps[32 * 64];   // g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]
+static __device__ unsigned long long g_stamps[32 * 64];   // per translation unit; g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]
 // Stamps stay in SGPRs until AXVS_STAMP_FLUSH at the end of the kernel: no VGPR cost where registers are tight
 // (a first version that stored each stamp immediately pushed a 250-VGPR kernel into spills and mis-measured it).
 #define AXVS_STAMP_DECL unsigned long long st_[16] = {}

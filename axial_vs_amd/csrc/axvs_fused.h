@@ -264,9 +264,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * kRows;
   const int nchunk = F / 256;
-  // blocks b and b+8 share an XCD (round-robin placement; speed only): different k-block rotations / chunk orders
-  const int rot = (blockIdx.x >> 3) & 7;
-  const int crot = (blockIdx.x >> 6) % nchunk;
+  // Every workgroup visits the k-blocks and hidden-unit chunks in the same order.  (Round 1 rotated both by workgroup index to
+  // spread the weight stream over L2 channels: measured no gain, and a summation order that depends on the tile index made the
+  // result of a clip depend on its position in the batch -- sharding a batch must be bit-exact.)
+  constexpr int rot = 0, crot = 0;
   u16x8 w1f[2][KB];
   load_wfrags<2, KB>(w1f, W1, F, 0, crot * 256 + wave * 32, fi, fg, rot);
   ffn_stage_params(l, b1, b2, g1, be1, g2, be2, F, tid);
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const int kstep = L * 32;
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+    AXVS_STAMP(11);
 #pragma unroll 2
     for (int f = 0; f < T; ++f) {
 #pragma unroll
@@ -509,6 +511,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         *reinterpret_cast<u16x8*>(xt + ((f * 8 + wave) * ROWS + row) * 32 + swz_chunk(row, fg) * 8) = cvt8<BF>(v);
       }
       lds_fence();                       // per frame: the LDS stores of several frames must never pile up (4-bit lgkmcnt)
+#ifdef AXVS_STAMPS
+      if (f == 0) { AXVS_STAMP(12); } else if (f == 1) { AXVS_STAMP(13); } else if (f == 2) { AXVS_STAMP(14); } else { AXVS_STAMP(15); }
+#endif
     }
     load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
   } else {
@@ -739,7 +744,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
   // with the FFN half following, the sweep leaves the first linear1 fragment set behind
-  const int crot = FFN ? (int)((blockIdx.x >> 6) % (fa.F / 256)) : 0;
+  constexpr int crot = 0;                          // fixed chunk order: results do not depend on the tile index (see ffn_fused_kernel)
   if constexpr (FFN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, fa.W1, fa.F, crot * 256 + wave * 32, fi, fg);
   else sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
   AXVS_STAMP(7);
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   AXVS_STAMP(10);
 #ifndef AXVS_STAMPS_QKV
-  AXVS_STAMP_FLUSH(11);
+  AXVS_STAMP_FLUSH(16);
 #endif
 }
 
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ bk, const float* __restrict__ bv,
                                                         u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
                                                         long long Mp, float qscale, u16* __restrict__ VT16, int N, int L, int T,
-                                                        int NKS) {
+                                                        int NKS, PosGen pg) {
   constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* tqk = smem;                       // (src + pos) tile [8][64][32]
@@ -816,19 +821,25 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
   QSTAMP(0);
   u16x8 wf[2][8];
   load_wfrags<2, 8>(wf, Wq, C, 0, wave * 32, fi, fg);
+  float bias3[3];                        // biases requested now, parked in LDS behind the row gather
+  if (tid < C) {
+    bias3[0] = bq[tid]; bias3[1] = bk[tid]; bias3[2] = bv[tid];
+  }
 
   // ---- gather + convert the 64 token rows: thread -> (row, float4 column), 64 consecutive threads cover one row ----
   {
     const int c4 = tid & 63;             // float4 index within the row
     // RowMap arithmetic once per wave: lane k computes the k-th of the wave's 8 rows (rows wave + 8k), v_readlane broadcasts
-    int off_lo, off_hi;
+    int off_lo, off_hi, coords = 0;
     {
       const int myrow = (tid >> 6) + 8 * (lane & 7);
       const long long mym = min(m0 + myrow, Mp - 1);
-      const long long myoff = nat_row(rm, (int)mym) * C;
+      const long long myoff = (pg.mode ? nat_row_coords(rm, (int)mym, pg.l_is_h, &coords) : nat_row(rm, (int)mym)) * C;
       off_lo = (int)(myoff & 0xffffffffll);
       off_hi = (int)(myoff >> 32);
     }
+    PosGenLane pl;
+    if (pg.mode) pl.init(pg, c4 * 4);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float4 a[4], p[4];
@@ -837,7 +848,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
         const int k = half * 4 + i;
         const long long off = (((long long)__builtin_amdgcn_readlane(off_hi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(off_lo, k)) + c4 * 4;
         a[i] = *reinterpret_cast<const float4*>(src + off);
-        p[i] = pos ? *reinterpret_cast<const float4*>(pos + off) : float4{0.f, 0.f, 0.f, 0.f};
+        if (pg.mode) p[i] = pl.eval(pg, __builtin_amdgcn_readlane(coords, k));      // sine embedding generated, not read
+        else p[i] = pos ? *reinterpret_cast<const float4*>(pos + off) : float4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -849,11 +861,11 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
       }
       lds_fence();
     }
-    if (tid < C) {
-      sbias[tid] = bq[tid];
-      sbias[C + tid] = bk[tid];
-      sbias[2 * C + tid] = bv[tid];
-    }
+  }
+  if (tid < C) {
+    sbias[tid] = bias3[0];
+    sbias[C + tid] = bias3[1];
+    sbias[2 * C + tid] = bias3[2];
   }
   QSTAMP(1);
   __syncthreads();

@@ -23,8 +23,8 @@ inline int fail(int code, const char* fmt, ...) {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember (device, kernel) pairs that have
-// been raised to the full 160 KiB so a second device in the same process is configured too.
-inline int ensure_max_lds(const void* fn) {
+// been raised (by default to the full 160 KiB) so a second device in the same process is configured too.
+inline int ensure_max_lds(const void* fn, int bytes = 160 * 1024) {
   constexpr int kCap = 256;
   struct Entry { int dev; const void* fn; };
   static thread_local Entry seen[kCap];
@@ -33,7 +33,7 @@ inline int ensure_max_lds(const void* fn) {
   if (hipGetDevice(&dev) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipGetDevice failed");
   for (int i = 0; i < nseen; ++i)
     if (seen[i].fn == fn && seen[i].dev == dev) return AXVS_OK;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
     return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
   if (nseen < kCap) seen[nseen++] = Entry{dev, fn};
   return AXVS_OK;

@@ -48,3 +48,10 @@ template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, (AXVS_INST_T <=
     int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*);
 
 }  // namespace axvs
+
+#if defined(AXVS_STAMPS) && !defined(AXVS_STAMPS_QKV) && AXVS_INST_BF == 0 && AXVS_INST_T == 4
+// diagnostic builds: phase stamps of the f16 / T = 4 trajectory kernels (tools/stamps.py)
+extern "C" int axvs_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(axvs::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -31,7 +31,13 @@ def local_slice(src: Tensor, pos: Tensor, rank: int, world: int) -> Tuple[Tensor
     """Cut this rank's clips out of replicated inputs.  src [(B T), (H W), C], pos [B, T, H, W, C]."""
     B, T = pos.shape[:2]
     s, e = shard_bounds(B, world)[rank]
-    return src[s * T:e * T].contiguous(), pos[s:e].contiguous()
+    p_loc = pos[s:e].contiguous()
+    tag = getattr(pos, "_axvs_sine3d", None)
+    if tag is not None and tag.version == pos._version and e > s:
+        # the sine embedding does not depend on the clip index: the slice keeps the specification (axial_vs_amd.modules.SineTag)
+        from .modules import tag_sine3d
+        tag_sine3d(p_loc, tag.temperature, tag.normalize, tag.scale, tag.level)
+    return src[s * T:e * T].contiguous(), p_loc
 
 
 def gather_clips(out_local: Tensor, n_clips_total: int, frames: int, group=None, async_op: bool = False):

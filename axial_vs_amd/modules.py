@@ -141,6 +141,28 @@ def _guarded(fn):
     return wrapper
 
 
+class SineTag:
+    """Side note carried by a position tensor made by PositionEmbeddingSine3D: the tensor still holds the real values, but a
+    layer that receives it can hand the SPECIFICATION to libaxvs (axvs_axial_layer_fwd_sine3d) and skip reading it.  `version`
+    pins the tensor's in-place modification counter: a tensor edited after tagging is used as a plain tensor."""
+    __slots__ = ("temperature", "normalize", "scale", "level", "shape", "version")
+
+    def __init__(self, temperature, normalize, scale, level, shape, version):
+        self.temperature, self.normalize, self.scale, self.level, self.shape, self.version = temperature, normalize, scale, level, shape, version
+
+
+def tag_sine3d(pos: Tensor, temperature: float, normalize: bool, scale: float, level: Optional[Tensor] = None) -> Tensor:
+    pos._axvs_sine3d = SineTag(float(temperature), bool(normalize), float(scale), level, tuple(pos.shape), pos._version)
+    return pos
+
+
+def _sine_tag(pos: Tensor) -> Optional[SineTag]:
+    tag = getattr(pos, "_axvs_sine3d", None)
+    if tag is None or tag.shape != tuple(pos.shape) or tag.version != pos._version or not pos.is_contiguous():
+        return None
+    return tag
+
+
 def _traj_struct(m: "TrajectoryAttention", keep: list) -> _lib.AxvsTrajParams:
     C_ = m.proj.weight.shape[0]
     if hasattr(m, "qkv"):  # cross-clip flavour: slices of the fused projection
@@ -248,6 +270,7 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         self.n_heads = n_heads
         self.mfma_dtype = mfma_dtype
         self.return_attn = False
+        self.use_generated_pos = True   # a `pos` made by PositionEmbeddingSine3D is evaluated in-kernel instead of read (SineTag)
         self._packed: Optional[Tensor] = None
         self._packed_key = None
 
@@ -302,6 +325,14 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             ha = torch.empty(B * W * self.n_heads, T * H, T, H, dtype=torch.float32, device=s.device)
             wa = torch.empty(B * H * self.n_heads, T * W, T, W, dtype=torch.float32, device=s.device)
         packed = self._pack()
+        tag = _sine_tag(pos) if self.use_generated_pos else None
+        if tag is not None:
+            sp = _lib.AxvsSinePos3D(tag.temperature, int(tag.normalize), tag.scale, tag.level.data_ptr() if tag.level is not None else None)
+            ws = _workspace(s.device, L.axvs_axial_layer_sine3d_workspace_bytes(B, T, H, W, C_, self.n_heads, F))
+            _lib.check(L.axvs_axial_layer_fwd_sine3d(s.data_ptr(), C.byref(sp), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
+                                                     self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(),
+                                                     _ptr(ha), _ptr(wa), _stream(s.device)), "axvs_axial_layer_fwd_sine3d")
+            return out, ha, wa
         nws = L.axvs_axial_layer_workspace_bytes(B, T, H, W, C_, self.n_heads, F)
         ws = _workspace(s.device, nws)
         _lib.check(L.axvs_axial_layer_fwd(s.data_ptr(), p.data_ptr(), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
@@ -395,7 +426,18 @@ class PositionEmbeddingSine3D(nn.Module):
         with _on(pos.device):
             _lib.check(_lib.lib().axvs_pos3d(pos.data_ptr(), B, T, H, W, Cc, float(self.temperature), int(self.normalize),
                                              float(self.scale), _stream(pos.device)), "axvs_pos3d")
-        return pos
+        return tag_sine3d(pos, self.temperature, self.normalize, self.scale)
+
+    @torch.no_grad()
+    def channels_last_with_level(self, B: int, T: int, H: int, W: int, level: Tensor) -> Tensor:
+        """pos + level[None,None,None,None,:] (the decoder's level_embed_3d, WC/msdeformattn.py:112-115), tagged so that the
+        trajectory layers can regenerate it in-kernel."""
+        lv = level.detach().to(torch.float32).contiguous()
+        pos = self.channels_last(B, T, H, W, lv.device)
+        with _on(pos.device):
+            _lib.check(_lib.lib().axvs_add_channel_vector(pos.data_ptr(), lv.data_ptr(), pos.numel(), pos.shape[-1], _stream(pos.device)),
+                       "axvs_add_channel_vector")
+        return tag_sine3d(pos, self.temperature, self.normalize, self.scale, lv)
 
     @torch.no_grad()
     def forward(self, x, mask=None, fmt="btchw"):
@@ -431,13 +473,13 @@ class AxialTrajectoryAttention5D(nn.Module):
         self._pos_cache: Dict[Tuple, Tensor] = {}
 
     def position(self, B, T, H, W, device) -> Tensor:
-        key = (B, T, H, W, str(device))
+        lv = self.level_embed_3d
+        key = (B, T, H, W, str(device), None if lv is None else (lv.data_ptr(), lv._version))
         pos = self._pos_cache.get(key)
         if pos is None:
-            pos = self.pos_embed.channels_last(B, T, H, W, device)
+            pos = (self.pos_embed.channels_last(B, T, H, W, device) if lv is None
+                   else self.pos_embed.channels_last_with_level(B, T, H, W, lv))
             self._pos_cache = {key: pos}
-        if self.level_embed_3d is not None:
-            pos = pos + self.level_embed_3d.view(1, 1, 1, 1, -1)
         return pos
 
     def forward(self, x: Tensor) -> Tensor:

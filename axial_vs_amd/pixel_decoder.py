@@ -238,10 +238,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                                              H * W, x.shape[1], Cd, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
             self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
             if self.transformer_temporal_layers > 0 and f in self.transformer_temporal_in_features:
-                p3 = self.pe_layer_3d.channels_last(B, T, H, W, dev)
                 lvl3d = _dev_f32(self.transformer.level_embed_3d.detach(), "level_embed_3d")
-                _lib.check(L.axvs_add_channel_vector(p3.data_ptr(), lvl3d[len(pos_3d)].data_ptr(), p3.numel(), Cd, st), "axvs_add_channel_vector")
-                pos_3d.append(p3)
+                pos_3d.append(self.pe_layer_3d.channels_last_with_level(B, T, H, W, lvl3d[len(pos_3d)]))
             row0 += H * W
         y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, pos, None, pos_3d)
         out = {}

@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured HIP graph per step instead of launching from Python")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--tensor-pos", action="store_true",
+                    help="read `pos` as a plain tensor (default: pos comes from PositionEmbeddingSine3D and is evaluated in-kernel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + AXVS_BENCH_SHARE_GPU=1 runs N ranks on ONE GPU (launcher smoke test only)")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (axvs_set_option)")
@@ -117,7 +119,14 @@ def main():
     layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=heads, mfma_dtype=args.dtype).eval()
     layer.load_state_dict(w, strict=True)
     layer = layer.to(dev)
-    src, pos = src_cpu.to(dev), pos_cpu.to(dev)
+    src = src_cpu.to(dev)
+    # `pos` as the reference's callers make it (WC/msdeformattn.py:108-115): PositionEmbeddingSine3D on the device.  The tensor
+    # carries its specification, so the layer evaluates the embedding in the q/k loaders instead of reading 16.8 MB per pass;
+    # --tensor-pos passes an untagged copy (read from HBM like any tensor).
+    pos = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, dev)
+    assert float((pos.cpu() - pos_cpu).abs().max()) < 1e-5
+    if args.tensor_pos:
+        pos = pos.clone()
 
     gathered = None
     side = None
@@ -172,7 +181,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"TemporalAxialTrajectoryAttentionLayer fwd, [B={B},T={T},C={C},H={H},W={W}] per GPU, "
                                f"heads={heads}, d_ffn={F}, fp32 in/out, {args.dtype} MFMA operands",
-                   "shape_per_gpu": [B, T, C, H, W], "launch": "python per step" if graphed is None else "hipGraph replay (4 kernels)",
+                   "shape_per_gpu": [B, T, C, H, W], "pos": "tensor read from HBM" if args.tensor_pos else "PositionEmbeddingSine3D, evaluated in-kernel",
+                   "launch": "python per step" if graphed is None else "hipGraph replay (4 kernels)",
                    "parallelism": f"dp{world} (clips sharded over ranks"
                    + (", RCCL all-gather of outputs overlapped)" if gathered is not None else ", no collective)")},
     }

@@ -97,6 +97,22 @@ int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const v
                          int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
                          float* h_attn, float* w_attn, void* stream);
 
+/* The same layer with `pos` given as a SPECIFICATION instead of a tensor: pos = PositionEmbeddingSine3D(num_pos_feats = C/2,
+ * temperature, normalize, scale)(x, fmt) in channels-last form (WC/pos_embeddings.py:86-130, mask = None) plus an optional
+ * per-channel vector (the decoder's level_embed_3d[lvl], WC/msdeformattn.py:112-115).  This is what every caller of the layer
+ * in the reference passes; the C = 256 / 8-head kernels then evaluate the embedding inside the q/k loaders instead of reading
+ * B*T*H*W*C floats per pass from HBM (other shapes: materialised into the workspace first, same results as axvs_pos3d). */
+typedef struct AxvsSinePos3D {
+  float temperature;
+  int normalize;
+  float scale;
+  const float* level_embed;   /* NULL or device fp32 [C] */
+} AxvsSinePos3D;
+size_t axvs_axial_layer_sine3d_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn);
+int axvs_axial_layer_fwd_sine3d(const float* src, const AxvsSinePos3D* pos, float* out, const void* packed, int B, int T, int H,
+                                int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
+                                float* h_attn, float* w_attn, void* stream);
+
 /* ---- the layer's feed-forward tail alone: out = norm2(y + linear2(relu(linear1(y)))), y = norm1(x)
  *      WC/temporal_attention.py:181-185 + :217.  x/out fp32 [M, C]; weights from a packed AxvsAxialLayerParams. */
 size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn);

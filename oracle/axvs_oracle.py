@@ -509,8 +509,10 @@ def conv1x1_group_norm(x: Tensor, w: Weights, name: str, groups: int = 32, eps: 
 
 def pixel_decoder(features: Dict[str, Tensor], w: Weights, spatial_in: Sequence[str], temporal_in: Sequence[str], num_stages: int,
                   temporal_layers_per_stage: int, heads: int = 8, n_points: int = 4, num_clip_frames: int = 1,
-                  B: int = 1) -> Dict[str, Tensor]:
+                  B: int = 1, trace: Optional[list] = None) -> Dict[str, Tensor]:
     """MSDeformAttnPixelDecoder.forward_features (WC/msdeformattn.py:404-437) with spatial and temporal layers in every stage.
+    `trace` (a list) receives ("setup", {pos, pos3d, ref, shapes, order}, src) and then (tag, input, output) of every stage's
+    spatial layer and temporal encoders -- the teacher inputs of the per-stage parity tests.
     `spatial_in` / `temporal_in`: feature names sorted by stride (high resolution first), as the constructor sorts them (:344-349).
     features[name]: [(B T), C_l, H_l, W_l].  Returns {name: [(B T), C_l, H_l, W_l]}."""
     order = list(spatial_in)[::-1]                                    # low -> high resolution (:411)
@@ -539,12 +541,20 @@ def pixel_decoder(features: Dict[str, Tensor], w: Weights, spatial_in: Sequence[
     ref = torch.cat(refs, 0)[None, :, None, :].expand(BT, -1, L, 2)
     sizes = [h * ww for h, ww in shapes]
     out = src
+    if trace is not None:
+        trace.append(("setup", dict(pos=pos, pos3d=pos3d, ref=ref, shapes=shapes, order=order), src))
     for s_i in range(num_stages):                                     # :247-266
+        x_in = out
         out = msda_encoder_layer(out, pos, ref, shapes, _sub(w, f"transformer.encoder.spatial_layers.{s_i}"), heads, L, n_points)
+        if trace is not None:
+            trace.append((f"s{s_i}_spatial", x_in, out))
         parts = list(torch.split(out, sizes, dim=1))
         for i in range(Lt):
+            x_in = parts[i]
             parts[i], _, _ = temporal_encoder(parts[i], pos3d[i], _sub(w, f"transformer.encoder.temporal_layers.{s_i}"),
                                               temporal_layers_per_stage, heads, want_attn=False)
+            if trace is not None:
+                trace.append((f"s{s_i}_temporal_{order[i]}", x_in, parts[i]))
         out = torch.cat(parts, 1)
     res = {}
     for i, z in enumerate(torch.split(out, sizes, dim=1)):            # :426-435

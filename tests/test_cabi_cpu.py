@@ -142,7 +142,7 @@ def test_msda_module_surface_matches_reference():
         mod.eval()(torch.zeros(1, 4, m["C"]), torch.zeros(1, 4, len(m["shapes"]), 2), torch.zeros(1, 252, m["C"]), m["shapes"])
 
 
-def _decoder_from_meta(m):
+def _decoder_from_meta(m, cross_clip_training=False):
     import axial_vs_amd as ax
 
     class Shape:
@@ -156,7 +156,7 @@ def _decoder_from_meta(m):
         transformer_spatial_layers=m["stages"], transformer_temporal_layers=m["stages"] * m["temporal_per_stage"],
         transformer_temporal_attn_type="axial-trajectory", transformer_conv_dims=256,
         transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
-        num_clip_frames=m["T"], cross_clip_training=False)
+        num_clip_frames=m["T"], cross_clip_training=cross_clip_training)
 
 
 def test_within_clip_module_state_dict_matches_reference():

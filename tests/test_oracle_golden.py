@@ -197,3 +197,22 @@ def test_tl_plugin_attention(name):
                                   m["skip_connect"], km)
     np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
     assert rel_err(out[:, ::m["stride"]], t(z["out"])) < 5e-5
+
+
+def test_pixel_decoder_full_size():
+    """BASELINE config 3 at its stated size (ConvNeXt-T pyramid 192x64^2 / 384x32^2 / 768x16^2, T = 4, 2 stages x (1 spatial +
+    2 temporal layers)): the oracle against the reference's outputs (strided subsamples + float64 checksums), and against the
+    reference's per-stage outputs captured with forward hooks."""
+    z, m = load("g8_pixel_decoder_full_T4_S2")
+    w = weights(z, m)
+    trace = []
+    out = orc.pixel_decoder(decoder_inputs(m), w, ["res3", "res4", "res5"], ["res4", "res5"], m["stages"], m["temporal_per_stage"],
+                            B=m["B"], trace=trace)
+    for k in m["chans"]:
+        sb = m["sub"][k]
+        assert rel_err(out[k][:, ::m["csub"], ::sb, ::sb], t(z["out_" + k])) < 2e-5, k
+        np.testing.assert_allclose(checks(out[k])[1:], z["chk_" + k][1:], rtol=1e-5)
+    assert [tag for tag, _, _ in trace[1:]] == ["s0_spatial", "s0_temporal_res5", "s0_temporal_res4", "s1_spatial", "s1_temporal_res5",
+                                               "s1_temporal_res4"]
+    for tag, _, y in trace[1:]:
+        assert rel_err(y[:, ::37, ::4], t(z["tr_" + tag])) < 2e-5, tag
