@@ -28,6 +28,7 @@ constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
+thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
@@ -202,12 +203,14 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
 template <bool BF>
 int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
                     float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr) {
+  // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
+  const int wt = (!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0;
   switch (T) {
-    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
     default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 5");
   }
 }
@@ -248,7 +251,8 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
         return fail(AXVS_ERR_LAUNCH, "memset failed");
       hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3((unsigned)((Mp + 63) / 64)), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
                          p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e,
-                         fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{});
+                         fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{},
+                         (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0);
       goto qkv_done;
     }
   }
@@ -691,6 +695,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "attn_waves")) { g_attn_waves = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }

@@ -235,6 +235,27 @@ __device__ __forceinline__ float wave_sum(float v) { return groups_sum(row16_sum
 __device__ __forceinline__ float wave_xor_max(float v, int m) { return fmaxf(v, __shfl_xor(v, m, kWave)); }
 __device__ __forceinline__ float wave_xor_sum(float v, int m) { return v + __shfl_xor(v, m, kWave); }
 
+// ---- write-through stores (sc1): data another kernel's workgroups on OTHER XCDs will read.  A plain store leaves the line
+//      dirty in this XCD's L2 until the end-of-kernel write-back, which then serialises behind the kernel (measured: the q/k/V^T
+//      kernel's 25 MB cost ~4 us after its last wave); a write-through store sends the bytes on while the kernel still runs.
+//      Buffer addressing: wave-uniform base in a descriptor + a 32-bit byte offset per lane (the host checks < 4 GiB).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+struct WtBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ explicit WtBuf(const void* base)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000)) {}
+  __device__ __forceinline__ void store16(unsigned byte_off, u16x8 v) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, byte_off, 0, 16);   // aux 16 = sc1
+  }
+  __device__ __forceinline__ void store16(unsigned byte_off, float4 v) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, byte_off, 0, 16);
+  }
+  __device__ __forceinline__ void store8(unsigned byte_off, u16x4 v) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, byte_off, 0, 16);
+  }
+};
+
 // ---- in-kernel phase stamps: diagnostic builds only (-DAXVS_STAMPS); the shipped library contains none ----
 #ifdef AXVS_STAMPS
 static __device__ unsigned long long g_stamps[32 * 64];   // per translation unit; g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]

@@ -148,7 +148,7 @@ __device__ __forceinline__ void ffn_stage_params(const FfnLds& l, const float* _
 // `row_off(r)`: element offset of tile row r in `out`, or < 0 for a row that does not exist (ragged last tile).
 template <bool BF, class RowOff>
 __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], const u16* __restrict__ W1, const u16* __restrict__ W2,
-                                         float* __restrict__ out, RowOff row_off, int F, int rot, int crot, int tid) {
+                                         float* __restrict__ out, RowOff row_off, int F, int rot, int crot, int tid, int wt = 0) {
   constexpr int C = 256, KB = 8;
   const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const float* sb1 = l.par;
@@ -235,9 +235,11 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
       const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
       const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
       const long long off = row_off(r);
-      if (off >= 0)
-        *reinterpret_cast<float4*>(out + off + lane * 4) =
-            float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
+      if (off >= 0) {
+        const float4 y = float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
+        if (wt) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);       // the next kernel reads these rows from other XCDs
+        else *reinterpret_cast<float4*>(out + off + lane * 4) = y;
+      }
       if (i == 3) lds_fence();
     }
   }
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              RowMap rm, long long Mp, int N, int L, float scale, const u16* __restrict__ Q16 = nullptr,
                                                              const u16* __restrict__ K16 = nullptr,
                                                              const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
-                                                             const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */) {
+                                                             const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */,
+                                                             int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -765,13 +768,16 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
     const float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
     if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
-    else if (m0 + row < Mp) *reinterpret_cast<float4*>(out + roff[i]) = y;
+    else if (m0 + row < Mp) {
+      if (wt) WtBuf(out).store16((unsigned)(roff[i] * 4), y);
+      else *reinterpret_cast<float4*>(out + roff[i]) = y;
+    }
   }
   AXVS_STAMP(8);
   if constexpr (FFN) {
     lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
     ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
-                 [=](int row) { return m0 + row < Mp ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid);   // rows of this wave
+                 [=](int row) { return m0 + row < Mp ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid, wt);   // rows of this wave
   }
   AXVS_STAMP(10);
 #ifndef AXVS_STAMPS_QKV
@@ -807,7 +813,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ bk, const float* __restrict__ bv,
                                                         u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
                                                         long long Mp, float qscale, u16* __restrict__ VT16, int N, int L, int T,
-                                                        int NKS, PosGen pg) {
+                                                        int NKS, PosGen pg, int wt /* write-through q/k/V^T stores (offsets < 4 GiB) */) {
   constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* tqk = smem;                       // (src + pos) tile [8][64][32]
@@ -819,6 +825,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
 
   QSTAMP_DECL;
   QSTAMP(0);
+  const WtBuf wq(Q16), wk(K16), wvt(VT16);
   u16x8 wf[2][8];
   load_wfrags<2, 8>(wf, Wq, C, 0, wave * 32, fi, fg);
   float bias3[3];                        // biases requested now, parked in LDS behind the row gather
@@ -907,10 +914,11 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
             if (mt0 < (unsigned)Mp) {
               const unsigned sf = mt0 / (unsigned)L;
               const int ks = (int)(mt0 - sf * L) >> 5;
-              u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + fg * 8;
+              const long long d = ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + fg * 8;
               float v[8] = {acc[nt][mp][0] + b, acc[nt][mp][1] + b, acc[nt][mp][2] + b, acc[nt][mp][3] + b,
                             acc[nt][mp + 1][0] + b, acc[nt][mp + 1][1] + b, acc[nt][mp + 1][2] + b, acc[nt][mp + 1][3] + b};
-              *reinterpret_cast<u16x8*>(d) = cvt8<BF>(v);
+              if (wt) wvt.store16((unsigned)(d * 2), cvt8<BF>(v));
+              else *reinterpret_cast<u16x8*>(VT16 + d) = cvt8<BF>(v);
             }
           }
         }
@@ -925,10 +933,11 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
             const unsigned sf = mt0 / (unsigned)L;
             const int l = (int)(mt0 - sf * L) + fg * 4;       // key index within the frame of the lane's first token
             const int ks = l >> 5, pp = fg * 8 + ((l >> 4) & 1) * 4;
-            u16* d = VT16 + ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
+            const long long d = ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
             f32x4 v = acc[nt][mt];
             v[0] += b; v[1] += b; v[2] += b; v[3] += b;
-            *reinterpret_cast<u16x4*>(d) = cvt4<BF>(v);
+            if (wt) wvt.store8((unsigned)(d * 2), cvt4<BF>(v));
+            else *reinterpret_cast<u16x4*>(VT16 + d) = cvt4<BF>(v);
           }
         }
       }
@@ -948,7 +957,9 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
           float v[8] = {(acc[0][mt][0] + b0.x) * sc, (acc[0][mt][1] + b0.y) * sc, (acc[0][mt][2] + b0.z) * sc,
                         (acc[0][mt][3] + b0.w) * sc, (acc[1][mt][0] + b1.x) * sc, (acc[1][mt][1] + b1.y) * sc,
                         (acc[1][mt][2] + b1.z) * sc, (acc[1][mt][3] + b1.w) * sc};
-          *reinterpret_cast<u16x8*>(dst + ((long long)wave * Mp + m) * 32 + fg * 8) = cvt8<BF>(v);
+          const long long d = ((long long)wave * Mp + m) * 32 + fg * 8;
+          if (wt) (which == 0 ? wq : wk).store16((unsigned)(d * 2), cvt8<BF>(v));
+          else *reinterpret_cast<u16x8*>(dst + d) = cvt8<BF>(v);
         } else {           // v: natural channel order
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {

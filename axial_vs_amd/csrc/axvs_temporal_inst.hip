@@ -12,14 +12,14 @@ namespace axvs {
 
 template <bool BF, int T, int MT, int NKS>
 static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                             float scale, hipStream_t st, const FfnArgs* fa) {
+                             float scale, hipStream_t st, const FfnArgs* fa, int wt) {
   const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
   if constexpr (NKS > 0 && MT == 4) {
     if (fa) {                                    // trajectory attention + FFN in one kernel
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS, true>))) return rc;
       const size_t lds_ffn = temporal_lds_bytes<T, MT, true>(fa->F);
       hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS, true>), dim3(grid), dim3(512), lds_ffn, st, w.x16, p.wpq, p.bpq, p.wpkv,
-                         p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa, p.wk2t);
+                         p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa, p.wk2t, wt);
       return AXVS_OK;
     }
   }
@@ -27,25 +27,25 @@ static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* 
   constexpr size_t lds = temporal_lds_bytes<T, MT>();
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS>))) return rc;
   hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
-                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t);
+                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t, wt);
   return AXVS_OK;
 }
 
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa) {
+                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt) {
   switch (nks) {
-    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
-    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa);
+    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
     default: return fail(AXVS_ERR_ARG, "bad nks");
   }
 }
 
 template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, (AXVS_INST_T <= 4 ? 4 : 2)>(
-    int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*);
+    int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int);
 
 }  // namespace axvs
 

@@ -13,7 +13,8 @@ src, pos = orc.synthetic_clip(B, T, C, H, W, 0)
 layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
 layer.load_state_dict(w, strict=True)
 layer = layer.cuda()
-s, p = src.cuda(), pos.cuda()
+s = src.cuda()
+p = pos.cuda() if os.environ.get("AXVS_TENSOR_POS") else ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
 for _ in range(3): layer(s, p)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
