@@ -404,6 +404,18 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 
   AXVS_STAMP_DECL;
   AXVS_STAMP(0);
+  // biases (and the FFN half's parameters) -> LDS
+  auto stage_small = [&]() {
+    if (tid < C) {
+      sbias[tid] = bpq[tid];
+      sbias[C + tid] = bpkv[C + tid];       // v2 half of the proj_kv bias
+      sbias[2 * C + tid] = bp[tid];
+    }
+    if constexpr (FFN) {
+      lds_fence();
+      ffn_stage_params(fl, fa.b1, fa.b2, fa.g1, fa.be1, fa.g2, fa.be2, fa.F, tid);
+    }
+  };
   // first weight set: Wpq rows of my head (with a long in-kernel attention phase it is fetched after that phase instead,
   // to keep 64 VGPRs free for the score tiles)
   u16x8 wf[2][8];
@@ -436,6 +448,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
     AXVS_STAMP(11);
+    stage_small();                       // behind the cold Q / K loads of the first frame instead of in front of the barrier
 #pragma unroll 2
     for (int f = 0; f < T; ++f) {
 #pragma unroll
@@ -544,13 +557,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
   }
-  if (tid < C) {
-    sbias[tid] = bpq[tid];
-    sbias[C + tid] = bpkv[C + tid];       // v2 half of the proj_kv bias
-    sbias[2 * C + tid] = bp[tid];
-  }
-  if constexpr (FFN) lds_fence();
-  if constexpr (FFN) ffn_stage_params(fl, fa.b1, fa.b2, fa.g1, fa.be1, fa.g2, fa.be2, fa.F, tid);
+  if constexpr (NKS == 0) stage_small();   // (with the spatial half in the kernel this happened before its first frame)
   __syncthreads();
 
   AXVS_STAMP(1);
