@@ -28,6 +28,7 @@ constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
+thread_local int g_spatial_only = 0;     // option "spatial_only": the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
@@ -204,7 +205,7 @@ template <bool BF>
 int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
                     float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
-  const int wt = (!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0;
+  const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? 2 : 0);
   switch (T) {
     case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
     case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
@@ -696,6 +697,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
+  if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }

@@ -375,7 +375,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const u16* __restrict__ K16 = nullptr,
                                                              const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
                                                              const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */,
-                                                             int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */) {
+                                                             int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */,
+                                                             int spatial_only = 0 /* measurement: stop after the QK^T / AV half */) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       if (f == 0) { AXVS_STAMP(12); } else if (f == 1) { AXVS_STAMP(13); } else if (f == 2) { AXVS_STAMP(14); } else { AXVS_STAMP(15); }
 #endif
     }
+    if (spatial_only) return;            // bench.py times QK^T / softmax / AV alone with this (nothing is written)
     load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
   } else {
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----

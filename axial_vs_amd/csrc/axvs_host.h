@@ -55,6 +55,6 @@ struct FfnArgs;   // axvs_fused.h
 // layer's FFN rides along (needs nks > 0 and 64-row tiles).
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt /* write-through output rows */);
+                      int L, float scale, hipStream_t st, const FfnArgs* fa, int flags /* bit 0: write-through output rows, bit 1: stop after the spatial half */);
 
 }  // namespace axvs

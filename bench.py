@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: axial-trajectory-attention forward, frames/s at [B=1,T=4,C=256,H=W=64] per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: starts its own N workers (torch.distributed.run child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one TemporalAxialTrajectoryAttentionLayer forward (height pass + width pass + LN + FFN + LN,
-WC/temporal_attention.py:187-220) over one clip resident in HBM.  With N ranks every rank owns its own clip
-(the path shards over B with no data-path collective: SURVEY.md 8e) -> "scaling": "weak"; `--gather` adds the
-north star's RCCL all-gather of the output maps, overlapped on a side stream.
+WC/temporal_attention.py:187-220) over one clip resident in HBM.  With N ranks every rank owns its own clip (the path shards
+over B with no data-path collective: SURVEY.md 8e) -> "scaling": "weak".
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     -- algorithmic FLOPs of the layer / mean forward time from HIP events on the launch stream,
-                  against the dense 16-bit MFMA peak (2.5 PFLOP/s), and the per-kernel split of that time
-  cpu_baseline -- the CPU oracle (torch port of the reference, oracle/axvs_oracle.py) timed on this host
+  roofline      algorithmic FLOPs of the layer / mean forward time from HIP events on the launch stream, against the dense
+                16-bit MFMA peak (2.5 PFLOP/s); per-kernel split; `qk_av_frac`: the QK^T / softmax / AV half timed alone
+  cpu_baseline  the CPU oracle (torch port of the reference, oracle/axvs_oracle.py) timed on this host (N = 1 only)
+  extras        secondary measurements, never the headline `value`:
+                  gather      (N > 1) the same steps with the north star's RCCL all-gather of the output maps, on a side stream
+                  cfg5_share  BASELINE config 5's per-GPU share [8,4,256,96,96] (batch-sharded layer), frames/s over all ranks
+                  cc_cfg4     BASELINE config 4: CrossClipTrackingModule forward, us per forward and output GB/s (N = 1)
 """
 from __future__ import annotations
 
@@ -29,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/f16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0
 
 
 def layer_flops(B, T, H, W, C, F):
@@ -53,10 +57,14 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--shape", default="1,4,256,64,64", help="B,T,C,H,W per rank")
     ap.add_argument("--d-ffn", type=int, default=1024)
-    ap.add_argument("--gather", action="store_true", help="all-gather every step's output across ranks (RCCL, side stream)")
+    ap.add_argument("--gather", action="store_true", help="make the all-gather of the outputs part of the timed steps (default: reported under extras)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--graph", action="store_true", help="replay a captured HIP graph per step instead of launching from Python")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed steady-state run before the W warm-up steps: the GPU needs ~50 ms of continuous work to reach its "
+                         "sustained clocks (measured: 133 us/step in the first 3 ms after idle, 106 us/step from ~50 ms on)")
     ap.add_argument("--tensor-pos", action="store_true",
                     help="read `pos` as a plain tensor (default: pos comes from PositionEmbeddingSine3D and is evaluated in-kernel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -106,70 +114,84 @@ def main():
     from axial_vs_amd import _lib
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import axvs_oracle as orc
+    L = _lib.lib()
     for kv in args.opt:
         k, v = kv.split("=")
-        _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), "axvs_set_option")
+        _lib.check(L.axvs_set_option(k.encode(), int(v)), "axvs_set_option")
+
+    heads = 8
+    F = args.d_ffn
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed(step, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks (s)."""
+        out = None
+        for _ in range(max(warmup, 1)):
+            out = step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, out
+
+    def make_workload(B, T, C, H, W, seed):
+        """Synthetic workload (SURVEY.md 8d recipe); every rank gets its own clips.  `pos` as the reference's callers make it
+        (WC/msdeformattn.py:108-115): PositionEmbeddingSine3D on the device -- the tensor carries its specification, so the layer
+        evaluates the embedding in the q/k loaders instead of reading it; --tensor-pos passes an untagged copy."""
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 0)
+        layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=heads, mfma_dtype=args.dtype).eval()
+        layer.load_state_dict(w, strict=True)
+        layer = layer.to(dev)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        src = torch.randn(B * T, H * W, C, device=dev, generator=g)
+        pos = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, dev)
+        if args.tensor_pos:
+            pos = pos.clone()
+        return layer, w, src, pos
 
     B, T, C, H, W = (int(v) for v in args.shape.split(","))
-    F = args.d_ffn
-    heads = 8
-    # synthetic workload (SURVEY.md 8d recipe); every rank gets its own clip
-    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 0)
-    src_cpu, pos_cpu = orc.synthetic_clip(B, T, C, H, W, seed=rank)
-    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=heads, mfma_dtype=args.dtype).eval()
-    layer.load_state_dict(w, strict=True)
-    layer = layer.to(dev)
-    src = src_cpu.to(dev)
-    # `pos` as the reference's callers make it (WC/msdeformattn.py:108-115): PositionEmbeddingSine3D on the device.  The tensor
-    # carries its specification, so the layer evaluates the embedding in the q/k loaders instead of reading 16.8 MB per pass;
-    # --tensor-pos passes an untagged copy (read from HBM like any tensor).
-    pos = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, dev)
-    assert float((pos.cpu() - pos_cpu).abs().max()) < 1e-5
-    if args.tensor_pos:
-        pos = pos.clone()
+    layer, w, src, pos = make_workload(B, T, C, H, W, seed=rank)
 
-    gathered = None
-    side = None
-    if args.gather and world > 1:
+    gathered = side = None
+    if world > 1 and args.backend == "nccl":
         gathered = torch.empty(world * B * T, H * W, C, device=dev)
         side = torch.cuda.Stream(dev)
 
-    # one step = one layer forward on the resident clip.  --graph replays the 4 launches from a captured HIP graph
-    # (axial_vs_amd.GraphedForward); measured on MI355X / ROCm 7.2 it is NOT faster at this size (137.7 vs 133.5 us per step: the
-    # Python launch path already keeps ahead of 130 us of GPU work and a graph launch costs more than 4 kernel launches), so the
-    # default stays the plain path.
+    # --graph replays the 4 launches from a captured HIP graph (axial_vs_amd.GraphedForward); measured on MI355X / ROCm 7.2 it is
+    # NOT faster at this size (the Python launch path keeps ahead of the GPU), so the default stays the plain path.
     graphed = ax.GraphedForward(layer, src, pos) if args.graph else None
 
-    def step():
+    def step(gather=args.gather):
         out = graphed()[0] if graphed is not None else layer(src, pos)[0]
-        if gathered is not None:
+        if gather and gathered is not None:
+            # the north star's reassembly of the output map: one contiguous RCCL all-gather (dim 0 is the shard dimension), on a
+            # side stream so that it overlaps the next step's kernels
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 dist.all_gather_into_tensor(gathered, out)
                 out.record_stream(side)
         return out
 
-    for _ in range(max(args.warmup, 1)):
-        out = step()
-    torch.cuda.synchronize(dev)
-
-    # ---- timed region: exactly K steps between barrier + synchronize on both sides ----
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # setup: bring the GPU to its sustained clocks (part of setup like weight packing and allocator warm-up; not timed)
+    t_set = time.perf_counter()
+    while (time.perf_counter() - t_set) * 1e3 < args.settle_ms:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
+    elapsed, out = timed(step, args.steps, args.warmup)
     assert torch.isfinite(out).all()
-
     frames = world * B * T * args.steps
     value = frames / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -181,15 +203,42 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"TemporalAxialTrajectoryAttentionLayer fwd, [B={B},T={T},C={C},H={H},W={W}] per GPU, "
                                f"heads={heads}, d_ffn={F}, fp32 in/out, {args.dtype} MFMA operands",
-                   "shape_per_gpu": [B, T, C, H, W], "pos": "tensor read from HBM" if args.tensor_pos else "PositionEmbeddingSine3D, evaluated in-kernel",
+                   "shape_per_gpu": [B, T, C, H, W],
+                   "pos": "tensor read from HBM" if args.tensor_pos else "PositionEmbeddingSine3D, evaluated in-kernel",
                    "launch": "python per step" if graphed is None else "hipGraph replay (4 kernels)",
+                   "settle_ms": args.settle_ms,
+                   "ranks": world, "collective_backend": ("RCCL" if args.backend == "nccl" else args.backend) if world > 1 else None,
                    "parallelism": f"dp{world} (clips sharded over ranks"
-                   + (", RCCL all-gather of outputs overlapped)" if gathered is not None else ", no collective)")},
+                   + (", RCCL all-gather of outputs overlapped)" if (args.gather and gathered is not None) else ", no collective)")},
     }
+    extras = {}
+
+    # ---- extras measured on every rank ----
+    if not args.no_extras:
+        if gathered is not None and not args.gather:
+            el, _ = timed(lambda: step(True), args.steps, 5)
+            torch.cuda.synchronize(dev)
+            extras["gather"] = {"value": round(world * B * T * args.steps / el, 1), "unit": "frames/s", "ms_per_step": round(el / args.steps * 1e3, 5),
+                                "what": f"the same {args.steps} steps, every step followed by one contiguous RCCL all-gather of the output maps "
+                                        f"({world * B * T * H * W * C * 4 / 1e6:.1f} MB gathered per rank per step) on a side stream"}
+        try:
+            B5, T5, C5, H5, W5 = 8, 4, 256, 96, 96
+            layer5, _, src5, pos5 = make_workload(B5, T5, C5, H5, W5, seed=100 + rank)
+            steps5 = max(10, min(args.steps // 4, 50))
+            el, o5 = timed(lambda: layer5(src5, pos5)[0], steps5, 3)
+            assert torch.isfinite(o5).all()
+            fl5 = layer_flops(B5, T5, H5, W5, C5, F)
+            extras["cfg5_share"] = {"value": round(world * B5 * T5 * steps5 / el, 1), "unit": "frames/s", "ms_per_step": round(el / steps5 * 1e3, 4),
+                                    "shape_per_gpu": [B5, T5, C5, H5, W5], "steps": steps5,
+                                    "mfma_frac_per_gpu": round(fl5 / (el / steps5) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                    "what": "BASELINE config 5 ([B=64,T=4,C=256,H=W=96] over 8 GPUs): each rank runs its 8-clip share, no collective"}
+            del layer5, src5, pos5, o5
+            torch.cuda.empty_cache()
+        except RuntimeError as e:           # e.g. out of memory on a shared debugging GPU
+            extras["cfg5_share"] = {"error": str(e)[:200]}
 
     if rank == 0:
         # ---- roofline: HIP events on the launch stream (torch's current stream), averaged over the same K steps ----
-        L = _lib.lib()
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
@@ -199,17 +248,24 @@ def main():
             e = ctypes.c_void_p()
             assert hip.hipEventCreate(ctypes.byref(e)) == 0
             evs[i] = e.value
-        stage_ms = [0.0] * nst
+
+        def stage_times(fn, reps):
+            """per-stage mean durations (us) from the events the library records between its launches"""
+            acc = [0.0] * nst
+            L.axvs_profile_stages(evs, nst)
+            for _ in range(reps):
+                fn()
+                torch.cuda.synchronize(dev)
+                for i in range(1, L.axvs_profile_stage_count()):
+                    ms = ctypes.c_float()
+                    assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[i - 1], evs[i]) == 0
+                    acc[i] += ms.value / reps
+            L.axvs_profile_stages(None, 0)
+            n = L.axvs_profile_stage_count()
+            return {L.axvs_profile_stage_name(i).decode(): round(acc[i] * 1e3, 2) for i in range(1, n)}
+
         reps = min(args.steps, 50)
-        L.axvs_profile_stages(evs, nst)
-        for _ in range(reps):
-            layer(src, pos)
-            torch.cuda.synchronize(dev)
-            for i in range(1, L.axvs_profile_stage_count()):
-                ms = ctypes.c_float()
-                assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[i - 1], evs[i]) == 0
-                stage_ms[i] += ms.value / reps
-        L.axvs_profile_stages(None, 0)
+        kernels = stage_times(lambda: layer(src, pos), reps)
         # whole-forward duration with events bracketing K back-to-back forwards (no host sync inside)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -220,26 +276,41 @@ def main():
         fwd_ms = e0.elapsed_time(e1) / args.steps
         flops = layer_flops(B, T, H, W, C, F)
         achieved = flops / (fwd_ms * 1e-3) / 1e12
-        nrun = L.axvs_profile_stage_count()
-        names = [L.axvs_profile_stage_name(i).decode() for i in range(nrun)]
-        kernels = {names[i]: round(stage_ms[i] * 1e3, 2) for i in range(1, nrun)}
         dom = max(kernels, key=kernels.get)
         # algorithmic FLOPs per launch (SURVEY 8d terms) -> per-kernel fraction of the MFMA peak, from the same HIP events
-        def f_qkv(S, L):
-            return S * T * L * C * C * 6
-        def f_traj(S, L):
-            N = T * L
+
+        def f_qkv(S, Lx):
+            return S * T * Lx * C * C * 6
+
+        def f_traj(S, Lx):
+            N = T * Lx
             return S * (N * C * C * (4 + 4 * T) + 4 * N * N * C + 4 * N * T * C)
         f_ffn = 4 * B * T * H * W * C * F
         stage_flops = {"h.qkv_proj": f_qkv(B * W, H), "w.qkv_proj": f_qkv(B * H, W), "h.traj_fused": f_traj(B * W, H),
                        "w.traj_fused": f_traj(B * H, W), "w.traj_fused+ffn": f_traj(B * H, W) + f_ffn, "norm1+ffn+norm2": f_ffn}
         stage_frac = {k: round(stage_flops[k] / (v * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) for k, v in kernels.items()
                       if k in stage_flops and v > 0}
+        # the north star's sub-target: QK^T / softmax / AV alone.  Option "spatial_only" makes the fused trajectory kernels return
+        # after that half (same launch, same loads of q / k / V^T, x tile written to LDS, nothing else): its duration against
+        # 4 S N^2 C FLOPs per pass.  Only meaningful when both passes run the fully fused kernels.
+        qk_av = None
+        if "h.traj_fused" in kernels and ("w.traj_fused+ffn" in kernels or "w.traj_fused" in kernels):
+            _lib.check(L.axvs_set_option(b"spatial_only", 1), "axvs_set_option")
+            try:
+                sp = stage_times(lambda: layer(src, pos), reps)
+            finally:
+                _lib.check(L.axvs_set_option(b"spatial_only", 0), "axvs_set_option")
+            t_h = sp["h.traj_fused"]
+            t_w = sp.get("w.traj_fused+ffn", sp.get("w.traj_fused"))
+            fl_h, fl_w = 4 * (B * W) * (T * H) ** 2 * C, 4 * (B * H) * (T * W) ** 2 * C
+            qk_av = {"frac": round((fl_h + fl_w) / ((t_h + t_w) * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "h_us": t_h, "w_us": t_w,
+                     "gflop": round((fl_h + fl_w) / 1e9, 2),
+                     "what": "fused trajectory kernels stopped after QK^T/softmax/AV (launch to last wave, events), 4*S*N^2*C FLOPs per pass"}
         # HBM traffic per layer forward from the TCC counters: collected by tools/pmc_traffic.sh (rocprofv3 --pmc passes of this
         # very command cannot run inside the timed process); reported only for the workload it was measured on
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
-        if os.path.exists(tpath) and (B, T, C, H, W, F, args.dtype) == (1, 4, 256, 64, 64, 1024, "f16") and not args.opt:
+        if os.path.exists(tpath) and (B, T, C, H, W, F, args.dtype) == (1, 4, 256, 64, 64, 1024, "f16") and not args.opt and not args.tensor_pos:
             tj = json.load(open(tpath))
             traffic, traffic_src = int(tj["layer_total_MB"] * 1e6), "profiles/hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
         result["roofline"] = {
@@ -250,11 +321,48 @@ def main():
             "algorithmic_gflop": round(flops / 1e9, 2), "algorithmic_mbytes": round(layer_bytes(B, T, H, W, C, F) / 1e6, 2),
             "hbm_frac_if_memory_bound": round(layer_bytes(B, T, H, W, C, F) / (fwd_ms * 1e-3) / 8e12, 4),
             "stage_us": kernels, "stage_frac": stage_frac, "dominant_stage": dom,
+            "qk_av_frac": qk_av["frac"] if qk_av else None, "qk_av": qk_av,
         }
+
+        # ---- BASELINE config 4: the cross-clip tracking module (launch/HBM-write bound: report us and GB/s) ----
+        if not args.no_extras and world == 1:
+            try:
+                Q, Tc, V, Hc, Wc, layers_cc, ncls = 128, 4, 4, 64, 64, 4, 124
+                cc = ax.CrossClipTrackingModule(num_layers=layers_cc, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
+                                                atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V, mfma_dtype=args.dtype).eval()
+                sd = cc.state_dict()
+                sd.update(orc.random_weights({k: tuple(v.shape) for k, v in sd.items() if v.dtype.is_floating_point}, 4))
+                cc.load_state_dict(sd, strict=True)
+                cc = cc.to(dev)
+                cc.eval_outputs_on_cpu = False          # time the device path (the reference's eval branch copies to the host afterwards)
+                g = torch.Generator(device=dev).manual_seed(4)
+                cq = torch.randn(1, Q, Tc, 256, device=dev, generator=g)
+                pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, Hc, Wc, device=dev, generator=g), dim=1)
+                for _ in range(5):
+                    cc(cq, pf)
+                torch.cuda.synchronize(dev)
+                n_cc = 30
+                e0.record()
+                for _ in range(n_cc):
+                    cc(cq, pf)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                us = e0.elapsed_time(e1) / n_cc * 1e3
+                out_bytes = layers_cc * (Q * Tc * V * Hc * Wc * 4 + 128 * Tc * V * Hc * Wc * 4)     # masks written + features read, per layer
+                extras["cc_cfg4"] = {"us_per_forward": round(us, 1), "unit": "us", "layers": layers_cc,
+                                     "shape": {"clip_query": [1, Q, Tc, 256], "panoptic_features": [1, 128, Tc * V, Hc, Wc]},
+                                     "algorithmic_mbytes": round(out_bytes / 1e6, 1),
+                                     "hbm_gbs": round(out_bytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(out_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "what": "BASELINE config 4: CrossClipTrackingModule.forward, 4 clips x 4 frames, 64x64, 4 layers; per-layer masks "
+                                             "[1,128,16,64,64] fp32 written, features read (HBM-write / launch bound, SURVEY 8d)"}
+                del cc, cq, pf
+            except RuntimeError as e:
+                extras["cc_cfg4"] = {"error": str(e)[:200]}
 
         # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would just wait)
             ncpu = os.cpu_count() or 1
+            src_cpu, pos_cpu = src.cpu(), pos.cpu()
             fwd = lambda: orc.axial_layer(src_cpu, pos_cpu, w, heads, want_attn=False)
             with torch.no_grad():
                 # torch's CPU kernels stop scaling (and thrash) far below a big host's core count: probe a few
@@ -281,6 +389,8 @@ def main():
                 "value": round(B * T / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                 "sample": f"{len(times)} forwards of the same [B={B},T={T},C={C},H={H},W={W}] layer after 1 warm-up, "
                           f"fp32, torch CPU {cores} threads (best of 8/16/32/64 on {ncpu} logical CPUs), median {med * 1e3:.1f} ms"}
+        if extras:
+            result["extras"] = extras
         print(json.dumps(result), flush=True)
 
     if world > 1:
