@@ -189,14 +189,16 @@ RowMap identity_map(long long rows) {
 
 template <bool BF, int NKS>
 int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int heads, long long Mp, hipStream_t st) {
-  const size_t lds = (size_t)T * NKS * 32 * 32 * 2 * sizeof(u16);
-  if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "sequence too long for the LDS-resident K/V (T=%d, L=%d)", T, L);
+  // K and V of a (sequence, head) are staged in LDS, as many frames at a time as fit (whole-video cross-clip inference: T = clips)
+  const size_t per_frame = (size_t)NKS * 32 * 32 * 2 * sizeof(u16);
+  const int tch = (int)((150 * 1024) / per_frame) < T ? (int)((150 * 1024) / per_frame) : T;
+  const size_t lds = per_frame * tch;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&spatial_attn_kernel<BF, NKS>))) return rc;
   const int wcap = g_attn_waves > 0 ? g_attn_waves : 8;
   const int nwaves = (N + 31) / 32 >= wcap ? wcap : (N + 31) / 32;  // 32 queries per wave, at most `wcap` waves
   dim3 grid((N + 32 * nwaves - 1) / (32 * nwaves), heads, S);
   hipLaunchKernelGGL((spatial_attn_kernel<BF, NKS>), grid, dim3(64 * nwaves), lds, st, w.q16, w.k16, w.v16, w.x16, attn, N, T, L,
-                     heads, Mp);
+                     heads, Mp, tch);
   return AXVS_OK;
 }
 
@@ -231,7 +233,6 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const int N = T * L, Cp = heads * 32, d = C / heads;
   const long long Mp = (long long)S * N;
   if (Mp * T > 2147483647LL / 2) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
-  if (T > 8) return fail(AXVS_ERR_ARG, "num_frames=%d > 8 is not supported yet", T);
   const int M = (int)Mp;
   const float scale = 1.0f / sqrtf((float)d);
   const float kLog2e = 1.4426950408889634f;
@@ -952,7 +953,7 @@ int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, f
   if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
   if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
   if (((long long)V * H * W) % 4) return fail(AXVS_ERR_ARG, "V*H*W must be a multiple of 4");
-  if (B * Tc > 64) return fail(AXVS_ERR_ARG, "B*Tc > 64 is not supported by the class head yet");
+  if (B * Tc > 1024) return fail(AXVS_ERR_ARG, "B*Tc > 1024 is not supported by the class head");
   if (workspace_bytes < axvs_cc_heads_workspace_bytes(B, Q, Tc)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == AXVS_BF16) return cc_heads_fwd_t<true>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
@@ -1013,7 +1014,7 @@ int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float*
   if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
   if (Cm != 128 && Cm != 256) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
   if (((long long)h * w) % 4) return fail(AXVS_ERR_ARG, "h*w must be a multiple of 4");
-  if (Tc > 64) return fail(AXVS_ERR_ARG, "more than 64 clips are not supported by the class head yet");
+  if (Tc > 1024) return fail(AXVS_ERR_ARG, "more than 1024 clips are not supported by the class head");
   if (workspace_bytes < axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == AXVS_BF16) return tl_heads_fwd_t<true>(clip_query, mask_feature, cls_logits, mask_logits, packed, B, Q, Tc, frames_per_clip, h, w, K1, Cm, workspace, st);

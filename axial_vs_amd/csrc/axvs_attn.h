@@ -28,12 +28,12 @@ template <bool BF, int NKS>  // NKS = 32-key steps per frame; LP = 32*NKS >= L
 __global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict__ Q16, const u16* __restrict__ K16,
                                                            const u16* __restrict__ V16, u16* __restrict__ X,
                                                            float* __restrict__ attn, int N, int T, int L, int heads,
-                                                           long long Mtot) {
+                                                           long long Mtot, int TCH /* frames whose K / V fit the LDS at a time */) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   constexpr int LP = NKS * 32;
   constexpr int QT = 2;                         // 16-query tiles per wave: every K / V fragment read feeds two MFMAs
   u16* sK = smem;
-  u16* sV = smem + (size_t)T * LP * 32;
+  u16* sV = smem + (size_t)TCH * LP * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
   const int h = blockIdx.y, s = blockIdx.z;
   const int fi = lane & 15, fg = lane >> 4;
@@ -41,20 +41,6 @@ __global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict
   const u16* Kh = K16 + (long long)h * Mtot * 32;
   const u16* Vh = V16 + (long long)h * Mtot * 32;
   const u16* Qh = Q16 + (long long)h * Mtot * 32;
-
-  // ---- stage K, V of this (sequence, head): 64-byte rows, 4 chunks of 16 B; pad keys are zero ----
-  for (int c = tid; c < T * LP * 4; c += nthreads) {
-    int row = c >> 2, g = c & 3;
-    int f = row / LP, l = row - f * LP;
-    u16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-    if (l < L) {
-      long long r = seq0 + f * L + l;
-      kv = *reinterpret_cast<const u16x8*>(Kh + r * 32 + g * 8);
-      vv = *reinterpret_cast<const u16x8*>(Vh + r * 32 + g * 8);
-    }
-    *reinterpret_cast<u16x8*>(sK + row * 32 + swz_chunk(row, g) * 8) = kv;
-    *reinterpret_cast<u16x8*>(sV + v_lds_off(row, g * 8)) = vv;
-  }
 
   const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * (16 * QT);
   int qi[QT];
@@ -66,17 +52,34 @@ __global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict
     qvalid[t] = (q0 + t * 16 + fi) < N;
     qfrag[t] = *reinterpret_cast<const u16x8*>(Qh + (seq0 + qi[t]) * 32 + fg * 8);
   }
-  __syncthreads();
-  if (q0 >= N) return;                          // whole wave out of range (wave-uniform)
-
   u16* Xh = X + (long long)h * Mtot * T * 32;
   const bool ragged = L != LP;                  // wave-uniform: pad keys need masking
-  for (int f = 0; f < T; ++f) {
+  const bool active = q0 < N;                   // whole wave out of range (wave-uniform): it only helps staging
+  for (int f0 = 0; f0 < T; f0 += TCH) {
+  const int nf = min(TCH, T - f0);
+  if (f0 > 0) __syncthreads();                  // every wave is done with the previous chunk
+  // ---- stage K, V of frames f0 .. f0+nf-1 of this (sequence, head): 64-byte rows, 4 chunks of 16 B; pad keys are zero ----
+  for (int c = tid; c < nf * LP * 4; c += nthreads) {
+    int row = c >> 2, g = c & 3;
+    int f = row / LP, l = row - f * LP;
+    u16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+    if (l < L) {
+      long long r = seq0 + (long long)(f0 + f) * L + l;
+      kv = *reinterpret_cast<const u16x8*>(Kh + r * 32 + g * 8);
+      vv = *reinterpret_cast<const u16x8*>(Vh + r * 32 + g * 8);
+    }
+    *reinterpret_cast<u16x8*>(sK + row * 32 + swz_chunk(row, g) * 8) = kv;
+    *reinterpret_cast<u16x8*>(sV + v_lds_off(row, g * 8)) = vv;
+  }
+  __syncthreads();
+  if (active)
+  for (int fl = 0; fl < nf; ++fl) {
+    const int f = f0 + fl;
     // S^T tiles: D[key][query]
     f32x4 sc[QT][2 * NKS];
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) {
-      int row = f * LP + kt * 16 + fi;
+      int row = fl * LP + kt * 16 + fi;
       u16x8 kf = *reinterpret_cast<const u16x8*>(sK + row * 32 + swz_chunk(row, fg) * 8);
 #pragma unroll
       for (int t = 0; t < QT; ++t) sc[t][kt] = H16<BF>::mfma(kf, qfrag[t], f32x4{0.f, 0.f, 0.f, 0.f});
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         // lane i of 16-lane group g supplies the address of row (i>>2), columns 4*(i&3).. of the 4x16 block
-        int key0 = f * LP + ks * 32 + fg * 4 + (fi >> 2);
+        int key0 = fl * LP + ks * 32 + fg * 4 + (fi >> 2);
         int dcol = nd * 16 + (fi & 3) * 4;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (s16x4 __attribute__((address_space(3)))*)(sV + v_lds_off(key0, dcol)));
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict
         *reinterpret_cast<u16x8*>(Xh + row * 32 + fg * 8) = cvt8<BF>(v);
       }
     }
+  }
   }
 }
 

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restr
                                                             const float* __restrict__ ba, const float* __restrict__ wc,
                                                             const float* __restrict__ bc, float* __restrict__ out, int Bv, int Q,
                                                             int Tc, int K1, float void_bias) {
-  constexpr int C = 256, MAXE = 64;
+  constexpr int C = 256, MAXE = 1024;
   __shared__ float logit[MAXE], pooled[C], red[4];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int E = Bv * Tc;                              // entries the softmax runs over (dim 0 of the reference tensor)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
 __global__ __launch_bounds__(256) void tl_class_head_kernel(const float* __restrict__ x, const float* __restrict__ wa,
                                                             const float* __restrict__ ba, const float* __restrict__ wc,
                                                             const float* __restrict__ bc, float* __restrict__ out, int Tc, int K1) {
-  constexpr int C = 256, MAXT = 64;
+  constexpr int C = 256, MAXT = 1024;
   __shared__ float logit[MAXT], pooled[C], red[4];
   const int bq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xr = x + (long long)bq * Tc * C;

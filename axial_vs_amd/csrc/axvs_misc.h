@@ -140,31 +140,22 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
   const int h = (int)(grp % heads);
   const int c = h * 32 + sub * 4;
   const float4 q = *reinterpret_cast<const float4*>(q2 + m * Cp + c);
-  float lg[8];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    lg[f] = -INFINITY;
-    if (f < T) {
-      float4 k = *reinterpret_cast<const float4*>(kv2 + ((long long)f * M + m) * 2 * Cp + c);
-      float p = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
-      p += __shfl_xor(p, 1, 64);
-      p += __shfl_xor(p, 2, 64);
-      p += __shfl_xor(p, 4, 64);
-      lg[f] = p;
-      mx = fmaxf(mx, p);
-    }
-  }
-  float sum = 0.f;
+  // online softmax over the frames: any T (whole-video cross-clip inference runs T = number of clips)
+  float mx = -INFINITY, sum = 0.f;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    if (f < T) {
-      float e = __expf(lg[f] - mx);
-      sum += e;
-      float4 v = *reinterpret_cast<const float4*>(kv2 + ((long long)f * M + m) * 2 * Cp + Cp + c);
-      o[0] += e * v.x; o[1] += e * v.y; o[2] += e * v.z; o[3] += e * v.w;
-    }
+  for (int f = 0; f < T; ++f) {
+    const float* row = kv2 + ((long long)f * M + m) * 2 * Cp + c;
+    const float4 k = *reinterpret_cast<const float4*>(row);
+    const float4 v = *reinterpret_cast<const float4*>(row + Cp);
+    float p = q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
+    p += __shfl_xor(p, 1, 64);
+    p += __shfl_xor(p, 2, 64);
+    p += __shfl_xor(p, 4, 64);
+    const float nm = fmaxf(mx, p);
+    const float corr = __expf(mx - nm), e = __expf(p - nm);
+    sum = sum * corr + e;
+    o[0] = o[0] * corr + e * v.x; o[1] = o[1] * corr + e * v.y; o[2] = o[2] * corr + e * v.z; o[3] = o[3] * corr + e * v.w;
+    mx = nm;
   }
   o *= 1.f / sum;
   if (valid) *reinterpret_cast<u16x4*>(O16 + blk_off(M, m, c)) = cvt4<BF>(o);

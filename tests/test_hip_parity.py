@@ -349,6 +349,67 @@ def test_tube_link_cross_clip_head_golden(name):
     assert e_m < TOL_F16 and e_m0 < TOL_F16
 
 
+@pytest.mark.parametrize("Q,Tc,V,H,W,layers", [(32, 12, 2, 8, 12, 2), (128, 24, 2, 16, 16, 1), (16, 40, 1, 8, 8, 1)])
+def test_cross_clip_module_many_clips(Q, Tc, V, H, W, layers):
+    """Whole-video inference runs the cross-clip module over ALL clips of a video (maxtron_cc_model.py:262-276 with
+    NUM_CLIP_FRAMES 2: Tc = video_len / 2), far beyond the 4-clip fixtures: Tc = 12, 24 and 40 against the float64 oracle
+    (itself pinned to the reference by the G5 fixtures).  Exercises the chunked K/V staging of the attention kernel, the
+    online-softmax temporal kernel (T > 5 leaves the fused tier) and the class head's softmax over > 64 clips."""
+    import axial_vs_amd as ax
+    ncls = 20
+    mod = ax.CrossClipTrackingModule(num_layers=layers, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
+                                     atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V).eval()
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
+    w = orc.random_weights(shapes, 1200 + Tc)
+    sd = mod.state_dict()
+    sd.update(w)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.cuda()
+    g = torch.Generator().manual_seed(1300 + Tc)
+    cq = torch.randn(1, Q, Tc, 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, H, W, generator=g), dim=1)
+    out = mod(dev(cq), dev(pf))
+    ref = orc.cross_clip_module(cq.double(), pf.double(), {k: v.double() for k, v in w.items()}, layers, V)
+    e_l, e_m = rel_err(out["pred_logits"], ref["pred_logits"]), rel_err(out["pred_masks"], ref["pred_masks"])
+    e_q = rel_err(mod.last_clip_query.cpu(), ref["clip_query"])
+    print(f"Q={Q} Tc={Tc}: logits {e_l:.2e} masks {e_m:.2e} clip_query {e_q:.2e}")
+    assert e_l < TOL_F16 and e_m < TOL_F16 and e_q < TOL_F16
+
+
+def test_tube_link_head_many_clips():
+    import axial_vs_amd as ax
+    B, Tc, Q, fpc, h, w_, layers, K, Cm = 1, 16, 20, 1, 8, 12, 2, 10, 256
+    mod = ax.TubeLinkCrossClipHead(num_classes=K, out_channels=Cm, num_cc_layers=layers).eval()
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
+    w = orc.random_weights(shapes, 1401)
+    mod.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    g = torch.Generator().manual_seed(1402)
+    cq = torch.randn(B, Tc, Q, 256, generator=g)
+    mf = torch.nn.functional.normalize(torch.randn(B, Tc * fpc, Cm, h, w_, generator=g), dim=2)
+    cls, masks = mod(dev(cq), dev(mf))
+    rc, rm = orc.tl_cross_clip_head(cq.double(), mf.double(), {k: v.double() for k, v in w.items()}, layers)
+    e_c, e_m = rel_err(cls[-1].cpu(), rc[-1]), rel_err(masks[-1].cpu(), rm[-1])
+    print(f"TL head Tc={Tc}: cls {e_c:.2e} masks {e_m:.2e}")
+    assert e_c < TOL_F16 and e_m < TOL_F16
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 256, 16, 16, 512), (1, 12, 64, 5, 7, 128)])
+def test_axial_layer_many_frames(shape):
+    """T > 8 frames per clip (round 1 refused them): generic temporal path with online softmax."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 41)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 41)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    out, _, _ = layer.cuda()(dev(src), dev(pos))
+    e = rel_err(out.cpu(), ref)
+    print(f"{shape}: {e:.2e}")
+    assert e < TOL_F16
+
+
 from golden_util import MSDA_CORE, MSDA_MODULE, msda_core_inputs, msda_module_case  # noqa: E402
 
 
