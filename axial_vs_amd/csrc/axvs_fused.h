@@ -393,15 +393,26 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   const int fi = lane & 15, fg = lane >> 4;
   // XCD-aware tile order (speed only): blocks b and b+8 share an XCD, hence an L2.  With the spatial half in the kernel the
   // N/ROWS row tiles of one sequence all read that sequence's K / V -- put them on the same XCD so it is fetched once.
+  // Row tiles: with the spatial half in the kernel a tile never straddles two sequences (its queries share one K / V): every
+  // sequence gets ceil(N / ROWS) tiles, the last one partly filled -- any axis length works, rows past the sequence's end are
+  // clamped copies that are computed and never stored.  Without it (x staged from HBM) tiles are plain ROWS-row slices.
   long long tile = blockIdx.x;
+  long long m0;                                                 // first sequence-order row of the tile
+  int nvalid;                                                   // rows of the tile that exist
   if constexpr (NKS > 0) {
-    const int tps = N / ROWS;                                   // tiles per sequence
+    const int tps = (N + ROWS - 1) / ROWS;                      // tiles per sequence
     if (gridDim.x % (8 * tps) == 0) {
       const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
       tile = ((long long)(j / tps) * 8 + xcd) * tps + (j % tps);
     }
+    const long long sq = tile / tps;
+    const int n0 = (int)(tile - sq * tps) * ROWS;
+    m0 = sq * N + n0;
+    nvalid = min(ROWS, N - n0);
+  } else {
+    m0 = tile * ROWS;
+    nvalid = (int)min((long long)ROWS, Mp - m0);
   }
-  const long long m0 = tile * ROWS;
 
   AXVS_STAMP_DECL;
   AXVS_STAMP(0);
@@ -424,14 +435,14 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 
   if constexpr (NKS > 0) {
     // ---- spatial half, head = wave (WC/temporal_attention.py:46-57) ----
-    const long long seq0 = (m0 / N) * N;                        // first row of my sequence (the tile never straddles two)
+    const long long seq0 = (m0 / N) * N;                        // first row of my sequence
     const u16* Qh = Q16 + (long long)wave * Mp * 32;
     const u16* Kh = K16 + (long long)wave * Mp * 32;
     const long long nsf = Mp / L;                               // frame slots (sequences x frames)
     const u16* Vh = VT16 + (long long)wave * nsf * NKS * 1024;
     u16x8 qf[MT];
 #pragma unroll
-    for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + qt * 16 + fi) * 32 + fg * 8);
+    for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + min(qt * 16 + fi, nvalid - 1)) * 32 + fg * 8);
     const bool ragged = L != NKS * 32;
     u16x8 ones;
 #pragma unroll
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   {
     constexpr int NCH = T * 8 * ROWS * 4;                       // 16-byte chunks
     constexpr int PER = (NCH + 511) / 512;                      // <= 16 for the instantiated (T, MT)
-    const int mrow_max = (int)(Mp - 1 - m0);                    // last valid row of this workgroup
+    const int mrow_max = nvalid - 1;                            // last valid row of this workgroup
     u16x8 v[PER];
 #pragma unroll
     for (int p = 0; p < PER; ++p) {                             // every load in flight before the first LDS write
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   {
     // own frame of every tile row: lane l computes it for row l (two integer divisions, once), ds_bpermute hands lane
     // (fi, fg) the value of row mt*16 + fi
-    const int mrow = (int)m0 + min(lane, (int)(Mp - 1 - m0));
+    const int mrow = (int)m0 + min(lane, nvalid - 1);
     const int fown_l = (int)(((unsigned)mrow % (unsigned)N) / (unsigned)L);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // v_readlane -- instead of RPW unrolled copies of the same ~75-instruction sequence
   {
     const int myrow = wave * RPW + (lane % RPW);
-    const int mym = (int)m0 + min(myrow, (int)(Mp - 1 - m0));
+    const int mym = (int)m0 + min(myrow, nvalid - 1);
     const long long myoff = nat_row(rm, mym) * C;
     const int lo = (int)(myoff & 0xffffffffll), hi = (int)(myoff >> 32);
 #pragma unroll
@@ -777,7 +788,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
     const float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
     if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
-    else if (m0 + row < Mp) {
+    else if (row < nvalid) {
       if (wt) WtBuf(out).store16((unsigned)(roff[i] * 4), y);
       else *reinterpret_cast<float4*>(out + roff[i]) = y;
     }
@@ -786,7 +797,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   if constexpr (FFN) {
     lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
     ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
-                 [=](int row) { return m0 + row < Mp ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid, wt);   // rows of this wave
+                 [=](int row) { return row < nvalid ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid, wt);   // rows of this wave
   }
   AXVS_STAMP(10);
 #ifndef AXVS_STAMPS_QKV
@@ -929,6 +940,30 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
               if (wt) wvt.store16((unsigned)(d * 2), cvt8<BF>(v));
               else *reinterpret_cast<u16x8*>(VT16 + d) = cvt8<BF>(v);
             }
+          }
+        }
+      } else if (L % 16 != 0) {
+        // any frame length: the 4 tokens of a lane may sit in different frames (even sequences) -> one 2-byte store per token.
+        // Key l of a frame goes to 32-key step l >> 5, position ((kk >> 2) & 3) * 8 + (kk >> 4) * 4 + (kk & 3), kk = l & 31 (the
+        // k-permuted order of the P^T operand, axvs_attn.h).
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          unsigned tok = (unsigned)m0 + mt * 16 + fg * 4;
+          unsigned sf = tok / (unsigned)L;
+          int l = (int)(tok - sf * L);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (tok < (unsigned)Mp) {
+              const int ks = l >> 5, kk = l & 31;
+              const int pp = ((kk >> 2) & 3) * 8 + (kk >> 4) * 4 + (kk & 3);
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) {
+                const long long d = ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
+                VT16[d] = H16<BF>::from_f32(acc[nt][mt][r] + sbias[2 * C + wave * 32 + nt * 16 + fi]);
+              }
+            }
+            ++tok;
+            if (++l == L) { l = 0; ++sf; }
           }
         }
       } else {

@@ -13,7 +13,8 @@ namespace axvs {
 template <bool BF, int T, int MT, int NKS>
 static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
                              float scale, hipStream_t st, const FfnArgs* fa, int wt) {
-  const unsigned grid = (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
+  // with the spatial half in the kernel every sequence gets its own ceil(N / rows) tiles (see temporal_fused_kernel)
+  const unsigned grid = NKS > 0 ? (unsigned)((Mp / N) * ((N + MT * 16 - 1) / (MT * 16))) : (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
   if constexpr (NKS > 0 && MT == 4) {
     if (fa) {                                    // trajectory attention + FFN in one kernel
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS, true>))) return rc;

@@ -245,6 +245,37 @@ def test_fused_kernels_all_frame_counts(shape):
     assert e < TOL_F16
 
 
+def _stage_names():
+    from axial_vs_amd import _lib
+    L = _lib.lib()
+    return [L.axvs_profile_stage_name(i).decode() for i in range(L.axvs_profile_stage_count())]
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 25, 43, 1024), (1, 4, 256, 49, 85, 1024), (2, 2, 256, 49, 85, 1024), (1, 5, 256, 25, 43, 512),
+                                   (1, 3, 256, 17, 127, 256), (1, 4, 256, 23, 40, 1024)])
+def test_ragged_axis_lengths_take_the_fused_tier(shape):
+    """The real VIPSeg pyramid sizes (res4 49x85 / res5 25x43; T = 2 in Video-kMaX, up to 5 in Tube-Link) have axis
+    lengths that are not multiples of 16 and sequences that are not multiples of the 64-row tile.  They stay on the fully fused
+    tier (x[q, f, C] never reaches HBM): row tiles are cut per sequence, partial key tiles masked, V^T stored per token --
+    checked through the stage names the library reports, against the float64 oracle."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 51)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 51)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    out, _, _ = layer(dev(src), dev(pos))
+    names = _stage_names()
+    assert "h.traj_fused" in names and ("w.traj_fused+ffn" in names if T <= 4 else "w.traj_fused" in names), names
+    assert not any("spatial_attn" in n for n in names), names
+    e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
+    print(f"{shape}: {names[1:]} max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < TOL_F16 and e2 < TOL_F16
+    assert torch.equal(out, layer(dev(src), dev(pos))[0])
+
+
 def test_ffn_tail_unit_and_determinism():
     """axvs_ffn_fwd alone against the fp64 oracle, and 50 repeated launches bit-identical (the lgkmcnt-overflow
     regression test: DESIGN.md section 5)."""
