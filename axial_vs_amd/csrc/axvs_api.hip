@@ -168,18 +168,43 @@ void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, h
 }
 
 // ---------------- one trajectory attention over sequence-ordered rows ----------------
-TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads) {
+// lean: the fully fused tier only round-trips q, k and V^T (x, the T-expanded attention output, stays in LDS)
+TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = false) {
   const size_t Cp = (size_t)heads * 32;
-  TrajWs w;
+  TrajWs w{};
   w.q16 = c.take<u16>(Cp * Mp);
   w.k16 = c.take<u16>(Cp * Mp);
+  w.vt16 = c.take<u16>(2 * Cp * Mp);      // block-transposed V (frames padded to a multiple of 32 keys: at most 2x)
+  if (lean) return w;
   w.v16 = c.take<u16>(Cp * Mp);
   w.x16 = c.take<u16>(Cp * Mp * T);
   w.o16 = c.take<u16>(Cp * Mp);
   w.q2 = c.take<float>(Cp * Mp);
   w.kv2 = c.take<float>(2 * Cp * Mp * T);
-  w.vt16 = c.take<u16>(2 * Cp * Mp);      // block-transposed V (frames padded to a multiple of 32 keys: at most 2x)
   return w;
+}
+
+// Full fusion (spatial half inside the temporal kernel, x never leaves LDS) needs: the fused kernels, no attention-map
+// output, 16..128 keys per frame (L >= 16: the 32-key padding of V^T stays within 2x).  Any axis length: row tiles are cut
+// per sequence, partial key tiles are masked.
+bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn) {
+  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 5 && !want_attn && L >= 16 && L <= 128;
+}
+bool can_fuse_ffn_into_pass(int T, int F) { return !g_no_ffn_fusion && T <= 4 && F % 256 == 0 && F <= 4096; }
+bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
+
+// what one axial layer's launch sequence touches in the workspace (the same predicates run_traj / run_ffn dispatch on)
+struct LayerPlan {
+  bool lean_traj;     // both passes fully fused
+  bool need_buf2;     // the width pass writes rows for a separate FFN launch
+  bool need_ffn_tmp;  // generic FFN (LayerNorm / GEMM / GEMM / LayerNorm): fp32 scratch + 16-bit y and h
+};
+LayerPlan plan_layer(int T, int H, int W, int C, int heads, int F, bool want_attn) {
+  LayerPlan p;
+  p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn) && can_fuse_attn(C, heads, T, W, want_attn);
+  p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn) && can_fuse_ffn_into_pass(T, F));
+  p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
+  return p;
 }
 
 RowMap identity_map(long long rows) {
@@ -237,10 +262,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const float scale = 1.0f / sqrtf((float)d);
   const float kLog2e = 1.4426950408889634f;
 
-  // Full fusion (spatial half inside the temporal kernel, x never leaves LDS) needs: the fused kernels, no attention-map
-  // output, at most 128 keys per frame.  Any axis length: row tiles are cut per sequence, partial key tiles are masked.
-  const bool fuse_attn = !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 5 && qsrc == ksrc && vsrc == qsrc &&
-                         attn == nullptr && L >= 16 && L <= 128;   // (L >= 16: the 32-key padding of V^T stays within 2x)
+  const bool fuse_attn = qsrc == ksrc && vsrc == qsrc && can_fuse_attn(C, heads, T, L, attn != nullptr);
   const int nks_fused = (L + 31) / 32;
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
   if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
@@ -268,7 +290,7 @@ qkv_done:
   mark(st, nm[0]);
   if (fuse_attn) {
     // the layer's FFN can ride along (64-row tiles, LDS budget): `out` then receives norm2(FFN(norm1(...)))
-    const bool with_ffn = ffn != nullptr && !g_no_ffn_fusion && T <= 4 && ffn->F % 256 == 0 && ffn->F <= 4096;
+    const bool with_ffn = ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F);
     int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr);
     if (rc != AXVS_OK) return rc;
     if (with_ffn) *ffn_done = true;
@@ -321,7 +343,7 @@ qkv_done:
 template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
             hipStream_t st) {
-  if (!g_generic_only && C == 256 && heads == 8 && F % 256 == 0) {
+  if (ffn_kernel_is_fused(C, heads, F)) {
     const size_t lds = ffn_lds_bytes(F);
     if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "d_ffn=%d too large for the fused FFN kernel", F);
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>))) return rc;
@@ -389,11 +411,12 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   LayerPacked p = carve_layer(pc, C, heads, F);
   const long long M = (long long)B * T * H * W;
   Carver wc(ws);
-  TrajWs tw = carve_traj_ws(wc, M, T, heads);
+  const LayerPlan plan = plan_layer(T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
+  TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
   float* buf1 = wc.take<float>((size_t)M * C);
-  float* buf2 = wc.take<float>((size_t)M * C);
-  u16* y16 = wc.take<u16>((size_t)M * C);
-  u16* h16 = wc.take<u16>((size_t)M * F);
+  float* buf2 = plan.need_buf2 ? wc.take<float>((size_t)M * C) : nullptr;
+  u16* y16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * C) : nullptr;
+  u16* h16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * F) : nullptr;
   const long long sB = (long long)T * H * W, sT = (long long)H * W;
 
   g_prof_next = 0;
@@ -777,15 +800,23 @@ int axvs_traj_attn_fwd(const float* query, const float* key, const float* value,
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
 }
 
-size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
+size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, int heads, int d_ffn, int want_attn_maps, int sine_pos) {
   const long long M = (long long)B * T * H * W;
   Carver c(nullptr);
-  carve_traj_ws(c, M, T, heads);
+  const LayerPlan plan = plan_layer(T, H, W, C, heads, d_ffn, want_attn_maps != 0);
+  carve_traj_ws(c, M, T, heads, plan.lean_traj);
   c.take<float>((size_t)M * C);
-  c.take<float>((size_t)M * C);
-  c.take<u16>((size_t)M * C);
-  c.take<u16>((size_t)M * d_ffn);
+  if (plan.need_buf2) c.take<float>((size_t)M * C);
+  if (plan.need_ffn_tmp) {
+    c.take<u16>((size_t)M * C);
+    c.take<u16>((size_t)M * d_ffn);
+  }
+  if (sine_pos && !sine_in_kernel(C, heads)) c.take<float>((size_t)M * C);     // materialised positions (tiers without in-kernel evaluation)
   return c.off;
+}
+
+size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
+  return axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C, heads, d_ffn, 1 /* upper bound: with attention maps */, 0);
 }
 
 static int axial_layer_entry(const float* src, const float* pos, const AxvsSinePos3D* sine, float* out, const void* packed, int B, int T,
@@ -797,7 +828,7 @@ static int axial_layer_entry(const float* src, const float* pos, const AxvsSineP
   if (int rc = check_cfg(C, heads)) return rc;
   if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
   if (sine && (T > 255 || H > 4095 || W > 4095)) return fail(AXVS_ERR_ARG, "grid too large for generated positions");
-  const size_t need = sine ? axvs_axial_layer_sine3d_workspace_bytes(B, T, H, W, C, heads, d_ffn) : axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn);
+  const size_t need = axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C, heads, d_ffn, h_attn != nullptr || w_attn != nullptr, sine != nullptr);
   if (workspace_bytes < need) return fail(AXVS_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == AXVS_BF16)
@@ -815,7 +846,7 @@ int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const v
 }
 
 size_t axvs_axial_layer_sine3d_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
-  return axvs_axial_layer_workspace_bytes(B, T, H, W, C, heads, d_ffn) + align_up((size_t)B * T * H * W * C * sizeof(float));
+  return axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C, heads, d_ffn, 1, 1);
 }
 
 int axvs_axial_layer_fwd_sine3d(const float* src, const AxvsSinePos3D* pos, float* out, const void* packed, int B, int T, int H, int W,

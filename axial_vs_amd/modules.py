@@ -328,12 +328,12 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         tag = _sine_tag(pos) if self.use_generated_pos else None
         if tag is not None:
             sp = _lib.AxvsSinePos3D(tag.temperature, int(tag.normalize), tag.scale, tag.level.data_ptr() if tag.level is not None else None)
-            ws = _workspace(s.device, L.axvs_axial_layer_sine3d_workspace_bytes(B, T, H, W, C_, self.n_heads, F))
+            ws = _workspace(s.device, L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, int(self.return_attn), 1))
             _lib.check(L.axvs_axial_layer_fwd_sine3d(s.data_ptr(), C.byref(sp), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
                                                      self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(),
                                                      _ptr(ha), _ptr(wa), _stream(s.device)), "axvs_axial_layer_fwd_sine3d")
             return out, ha, wa
-        nws = L.axvs_axial_layer_workspace_bytes(B, T, H, W, C_, self.n_heads, F)
+        nws = L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, int(self.return_attn), 0)
         ws = _workspace(s.device, nws)
         _lib.check(L.axvs_axial_layer_fwd(s.data_ptr(), p.data_ptr(), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
                                           self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(),
@@ -512,9 +512,16 @@ class GraphedForward:
                 module(*self.inputs)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        before = set(_workspaces)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = module(*self.inputs)
+        # scratch buffers allocated on the capture stream belong to this graph (its private pool): they go with it
+        self._ws_keys = [k for k in _workspaces if k not in before]
+
+    def __del__(self):
+        for k in getattr(self, "_ws_keys", ()):
+            _workspaces.pop(k, None)
 
     def __call__(self, *inputs: Tensor):
         for dst, src in zip(self.inputs, inputs):

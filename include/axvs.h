@@ -108,6 +108,11 @@ typedef struct AxvsSinePos3D {
   float scale;
   const float* level_embed;   /* NULL or device fp32 [C] */
 } AxvsSinePos3D;
+/* Exact workspace of one call, by the kernel tier it will take (the fully fused C = 256 tier only round-trips q, k and V^T:
+ * ~7x less than the upper bound axvs_axial_layer_workspace_bytes returns).  want_attn_maps: h_attn / w_attn will be non-NULL;
+ * sine_pos: the call is axvs_axial_layer_fwd_sine3d.  Depends on axvs_set_option state of the calling thread. */
+size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, int heads, int d_ffn, int want_attn_maps,
+                                           int sine_pos);
 size_t axvs_axial_layer_sine3d_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn);
 int axvs_axial_layer_fwd_sine3d(const float* src, const AxvsSinePos3D* pos, float* out, const void* packed, int B, int T, int H,
                                 int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
