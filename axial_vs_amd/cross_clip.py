@@ -97,6 +97,18 @@ class MaXTronCCPredictor(nn.Module):         # CC:30-43
         nn.init.constant_(self._pixel_space_mask_batch_norm.weight, 0.1)
 
 
+_aux_streams = {}
+
+
+def _aux_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """One auxiliary stream per (device, current stream): the predictor heads run on it beside the next layer's chain."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    st = _aux_streams.get(key)
+    if st is None:
+        st = _aux_streams[key] = torch.cuda.Stream(dev)
+    return st
+
+
 def _bn(m) -> _lib.AxvsBN:
     return m.weight, m.bias, m.running_mean, m.running_var
 
@@ -147,6 +159,7 @@ class CrossClipTrackingModule(nn.Module):
         self._predictor = MaXTronCCPredictor(num_classes=num_classes + 1)
         self.mfma_dtype = mfma_dtype
         self.eval_outputs_on_cpu = True     # the reference's eval branch returns CPU tensors (CC:59,70)
+        self.overlap_heads = True           # predictor heads of layer i on an auxiliary stream beside the chain of layer i+1
         self._packed = None
         self._packed_key = None
 
@@ -205,22 +218,28 @@ class CrossClipTrackingModule(nn.Module):
         L = _lib.lib()
         layers, hbuf, K1 = self._pack()
         dt = _lib.DTYPES[self._dtype()]
-        dev, st = cq.device, _stream(cq.device)
-        ws = _workspace(dev, max(L.axvs_cc_layer_workspace_bytes(B, Q, Tc), L.axvs_cc_heads_workspace_bytes(B, Q, Tc)))
+        dev = cq.device
+        nl = self.num_layers
         rates = (C.c_int * 3)(*[int(r) for r in self.atrous_rates])
-        cls_all, mask_all = [], []
-        cur = cq
-        for i in range(self.num_layers):
-            nxt = torch.empty_like(cur)
-            _lib.check(L.axvs_cc_layer_fwd(cur.data_ptr(), nxt.data_ptr(), layers[i].data_ptr(), B, Q, Tc, rates, dt, ws.data_ptr(),
-                                           ws.numel(), st), "axvs_cc_layer_fwd")
-            cur = nxt
-            logits = torch.empty(1, Q, K1, dtype=torch.float32, device=dev)
-            masks = torch.empty(B, Q, TV, H, W, dtype=torch.float32, device=dev)
-            _lib.check(L.axvs_cc_heads_fwd(cur.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), hbuf.data_ptr(), B, Q,
-                                           Tc, V, H, W, K1, dt, ws.data_ptr(), ws.numel(), st), "axvs_cc_heads_fwd")
-            cls_all.append(logits)
-            mask_all.append(masks)
+        # ONE library call runs the whole layer loop (CC:283-318).  The layer chain (trajectory attention -> ASPP -> norms) of layer
+        # i+1 only needs layer i's clip queries, not its predictions: the predictor heads of layer i (embedding projections, class
+        # head, the HBM-bound mask einsum) run on an auxiliary stream beside it.
+        main = torch.cuda.current_stream(dev)
+        aux = _aux_stream(dev) if self.overlap_heads else None
+        ws = _workspace(dev, L.axvs_cc_module_workspace_bytes(B, Q, Tc, nl))
+        logits = torch.empty(nl, 1, Q, K1, dtype=torch.float32, device=dev)
+        masks = torch.empty(nl, B, Q, TV, H, W, dtype=torch.float32, device=dev)
+        last = torch.empty_like(cq)
+        pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
+        _lib.check(L.axvs_cc_module_fwd(cq.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
+                                        nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream,
+                                        aux.cuda_stream if aux is not None else None), "axvs_cc_module_fwd")
+        if aux is not None:                      # the auxiliary stream touched these (it has been joined back into `main`)
+            for t_ in (pf, logits, masks, ws):
+                t_.record_stream(aux)
+        cur = last
+        cls_all = [logits[i] for i in range(nl)]
+        mask_all = [masks[i] for i in range(nl)]
         if self.eval_outputs_on_cpu:
             cls_all = [c.cpu() for c in cls_all]
             mask_all = [m.cpu() for m in mask_all]
@@ -267,6 +286,7 @@ class TubeLinkCrossClipHead(nn.Module):
             self.conv_short_aggregate_layers.append(ASPP(256, 256, list(kernel_sizes), list(atrous_rates), drop_path_prob, aspp_norm_fn))
             self.conv_norms.append(nn.LayerNorm(256))
         self.activation_proj = nn.Linear(256, 1)
+        self.overlap_heads = True
         self.mfma_dtype = mfma_dtype
         self._packed = None
         self._packed_key = None
@@ -316,20 +336,23 @@ class TubeLinkCrossClipHead(nn.Module):
         T, h, w = mf.shape[1], mf.shape[3], mf.shape[4]
         L = _lib.lib()
         dt = _lib.DTYPES[self._dtype()]
-        dev, st = cq.device, _stream(cq.device)
-        ws = _workspace(dev, max(L.axvs_cc_layer_workspace_bytes(B, Q, Tc), L.axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm)))
+        dev = cq.device
+        nl = self.num_cc_layers
         rates = (C.c_int * 3)(*[int(r) for r in self.atrous_rates])
+        main = torch.cuda.current_stream(dev)          # one library call for the whole loop, heads on an auxiliary stream (see CrossClipTrackingModule)
+        aux = _aux_stream(dev) if self.overlap_heads else None
+        ws = _workspace(dev, L.axvs_tl_cc_module_workspace_bytes(B, Q, Tc, Cm, nl))
         cur = cq.permute(0, 2, 1, 3).contiguous()          # [B,Q,Tc,C]: the token order of 'b c t q -> b (t q) c' (TLCC:931)
-        cls_all, mask_all = [], []
-        for i in range(self.num_cc_layers):
-            nxt = torch.empty_like(cur)
-            _lib.check(L.axvs_cc_layer_fwd(cur.data_ptr(), nxt.data_ptr(), layers[i].data_ptr(), B, Q, Tc, rates, dt, ws.data_ptr(),
-                                           ws.numel(), st), "axvs_cc_layer_fwd")
-            cur = nxt
-            logits = torch.empty(B, Q, K1, dtype=torch.float32, device=dev)
-            masks = torch.empty(B, T, Q, h, w, dtype=torch.float32, device=dev)
-            _lib.check(L.axvs_tl_heads_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), hbuf.data_ptr(), B, Q, Tc,
-                                           T // Tc, h, w, K1, Cm, dt, ws.data_ptr(), ws.numel(), st), "axvs_tl_heads_fwd")
-            cls_all.append(logits)
-            mask_all.append(masks)
+        logits = torch.empty(nl, B, Q, K1, dtype=torch.float32, device=dev)
+        masks = torch.empty(nl, B, T, Q, h, w, dtype=torch.float32, device=dev)
+        last = torch.empty_like(cur)
+        pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
+        _lib.check(L.axvs_tl_cc_module_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
+                                           nl, B, Q, Tc, T // Tc, h, w, K1, Cm, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream,
+                                           aux.cuda_stream if aux is not None else None), "axvs_tl_cc_module_fwd")
+        if aux is not None:
+            for t_ in (mf, logits, masks, ws):
+                t_.record_stream(aux)
+        cls_all = [logits[i] for i in range(nl)]
+        mask_all = [masks[i] for i in range(nl)]
         return tuple(cls_all), tuple(mask_all)

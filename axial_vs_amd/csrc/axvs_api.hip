@@ -64,7 +64,7 @@ int check_cfg(int C, int heads) {
 // ---------------- packed weights ----------------
 TrajPacked carve_traj(Carver& c, int C, int heads) {
   const size_t Cp = (size_t)heads * 32;
-  TrajPacked t;
+  TrajPacked t{};
   t.wq = c.take<u16>(Cp * C);
   t.wk = c.take<u16>(Cp * C);
   t.wv = c.take<u16>(Cp * C);
@@ -527,18 +527,30 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   mark(st, "begin");
   // trajectory attention over (t q) tokens of each video, read in place from [B,Q,Tc,C]:  row (b; t,q) -> b*Q*Tc + q*Tc + t
   RowMap rm{Tc * Q, Q, 1, (long long)Q * Tc, 1, Tc, 0};
-  int rc = run_traj<BF>(x, x, x, nullptr, x, w.t1, nullptr, p.t, w.tw, rm, B, Tc, Q, 256, 8, st, 0);
-  if (rc != AXVS_OK) return rc;
   const unsigned lnblocks = (unsigned)((R + 3) / 4);
-  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, w.t1, p.norm_w, p.norm_b, w.t2, (u16*)nullptr, R, 256,
-                     1e-5f);
-  mark(st, "cc.norm");
+  // the post-norm LayerNorm(x + attn(x)) rides in the trajectory kernel's row-wise epilogue when a fused kernel runs (T <= 5)
+  const bool ln_in_kernel = !g_generic_only && Tc <= 5;
+  if (ln_in_kernel) {
+    p.t.post_ln_g = p.norm_w;
+    p.t.post_ln_b = p.norm_b;
+  }
+  int rc = run_traj<BF>(x, x, x, nullptr, x, ln_in_kernel ? w.t2 : w.t1, nullptr, p.t, w.tw, rm, B, Tc, Q, 256, 8, st, 0);
+  if (rc != AXVS_OK) return rc;
+  if (!ln_in_kernel) {
+    hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, w.t1, p.norm_w, p.norm_b, w.t2, (u16*)nullptr, R, 256,
+                       1e-5f);
+    mark(st, "cc.norm");
+  }
   // temporal ASPP: three dilated 3-tap convs over the clip axis -> concat (blocked 16-bit) -> 1x1 projection
-  for (int br = 0; br < 3; ++br) {
-    ALoadShift3<BF> a{w.t2, 256, Tc, rates[br], (int)R};
-    EpiBlocked16<BF> e{w.cat16, R, p.aspp_b[br], 1.f, 0, 0};
-    e.n_off = br * 256;
-    launch_gemm<BF>(a, p.aspp[br], e, (int)R, 256, 768, st);
+  {
+    GemmBatch<ALoadShift3<BF>, EpiBlocked16<BF>, 3> gb;
+    for (int br = 0; br < 3; ++br) {
+      gb.al[br] = ALoadShift3<BF>{w.t2, 256, Tc, rates[br], (int)R};
+      gb.W[br] = p.aspp[br];
+      gb.epi[br] = EpiBlocked16<BF>{w.cat16, R, p.aspp_b[br], 1.f, 0, 0};
+      gb.epi[br].n_off = br * 256;
+    }
+    launch_gemm_batched<BF>(gb, (int)R, 256, 768, st);        // the three dilated branches in one launch
   }
   ALoadBlocked<BF> ac{w.cat16, R, (int)R, 0, 1, 1};
   launch_gemm<BF>(ac, p.aspp_proj, EpiRowsF32{w.y, nullptr, nullptr, identity_map(R), 256, 1.f}, (int)R, 256, 768, st);
@@ -693,6 +705,64 @@ int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* 
   return last_launch_status();
 }
 
+}  // namespace
+
+namespace {
+hipEvent_t module_event(int i) {          // per-thread pool of timing-free events
+  constexpr int kMax = 2 * 64 + 2;
+  static thread_local hipEvent_t ev[kMax] = {};
+  if (i < 0 || i >= kMax) return nullptr;
+  if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  return ev[i];
+}
+
+struct ModuleWs {
+  void *chain, *heads;
+  float* q;            // [layers][R][256] clip queries after every layer
+};
+ModuleWs carve_module_ws(Carver& c, size_t chain_bytes, size_t heads_bytes, long long R, int layers) {
+  ModuleWs m;
+  m.chain = c.take<char>(chain_bytes);
+  m.heads = c.take<char>(heads_bytes);
+  m.q = c.take<float>((size_t)layers * R * 256);
+  return m;
+}
+
+// heads(i, clip queries of layer i, stream) launches the predictor heads of layer i
+template <class Heads>
+int run_cc_module(const float* clip_query, const void* const* packed_layers, int layers, float* last_query, int B, int Q, int Tc, const int* rates,
+                  int dtype, const ModuleWs& w, hipStream_t st, hipStream_t aux, Heads heads) {
+  const long long R = (long long)B * Q * Tc;
+  if (layers <= 0 || layers > 64) return fail(AXVS_ERR_ARG, "num_layers=%d must be in 1..64", layers);
+  if (aux == st) aux = nullptr;
+  if (aux) {                                      // fork: the auxiliary stream joins behind everything queued on `st`
+    hipEvent_t e = module_event(0);
+    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "event fork failed");
+  }
+  const float* cur = clip_query;
+  for (int i = 0; i < layers; ++i) {
+    float* nxt = w.q + (size_t)i * R * 256;
+    int rc = dtype == AXVS_BF16 ? cc_layer_fwd_t<true>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st)
+                                : cc_layer_fwd_t<false>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st);
+    if (rc != AXVS_OK) return rc;
+    cur = nxt;
+    hipStream_t hs = st;
+    if (aux) {
+      hipEvent_t e = module_event(1 + i);
+      if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "event fork failed");
+      hs = aux;
+    }
+    rc = heads(i, cur, hs);
+    if (rc != AXVS_OK) return rc;
+  }
+  if (hipMemcpyAsync(last_query, cur, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(AXVS_ERR_LAUNCH, "copy failed");
+  if (aux) {                                      // join
+    hipEvent_t e = module_event(65);
+    if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "event join failed");
+  }
+  return last_launch_status();
+}
 }  // namespace
 
 // =====================================================================================
@@ -989,6 +1059,67 @@ int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, f
   if (dtype == AXVS_BF16) return cc_heads_fwd_t<true>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
   if (dtype == AXVS_F16) return cc_heads_fwd_t<false>(clip_query, panoptic_features, pred_logits, pred_masks, packed, B, Q, Tc, V, H, W, K1, workspace, st);
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+}
+
+// ---- the whole layer loop of the cross-clip modules in ONE call (CC/...:283-318, TLCC:925-950): the Python host of round 1 made
+//      2 library calls + 3 allocations per layer and became the bottleneck once the kernels were fused (494 us of host time per
+//      forward against ~430 us of GPU time at BASELINE config 4).  The layer chain (trajectory attention -> ASPP -> norms) of layer
+//      i+1 only needs layer i's clip queries, not its predictions: with an auxiliary stream the predictor heads of layer i run
+//      beside the chain of layer i+1 (fork / join with events, capturable into a HIP graph).
+size_t axvs_cc_module_workspace_bytes(int B, int Q, int Tc, int num_layers) {
+  Carver c(nullptr);
+  carve_module_ws(c, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_cc_heads_workspace_bytes(B, Q, Tc), (long long)B * Q * Tc, num_layers);
+  return c.off;
+}
+
+int axvs_cc_module_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks, float* last_query,
+                       const void* const* packed_layers, const void* packed_heads, int num_layers, int B, int Q, int Tc, int V, int H, int W,
+                       int K1, const int* rates, int dtype, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream) {
+  if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !last_query || !packed_layers || !packed_heads || !rates || !workspace)
+    return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (((long long)V * H * W) % 4) return fail(AXVS_ERR_ARG, "V*H*W must be a multiple of 4");
+  if (B * Tc > 1024) return fail(AXVS_ERR_ARG, "B*Tc > 1024 is not supported by the class head");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  if (workspace_bytes < axvs_cc_module_workspace_bytes(B, Q, Tc, num_layers)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  Carver wc(workspace);
+  const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_cc_heads_workspace_bytes(B, Q, Tc), (long long)B * Q * Tc, num_layers);
+  const size_t lstride = (size_t)Q * K1, mstride = (size_t)B * Q * Tc * V * H * W;
+  auto heads = [&](int i, const float* q, hipStream_t hs) {
+    return dtype == AXVS_BF16 ? cc_heads_fwd_t<true>(q, panoptic_features, pred_logits + i * lstride, pred_masks + i * mstride, packed_heads, B, Q, Tc, V, H, W, K1, w.heads, hs)
+                              : cc_heads_fwd_t<false>(q, panoptic_features, pred_logits + i * lstride, pred_masks + i * mstride, packed_heads, B, Q, Tc, V, H, W, K1, w.heads, hs);
+  };
+  return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream),
+                       static_cast<hipStream_t>(aux_stream), heads);
+}
+
+size_t axvs_tl_cc_module_workspace_bytes(int B, int Q, int Tc, int Cm, int num_layers) {
+  Carver c(nullptr);
+  carve_module_ws(c, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm), (long long)B * Q * Tc, num_layers);
+  return c.off;
+}
+
+int axvs_tl_cc_module_fwd(const float* clip_query, const float* mask_feature, float* cls_logits, float* mask_logits, float* last_query,
+                          const void* const* packed_layers, const void* packed_heads, int num_layers, int B, int Q, int Tc, int frames_per_clip,
+                          int h, int w_, int K1, int Cm, const int* rates, int dtype, void* workspace, size_t workspace_bytes, void* stream,
+                          void* aux_stream) {
+  if (!clip_query || !mask_feature || !cls_logits || !mask_logits || !last_query || !packed_layers || !packed_heads || !rates || !workspace)
+    return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w_ <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (Cm != 128 && Cm != 256) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
+  if (((long long)h * w_) % 4) return fail(AXVS_ERR_ARG, "h*w must be a multiple of 4");
+  if (Tc > 1024) return fail(AXVS_ERR_ARG, "more than 1024 clips are not supported by the class head");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  if (workspace_bytes < axvs_tl_cc_module_workspace_bytes(B, Q, Tc, Cm, num_layers)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  Carver wc(workspace);
+  const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm), (long long)B * Q * Tc, num_layers);
+  const size_t lstride = (size_t)B * Q * K1, mstride = (size_t)B * Tc * frames_per_clip * Q * h * w_;
+  auto heads = [&](int i, const float* q, hipStream_t hs) {
+    return dtype == AXVS_BF16 ? tl_heads_fwd_t<true>(q, mask_feature, cls_logits + i * lstride, mask_logits + i * mstride, packed_heads, B, Q, Tc, frames_per_clip, h, w_, K1, Cm, w.heads, hs)
+                              : tl_heads_fwd_t<false>(q, mask_feature, cls_logits + i * lstride, mask_logits + i * mstride, packed_heads, B, Q, Tc, frames_per_clip, h, w_, K1, Cm, w.heads, hs);
+  };
+  return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream),
+                       static_cast<hipStream_t>(aux_stream), heads);
 }
 
 size_t axvs_tl_heads_packed_bytes(int K1, int Cm) {

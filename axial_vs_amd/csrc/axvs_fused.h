@@ -376,7 +376,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
                                                              const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */,
                                                              int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */,
-                                                             int spatial_only = 0 /* measurement: stop after the QK^T / AV half */) {
+                                                             int spatial_only = 0 /* measurement: stop after the QK^T / AV half */,
+                                                             const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
+                                                             const float* __restrict__ ln_b = nullptr) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -786,7 +788,16 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   for (int i = 0; i < RPW; ++i) {
     const int row = wave * RPW + i;
     const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
-    const float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
+    float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
+    if constexpr (!FFN) {
+      if (ln_g) {      // post-norm layer (cross-clip TrajectoryAttentionLayer.forward_post, CC/...:156-161): LayerNorm(x + attn(x)), eps 1e-5
+        const float mu = wave_sum(y.x + y.y + y.z + y.w) * (1.f / C);
+        const float d0 = y.x - mu, d1 = y.y - mu, d2 = y.z - mu, d3 = y.w - mu;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
+        const float4 g = *reinterpret_cast<const float4*>(ln_g + lane * 4), b = *reinterpret_cast<const float4*>(ln_b + lane * 4);
+        y = float4{d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
+      }
+    }
     if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
     else if (row < nvalid) {
       if (wt) WtBuf(out).store16((unsigned)(roff[i] * 4), y);

@@ -186,7 +186,7 @@ struct EpiRowsF32 {
 
 // ---------------- v1 kernel: 64x64 tile, 4 waves (2x2), both operands staged through LDS ----------------
 template <bool BF, class ALoad, class Epi>
-__global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
+__device__ __forceinline__ void gemm64_body(const ALoad& al, const u16* __restrict__ Wp, const Epi& epi, int M, int Nout, int K) {
   __shared__ __attribute__((aligned(16))) u16 sX[2][64 * 32];      // two buffers, used alternately: one barrier per k-step
   __shared__ __attribute__((aligned(16))) u16 sW[2][64 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -256,7 +256,103 @@ __global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __rest
 }
 
 template <bool BF, class ALoad, class Epi>
+__global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
+  gemm64_body<BF>(al, Wp, epi, M, Nout, K);
+}
+
+// ---------------- small problems: one wave per 16 x (16 NT) tile, operands straight from L2 to VGPRs ----------------
+// A GEMM with a few hundred rows (the cross-clip module: 512 clip queries) gives the 64x64 kernel only a handful of workgroups,
+// each walking K in dependent global -> LDS -> barrier -> MFMA steps (~0.5 us per k-step measured).  Here every wave owns a
+// 16-row x 16*NT-column tile and streams its operand fragments with D k-blocks in flight -- both blocked layouts make a fragment
+// 1 KiB contiguous --, no LDS, no barriers; the redundant activation loads of the waves sharing a row tile hit L1 / L2.
+template <bool BF, class ALoad, class Epi, int NT>
+__device__ __forceinline__ void gemm_direct_body(const ALoad& al, const u16* __restrict__ Wp, const Epi& epi, int M, int Nout, int K) {
+  constexpr int D = 8;
+  const int lane = threadIdx.x & 63, fi = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NT;
+  const int nkb = K >> 5;
+  int nrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) nrow[nt] = min(n0 + nt * 16 + fi, Nout - 1);
+  u16x8 xb[D], wa[D][NT];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int k = min(d, nkb - 1) * 32 + fg * 8;
+    xb[d] = al.load(m0 + fi, k);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wa[d][nt] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, nrow[nt], k));
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb0 = 0; kb0 < nkb; kb0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      if (kb0 + u < nkb) {                  // uniform
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = H16<BF>::mfma(wa[u][nt], xb[u], acc[nt]);
+        const int k = min(kb0 + u + D, nkb - 1) * 32 + fg * 8;   // unconditional (clamped) refill of the slot just used
+        xb[u] = al.load(m0 + fi, k);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wa[u][nt] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, nrow[nt], k));
+      }
+    }
+  }
+  const int m = m0 + fi;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 16 + fg * 4;
+    if (m < M && n < Nout) epi.store(m, n, acc[nt]);
+  }
+}
+
+template <bool BF, class ALoad, class Epi, int NT>
+__global__ __launch_bounds__(64) void gemm_direct_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
+  gemm_direct_body<BF, ALoad, Epi, NT>(al, Wp, epi, M, Nout, K);
+}
+
+// 64x64 tiles unless they would leave most of the chip idle
+inline bool gemm_is_small(int M, int Nout, int nb = 1) { return (long long)((M + 63) / 64) * ((Nout + 63) / 64) * nb <= 128; }
+
+// NB independent GEMMs of the same shape in ONE launch (blockIdx.z picks the problem): small dependent-free GEMMs such as the
+// three dilated branches of the temporal ASPP fill the chip together instead of queueing behind each other.
+template <class ALoad, class Epi, int NB>
+struct GemmBatch {
+  ALoad al[NB];
+  const u16* W[NB];
+  Epi epi[NB];
+};
+template <bool BF, class ALoad, class Epi, int NB>
+__global__ __launch_bounds__(256) void gemm64_batched_kernel(GemmBatch<ALoad, Epi, NB> b, int M, int Nout, int K) {
+  const int z = blockIdx.z;
+  gemm64_body<BF>(b.al[z], b.W[z], b.epi[z], M, Nout, K);
+}
+template <bool BF, class ALoad, class Epi, int NB>
+__global__ __launch_bounds__(64) void gemm_direct_batched_kernel(GemmBatch<ALoad, Epi, NB> b, int M, int Nout, int K) {
+  const int z = blockIdx.z;
+  gemm_direct_body<BF, ALoad, Epi, 4>(b.al[z], b.W[z], b.epi[z], M, Nout, K);
+}
+template <bool BF, class ALoad, class Epi, int NB>
+inline void launch_gemm_batched(const GemmBatch<ALoad, Epi, NB>& b, int M, int Nout, int K, hipStream_t st) {
+  if (gemm_is_small(M, Nout, NB)) {
+    dim3 grid((M + 15) / 16, (Nout + 63) / 64, NB);
+    hipLaunchKernelGGL((gemm_direct_batched_kernel<BF, ALoad, Epi, NB>), grid, dim3(64), 0, st, b, M, Nout, K);
+    return;
+  }
+  dim3 grid((M + 63) / 64, (Nout + 63) / 64, NB);
+  hipLaunchKernelGGL((gemm64_batched_kernel<BF, ALoad, Epi, NB>), grid, dim3(256), 0, st, b, M, Nout, K);
+}
+
+template <bool BF, class ALoad, class Epi>
 inline void launch_gemm(const ALoad& al, const u16* Wp, const Epi& epi, int M, int Nout, int K, hipStream_t st) {
+  if (gemm_is_small(M, Nout)) {
+    if ((long long)((M + 15) / 16) * ((Nout + 63) / 64) >= 256) {
+      hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 4>), dim3((M + 15) / 16, (Nout + 63) / 64), dim3(64), 0, st, al, Wp, epi, M, Nout, K);
+    } else {   // narrower tiles: twice the waves
+      hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 2>), dim3((M + 15) / 16, (Nout + 31) / 32), dim3(64), 0, st, al, Wp, epi, M, Nout, K);
+    }
+    return;
+  }
   dim3 grid((M + 63) / 64, (Nout + 63) / 64);
   hipLaunchKernelGGL((gemm64_kernel<BF, ALoad, Epi>), grid, dim3(256), 0, st, al, Wp, epi, M, Nout, K);
 }

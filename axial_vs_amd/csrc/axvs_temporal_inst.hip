@@ -28,7 +28,7 @@ static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* 
   constexpr size_t lds = temporal_lds_bytes<T, MT>();
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS>))) return rc;
   hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
-                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t, wt & 1, wt >> 1);
+                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t, wt & 1, wt >> 1, p.post_ln_g, p.post_ln_b);
   return AXVS_OK;
 }
 
