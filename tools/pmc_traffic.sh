@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --settle-ms 0 > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
