@@ -106,6 +106,8 @@ SIGNATURES = {
     "axvs_linear_sum_assignment": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "axvs_match_embds_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_match_embds": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
+    "axvs_match_clips_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "axvs_match_clips": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, C.c_size_t, _fp]),
     "axvs_add_channel_vector": (C.c_int, [_fp, _fp, C.c_size_t, C.c_int, _fp]),
     "axvs_pos2d": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [C.c_longlong, C.c_longlong, C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_msda_packed_bytes": (C.c_size_t, [C.c_int] * 4),

@@ -1449,14 +1449,23 @@ int axvs_pos2d(float* pos, const float* add, int N, int H, int W, int C, long lo
 }
 
 // ---- clip-to-clip query alignment ----
-static int launch_lsap(const float* cost, long long* col4row, int batch, int n, hipStream_t st) {
+static int launch_lsap(const float* cost, long long* col4row, int batch, int n, hipStream_t st, int chain = 1) {
   const size_t bytes = (size_t)n * n * sizeof(float);
-  if (bytes <= 128 * 1024) {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<true>), 128 * 1024)   /* + static state arrays */) return rc;
-    hipLaunchKernelGGL((lsap_kernel<true>), dim3(batch), dim3(64), bytes, st, cost, col4row, n);
-  } else {
-    hipLaunchKernelGGL((lsap_kernel<false>), dim3(batch), dim3(64), 0, st, cost, col4row, n);
-  }
+  const bool lds = bytes <= 128 * 1024;
+#define AXVS_LSAP(CPL)                                                                                                        \
+  do {                                                                                                                        \
+    if (lds) {                                                                                                                \
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<CPL, true>), 128 * 1024)) return rc;             \
+      hipLaunchKernelGGL((lsap_kernel<CPL, true>), dim3(batch), dim3(64), bytes, st, cost, col4row, n, chain);                \
+    } else {                                                                                                                  \
+      hipLaunchKernelGGL((lsap_kernel<CPL, false>), dim3(batch), dim3(64), 0, st, cost, col4row, n, chain);                   \
+    }                                                                                                                         \
+  } while (0)
+  if (n <= 64) AXVS_LSAP(1);
+  else if (n <= 128) AXVS_LSAP(2);
+  else if (n <= 256) AXVS_LSAP(4);
+  else AXVS_LSAP(8);
+#undef AXVS_LSAP
   return last_launch_status();
 }
 
@@ -1479,6 +1488,25 @@ int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* 
   hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((2 * Q + 3) / 4)), dim3(256), 0, st, tgt_embds, cur_embds, nrm, Q, C);
   hipLaunchKernelGGL(cosine_cost_kernel, dim3((unsigned)((Q * Q + 255) / 256)), dim3(256), 0, st, nrm, cost, Q, C);
   return launch_lsap(cost, indices, 1, Q, st);
+}
+
+// the whole clip-alignment loop of a batch of videos (maxtron_cc_model.py:280-301) in three launches
+size_t axvs_match_clips_workspace_bytes(int V, int Tc, int Q, int C) {
+  return ((size_t)V * Tc * Q * C + (size_t)V * (Tc > 1 ? Tc - 1 : 1) * Q * Q) * sizeof(float);
+}
+
+int axvs_match_clips(const float* mask_embeddings, long long* indices, int V, int Tc, int Q, int C, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (!mask_embeddings || !indices || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (V <= 0 || Tc <= 1 || C <= 0 || Q <= 0 || Q > kLsapMax) return fail(AXVS_ERR_ARG, "need V >= 1, Tc >= 2, Q in 1..%d", kLsapMax);
+  if (workspace_bytes < axvs_match_clips_workspace_bytes(V, Tc, Q, C)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* nrm = static_cast<float*>(workspace);
+  float* cost = nrm + (size_t)V * Tc * Q * C;
+  const long long R = (long long)V * Tc * Q, total = (long long)V * (Tc - 1) * Q * Q;
+  hipLaunchKernelGGL(normalize_rows1_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, mask_embeddings, nrm, R, C);
+  hipLaunchKernelGGL(pair_cost_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nrm, cost, Tc, Q, C, total);
+  return launch_lsap(cost, indices, V, Q, st, Tc - 1);
 }
 
 int axvs_add_channel_vector(float* x, const float* v, size_t n, int C, void* stream) {

@@ -85,80 +85,194 @@ __device__ __forceinline__ LsapCand lsap_wave_best(LsapCand best) {
   return best;
 }
 
-// One wave per assignment problem (blockIdx.x = problem), n x n costs (fp32 -> double), n <= kLsapMax.
-// out[t] = column assigned to row t (int64, like the reference's indices[1]).
+template <int CTRL>
+__device__ __forceinline__ double lsap_dpp_f64(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)b, CTRL, 0xF, 0xF, true);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lsap_wave_min_f64(double x) {
+  x = fmin(x, lsap_dpp_f64<0xB1>(x));
+  x = fmin(x, lsap_dpp_f64<0x4E>(x));
+  x = fmin(x, lsap_dpp_f64<0x141>(x));
+  x = fmin(x, lsap_dpp_f64<0x140>(x));
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  auto rl = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+  auto rh = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+  x = fmin(__builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]), __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]));
+  const unsigned long long b2 = __builtin_bit_cast(unsigned long long, x);
+  rl = __builtin_amdgcn_permlane32_swap((unsigned)b2, (unsigned)b2, false, false);
+  rh = __builtin_amdgcn_permlane32_swap((unsigned)(b2 >> 32), (unsigned)(b2 >> 32), false, false);
+  return fmin(__builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]), __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]));
+}
+__device__ __forceinline__ int lsap_wave_min_i32(int k) {
+  k = min(k, (int)__builtin_amdgcn_update_dpp(0u, (unsigned)k, 0xB1, 0xF, 0xF, true));
+  k = min(k, (int)__builtin_amdgcn_update_dpp(0u, (unsigned)k, 0x4E, 0xF, 0xF, true));
+  k = min(k, (int)__builtin_amdgcn_update_dpp(0u, (unsigned)k, 0x141, 0xF, 0xF, true));
+  k = min(k, (int)__builtin_amdgcn_update_dpp(0u, (unsigned)k, 0x140, 0xF, 0xF, true));
+  auto r = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+  k = min((int)r[0], (int)r[1]);
+  r = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+  return min((int)r[0], (int)r[1]);
+}
+
+// One wave per assignment problem, n x n costs (fp32 -> double), n <= kLsapMax.  out[t] = column assigned to row t (int64, like the
+// reference's indices[1]).
+//
+// Column state lives in REGISTERS: lane l owns columns l, l + 64, ... (CPL per lane): shortest-path cost `spc`, dual `v`,
+// `row4col`, the "removed" flag and -- instead of SciPy's `remaining` array -- the column's current POSITION in that array, which
+// is all the tie rule needs (the scan visits positions in increasing order; removal moves the last position into the freed one,
+// exactly the reference's `remaining[index] = remaining[--num_remaining]`).  Per augmenting step the wave reads one row of the
+// cost matrix and u[i] from LDS, updates its columns, arg-min-reduces on the VALU (DPP / permlane), and finds the winner's column
+// with a ballot + v_readlane: no barrier, no dependent LDS chain through `remaining[it] -> column -> cost / duals` (that chain was
+// ~500 cycles per step in round 1: 275 us at n = 128; now ~120 us).  Row duals `u`, `col4row`, `path` and the master copy of
+// `row4col` stay in LDS (the augmenting walk is a sequential pointer chase by lane 0).
+//
+// `chain` > 1: problems k = 0 .. chain-1 of a batch entry are solved one after the other and problem k's ROWS are taken in the order
+// of problem k-1's result (row t of problem k is row out[k-1][t] of its stored matrix): the clip loop of maxtron_cc_model.py:280-301
+// (`prev = cur[idx]` before the next match) on raw pair-wise cost matrices, in one launch per batch of videos.
 constexpr int kLsapMax = 512;
-// LDS_COST: the cost matrix is copied into dynamic LDS first (n*n*4 bytes <= 128 KiB): every augmenting step reads one row of
-// it, and an L2 round trip per step dominated the run time.
-template <bool LDS_COST>
-__global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost_all, long long* __restrict__ out_all, int n) {
+template <int CPL, bool LDS_COST>
+__global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost_all, long long* __restrict__ out_all, int n, int chain) {
   extern __shared__ float scost[];
-  __shared__ double u[kLsapMax], v[kLsapMax], spc[kLsapMax];
-  __shared__ int path[kLsapMax], row4col[kLsapMax], col4row[kLsapMax], remaining[kLsapMax];
-  __shared__ unsigned char SR[kLsapMax], SC[kLsapMax];
+  __shared__ double u[kLsapMax];
+  __shared__ int path[kLsapMax], row4col_m[kLsapMax], col4row[kLsapMax], rowperm[kLsapMax];
   const int lane = threadIdx.x;
-  const float* gcost = cost_all + (long long)blockIdx.x * n * n;
-  long long* out = out_all + (long long)blockIdx.x * n;
-  if (LDS_COST) {
-    for (int i = lane; i < n * n; i += 64) scost[i] = gcost[i];
-  }
-  const float* cost = LDS_COST ? scost : gcost;
-  for (int i = lane; i < n; i += 64) { u[i] = 0.0; v[i] = 0.0; row4col[i] = -1; col4row[i] = -1; path[i] = -1; }
-  __syncthreads();
   const double INF = __builtin_huge_val();
-  for (int curRow = 0; curRow < n; ++curRow) {
-    // ---- augmenting_path ----
-    double minVal = 0.0;
-    int num_remaining = n;
-    for (int it = lane; it < n; it += 64) { remaining[it] = n - it - 1; SR[it] = 0; SC[it] = 0; spc[it] = INF; }
+  for (int i = lane; i < n; i += 64) rowperm[i] = i;
+  for (int k = 0; k < chain; ++k) {
+    const float* gcost = cost_all + ((long long)blockIdx.x * chain + k) * n * n;
+    long long* out = out_all + ((long long)blockIdx.x * chain + k) * n;
+    __syncthreads();                                   // (one wave: orders the LDS traffic of consecutive problems)
+    if (LDS_COST) {
+      for (int i = lane; i < n * n; i += 64) scost[i] = gcost[i];
+    }
+    const float* cost = LDS_COST ? scost : gcost;
+    for (int i = lane; i < n; i += 64) { u[i] = 0.0; row4col_m[i] = -1; col4row[i] = -1; path[i] = -1; }
+    double v[CPL], spc[CPL];
+    int row4col[CPL], pos[CPL];
+    bool removed[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; row4col[c] = -1; }
     __syncthreads();
-    int sink = -1, i = curRow;
-    while (sink == -1) {
-      if (lane == 0) SR[i] = 1;
-      const double ui = u[i];
-      LsapCand best{INF, 0x7fffffff};
-      for (int it = lane; it < num_remaining; it += 64) {
-        const int j = remaining[it];
-        const double r = minVal + (double)cost[(long long)i * n + j] - ui - v[j];
-        if (r < spc[j]) { path[j] = i; spc[j] = r; }
-        const LsapCand c{spc[j], lsap_key(row4col[j] == -1, it)};
-        if (lsap_better(c, best)) best = c;
+    for (int curRow = 0; curRow < n; ++curRow) {
+      // ---- augmenting_path ----
+      double minVal = 0.0;
+      int num_remaining = n;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int j = lane + 64 * c;
+        pos[c] = n - 1 - j;                            // remaining[it] = n - it - 1
+        removed[c] = j >= n;
+        spc[c] = INF;
       }
-      best = lsap_wave_best(best);
-      minVal = best.v;
-      if (minVal == INF) { sink = -2; break; }                 // infeasible (cannot happen with finite costs)
-      const int index = best.k2 < 0 ? -1 - best.k2 : best.k2;
-      const int j = remaining[index];
-      __syncthreads();                                          // every lane has read remaining[index]
-      if (row4col[j] == -1) sink = j; else i = row4col[j];
-      if (lane == 0) { SC[j] = 1; remaining[index] = remaining[num_remaining - 1]; }
-      --num_remaining;
+      int sink = -1, i = curRow;
+      while (sink == -1) {
+        const double ui = u[i];
+        const float* crow = cost + (long long)rowperm[i] * n;
+        LsapCand best{INF, 0x7fffffff};
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          const int j = lane + 64 * c;
+          if (!removed[c]) {
+            const double r = minVal + (double)crow[j] - ui - v[c];
+            if (r < spc[c]) { path[j] = i; spc[c] = r; }
+            const LsapCand cand{spc[c], lsap_key(row4col[c] == -1, pos[c])};
+            if (lsap_better(cand, best)) best = cand;
+          }
+        }
+        // two-phase arg-min: the minimum value first (v_min_f64 butterflies), then the smallest tie key among the lanes that hold it
+        // (32-bit butterflies) -- about half the instructions of reducing (value, key) pairs together
+        minVal = lsap_wave_min_f64(best.v);
+        if (minVal == INF) { sink = -2; break; }       // infeasible (cannot happen with finite costs)
+        const int k2 = lsap_wave_min_i32(best.v == minVal ? best.k2 : 0x7fffffff);
+        const int index = k2 < 0 ? -1 - k2 : k2;
+        // the winner is the live column at position `index`; the column at the last position moves into it
+        int wj = -1, wr = -1;
+        const int last = num_remaining - 1;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          if (!removed[c]) {
+            if (pos[c] == index) { wj = lane + 64 * c; wr = row4col[c]; removed[c] = true; }
+            else if (pos[c] == last) pos[c] = index;
+          }
+        }
+        const unsigned long long m = __ballot(wj >= 0);
+        const int wl = __builtin_ctzll(m);
+        const int j = __builtin_amdgcn_readlane(wj, wl);
+        const int r4c = __builtin_amdgcn_readlane(wr, wl);
+        if (r4c == -1) sink = j; else i = r4c;
+        --num_remaining;
+      }
+      if (sink < 0) break;
+      // ---- update the dual variables: visited rows are curRow and row4col[j] of the visited columns j != sink ----
+      if (lane == 0) u[curRow] += minVal;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int j = lane + 64 * c;
+        if (removed[c] && j < n) {
+          if (j != sink) u[row4col[c]] += minVal - spc[c];
+          v[c] -= minVal - spc[c];
+        }
+      }
       __syncthreads();
-    }
-    if (sink < 0) break;
-    // ---- update the dual variables ----
-    if (lane == 0) u[curRow] += minVal;
-    __syncthreads();
-    for (int r = lane; r < n; r += 64)
-      if (SR[r] && r != curRow) u[r] += minVal - spc[col4row[r]];
-    for (int c = lane; c < n; c += 64)
-      if (SC[c]) v[c] -= minVal - spc[c];
-    __syncthreads();
-    // ---- augment the previous solution ----
-    if (lane == 0) {
-      int j = sink;
-      while (true) {
-        const int r = path[j];
-        row4col[j] = r;
-        const int t = col4row[r];
-        col4row[r] = j;
-        j = t;
-        if (r == curRow) break;
+      // ---- augment the previous solution ----
+      if (lane == 0) {
+        int j = sink;
+        while (true) {
+          const int r = path[j];
+          row4col_m[j] = r;
+          const int t = col4row[r];
+          col4row[r] = j;
+          j = t;
+          if (r == curRow) break;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int j = lane + 64 * c;
+        if (j < n) row4col[c] = row4col_m[j];
       }
     }
     __syncthreads();
+    for (int r = lane; r < n; r += 64) out[r] = col4row[r];
+    if (k + 1 < chain) {                               // next problem: rows in the order of this result (prev = cur[idx])
+      for (int r = lane; r < n; r += 64) rowperm[r] = col4row[r];
+    }
   }
-  for (int r = lane; r < n; r += 64) out[r] = col4row[r];
+}
+
+// raw pair-wise cosine costs of consecutive clips: cost[v][i][s][j] = 1 - <e[v][i][s], e[v][i+1][j]> on row-normalised embeddings
+// e [V][Tc][Q][C]; the same sequential fp32 dot as cosine_cost_kernel (so the values equal the per-pair path's bit for bit)
+__global__ __launch_bounds__(256) void pair_cost_kernel(const float* __restrict__ nrm, float* __restrict__ cost, int Tc, int Q, int C,
+                                                        long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % Q);
+  long long r = idx / Q;
+  const int s = (int)(r % Q);
+  r /= Q;
+  const int i = (int)(r % (Tc - 1));
+  const long long vid = r / (Tc - 1);
+  const float* a = nrm + ((vid * Tc + i) * Q + s) * C;
+  const float* b = nrm + ((vid * Tc + i + 1) * Q + j) * C;
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) dot += b[c] * a[c];
+  cost[idx] = 1.f - dot;
+}
+
+// rows of x [R][C] divided by their norm (`x / x.norm(dim=1)[:, None]`), one wave per row
+__global__ __launch_bounds__(256) void normalize_rows1_kernel(const float* __restrict__ x_all, float* __restrict__ out, long long R, int C) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* x = x_all + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += x[c] * x[c];
+  const float nrm = sqrtf(wave_sum(s));
+  for (int c = lane; c < C; c += 64) out[row * C + c] = x[c] / nrm;
 }
 
 }  // namespace axvs

@@ -50,14 +50,16 @@ def match_clips(pred_mask_embeddings: Tensor, pred_cluster_centers: Tensor) -> T
     """maxtron_cc_model.py:280-301: per video, align the queries of clip i to the already aligned clip i-1 by their mask
     embeddings and carry the cluster centres along.  pred_mask_embeddings / pred_cluster_centers [B, Tc, Q, C*] ->
     matched cluster centres [B, Q, Tc, C] (the `clip_query` input of CrossClipTrackingModule)."""
-    B, Tc = pred_mask_embeddings.shape[:2]
-    videos = []
-    for b in range(B):
-        prev = pred_mask_embeddings[b, 0]
-        centers = [pred_cluster_centers[b, 0]]
-        for i in range(1, Tc):
-            idx = match_from_embds(prev, pred_mask_embeddings[b, i])
-            prev = pred_mask_embeddings[b, i].index_select(0, idx)
-            centers.append(pred_cluster_centers[b, i].index_select(0, idx))
-        videos.append(torch.stack(centers, dim=1))
-    return torch.stack(videos, dim=0)
+    emb = _dev_f32(pred_mask_embeddings, "pred_mask_embeddings")
+    cen = pred_cluster_centers
+    B, Tc, Q, Cc = emb.shape
+    if Tc == 1:
+        return cen.permute(0, 2, 1, 3).contiguous()
+    L = _lib.lib()
+    ws = _workspace(emb.device, L.axvs_match_clips_workspace_bytes(B, Tc, Q, Cc))
+    idx = torch.empty(B, Tc - 1, Q, dtype=torch.int64, device=emb.device)
+    _lib.check(L.axvs_match_clips(emb.data_ptr(), idx.data_ptr(), B, Tc, Q, Cc, ws.data_ptr(), ws.numel(), _stream(emb.device)),
+               "axvs_match_clips")
+    # carry the cluster centres along: clip 0 as is, clip i permuted by its alignment (plumbing: one gather)
+    aligned = torch.cat([cen[:, :1], torch.gather(cen[:, 1:], 2, idx[..., None].expand(-1, -1, -1, cen.shape[-1]))], dim=1)
+    return aligned.permute(0, 2, 1, 3).contiguous()

@@ -289,6 +289,12 @@ int axvs_linear_sum_assignment(const float* cost, long long* col4row, int batch,
 size_t axvs_match_embds_workspace_bytes(int Q, int C);
 int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* indices, int Q, int C, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* The per-video clip loop of maxtron_cc_model.py:280-301 for a batch of videos in three launches:
+ *   prev = e[v,0];  for i in 1..Tc-1:  idx = match_from_embds(prev, e[v,i]);  prev = e[v,i][idx];  indices[v,i-1,:] = idx
+ * mask_embeddings fp32 [V,Tc,Q,C]; indices int64 [V,Tc-1,Q] (the permutation that aligns clip i to the aligned clip i-1). */
+size_t axvs_match_clips_workspace_bytes(int V, int Tc, int Q, int C);
+int axvs_match_clips(const float* mask_embeddings, long long* indices, int V, int Tc, int Q, int C, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---- PositionEmbeddingSine3D.forward(x, mask=None) in channels-last form
  *      WC/pos_embeddings.py:86-130: pos fp32 [B,T,H,W,C], C = 2*num_pos_feats. */
