@@ -28,6 +28,7 @@ constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
+thread_local int* g_status = nullptr;     // axvs_set_status_buffer: device word that kernels OR condition bits into
 thread_local int g_spatial_only = 0;     // option "spatial_only": the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
@@ -275,7 +276,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
       hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3((unsigned)((Mp + 63) / 64)), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
                          p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e,
                          fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{},
-                         (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0);
+                         (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0, g_status);
       goto qkv_done;
     }
   }
@@ -794,6 +795,11 @@ int axvs_set_option(const char* key, int value) {
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }
+
+int axvs_set_status_buffer(int* device_word) {
+  g_status = device_word;
+  return AXVS_OK;
+}
 
 size_t axvs_traj_packed_bytes(int C, int heads) {
   Carver c(nullptr);

@@ -844,7 +844,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ bk, const float* __restrict__ bv,
                                                         u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
                                                         long long Mp, float qscale, u16* __restrict__ VT16, int N, int L, int T,
-                                                        int NKS, PosGen pg, int wt /* write-through q/k/V^T stores (offsets < 4 GiB) */) {
+                                                        int NKS, PosGen pg, int wt /* write-through q/k/V^T stores (offsets < 4 GiB) */,
+                                                        int* __restrict__ status /* nullable: bit 0 <- an operand left the fp16 range */) {
   constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* tqk = smem;                       // (src + pos) tile [8][64][32]
@@ -878,6 +879,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
     }
     PosGenLane pl;
     if (pg.mode) pl.init(pg, c4 * 4);
+    float amax = 0.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float4 a[4], p[4];
@@ -896,9 +898,15 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
         const int o = (kb * ROWS + row) * 32 + swz_chunk(row, k >> 3) * 8 + (k & 7);
         *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{a[i].x, a[i].y, a[i].z, a[i].w});
         *reinterpret_cast<u16x4*>(tqk + o) = cvt4<BF>(f32x4{a[i].x + p[i].x, a[i].y + p[i].y, a[i].z + p[i].z, a[i].w + p[i].w});
+        if (!BF) {     // fp16 operands: remember the largest magnitude that gets rounded (range check below)
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[i].x), fabsf(a[i].y)), fmaxf(fabsf(a[i].z), fabsf(a[i].w))));
+          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[i].x + p[i].x), fabsf(a[i].y + p[i].y)), fmaxf(fabsf(a[i].z + p[i].z), fabsf(a[i].w + p[i].w))));
+        }
       }
       lds_fence();
     }
+    // a value beyond the fp16 range (or a NaN) would silently become inf in the MFMA operands: report it (axvs_set_status_buffer)
+    if (!BF && status != nullptr && !(amax <= 65504.f)) atomicOr(status, 1);
   }
   if (tid < C) {
     sbias[tid] = bias3[0];

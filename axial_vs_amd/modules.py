@@ -163,6 +163,39 @@ def _sine_tag(pos: Tensor) -> Optional[SineTag]:
     return tag
 
 
+_status_words: Dict[str, Tensor] = {}
+
+
+def enable_range_check(device="cuda") -> None:
+    """Register a device status word with libaxvs: the fused q/k/v loaders then flag operands outside the fp16 range (the f16
+    operand mode would turn them into inf silently).  Asynchronous -- read it with `range_check_report()`."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    w = _status_words.get(str(dev))
+    if w is None:
+        w = _status_words[str(dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().axvs_set_status_buffer(w.data_ptr()), "axvs_set_status_buffer")
+
+
+def range_check_report(device="cuda", reset: bool = True) -> bool:
+    """True if a fused loader saw an operand beyond the fp16 range since the last reset (synchronises the device)."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    w = _status_words.get(str(dev))
+    if w is None:
+        raise RuntimeError("axial_vs_amd: call enable_range_check() first")
+    hit = bool(int(w.item()) & 1)
+    if reset:
+        w.zero_()
+    return hit
+
+
+def disable_range_check() -> None:
+    _lib.check(_lib.lib().axvs_set_status_buffer(None), "axvs_set_status_buffer")
+
+
 def _traj_struct(m: "TrajectoryAttention", keep: list) -> _lib.AxvsTrajParams:
     C_ = m.proj.weight.shape[0]
     if hasattr(m, "qkv"):  # cross-clip flavour: slices of the fused projection

@@ -101,6 +101,26 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         return output, h_attn, w_attn
 
 
+class TemporalTransformerEncoder(nn.Module):
+    """Temporal-only stage loop (WC/msdeformattn.py:276-290): per stage, the temporal encoder on the coarsest levels; the other
+    levels pass through.  Works on the concatenated [BT, S, C] token buffer like the spatial + temporal encoder."""
+
+    def __init__(self, temporal_layer, num_stages, transformer_num_temporal_feature_levels=2):
+        super().__init__()
+        self.temporal_layers = _get_clones(temporal_layer, num_stages)
+        self.transformer_num_temporal_feature_levels = transformer_num_temporal_feature_levels
+
+    @_guarded
+    def forward(self, src, spatial_shapes, pos_3d):
+        sizes = [h * w for h, w in spatial_shapes]
+        parts = list(torch.split(src, sizes, dim=1))
+        h_attn = w_attn = None
+        for temporal_layer in self.temporal_layers:
+            for j in range(self.transformer_num_temporal_feature_levels):
+                parts[j], h_attn, w_attn = temporal_layer(src=parts[j].contiguous(), pos=pos_3d[j])
+        return torch.cat(parts, dim=1), h_attn, w_attn
+
+
 class MSDeformAttnTransformerEncoderOnly(nn.Module):
     def __init__(self, d_model=256, nhead=8, num_stages=2, num_spatial_layers=2, num_temporal_layers=4,
                  temporal_attn_type="axial_trajectory", dim_feedforward=1024, dropout=0.1, attn_drop=0.1, activation="relu",
@@ -109,19 +129,22 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         self.d_model, self.nhead = d_model, nhead
         self.num_spatial_layers, self.num_temporal_layers = num_spatial_layers, num_temporal_layers
         assert num_spatial_layers + num_temporal_layers > 0, "number of layers should be greater than 0"
-        if num_spatial_layers == 0:
-            raise NotImplementedError("axial_vs_amd: temporal-only decoders (TemporalTransformerEncoder) are not built")
-        assert num_spatial_layers == num_stages, "number of spatial layers should be equal to number of stages"
-        spatial_layer = MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation, num_spatial_feature_levels,
-                                                            nhead, enc_n_points)
+        if num_spatial_layers > 0:
+            assert num_spatial_layers == num_stages, "number of spatial layers should be equal to number of stages"
+            spatial_layer = MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation, num_spatial_feature_levels,
+                                                                nhead, enc_n_points)
         if num_temporal_layers > 0:
             temporal_layer = TemporalEncoder(d_model, dim_feedforward, dropout, attn_drop, activation, nhead, temporal_attn_type,
                                              num_temporal_layers // num_stages)
+        if num_spatial_layers > 0 and num_temporal_layers > 0:
             self.encoder = MSDeformAttnTransformerEncoder(spatial_layer, num_spatial_layers, num_spatial_feature_levels,
                                                           num_temporal_feature_levels, temporal_layer)
-        else:
+        elif num_spatial_layers > 0:
             self.encoder = MSDeformAttnTransformerEncoder(spatial_layer, num_spatial_layers, num_spatial_feature_levels)
-        self.level_embed_2d = nn.Parameter(torch.Tensor(num_spatial_feature_levels, d_model))
+        else:                                                                   # temporal-only decoder (WC/msdeformattn.py:59-61)
+            self.encoder = TemporalTransformerEncoder(temporal_layer, num_stages, num_temporal_feature_levels)
+        if num_spatial_layers > 0:
+            self.level_embed_2d = nn.Parameter(torch.Tensor(num_spatial_feature_levels, d_model))
         if num_temporal_layers > 0:
             self.level_embed_3d = nn.Parameter(torch.Tensor(num_temporal_feature_levels, d_model))
         self._reset_parameters()
@@ -133,7 +156,8 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         for m in self.modules():
             if isinstance(m, MSDeformAttn):
                 m._reset_parameters()
-        nn.init.normal_(self.level_embed_2d)
+        if self.num_spatial_layers > 0:
+            nn.init.normal_(self.level_embed_2d)
         if self.num_temporal_layers > 0:
             nn.init.normal_(self.level_embed_3d)
 
@@ -225,23 +249,28 @@ class MSDeformAttnPixelDecoder(nn.Module):
         dt = _lib.DTYPES[self._dtype()]
         st = _stream(dev)
         pin, pout = self._pack_projs()
+        spatial = self.transformer.num_spatial_layers > 0
         src = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev)
-        pos = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev)
+        pos = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev) if spatial else None
         wsb = max(L.axvs_conv1x1_gn_workspace_bytes(BT, hw, max(Cd, x.shape[1]), 32) for hw, x in zip(sizes, xs))
         ws = _workspace(dev, wsb)
-        lvl2d = _dev_f32(self.transformer.level_embed_2d.detach(), "level_embed_2d")
+        lvl2d = _dev_f32(self.transformer.level_embed_2d.detach(), "level_embed_2d") if spatial else None
         pos_3d = []
         row0 = 0
         for idx, (f, x) in enumerate(zip(order, xs)):
             H, W = shapes[idx]
             _lib.check(L.axvs_conv1x1_gn_fwd(x.data_ptr(), 0, 0, 0, src.data_ptr() + row0 * Cd * 4, 1, S * Cd, Cd, pin[idx].data_ptr(), BT,
                                              H * W, x.shape[1], Cd, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
-            self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
+            if spatial:
+                self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
             if self.transformer_temporal_layers > 0 and f in self.transformer_temporal_in_features:
                 lvl3d = _dev_f32(self.transformer.level_embed_3d.detach(), "level_embed_3d")
                 pos_3d.append(self.pe_layer_3d.channels_last_with_level(B, T, H, W, lvl3d[len(pos_3d)]))
             row0 += H * W
-        y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, pos, None, pos_3d)
+        if spatial:
+            y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, pos, None, pos_3d)
+        else:                                                           # temporal-only decoder (WC/msdeformattn.py:152-170)
+            y, h_attn, w_attn = self.transformer.encoder(src, shapes, pos_3d)
         out = {}
         row0 = 0
         for i, f in enumerate(order):

@@ -60,6 +60,13 @@ typedef struct AxvsAxialLayerParams {
 int axvs_version(void);
 const char* axvs_last_error(void);
 
+/* Asynchronous condition bits.  The entry points never synchronise, so conditions only a kernel can see are OR-ed into a device
+ * word the caller registers (per calling thread; NULL disables) and reads back when it likes:
+ *   bit 0  AXVS_STATUS_FP16_RANGE: a q/k/v operand of the C = 256 fused kernels (src or src + pos) exceeded the fp16 range
+ *          (|x| > 65504) or was NaN -- with f16 MFMA operands the result would silently contain inf / NaN; use AXVS_BF16. */
+#define AXVS_STATUS_FP16_RANGE 1
+int axvs_set_status_buffer(int* device_word);
+
 /* ---- optional per-stage timing of axvs_axial_layer_fwd (used by bench.py; thread-local).
  *      events: array of `capacity` hipEvent_t created by the caller, or NULL to switch off.  While set, the layer
  *      records events[i] on its stream after stage i (events[0] at entry).  Returns the maximum stage count;

@@ -509,10 +509,11 @@ def conv1x1_group_norm(x: Tensor, w: Weights, name: str, groups: int = 32, eps: 
 
 def pixel_decoder(features: Dict[str, Tensor], w: Weights, spatial_in: Sequence[str], temporal_in: Sequence[str], num_stages: int,
                   temporal_layers_per_stage: int, heads: int = 8, n_points: int = 4, num_clip_frames: int = 1,
-                  B: int = 1, trace: Optional[list] = None) -> Dict[str, Tensor]:
+                  B: int = 1, trace: Optional[list] = None, with_spatial: bool = True) -> Dict[str, Tensor]:
     """MSDeformAttnPixelDecoder.forward_features (WC/msdeformattn.py:404-437) with spatial and temporal layers in every stage.
     `trace` (a list) receives ("setup", {pos, pos3d, ref, shapes, order}, src) and then (tag, input, output) of every stage's
     spatial layer and temporal encoders -- the teacher inputs of the per-stage parity tests.
+    `with_spatial` False: the temporal-only decoder (SPATIAL_LAYERS 0: TemporalTransformerEncoder, WC/msdeformattn.py:276-290).
     `spatial_in` / `temporal_in`: feature names sorted by stride (high resolution first), as the constructor sorts them (:344-349).
     features[name]: [(B T), C_l, H_l, W_l].  Returns {name: [(B T), C_l, H_l, W_l]}."""
     order = list(spatial_in)[::-1]                                    # low -> high resolution (:411)
@@ -527,12 +528,13 @@ def pixel_decoder(features: Dict[str, Tensor], w: Weights, spatial_in: Sequence[
         _, _, H, W = y.shape
         shapes.append((H, W))
         srcs.append(y.flatten(2).transpose(1, 2))                     # [(B T), HW, C]
-        poss.append(pos_embed_sine_2d(BT, H, W, C // 2, dtype=x.dtype).reshape(BT, H * W, C)
-                    + w["transformer.level_embed_2d"][idx].view(1, 1, -1))
+        if with_spatial:
+            poss.append(pos_embed_sine_2d(BT, H, W, C // 2, dtype=x.dtype).reshape(BT, H * W, C)
+                        + w["transformer.level_embed_2d"][idx].view(1, 1, -1))
         if f in temporal_in:
             pos3d.append(pos_embed_sine_3d(B, T, H, W, C // 2, dtype=x.dtype) + w["transformer.level_embed_3d"][len(pos3d)].view(1, 1, 1, 1, -1))
     src = torch.cat(srcs, 1)
-    pos = torch.cat(poss, 1)
+    pos = torch.cat(poss, 1) if with_spatial else None
     refs = []
     for (H, W) in shapes:                                             # get_reference_points, valid ratios = 1 (:229-242)
         ys = (torch.arange(H, dtype=src.dtype) + 0.5) / H
@@ -544,10 +546,11 @@ def pixel_decoder(features: Dict[str, Tensor], w: Weights, spatial_in: Sequence[
     if trace is not None:
         trace.append(("setup", dict(pos=pos, pos3d=pos3d, ref=ref, shapes=shapes, order=order), src))
     for s_i in range(num_stages):                                     # :247-266
-        x_in = out
-        out = msda_encoder_layer(out, pos, ref, shapes, _sub(w, f"transformer.encoder.spatial_layers.{s_i}"), heads, L, n_points)
-        if trace is not None:
-            trace.append((f"s{s_i}_spatial", x_in, out))
+        if with_spatial:
+            x_in = out
+            out = msda_encoder_layer(out, pos, ref, shapes, _sub(w, f"transformer.encoder.spatial_layers.{s_i}"), heads, L, n_points)
+            if trace is not None:
+                trace.append((f"s{s_i}_spatial", x_in, out))
         parts = list(torch.split(out, sizes, dim=1))
         for i in range(Lt):
             x_in = parts[i]

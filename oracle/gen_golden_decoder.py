@@ -24,9 +24,11 @@ def main():
     ms = gen_golden._load(WC + ".msdeformattn")
     ShapeSpec = sys.modules["detectron2.layers"].ShapeSpec
     only_full = "--full-only" in sys.argv
-    for (B, T, chans, sizes, stages, tl, seed, dffn, store_all) in [
+    for (B, T, chans, sizes, stages, tl, seed, dffn, store_all, *rest) in [
             (1, 2, {"res3": 64, "res4": 96, "res5": 128}, {"res3": (16, 16), "res4": (8, 8), "res5": (4, 4)}, 2, 2, 81, 512, True),   # toy sizes: every output stored whole
             (1, 3, {"res3": 32, "res4": 64, "res5": 64}, {"res3": (12, 20), "res4": (6, 10), "res5": (3, 5)}, 1, 2, 82, 512, True),
+            # temporal-only decoder (SPATIAL_LAYERS 0 -> TemporalTransformerEncoder, WC/msdeformattn.py:59-61,276-290)
+            (1, 2, {"res3": 32, "res4": 64, "res5": 96}, {"res3": (16, 24), "res4": (8, 12), "res5": (4, 6)}, 2, 1, 84, 256, True, "temporal_only"),
             # BASELINE config 3 at full size: ConvNeXt-T pyramid of a 512 x 512 clip of T = 4 frames, the shipped
             # stage layout (NUM_STAGES 2, SPATIAL_LAYERS 2, TEMPORAL_LAYERS 4: configs/VIPSeg/.../maxtron_wc_*.yaml), d_ffn 1024.
             # Outputs are stored as strided subsamples + float64 checksums; so are the outputs of every stage's spatial layer and
@@ -34,11 +36,14 @@ def main():
             (1, 4, {"res3": 192, "res4": 384, "res5": 768}, {"res3": (64, 64), "res4": (32, 32), "res5": (16, 16)}, 2, 2, 83, 1024, False)]:
         if only_full and store_all:
             continue
+        temporal_only = "temporal_only" in rest
+        if "--temporal-only" in sys.argv and not temporal_only:
+            continue
         strides = {"res3": 8, "res4": 16, "res5": 32}
         shape = {k: ShapeSpec(channels=c, stride=strides[k]) for k, c in chans.items()}
         m = ms.MSDeformAttnPixelDecoder(shape, transformer_dropout=0.0, transformer_attn_drop=0.0, transformer_nheads=8,
                                         transformer_dim_feedforward=dffn, transformer_num_stages=stages,
-                                        transformer_spatial_layers=stages, transformer_temporal_layers=stages * tl,
+                                        transformer_spatial_layers=0 if temporal_only else stages, transformer_temporal_layers=stages * tl,
                                         transformer_temporal_attn_type="axial-trajectory", conv_dims=256,
                                         transformer_spatial_in_features=["res3", "res4", "res5"],
                                         transformer_temporal_in_features=["res4", "res5"], num_clip_frames=T,
@@ -56,10 +61,12 @@ def main():
             out, _, _ = m.forward_features({k: v.clone() for k, v in feats.items()})
         mt = dict(B=B, T=T, chans=chans, sizes=sizes, stages=stages, temporal_per_stage=tl, d_ffn=dffn, seed=seed, shapes=shp)
         arrs = dict(wsum=np.float64(wsum(w)))
+        if temporal_only:
+            mt["temporal_only"] = True
         if store_all:
             for k, v in out.items():
                 arrs["out_" + k] = v
-            name = f"g8_pixel_decoder_T{T}_S{stages}"
+            name = f"g8_pixel_decoder_T{T}_S{stages}" + ("_temporal_only" if temporal_only else "")
         else:
             sub = {"res3": 8, "res4": 4, "res5": 2}            # spatial stride of the stored subsample (every 4th channel)
             mt.update(sub=sub, csub=4, full_size=True)

@@ -153,7 +153,7 @@ def _decoder_from_meta(m, cross_clip_training=False):
     return ax.WithinClipTrackingModule(
         {k: Shape(c, strides[k]) for k, c in m["chans"].items()}, transformer_dropout=0.0, transformer_attn_drop=0.0,
         transformer_nheads=8, transformer_dim_feedforward=m["d_ffn"], transformer_num_stages=m["stages"],
-        transformer_spatial_layers=m["stages"], transformer_temporal_layers=m["stages"] * m["temporal_per_stage"],
+        transformer_spatial_layers=0 if m.get("temporal_only") else m["stages"], transformer_temporal_layers=m["stages"] * m["temporal_per_stage"],
         transformer_temporal_attn_type="axial-trajectory", transformer_conv_dims=256,
         transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
         num_clip_frames=m["T"], cross_clip_training=cross_clip_training)

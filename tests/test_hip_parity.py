@@ -555,6 +555,33 @@ def test_tube_link_plugin_golden(name):
     np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=2e-3)
 
 
+def test_fp16_range_check():
+    """Inputs beyond the fp16 range cannot be represented by the f16 MFMA operands: the fused q/k/v loader reports them through
+    the status word (asynchronously, no sync in the forward); in-range inputs do not trip it; bf16 operands are unaffected."""
+    import axial_vs_amd as ax
+    C, F = 256, 512
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 61)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    src, pos = orc.synthetic_clip(1, 2, C, 16, 16, 61)
+    ax.enable_range_check()
+    try:
+        out = layer(dev(src), dev(pos))[0]
+        assert not ax.range_check_report() and torch.isfinite(out).all()
+        big = src.clone()
+        big[1, 77, 5] = 1.0e5
+        out = layer(dev(big), dev(pos))[0]
+        assert ax.range_check_report()                       # reported ...
+        assert not ax.range_check_report()                   # ... and reset
+        layer_bf = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8, mfma_dtype="bf16").eval()
+        layer_bf.load_state_dict(w, strict=True)
+        out = layer_bf.cuda()(dev(big), dev(pos))[0]
+        assert not ax.range_check_report() and torch.isfinite(out).all()
+    finally:
+        ax.disable_range_check()
+
+
 def test_graphed_forward_matches_eager():
     """The whole forward is capturable into a HIP graph (no allocation / sync inside the library): replay == eager, bitwise,
     also after the inputs change."""
@@ -572,7 +599,7 @@ def test_graphed_forward_matches_eager():
     assert torch.equal(out2, layer(dev(src2), dev(pos))[0])
 
 
-@pytest.mark.parametrize("name", ["g8_pixel_decoder_T2_S2", "g8_pixel_decoder_T3_S1"])
+@pytest.mark.parametrize("name", ["g8_pixel_decoder_T2_S2", "g8_pixel_decoder_T3_S1", "g8_pixel_decoder_T2_S2_temporal_only"])
 def test_within_clip_module_golden(name):
     """WithinClipTrackingModule.forward_features (the registry hook of SURVEY 8b): NCHW backbone maps -> 1x1 conv + GroupNorm ->
     stages of deformable spatial layer + axial-trajectory temporal layers -> 1x1 conv + GroupNorm -> NCHW maps, against the

@@ -164,7 +164,7 @@ def test_msda_encoder_layer(name):
     assert rel_err(out, t(z["out"])) < 5e-5
 
 
-PIXEL_DECODER = ["g8_pixel_decoder_T2_S2", "g8_pixel_decoder_T3_S1"]
+PIXEL_DECODER = ["g8_pixel_decoder_T2_S2", "g8_pixel_decoder_T3_S1", "g8_pixel_decoder_T2_S2_temporal_only"]
 
 
 def decoder_inputs(m):
@@ -179,7 +179,7 @@ def test_pixel_decoder(name):
     z, m = load(name)
     w = weights(z, m)
     out = orc.pixel_decoder(decoder_inputs(m), w, ["res3", "res4", "res5"], ["res4", "res5"], m["stages"], m["temporal_per_stage"],
-                            B=m["B"])
+                            B=m["B"], with_spatial=not m.get("temporal_only", False))
     for k in m["chans"]:
         assert rel_err(out[k], t(z["out_" + k])) < 2e-4, k
 
