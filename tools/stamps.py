@@ -27,3 +27,13 @@ d = np.diff(a, axis=0)
 print("per-phase cycles (s_memtime ticks = shader cycles... 100MHz const clock on some parts), median over 64 waves:")
 for i in range(nslots - 1): print(f"  phase {order[i]}->{order[i+1]}: median {int(np.median(d[i])):8d}  min {int(d[i].min()):8d}  max {int(d[i].max()):8d}")
 print("  total", int(np.median(a[nslots-1] - a[0])))
+if os.environ.get("AXVS_STAMPS_JSON"):
+    import json
+    path = os.environ["AXVS_STAMPS_JSON"]
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[os.environ.get("AXVS_STAMPS_TAG", "kernel")] = {
+        "phases": [{"from": order[i], "to": order[i + 1], "median_cycles": int(np.median(d[i])), "min": int(d[i].min()), "max": int(d[i].max())}
+                   for i in range(nslots - 1)],
+        "total_median_cycles": int(np.median(a[nslots - 1] - a[0])), "waves": 64,
+        "note": "s_memtime stamps (shader cycles) of workgroups 0-7, all 8 waves; -DAXVS_STAMPS diagnostic build"}
+    json.dump(doc, open(path, "w"), indent=1)
