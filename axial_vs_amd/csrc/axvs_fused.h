@@ -113,6 +113,26 @@ __device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __re
 // place, norm2 is applied per whole row on the way out.
 // LDS: xtile 65 KiB fp32 | ytile 32 KiB | htile 32 KiB (single buffer: 2 barriers per 256-unit chunk) | parameters.
 // =====================================================================================================
+// diagnostic builds (-DAXVS_STAMPS -DAXVS_STAMPS_FFN): phase stamps INSIDE ffn_body instead of the enclosing kernel's
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFN)
+#define FSTAMP_DECL unsigned long long fst_[16] = {}
+#define FSTAMP(s)                                                                          \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fst_[s])::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+#define FSTAMP_FLUSH(n)                                                                    \
+  do {                                                                                     \
+    if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)                                         \
+      for (int i_ = 0; i_ < (n); ++i_) ::axvs::g_stamps[i_ * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = fst_[i_]; \
+  } while (0)
+#else
+#define FSTAMP_DECL
+#define FSTAMP(s)
+#define FSTAMP_FLUSH(n)
+#endif
+
 struct FfnLds {
   float* xtile;   // [64][kEpiLd] fp32
   u16* ytile;     // [8][64][32]
@@ -156,6 +176,8 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
   const float *sg1 = sb2 + C, *sbe1 = sb2 + 2 * C, *sg2 = sb2 + 3 * C, *sbe2 = sb2 + 4 * C;
   const int nchunk = F / 256;
   u16x8 w2f[2][KB];
+  FSTAMP_DECL;
+  FSTAMP(0);
 
   // ---- norm1, row-wise: y (fp32) back into xtile, y (16-bit) into ytile ----
   {
@@ -173,7 +195,9 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
       if (rr == 3) lds_fence();
     }
   }
+  FSTAMP(1);
   __syncthreads();
+  FSTAMP(2);
 
   f32x4 acc2[2][4];
 #pragma unroll
@@ -191,6 +215,7 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     gemm_phase_pf<BF, 2, 4, KB, 2>(acc1, w1f, l.ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot);
+    if (ci == 0) FSTAMP(3);
     if (ci > 0) __syncthreads();                         // every wave is done reading the previous chunk's h
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -204,11 +229,17 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
         act_store4<BF>(l.htile, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
       }
     }
+    if (ci == 0) FSTAMP(4);
     __syncthreads();
+    if (ci == 0) FSTAMP(5);
     // ---- linear2 partial: += W2[my 32 channels, chunk] . h ; meanwhile fetch the next chunk's linear1 fragments
     //      (unconditional: the last iteration re-loads its own chunk, which keeps the vmcnt bookkeeping branch-free) ----
     gemm_phase_pf<BF, 2, 4, KB, 2>(acc2, w2f, l.htile, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
+    if (ci == 0) FSTAMP(6);
+    if (ci == 1) FSTAMP(7);
+    if (ci == 2) FSTAMP(8);
   }
+  FSTAMP(9);
 
   // ---- xtile (= y) += acc2 + b2, in the accumulator layout; then norm2 per whole row and one 1-KiB store per row ----
 #pragma unroll
@@ -224,7 +255,9 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     }
     lds_fence();
   }
+  FSTAMP(10);
   __syncthreads();
+  FSTAMP(11);
   {
     const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
 #pragma unroll
@@ -243,6 +276,8 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
       if (i == 3) lds_fence();
     }
   }
+  FSTAMP(12);
+  FSTAMP_FLUSH(13);
 }
 
 constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kTileElems * sizeof(u16);   // x | y | h
@@ -811,7 +846,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                  [=](int row) { return row < nvalid ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid, wt);   // rows of this wave
   }
   AXVS_STAMP(10);
-#ifndef AXVS_STAMPS_QKV
+#if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)
   AXVS_STAMP_FLUSH(16);
 #endif
 }

@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + AXVS_BENCH_SHARE_GPU=1 runs N ranks on ONE GPU (launcher smoke test only)")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option key=value (axvs_set_option)")
+    ap.add_argument("--workload", default="layer", choices=["layer", "cc"],
+                    help="layer: the headline metric (default); cc: BASELINE config 4, the cross-clip tracking module alone "
+                         "(one JSON line: us per forward, frames/s, HBM GB/s against 8 TB/s; single GPU)")
     args = ap.parse_args()
 
     import __graft_entry__ as ge
@@ -160,6 +163,54 @@ def main():
         if args.tensor_pos:
             pos = pos.clone()
         return layer, w, src, pos
+
+    def measure_cc(n_cc=30, graph=False):
+        """BASELINE config 4: CrossClipTrackingModule.forward over 4 clips x 4 frames, [C=256, H=W=64] features, 4 layers."""
+        Q, Tc, V, Hc, Wc, layers_cc, ncls = 128, 4, 4, 64, 64, 4, 124
+        cc = ax.CrossClipTrackingModule(num_layers=layers_cc, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
+                                        atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V, mfma_dtype=args.dtype).eval()
+        sd = cc.state_dict()
+        sd.update(orc.random_weights({k: tuple(v.shape) for k, v in sd.items() if v.dtype.is_floating_point}, 4))
+        cc.load_state_dict(sd, strict=True)
+        cc = cc.to(dev)
+        cc.eval_outputs_on_cpu = False          # time the device path (the reference's eval branch copies to the host afterwards)
+        g = torch.Generator(device=dev).manual_seed(4)
+        cq = torch.randn(1, Q, Tc, 256, device=dev, generator=g)
+        pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, Hc, Wc, device=dev, generator=g), dim=1)
+        run = ax.GraphedForward(cc, cq, pf) if graph else (lambda: cc(cq, pf))
+        t_set = time.perf_counter()
+        while (time.perf_counter() - t_set) * 1e3 < min(args.settle_ms, 200.0):
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(n_cc):
+            run()
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        us = ev0.elapsed_time(ev1) / n_cc * 1e3
+        out_bytes = layers_cc * (Q * Tc * V * Hc * Wc * 4 + 128 * Tc * V * Hc * Wc * 4)     # masks written + features read, per layer
+        return {"us_per_forward": round(us, 1), "unit": "us", "layers": layers_cc, "frames_per_s": round(Tc * V / (us * 1e-6), 1),
+                "shape": {"clip_query": [1, Q, Tc, 256], "panoptic_features": [1, 128, Tc * V, Hc, Wc]},
+                "launch": "hipGraph replay" if graph else "python, 1 library call per forward, heads on an auxiliary stream",
+                "algorithmic_mbytes": round(out_bytes / 1e6, 1),
+                "hbm_gbs": round(out_bytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(out_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "what": "BASELINE config 4: CrossClipTrackingModule.forward, 4 clips x 4 frames, 64x64, 4 layers; per-layer masks "
+                        "[1,128,16,64,64] fp32 written, features read (HBM-write / launch bound, SURVEY 8d)"}
+
+    if args.workload == "cc":
+        if world != 1:
+            raise SystemExit("--workload cc is a single-GPU measurement (replicas only across GPUs)")
+        r = measure_cc(max(args.steps, 10), graph=args.graph)
+        line = {"metric": "cross-clip tracking module fwd at BASELINE config 4 (4 clips x T=4, [C=256,H=W=64], 4 layers)",
+                "value": r["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "steps": max(args.steps, 10), "warmup": 5,
+                "ms_per_step": round(r["us_per_forward"] / 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic", "config": {"workload": r["what"], "launch": r["launch"]},
+                "roofline": {"bound": "hbm", "achieved": r["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["hbm_frac"], "traffic": None,
+                             "algorithmic_mbytes": r["algorithmic_mbytes"]}}
+        print(json.dumps(line), flush=True)
+        return
 
     B, T, C, H, W = (int(v) for v in args.shape.split(","))
     layer, w, src, pos = make_workload(B, T, C, H, W, seed=rank)
@@ -327,35 +378,7 @@ def main():
         # ---- BASELINE config 4: the cross-clip tracking module (launch/HBM-write bound: report us and GB/s) ----
         if not args.no_extras and world == 1:
             try:
-                Q, Tc, V, Hc, Wc, layers_cc, ncls = 128, 4, 4, 64, 64, 4, 124
-                cc = ax.CrossClipTrackingModule(num_layers=layers_cc, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
-                                                atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V, mfma_dtype=args.dtype).eval()
-                sd = cc.state_dict()
-                sd.update(orc.random_weights({k: tuple(v.shape) for k, v in sd.items() if v.dtype.is_floating_point}, 4))
-                cc.load_state_dict(sd, strict=True)
-                cc = cc.to(dev)
-                cc.eval_outputs_on_cpu = False          # time the device path (the reference's eval branch copies to the host afterwards)
-                g = torch.Generator(device=dev).manual_seed(4)
-                cq = torch.randn(1, Q, Tc, 256, device=dev, generator=g)
-                pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, Hc, Wc, device=dev, generator=g), dim=1)
-                for _ in range(5):
-                    cc(cq, pf)
-                torch.cuda.synchronize(dev)
-                n_cc = 30
-                e0.record()
-                for _ in range(n_cc):
-                    cc(cq, pf)
-                e1.record()
-                torch.cuda.synchronize(dev)
-                us = e0.elapsed_time(e1) / n_cc * 1e3
-                out_bytes = layers_cc * (Q * Tc * V * Hc * Wc * 4 + 128 * Tc * V * Hc * Wc * 4)     # masks written + features read, per layer
-                extras["cc_cfg4"] = {"us_per_forward": round(us, 1), "unit": "us", "layers": layers_cc,
-                                     "shape": {"clip_query": [1, Q, Tc, 256], "panoptic_features": [1, 128, Tc * V, Hc, Wc]},
-                                     "algorithmic_mbytes": round(out_bytes / 1e6, 1),
-                                     "hbm_gbs": round(out_bytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(out_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "what": "BASELINE config 4: CrossClipTrackingModule.forward, 4 clips x 4 frames, 64x64, 4 layers; per-layer masks "
-                                             "[1,128,16,64,64] fp32 written, features read (HBM-write / launch bound, SURVEY 8d)"}
-                del cc, cq, pf
+                extras["cc_cfg4"] = measure_cc()
             except RuntimeError as e:
                 extras["cc_cfg4"] = {"error": str(e)[:200]}
 
