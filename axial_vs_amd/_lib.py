@@ -123,9 +123,9 @@ SIGNATURES = {
     "axvs_msda_layer_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
     "axvs_msda_core_fwd": (C.c_int, [_fp, C.POINTER(C.c_int), _fp, _fp, _fp] + [C.c_int] * 7 + [_fp]),
     "axvs_cc_module_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
-    "axvs_cc_module_fwd": (C.c_int, [_fp] * 5 + [C.POINTER(_fp), _fp] + [C.c_int] * 8 + [C.POINTER(C.c_int), C.c_int, _fp, C.c_size_t, _fp, _fp]),
+    "axvs_cc_module_fwd": (C.c_int, [_fp] * 5 + [C.POINTER(_fp), _fp] + [C.c_int] * 8 + [C.POINTER(C.c_int), C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_tl_cc_module_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
-    "axvs_tl_cc_module_fwd": (C.c_int, [_fp] * 5 + [C.POINTER(_fp), _fp] + [C.c_int] * 9 + [C.POINTER(C.c_int), C.c_int, _fp, C.c_size_t, _fp, _fp]),
+    "axvs_tl_cc_module_fwd": (C.c_int, [_fp] * 5 + [C.POINTER(_fp), _fp] + [C.c_int] * 9 + [C.POINTER(C.c_int), C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_tl_heads_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_tl_heads_pack": (C.c_int, [C.POINTER(AxvsTLHeadParams), _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "axvs_tl_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

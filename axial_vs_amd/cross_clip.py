@@ -97,18 +97,6 @@ class MaXTronCCPredictor(nn.Module):         # CC:30-43
         nn.init.constant_(self._pixel_space_mask_batch_norm.weight, 0.1)
 
 
-_aux_streams = {}
-
-
-def _aux_stream(dev: torch.device) -> "torch.cuda.Stream":
-    """One auxiliary stream per (device, current stream): the predictor heads run on it beside the next layer's chain."""
-    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
-    st = _aux_streams.get(key)
-    if st is None:
-        st = _aux_streams[key] = torch.cuda.Stream(dev)
-    return st
-
-
 def _bn(m) -> _lib.AxvsBN:
     return m.weight, m.bias, m.running_mean, m.running_var
 
@@ -159,7 +147,6 @@ class CrossClipTrackingModule(nn.Module):
         self._predictor = MaXTronCCPredictor(num_classes=num_classes + 1)
         self.mfma_dtype = mfma_dtype
         self.eval_outputs_on_cpu = True     # the reference's eval branch returns CPU tensors (CC:59,70)
-        self.overlap_heads = True           # predictor heads of layer i on an auxiliary stream beside the chain of layer i+1
         self._packed = None
         self._packed_key = None
 
@@ -221,22 +208,18 @@ class CrossClipTrackingModule(nn.Module):
         dev = cq.device
         nl = self.num_layers
         rates = (C.c_int * 3)(*[int(r) for r in self.atrous_rates])
-        # ONE library call runs the whole layer loop (CC:283-318).  The layer chain (trajectory attention -> ASPP -> norms) of layer
-        # i+1 only needs layer i's clip queries, not its predictions: the predictor heads of layer i (embedding projections, class
-        # head, the HBM-bound mask einsum) run on an auxiliary stream beside it.
+        # ONE library call runs the whole layer loop (CC:283-318): the layer chain first (layer i+1 only needs layer i's clip
+        # queries, not its predictions), then the predictor heads of all layers at once (their weights are shared across layers) and
+        # the mask einsum of all layers in one pass over the pixel features.
         main = torch.cuda.current_stream(dev)
-        aux = _aux_stream(dev) if self.overlap_heads else None
         ws = _workspace(dev, L.axvs_cc_module_workspace_bytes(B, Q, Tc, nl))
         logits = torch.empty(nl, 1, Q, K1, dtype=torch.float32, device=dev)
         masks = torch.empty(nl, B, Q, TV, H, W, dtype=torch.float32, device=dev)
         last = torch.empty_like(cq)
         pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
         _lib.check(L.axvs_cc_module_fwd(cq.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
-                                        nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream,
-                                        aux.cuda_stream if aux is not None else None), "axvs_cc_module_fwd")
-        if aux is not None:                      # the auxiliary stream touched these (it has been joined back into `main`)
-            for t_ in (pf, logits, masks, ws):
-                t_.record_stream(aux)
+                                        nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
+                   "axvs_cc_module_fwd")
         cur = last
         cls_all = [logits[i] for i in range(nl)]
         mask_all = [masks[i] for i in range(nl)]
@@ -286,7 +269,6 @@ class TubeLinkCrossClipHead(nn.Module):
             self.conv_short_aggregate_layers.append(ASPP(256, 256, list(kernel_sizes), list(atrous_rates), drop_path_prob, aspp_norm_fn))
             self.conv_norms.append(nn.LayerNorm(256))
         self.activation_proj = nn.Linear(256, 1)
-        self.overlap_heads = True
         self.mfma_dtype = mfma_dtype
         self._packed = None
         self._packed_key = None
@@ -339,8 +321,7 @@ class TubeLinkCrossClipHead(nn.Module):
         dev = cq.device
         nl = self.num_cc_layers
         rates = (C.c_int * 3)(*[int(r) for r in self.atrous_rates])
-        main = torch.cuda.current_stream(dev)          # one library call for the whole loop, heads on an auxiliary stream (see CrossClipTrackingModule)
-        aux = _aux_stream(dev) if self.overlap_heads else None
+        main = torch.cuda.current_stream(dev)          # one library call for the whole loop (see CrossClipTrackingModule)
         ws = _workspace(dev, L.axvs_tl_cc_module_workspace_bytes(B, Q, Tc, Cm, nl))
         cur = cq.permute(0, 2, 1, 3).contiguous()          # [B,Q,Tc,C]: the token order of 'b c t q -> b (t q) c' (TLCC:931)
         logits = torch.empty(nl, B, Q, K1, dtype=torch.float32, device=dev)
@@ -348,11 +329,8 @@ class TubeLinkCrossClipHead(nn.Module):
         last = torch.empty_like(cur)
         pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
         _lib.check(L.axvs_tl_cc_module_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
-                                           nl, B, Q, Tc, T // Tc, h, w, K1, Cm, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream,
-                                           aux.cuda_stream if aux is not None else None), "axvs_tl_cc_module_fwd")
-        if aux is not None:
-            for t_ in (mf, logits, masks, ws):
-                t_.record_stream(aux)
+                                           nl, B, Q, Tc, T // Tc, h, w, K1, Cm, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
+                   "axvs_tl_cc_module_fwd")
         cls_all = [logits[i] for i in range(nl)]
         mask_all = [masks[i] for i in range(nl)]
         return tuple(cls_all), tuple(mask_all)

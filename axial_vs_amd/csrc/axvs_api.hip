@@ -29,6 +29,7 @@ thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
 thread_local int* g_status = nullptr;     // axvs_set_status_buffer: device word that kernels OR condition bits into
+thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
 thread_local int g_spatial_only = 0;     // option "spatial_only": the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
@@ -234,6 +235,18 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
                     float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
   const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? 2 : 0);
+  // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
+  const long long tiles64 = nks > 0 ? (Mp / N) * ((N + 63) / 64) : (Mp + 63) / 64;
+  if (fa == nullptr && tiles64 < 128 && !g_no_small_tiles) {
+    switch (T) {
+      case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 3: return launch_temporal_n<BF, 3, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 4: return launch_temporal_n<BF, 4, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 5: return launch_temporal_n<BF, 5, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      default: break;
+    }
+  }
   switch (T) {
     case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
     case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
@@ -561,17 +574,16 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   return last_launch_status();
 }
 
+// embeddings + mask-head kernels (-> kern16, blocked [4][R][32]) + class head; the mask einsum follows separately so that the
+// module loop can run it once for all layers
+// x: the clip queries of `nl` layers back to back ([nl][R][256]); the projections share their weights across layers, so all layers
+// go through ONE launch per GEMM (kern16: blocked [4][nl*R][32], logits [nl][Q][K1])
 template <bool BF>
-int cc_heads_fwd_t(const float* x, const float* pf, float* logits, float* masks, const void* packed, int B, int Q, int Tc, int V, int H,
-                   int W, int K1, void* ws, hipStream_t st) {
+int cc_heads_small_t(const float* x, float* logits, u16* kern16, const void* packed, int B, int Q, int Tc, int K1, float* emb, hipStream_t st,
+                     int nl = 1) {
   Carver pc(const_cast<void*>(packed));
   CCHeadsPacked p = carve_cc_heads(pc, K1);
-  const long long R = (long long)B * Q * Tc, P = (long long)V * H * W;
-  Carver wc(ws);
-  float* emb = wc.take<float>((size_t)R * 512);
-  u16* kern16 = wc.take<u16>((size_t)R * 128);
-  g_prof_next = 0;
-  mark(st, "begin");
+  const long long R = (long long)nl * B * Q * Tc;
   ALoadRowsLd<BF> ax{x, 256, 0, (int)R};
   EpiRowsF32 ee{emb, nullptr, p.emb_add, identity_map(R), 512, 1.f};
   ee.mul = p.emb_mul;
@@ -583,13 +595,37 @@ int cc_heads_fwd_t(const float* x, const float* pf, float* logits, float* masks,
   launch_gemm<BF>(am, p.wmh, ek, (int)R, 128, 256, st);
   mark(st, "cc.embeddings");
   const float void_bias = logf((float)(K1 - 1) * 0.9f / (1.f - 0.9f));
-  hipLaunchKernelGGL(cc_class_head_kernel, dim3(Q), dim3(256), 0, st, emb, 512, p.wa, p.ba, p.wc, p.bc, logits, B, Q, Tc, K1, void_bias);
+  hipLaunchKernelGGL(cc_class_head_kernel, dim3(Q, nl), dim3(256), 0, st, emb, 512, p.wa, p.ba, p.wc, p.bc, logits, B, Q, Tc, K1, void_bias);
   mark(st, "cc.class_head");
+  return AXVS_OK;
+}
+
+// masks of `nl` layers (kernels kstride apart, outputs ostride apart) from one pass over the pixel features
+template <bool BF>
+int cc_masks_t(const float* pf, const u16* kern16, float* masks, const void* packed, int B, int Q, int Tc, int V, int H, int W, int K1, int nl,
+               long long kstride, long long ostride, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  CCHeadsPacked p = carve_cc_heads(pc, K1);
+  const long long R = (long long)nl * B * Q * Tc, P = (long long)V * H * W;      // rows of the blocked kernel matrix: all layers
   dim3 grid((unsigned)((P + 63) / 64), B * Tc);
   const long long TP = (long long)Tc * P;
   const EinsumMap mp{128 * TP, P, TP, (long long)Q * TP, P, TP, Tc, 1};
-  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix);
+  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride);
   mark(st, "cc.mask_einsum");
+  return AXVS_OK;
+}
+
+template <bool BF>
+int cc_heads_fwd_t(const float* x, const float* pf, float* logits, float* masks, const void* packed, int B, int Q, int Tc, int V, int H,
+                   int W, int K1, void* ws, hipStream_t st) {
+  const long long R = (long long)B * Q * Tc;
+  Carver wc(ws);
+  float* emb = wc.take<float>((size_t)R * 512);
+  u16* kern16 = wc.take<u16>((size_t)R * 128);
+  g_prof_next = 0;
+  mark(st, "begin");
+  cc_heads_small_t<BF>(x, logits, kern16, packed, B, Q, Tc, K1, emb, st);
+  cc_masks_t<BF>(pf, kern16, masks, packed, B, Q, Tc, V, H, W, K1, 1, 0, 0, st);
   return last_launch_status();
 }
 
@@ -608,34 +644,60 @@ TLHeadsPacked carve_tl_heads(Carver& c, int K1, int Cm) {
   return h;
 }
 
+struct TLHeadsWs {
+  float* xn;
+  u16 *xn16, *h1, *h2;
+};
+TLHeadsWs carve_tl_heads_ws(Carver& c, long long R) {
+  TLHeadsWs w;
+  w.xn = c.take<float>((size_t)R * 256);
+  w.xn16 = c.take<u16>((size_t)R * 256);
+  w.h1 = c.take<u16>((size_t)R * 256);
+  w.h2 = c.take<u16>((size_t)R * 256);
+  return w;
+}
+
+template <bool BF>
+int tl_heads_small_t(const float* x, float* logits, u16* kern16, const void* packed, int B, int Q, int Tc, int K1, int Cm, const TLHeadsWs& w,
+                     hipStream_t st, int nl = 1) {
+  Carver pc(const_cast<void*>(packed));
+  TLHeadsPacked p = carve_tl_heads(pc, K1, Cm);
+  const long long R = (long long)nl * B * Q * Tc;
+  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, p.pn_w, p.pn_b, w.xn, w.xn16, R, 256, 1e-5f);
+  mark(st, "tl.post_norm");
+  hipLaunchKernelGGL(tl_class_head_kernel, dim3((unsigned)(B * Q), nl), dim3(256), 0, st, w.xn, p.wa, p.ba, p.wc, p.bc, logits, Tc, K1);
+  mark(st, "tl.class_head");
+  launch_gemm<BF>(ALoadBlocked<BF>{w.xn16, R, (int)R, 0, 1, 1}, p.w0, EpiBlocked16<BF>{w.h1, R, p.b0, 1.f, 0, 1}, (int)R, 256, 256, st);
+  launch_gemm<BF>(ALoadBlocked<BF>{w.h1, R, (int)R, 0, 1, 1}, p.w1, EpiBlocked16<BF>{w.h2, R, p.b1, 1.f, 0, 1}, (int)R, 256, 256, st);
+  launch_gemm<BF>(ALoadBlocked<BF>{w.h2, R, (int)R, 0, 1, 1}, p.w2, EpiBlocked16<BF>{kern16, R, p.b2, 1.f, 0, 0}, (int)R, Cm, 256, st);
+  mark(st, "tl.mask_embed");
+  return AXVS_OK;
+}
+
+template <bool BF>
+int tl_masks_t(const float* mf, const u16* kern16, float* masks, int B, int Q, int Tc, int fpc, int h, int w, int Cm, int nl, long long kstride,
+               long long ostride, hipStream_t st) {
+  const long long R = (long long)nl * B * Q * Tc, P = (long long)h * w;
+  const int T = Tc * fpc;
+  dim3 grid((unsigned)((P + 63) / 64), B * T);
+  const EinsumMap mp{(long long)T * Cm * P, (long long)Cm * P, P, (long long)T * Q * P, (long long)Q * P, P, T, fpc};
+  if (Cm == 128) hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+  else hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+  mark(st, "tl.mask_einsum");
+  return AXVS_OK;
+}
+
 template <bool BF>
 int tl_heads_fwd_t(const float* x, const float* mf, float* logits, float* masks, const void* packed, int B, int Q, int Tc, int fpc,
                    int h, int w, int K1, int Cm, void* ws, hipStream_t st) {
-  Carver pc(const_cast<void*>(packed));
-  TLHeadsPacked p = carve_tl_heads(pc, K1, Cm);
-  const long long R = (long long)B * Q * Tc, P = (long long)h * w;
-  const int T = Tc * fpc;
+  const long long R = (long long)B * Q * Tc;
   Carver wc(ws);
-  float* xn = wc.take<float>((size_t)R * 256);
-  u16* xn16 = wc.take<u16>((size_t)R * 256);
-  u16* h1 = wc.take<u16>((size_t)R * 256);
-  u16* h2 = wc.take<u16>((size_t)R * 256);
+  const TLHeadsWs hw = carve_tl_heads_ws(wc, R);
   u16* kern16 = wc.take<u16>((size_t)R * Cm);
   g_prof_next = 0;
   mark(st, "begin");
-  hipLaunchKernelGGL((layernorm_kernel<BF>), dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, x, p.pn_w, p.pn_b, xn, xn16, R, 256, 1e-5f);
-  mark(st, "tl.post_norm");
-  hipLaunchKernelGGL(tl_class_head_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, st, xn, p.wa, p.ba, p.wc, p.bc, logits, Tc, K1);
-  mark(st, "tl.class_head");
-  launch_gemm<BF>(ALoadBlocked<BF>{xn16, R, (int)R, 0, 1, 1}, p.w0, EpiBlocked16<BF>{h1, R, p.b0, 1.f, 0, 1}, (int)R, 256, 256, st);
-  launch_gemm<BF>(ALoadBlocked<BF>{h1, R, (int)R, 0, 1, 1}, p.w1, EpiBlocked16<BF>{h2, R, p.b1, 1.f, 0, 1}, (int)R, 256, 256, st);
-  launch_gemm<BF>(ALoadBlocked<BF>{h2, R, (int)R, 0, 1, 1}, p.w2, EpiBlocked16<BF>{kern16, R, p.b2, 1.f, 0, 0}, (int)R, Cm, 256, st);
-  mark(st, "tl.mask_embed");
-  dim3 grid((unsigned)((P + 63) / 64), B * T);
-  const EinsumMap mp{(long long)T * Cm * P, (long long)Cm * P, P, (long long)T * Q * P, (long long)Q * P, P, T, fpc};
-  if (Cm == 128) hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr);
-  else hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr);
-  mark(st, "tl.mask_einsum");
+  tl_heads_small_t<BF>(x, logits, kern16, packed, B, Q, Tc, K1, Cm, hw, st);
+  tl_masks_t<BF>(mf, kern16, masks, B, Q, Tc, fpc, h, w, Cm, 1, 0, 0, st);
   return last_launch_status();
 }
 
@@ -709,37 +771,29 @@ int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* 
 }  // namespace
 
 namespace {
-hipEvent_t module_event(int i) {          // per-thread pool of timing-free events
-  constexpr int kMax = 2 * 64 + 2;
-  static thread_local hipEvent_t ev[kMax] = {};
-  if (i < 0 || i >= kMax) return nullptr;
-  if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-  return ev[i];
-}
-
 struct ModuleWs {
   void *chain, *heads;
-  float* q;            // [layers][R][256] clip queries after every layer
+  float* q;            // [layers][R][256] clip queries after every layer: the predictor heads run on all of them at once
+  u16* kern;           // blocked [Cm/32][layers*R][32] mask kernels of every layer
 };
-ModuleWs carve_module_ws(Carver& c, size_t chain_bytes, size_t heads_bytes, long long R, int layers) {
+ModuleWs carve_module_ws(Carver& c, size_t chain_bytes, size_t heads_bytes, long long R, int layers, int Cm) {
   ModuleWs m;
   m.chain = c.take<char>(chain_bytes);
   m.heads = c.take<char>(heads_bytes);
   m.q = c.take<float>((size_t)layers * R * 256);
+  m.kern = c.take<u16>((size_t)layers * R * Cm);
   return m;
 }
 
-// heads(i, clip queries of layer i, stream) launches the predictor heads of layer i
+// The layer chain (trajectory attention -> ASPP -> norms) of layer i+1 only needs layer i's clip queries, not its predictions, and
+// the predictor heads share their weights across layers: the chain runs first, then heads(stream) computes the class logits and
+// mask kernels of ALL layers (one launch per GEMM over layers*R rows) and the mask einsum of all layers in one pass over the pixel
+// features (read once instead of once per layer).
 template <class Heads>
 int run_cc_module(const float* clip_query, const void* const* packed_layers, int layers, float* last_query, int B, int Q, int Tc, const int* rates,
-                  int dtype, const ModuleWs& w, hipStream_t st, hipStream_t aux, Heads heads) {
+                  int dtype, const ModuleWs& w, hipStream_t st, Heads heads) {
   const long long R = (long long)B * Q * Tc;
   if (layers <= 0 || layers > 64) return fail(AXVS_ERR_ARG, "num_layers=%d must be in 1..64", layers);
-  if (aux == st) aux = nullptr;
-  if (aux) {                                      // fork: the auxiliary stream joins behind everything queued on `st`
-    hipEvent_t e = module_event(0);
-    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "event fork failed");
-  }
   const float* cur = clip_query;
   for (int i = 0; i < layers; ++i) {
     float* nxt = w.q + (size_t)i * R * 256;
@@ -747,21 +801,10 @@ int run_cc_module(const float* clip_query, const void* const* packed_layers, int
                                 : cc_layer_fwd_t<false>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st);
     if (rc != AXVS_OK) return rc;
     cur = nxt;
-    hipStream_t hs = st;
-    if (aux) {
-      hipEvent_t e = module_event(1 + i);
-      if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "event fork failed");
-      hs = aux;
-    }
-    rc = heads(i, cur, hs);
-    if (rc != AXVS_OK) return rc;
   }
   if (hipMemcpyAsync(last_query, cur, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(AXVS_ERR_LAUNCH, "copy failed");
-  if (aux) {                                      // join
-    hipEvent_t e = module_event(65);
-    if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "event join failed");
-  }
+  if (int rc = heads(st)) return rc;
   return last_launch_status();
 }
 }  // namespace
@@ -792,6 +835,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }
@@ -1074,58 +1118,74 @@ int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, f
 //      beside the chain of layer i+1 (fork / join with events, capturable into a HIP graph).
 size_t axvs_cc_module_workspace_bytes(int B, int Q, int Tc, int num_layers) {
   Carver c(nullptr);
-  carve_module_ws(c, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_cc_heads_workspace_bytes(B, Q, Tc), (long long)B * Q * Tc, num_layers);
+  carve_module_ws(c, axvs_cc_layer_workspace_bytes(B, Q, Tc), (size_t)num_layers * B * Q * Tc * 512 * sizeof(float), (long long)B * Q * Tc, num_layers, 128);
   return c.off;
 }
 
 int axvs_cc_module_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks, float* last_query,
                        const void* const* packed_layers, const void* packed_heads, int num_layers, int B, int Q, int Tc, int V, int H, int W,
-                       int K1, const int* rates, int dtype, void* workspace, size_t workspace_bytes, void* stream, void* aux_stream) {
+                       int K1, const int* rates, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !last_query || !packed_layers || !packed_heads || !rates || !workspace)
     return fail(AXVS_ERR_ARG, "null pointer");
-  if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0 || num_layers <= 0) return fail(AXVS_ERR_ARG, "empty shape");
   if (((long long)V * H * W) % 4) return fail(AXVS_ERR_ARG, "V*H*W must be a multiple of 4");
   if (B * Tc > 1024) return fail(AXVS_ERR_ARG, "B*Tc > 1024 is not supported by the class head");
   if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
   if (workspace_bytes < axvs_cc_module_workspace_bytes(B, Q, Tc, num_layers)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  const long long R = (long long)B * Q * Tc;
   Carver wc(workspace);
-  const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_cc_heads_workspace_bytes(B, Q, Tc), (long long)B * Q * Tc, num_layers);
-  const size_t lstride = (size_t)Q * K1, mstride = (size_t)B * Q * Tc * V * H * W;
-  auto heads = [&](int i, const float* q, hipStream_t hs) {
-    return dtype == AXVS_BF16 ? cc_heads_fwd_t<true>(q, panoptic_features, pred_logits + i * lstride, pred_masks + i * mstride, packed_heads, B, Q, Tc, V, H, W, K1, w.heads, hs)
-                              : cc_heads_fwd_t<false>(q, panoptic_features, pred_logits + i * lstride, pred_masks + i * mstride, packed_heads, B, Q, Tc, V, H, W, K1, w.heads, hs);
+  const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), (size_t)num_layers * R * 512 * sizeof(float), R, num_layers, 128);
+  const long long mstride = (long long)B * Q * Tc * V * H * W;
+  g_prof_next = 0;
+  auto heads = [&](hipStream_t hs) {
+    float* emb = static_cast<float*>(w.heads);
+    if (dtype == AXVS_BF16) {
+      cc_heads_small_t<true>(w.q, pred_logits, w.kern, packed_heads, B, Q, Tc, K1, emb, hs, num_layers);
+      return cc_masks_t<true>(panoptic_features, w.kern, pred_masks, packed_heads, B, Q, Tc, V, H, W, K1, num_layers, R * 32, mstride, hs);
+    }
+    cc_heads_small_t<false>(w.q, pred_logits, w.kern, packed_heads, B, Q, Tc, K1, emb, hs, num_layers);
+    return cc_masks_t<false>(panoptic_features, w.kern, pred_masks, packed_heads, B, Q, Tc, V, H, W, K1, num_layers, R * 32, mstride, hs);
   };
-  return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream),
-                       static_cast<hipStream_t>(aux_stream), heads);
+  return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream), heads);
 }
 
 size_t axvs_tl_cc_module_workspace_bytes(int B, int Q, int Tc, int Cm, int num_layers) {
   Carver c(nullptr);
-  carve_module_ws(c, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm), (long long)B * Q * Tc, num_layers);
+  Carver h(nullptr);
+  carve_tl_heads_ws(h, (long long)num_layers * B * Q * Tc);
+  carve_module_ws(c, axvs_cc_layer_workspace_bytes(B, Q, Tc), h.off, (long long)B * Q * Tc, num_layers, Cm);
   return c.off;
 }
 
 int axvs_tl_cc_module_fwd(const float* clip_query, const float* mask_feature, float* cls_logits, float* mask_logits, float* last_query,
                           const void* const* packed_layers, const void* packed_heads, int num_layers, int B, int Q, int Tc, int frames_per_clip,
-                          int h, int w_, int K1, int Cm, const int* rates, int dtype, void* workspace, size_t workspace_bytes, void* stream,
-                          void* aux_stream) {
+                          int h, int w_, int K1, int Cm, const int* rates, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   if (!clip_query || !mask_feature || !cls_logits || !mask_logits || !last_query || !packed_layers || !packed_heads || !rates || !workspace)
     return fail(AXVS_ERR_ARG, "null pointer");
-  if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w_ <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w_ <= 0 || K1 <= 0 || num_layers <= 0) return fail(AXVS_ERR_ARG, "empty shape");
   if (Cm != 128 && Cm != 256) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
   if (((long long)h * w_) % 4) return fail(AXVS_ERR_ARG, "h*w must be a multiple of 4");
   if (Tc > 1024) return fail(AXVS_ERR_ARG, "more than 1024 clips are not supported by the class head");
   if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
   if (workspace_bytes < axvs_tl_cc_module_workspace_bytes(B, Q, Tc, Cm, num_layers)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  const long long R = (long long)B * Q * Tc;
+  Carver hsz(nullptr);
+  carve_tl_heads_ws(hsz, (long long)num_layers * R);
   Carver wc(workspace);
-  const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm), (long long)B * Q * Tc, num_layers);
-  const size_t lstride = (size_t)B * Q * K1, mstride = (size_t)B * Tc * frames_per_clip * Q * h * w_;
-  auto heads = [&](int i, const float* q, hipStream_t hs) {
-    return dtype == AXVS_BF16 ? tl_heads_fwd_t<true>(q, mask_feature, cls_logits + i * lstride, mask_logits + i * mstride, packed_heads, B, Q, Tc, frames_per_clip, h, w_, K1, Cm, w.heads, hs)
-                              : tl_heads_fwd_t<false>(q, mask_feature, cls_logits + i * lstride, mask_logits + i * mstride, packed_heads, B, Q, Tc, frames_per_clip, h, w_, K1, Cm, w.heads, hs);
+  const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), hsz.off, R, num_layers, Cm);
+  const long long mstride = (long long)B * Tc * frames_per_clip * Q * h * w_;
+  g_prof_next = 0;
+  auto heads = [&](hipStream_t hs) {
+    Carver hc(w.heads);
+    const TLHeadsWs hw = carve_tl_heads_ws(hc, (long long)num_layers * R);
+    if (dtype == AXVS_BF16) {
+      tl_heads_small_t<true>(w.q, cls_logits, w.kern, packed_heads, B, Q, Tc, K1, Cm, hw, hs, num_layers);
+      return tl_masks_t<true>(mask_feature, w.kern, mask_logits, B, Q, Tc, frames_per_clip, h, w_, Cm, num_layers, R * 32, mstride, hs);
+    }
+    tl_heads_small_t<false>(w.q, cls_logits, w.kern, packed_heads, B, Q, Tc, K1, Cm, hw, hs, num_layers);
+    return tl_masks_t<false>(mask_feature, w.kern, mask_logits, B, Q, Tc, frames_per_clip, h, w_, Cm, num_layers, R * 32, mstride, hs);
   };
-  return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream),
-                       static_cast<hipStream_t>(aux_stream), heads);
+  return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream), heads);
 }
 
 size_t axvs_tl_heads_packed_bytes(int K1, int Cm) {

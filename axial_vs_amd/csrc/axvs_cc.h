@@ -65,6 +65,8 @@ __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restr
   constexpr int C = 256, MAXE = 1024;
   __shared__ float logit[MAXE], pooled[C], red[4];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  emb += (long long)blockIdx.y * Bv * Q * Tc * ld;    // blockIdx.y: layer (the module loop runs the heads of all layers in one launch)
+  out += (long long)blockIdx.y * Q * K1;
   const int E = Bv * Tc;                              // entries the softmax runs over (dim 0 of the reference tensor)
   const float wac = wa[tid];
   for (int e = 0; e < E; ++e) {
@@ -110,7 +112,10 @@ struct EinsumMap {
 template <bool BF, int CK>
 __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restrict__ pf, const u16* __restrict__ kern16,
                                                           float* __restrict__ out, int Q, int Tc, long long P, long long Rk,
-                                                          EinsumMap mp, const float* __restrict__ pix_bn /* {mul, add} or null */) {
+                                                          EinsumMap mp, const float* __restrict__ pix_bn /* {mul, add} or null */,
+                                                          int nl = 1 /* layers sharing the staged feature tile */,
+                                                          long long kstride = 0 /* elements between the layers' kernels */,
+                                                          long long ostride = 0 /* ... and between their outputs */) {
   constexpr int KB = CK / 32;
   __shared__ __attribute__((aligned(16))) u16 spx[KB * 64 * 32];      // [kb][pixel][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
@@ -147,19 +152,25 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
     const int px = wave * 16 + fi;
     af[kb] = *reinterpret_cast<const u16x8*>(spx + (kb * 64 + px) * 32 + swz_chunk(px, fg) * 8);
   }
-  for (int qt = 0; qt * 16 < Q; ++qt) {
-    const int q = min(qt * 16 + fi, Q - 1);
-    const long long r = ((long long)b * Q + q) * Tc + clip;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // The feature tile is staged ONCE and contracted with the mask kernels of every layer: the per-layer predictions of the
+  // cross-clip modules all read the same pixel features (4 layers: 33.5 MB read once instead of four times)
+  for (int ly = 0; ly < nl; ++ly) {
+    const u16* kl = kern16 + ly * kstride;
+    float* ol = out + ly * ostride;
+    for (int qt = 0; qt * 16 < Q; ++qt) {
+      const int q = min(qt * 16 + fi, Q - 1);
+      const long long r = ((long long)b * Q + q) * Tc + clip;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const u16x8 bf = *reinterpret_cast<const u16x8*>(kern16 + ((long long)kb * Rk + r) * 32 + fg * 8);
-      acc = H16<BF>::mfma(af[kb], bf, acc);          // D[pixel][query]
+      for (int kb = 0; kb < KB; ++kb) {
+        const u16x8 bf = *reinterpret_cast<const u16x8*>(kl + ((long long)kb * Rk + r) * 32 + fg * 8);
+        acc = H16<BF>::mfma(af[kb], bf, acc);          // D[pixel][query]
+      }
+      const long long p = p0 + wave * 16 + fg * 4;
+      if (qt * 16 + fi < Q && p + 3 < P)
+        *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) =
+            float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
     }
-    const long long p = p0 + wave * 16 + fg * 4;
-    if (qt * 16 + fi < Q && p + 3 < P)
-      *reinterpret_cast<float4*>(out + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) =
-          float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
   }
 }
 
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(256) void tl_class_head_kernel(const float* __restr
   constexpr int C = 256, MAXT = 1024;
   __shared__ float logit[MAXT], pooled[C], red[4];
   const int bq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* xr = x + (long long)bq * Tc * C;
+  const float* xr = x + ((long long)blockIdx.y * gridDim.x + bq) * Tc * C;   // blockIdx.y: layer
+  out += (long long)blockIdx.y * gridDim.x * K1;
   const float wac = wa[tid];
   for (int t = 0; t < Tc; ++t) {
     const float s = wave_sum(xr[t * C + tid] * wac);

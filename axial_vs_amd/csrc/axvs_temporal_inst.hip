@@ -5,7 +5,10 @@
 #include "axvs_fused.h"
 
 #if !defined(AXVS_INST_BF) || !defined(AXVS_INST_T)
-#error "compile with -DAXVS_INST_BF=<0|1> -DAXVS_INST_T=<frames>"
+#error "compile with -DAXVS_INST_BF=<0|1> -DAXVS_INST_T=<frames> [-DAXVS_INST_MT=<16-row tiles per workgroup>]"
+#endif
+#ifndef AXVS_INST_MT   // default tile: 64 rows (32 for T = 5); MT = 1 (16 rows) units serve problems with few rows (cross-clip queries)
+#define AXVS_INST_MT (AXVS_INST_T <= 4 ? 4 : 2)
 #endif
 
 namespace axvs {
@@ -45,12 +48,12 @@ int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float
   }
 }
 
-template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, (AXVS_INST_T <= 4 ? 4 : 2)>(
+template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, AXVS_INST_MT>(
     int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int);
 
 }  // namespace axvs
 
-#if defined(AXVS_STAMPS) && !defined(AXVS_STAMPS_QKV) && AXVS_INST_BF == 0 && AXVS_INST_T == 4
+#if defined(AXVS_STAMPS) && !defined(AXVS_STAMPS_QKV) && AXVS_INST_BF == 0 && AXVS_INST_T == 4 && AXVS_INST_MT == 4
 // diagnostic builds: phase stamps of the f16 / T = 4 trajectory kernels (tools/stamps.py)
 extern "C" int axvs_debug_read_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(axvs::g_stamps), sizeof(unsigned long long) * n);

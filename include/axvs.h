@@ -198,18 +198,18 @@ int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float*
  *      :783-797).  packed_layers: HOST array of num_layers device pointers (axvs_cc_layer_pack); packed_heads: axvs_cc_heads_pack /
  *      axvs_tl_heads_pack.  Outputs for EVERY layer (the reference collects them for aux_outputs): pred_logits fp32
  *      [num_layers][1 | B][Q][K1], pred_masks fp32 [num_layers][...one layer's mask tensor...]; last_query fp32 [B,Q,Tc,256].
- *      aux_stream: NULL, or a second stream on which the predictor heads of layer i run beside the layer chain of layer i+1
- *      (forked from / joined back into `stream` with events; capturable).  */
+ *      The layer chain runs first; the predictor heads share their weights across layers, so the class logits and mask kernels
+ *      of all layers are one launch per GEMM and the mask einsum reads the pixel features once for all layers.  */
 size_t axvs_cc_module_workspace_bytes(int B, int Q, int Tc, int num_layers);
 int axvs_cc_module_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks,
                        float* last_query, const void* const* packed_layers, const void* packed_heads, int num_layers, int B,
                        int Q, int Tc, int V, int H, int W, int K1, const int* rates, int dtype, void* workspace,
-                       size_t workspace_bytes, void* stream, void* aux_stream);
+                       size_t workspace_bytes, void* stream);
 size_t axvs_tl_cc_module_workspace_bytes(int B, int Q, int Tc, int Cm, int num_layers);
 int axvs_tl_cc_module_fwd(const float* clip_query, const float* mask_feature, float* cls_logits, float* mask_logits,
                           float* last_query, const void* const* packed_layers, const void* packed_heads, int num_layers, int B,
                           int Q, int Tc, int frames_per_clip, int h, int w, int K1, int Cm, const int* rates, int dtype,
-                          void* workspace, size_t workspace_bytes, void* stream, void* aux_stream);
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- Multi-scale deformable attention forward.
  *      OPS = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_tracking_module/ops

@@ -39,12 +39,3 @@ for _ in range(10): mod(cq, pf)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 print(f"  host enqueue time: {(t1 - t0) / 10 * 1e6:.0f} us per forward")
-mod.overlap_heads = False
-for _ in range(3): mod(cq, pf)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10): mod(cq, pf)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"  single stream: host enqueue {(t1 - t0) / 10 * 1e6:.0f} us, wall {(t2 - t0) / 10 * 1e6:.0f} us per forward")
