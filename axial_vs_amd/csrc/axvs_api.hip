@@ -607,10 +607,11 @@ int cc_masks_t(const float* pf, const u16* kern16, float* masks, const void* pac
   Carver pc(const_cast<void*>(packed));
   CCHeadsPacked p = carve_cc_heads(pc, K1);
   const long long R = (long long)nl * B * Q * Tc, P = (long long)V * H * W;      // rows of the blocked kernel matrix: all layers
-  dim3 grid((unsigned)((P + 63) / 64), B * Tc);
+  dim3 grid((unsigned)((P + kEinsumPx - 1) / kEinsumPx), B * Tc);
   const long long TP = (long long)Tc * P;
   const EinsumMap mp{128 * TP, P, TP, (long long)Q * TP, P, TP, Tc, 1};
-  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride);
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128>))) return rc;
+  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride);
   mark(st, "cc.mask_einsum");
   return AXVS_OK;
 }
@@ -679,10 +680,15 @@ int tl_masks_t(const float* mf, const u16* kern16, float* masks, int B, int Q, i
                long long ostride, hipStream_t st) {
   const long long R = (long long)nl * B * Q * Tc, P = (long long)h * w;
   const int T = Tc * fpc;
-  dim3 grid((unsigned)((P + 63) / 64), B * T);
+  dim3 grid((unsigned)((P + kEinsumPx - 1) / kEinsumPx), B * T);
   const EinsumMap mp{(long long)T * Cm * P, (long long)Cm * P, P, (long long)T * Q * P, (long long)Q * P, P, T, fpc};
-  if (Cm == 128) hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
-  else hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), 0, st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+  if (Cm == 128) {
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128>))) return rc;
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+  } else {
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 256>))) return rc;
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), einsum_lds_bytes<256>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+  }
   mark(st, "tl.mask_einsum");
   return AXVS_OK;
 }

@@ -116,21 +116,23 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
                                                           int nl = 1 /* layers sharing the staged feature tile */,
                                                           long long kstride = 0 /* elements between the layers' kernels */,
                                                           long long ostride = 0 /* ... and between their outputs */) {
-  constexpr int KB = CK / 32;
-  __shared__ __attribute__((aligned(16))) u16 spx[KB * 64 * 32];      // [kb][pixel][32]
+  // Workgroup = 256 pixels of one unit (4 waves x 64 pixels = 4 MFMA row tiles per wave): every kernel fragment fetched from L2
+  // feeds 4 MFMAs, and a wave's stores cover 256 contiguous bytes of a query's row (round 2; 64 pixels per workgroup before: the
+  // kernel fragments were 3x the traffic of the features).
+  constexpr int KB = CK / 32, PXW = 4, PXT = 64 * PXW;      // px tiles per wave, pixels per workgroup
+  extern __shared__ __attribute__((aligned(16))) u16 spx[];   // [kb][pixel][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const int bu = blockIdx.y, b = bu / mp.units, u = bu - b * mp.units, clip = u / mp.upc;
-  const long long p0 = (long long)blockIdx.x * 64;
+  const long long p0 = (long long)blockIdx.x * PXT;
   const float bn_mul = pix_bn ? pix_bn[0] : 1.f, bn_add = pix_bn ? pix_bn[1] : 0.f;
-  // stage: thread -> (channel c, 32-pixel half); 8 float4 loads of 128 contiguous bytes
-#pragma unroll
-  for (int cp = 0; cp < CK / 128; ++cp) {
-    const int c = cp * 128 + (tid >> 1), half = tid & 1;
-    const float* src = pf + b * mp.f_b + u * mp.f_u + c * mp.f_c + p0 + half * 32;
+  // stage: thread -> (channel c, 32-pixel segment); 8 float4 loads of 128 contiguous bytes
+  for (int idx = tid; idx < CK * (PXT / 32); idx += 256) {
+    const int c = idx / (PXT / 32), seg = idx - c * (PXT / 32);
+    const float* src = pf + b * mp.f_b + u * mp.f_u + c * mp.f_c + p0 + seg * 32;
     float4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const long long p = p0 + half * 32 + i * 4;
+      const long long p = p0 + seg * 32 + i * 4;
       v[i] = p + 3 < P ? *reinterpret_cast<const float4*>(src + i * 4) : float4{0.f, 0.f, 0.f, 0.f};
     }
     const int kb = c >> 5, k = c & 31;
@@ -139,19 +141,21 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
       const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int px = half * 32 + i * 4 + j;
-        spx[(kb * 64 + px) * 32 + swz_chunk(px, k >> 3) * 8 + (k & 7)] = H16<BF>::from_f32(e[j]);
+        const int px = seg * 32 + i * 4 + j;
+        spx[(kb * PXT + px) * 32 + swz_chunk(px, k >> 3) * 8 + (k & 7)] = H16<BF>::from_f32(e[j]);
       }
       if ((i & 1) == 1) lds_fence();
     }
   }
   __syncthreads();
-  u16x8 af[KB];
+  u16x8 af[PXW][KB];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-    const int px = wave * 16 + fi;
-    af[kb] = *reinterpret_cast<const u16x8*>(spx + (kb * 64 + px) * 32 + swz_chunk(px, fg) * 8);
-  }
+  for (int t = 0; t < PXW; ++t)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int px = wave * (16 * PXW) + t * 16 + fi;
+      af[t][kb] = *reinterpret_cast<const u16x8*>(spx + (kb * PXT + px) * 32 + swz_chunk(px, fg) * 8);
+    }
   // The feature tile is staged ONCE and contracted with the mask kernels of every layer: the per-layer predictions of the
   // cross-clip modules all read the same pixel features (4 layers: 33.5 MB read once instead of four times)
   for (int ly = 0; ly < nl; ++ly) {
@@ -160,19 +164,25 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
     for (int qt = 0; qt * 16 < Q; ++qt) {
       const int q = min(qt * 16 + fi, Q - 1);
       const long long r = ((long long)b * Q + q) * Tc + clip;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      u16x8 bf[KB];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const u16x8 bf = *reinterpret_cast<const u16x8*>(kl + ((long long)kb * Rk + r) * 32 + fg * 8);
-        acc = H16<BF>::mfma(af[kb], bf, acc);          // D[pixel][query]
+      for (int kb = 0; kb < KB; ++kb) bf[kb] = *reinterpret_cast<const u16x8*>(kl + ((long long)kb * Rk + r) * 32 + fg * 8);
+#pragma unroll
+      for (int t = 0; t < PXW; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc = H16<BF>::mfma(af[t][kb], bf[kb], acc);          // D[pixel][query]
+        const long long p = p0 + wave * (16 * PXW) + t * 16 + fg * 4;
+        if (qt * 16 + fi < Q && p + 3 < P)
+          *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) =
+              float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
       }
-      const long long p = p0 + wave * 16 + fg * 4;
-      if (qt * 16 + fi < Q && p + 3 < P)
-        *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) =
-            float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
     }
   }
 }
+constexpr int kEinsumPx = 256;   // pixels per workgroup of mask_einsum_kernel
+template <int CK>
+constexpr size_t einsum_lds_bytes() { return (size_t)(CK / 32) * kEinsumPx * 32 * sizeof(u16); }
 
 // Tube-Link class head (TLCC:783-797), one workgroup (256 threads = channels) per (b, q):
 //   a_t = softmax_t(w_a . x[b,q,t,:] + b_a);  pooled = sum_t a_t x[b,q,t,:];  logits = W_c pooled + b_c.
