@@ -86,6 +86,7 @@ SIGNATURES = {
     "axvs_traj_attn_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [C.c_int] * 6 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_axial_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
+    "axvs_axial_pass_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes_ex": (C.c_size_t, [C.c_int] * 9),
     "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_axial_layer_fwd_sine3d": (C.c_int, [_fp, C.POINTER(AxvsSinePos3D), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),

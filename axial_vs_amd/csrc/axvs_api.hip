@@ -420,7 +420,8 @@ PosGen make_posgen(const AxvsSinePos3D& sp, int T, int H, int W, int C, int l_is
 
 template <bool BF>
 int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W, int C,
-                      int heads, int F, void* ws, float* h_attn, float* w_attn, hipStream_t st, const AxvsSinePos3D* sine = nullptr) {
+                      int heads, int F, void* ws, float* h_attn, float* w_attn, hipStream_t st, const AxvsSinePos3D* sine = nullptr,
+                      int which = 0 /* 0: whole layer; 1: height pass only (out = src + height_attn); 2: width pass + norm1 + FFN + norm2 on src */) {
   Carver pc(const_cast<void*>(packed));
   LayerPacked p = carve_layer(pc, C, heads, F);
   const long long M = (long long)B * T * H * W;
@@ -428,6 +429,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   const LayerPlan plan = plan_layer(T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
   TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
   float* buf1 = wc.take<float>((size_t)M * C);
+  float* const scratch1 = buf1;                // fp32 scratch of the generic FFN path (free once the width pass has read the rows)
   float* buf2 = plan.need_buf2 ? wc.take<float>((size_t)M * C) : nullptr;
   u16* y16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * C) : nullptr;
   u16* h16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * F) : nullptr;
@@ -459,8 +461,14 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   }
   // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
   RowMap rmh{T * H, H, W, sB, sT, W, 1};
-  int rc = run_traj<BF>(src, src, src, pos, src, buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1, nullptr, nullptr, nullptr, ph);
-  if (rc != AXVS_OK) return rc;
+  int rc = AXVS_OK;
+  if (which != 2) {
+    rc = run_traj<BF>(src, src, src, pos, src, which == 1 ? out : buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1, nullptr, nullptr, nullptr, ph);
+    if (rc != AXVS_OK) return rc;
+    if (which == 1) return last_launch_status();
+  } else {
+    buf1 = const_cast<float*>(src);            // the caller's tensor IS the height pass's output (read only below)
+  }
   // width pass: sequences (b, h), tokens (t, w)         :206-213
   RowMap rmw{T * W, W, H, sB, sT, 1, W};
   const FfnArgs fa{p.w1, p.w2, p.b1, p.b2, p.g1, p.be1, p.g2, p.be2, F};
@@ -470,7 +478,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
   // norm1 -> FFN -> norm2                               :181-185, :217-218
-  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, buf1, y16, h16, st);
+  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, scratch1, y16, h16, st);
   if (rc2 != AXVS_OK) return rc2;
   return last_launch_status();
 }
@@ -969,6 +977,21 @@ int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const v
                          float* w_attn, void* stream) {
   if (!pos) return fail(AXVS_ERR_ARG, "null pointer");
   return axial_layer_entry(src, pos, nullptr, out, packed, B, T, H, W, C, heads, d_ffn, dtype, workspace, workspace_bytes, h_attn, w_attn, stream);
+}
+
+int axvs_axial_pass_fwd(const float* src, const float* pos, float* out, const void* packed, int pass, int B, int T, int H, int W, int C,
+                        int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!src || !pos || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (pass != 0 && pass != 1) return fail(AXVS_ERR_ARG, "pass must be 0 (height) or 1 (width + FFN)");
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return fail(AXVS_ERR_ARG, "empty shape B=%d T=%d H=%d W=%d", B, T, H, W);
+  if (src == out) return fail(AXVS_ERR_ARG, "out may not alias src");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (workspace_bytes < axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C, heads, d_ffn, 0, 0)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return axial_layer_fwd_t<true>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, nullptr, nullptr, st, nullptr, pass + 1);
+  if (dtype == AXVS_F16) return axial_layer_fwd_t<false>(src, pos, out, packed, B, T, H, W, C, heads, d_ffn, workspace, nullptr, nullptr, st, nullptr, pass + 1);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
 }
 
 size_t axvs_axial_layer_sine3d_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {

@@ -88,3 +88,53 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
     if not gather or world == 1:
         return out_local
     return gather_clips(out_local, total, T, group)
+
+
+def _exchange(blocks: List[Tensor], group=None) -> List[Tensor]:
+    """all-to-all of equally shaped blocks: blocks[j] goes to rank j, the result's entry i came from rank i.  RCCL / MPI:
+    `all_to_all_single`; backends without it (gloo, used by the CPU tests): an all-gather of everything, keeping my column."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    send = torch.stack(blocks, 0).contiguous()
+    try:
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        return list(recv.unbind(0))
+    except (RuntimeError, NotImplementedError):
+        every = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(every, send, group=group)
+        return [every[i][rank] for i in range(world)]
+
+
+def offaxis_forward(pass_fn: Callable[[Tensor, Tensor, int], Tensor], src: Tensor, pos: Tensor, group=None, gather: bool = True) -> Tensor:
+    """One clip (or a batch smaller than the GPU count) over several GPUs: SURVEY.md 8e option (ii).
+
+    The height pass mixes tokens along H only -> rank r runs it on its block of COLUMNS; the width pass, norm1, FFN and norm2 mix
+    along W / per token only -> rank r runs them on its block of ROWS; in between the [H, W_r] blocks are re-cut into [H_r, W]
+    blocks with ONE all-to-all (the whole activation crosses the links once: B*T*H*W*C*4 bytes in total).  At the metric shape
+    the exchange is 16.8 MB against ~50 us of compute per rank: latency-dominated -- this path exists for clips too large for
+    one GPU or batches smaller than the node, not to speed up B = 1.
+
+    `pass_fn(x [B,T,h,w,C], pos block, which)`: `layer.forward_pass`.  src [(B T),(H W),C] and pos [B,T,H,W,C] are replicated on
+    every rank; H and W must be multiples of the world size.  Returns the full output [(B T),(H W),C] (gather=True) or this
+    rank's rows [B,T,H_r,W,C]."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B, T, H, W, C = pos.shape
+    x = src.reshape(B, T, H, W, C)
+    if world == 1:
+        y = pass_fn(pass_fn(x, pos, 0), pos, 1)
+        return y.reshape(B * T, H * W, C) if gather else y
+    if H % world or W % world:
+        raise RuntimeError(f"offaxis_forward: H={H} and W={W} must be multiples of the world size {world}")
+    hb, wb = H // world, W // world
+    w0, h0 = rank * wb, rank * hb
+    y_cols = pass_fn(x[:, :, :, w0:w0 + wb].contiguous(), pos[:, :, :, w0:w0 + wb].contiguous(), 0)            # [B,T,H,wb,C]
+    recv = _exchange([y_cols[:, :, j * hb:(j + 1) * hb].contiguous() for j in range(world)], group)              # from rank i: [B,T,hb,wb_i,C]
+    y_rows = torch.cat(recv, dim=3)                                                                             # [B,T,hb,W,C]
+    out_rows = pass_fn(y_rows, pos[:, :, h0:h0 + hb].contiguous(), 1)
+    if not gather:
+        return out_rows
+    parts = [torch.empty_like(out_rows) for _ in range(world)]
+    dist.all_gather(parts, out_rows.contiguous(), group=group)
+    return torch.cat(parts, dim=2).reshape(B * T, H * W, C)

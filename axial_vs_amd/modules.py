@@ -374,6 +374,28 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         return out, ha, wa
 
 
+    @_guarded
+    def forward_pass(self, x: Tensor, pos: Tensor, which: int) -> Tensor:
+        """One axial pass on a LOCAL block [B,T,H,W,C] of the token grid (`pos`: the matching block of the embedding):
+        which = 0: x + height_attn(x + pos, x) -- valid on any block of columns;
+        which = 1: norm2(FFN(norm1(x + width_attn(x + pos, x)))) -- valid on any block of rows.
+        The building block of `axial_vs_amd.dist.offaxis_forward` (one clip over several GPUs)."""
+        _require_eval(self)
+        xs, ps = _dev_f32(x, "x"), _dev_f32(pos, "pos")
+        if xs.dim() != 5 or xs.shape != ps.shape:
+            raise RuntimeError(f"x {tuple(x.shape)} and pos {tuple(pos.shape)} must be equal [B,T,H,W,C] blocks")
+        B, T, H, W, C_ = xs.shape
+        L = _lib.lib()
+        F = self.linear1.out_features
+        out = torch.empty_like(xs)
+        packed = self._pack()
+        ws = _workspace(xs.device, L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, 0, 0))
+        _lib.check(L.axvs_axial_pass_fwd(xs.data_ptr(), ps.data_ptr(), out.data_ptr(), packed.data_ptr(), int(which), B, T, H, W, C_,
+                                         self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(), _stream(xs.device)),
+                   "axvs_axial_pass_fwd")
+        return out
+
+
 class TemporalTrajectoryAttentionLayer(nn.Module):
     """Full T*H*W trajectory attention (WC/temporal_attention.py:103-155).  Unused by every shipped config
     (all select 'axial-trajectory'); kept for state-dict compatibility, no HIP path."""

@@ -16,6 +16,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
   extras        secondary measurements, never the headline `value`:
                   gather      (N > 1) the same steps with the north star's RCCL all-gather of the output maps, on a side stream
                   cfg5_share  BASELINE config 5's per-GPU share [8,4,256,96,96] (batch-sharded layer), frames/s over all ranks
+                  offaxis_one_clip  (N > 1) ONE clip sharded over the ranks with an all-to-all between the passes ("strong" scaling)
                   cc_cfg4     BASELINE config 4: CrossClipTrackingModule forward, us per forward and output GB/s (N = 1)
 """
 from __future__ import annotations
@@ -272,6 +273,22 @@ def main():
             extras["gather"] = {"value": round(world * B * T * args.steps / el, 1), "unit": "frames/s", "ms_per_step": round(el / args.steps * 1e3, 5),
                                 "what": f"the same {args.steps} steps, every step followed by one contiguous RCCL all-gather of the output maps "
                                         f"({world * B * T * H * W * C * 4 / 1e6:.1f} MB gathered per rank per step) on a side stream"}
+        if world > 1 and H % world == 0 and W % world == 0:
+            # ONE clip over all ranks (SURVEY 8e option ii, "strong" scaling): height pass on column blocks, one all-to-all, width
+            # pass + FFN on row blocks (axial_vs_amd.dist.offaxis_forward).  Latency-dominated at this size by construction.
+            try:
+                from axial_vs_amd import dist as axd
+                g0 = torch.Generator(device=dev).manual_seed(12345)
+                src_same = torch.randn(B * T, H * W, C, device=dev, generator=g0)       # the same clip on every rank
+                pos_plain = pos.clone()
+                so = max(10, args.steps // 4)
+                el, oo = timed(lambda: axd.offaxis_forward(layer.forward_pass, src_same, pos_plain, gather=False), so, 3)
+                assert torch.isfinite(oo).all()
+                extras["offaxis_one_clip"] = {"value": round(B * T * so / el, 1), "unit": "frames/s", "ms_per_step": round(el / so * 1e3, 5), "scaling": "strong",
+                                              "what": f"ONE [B={B},T={T},C={C},H={H},W={W}] clip sharded over {world} ranks: column blocks -> all-to-all "
+                                                      f"({B * T * H * W * C * 4 / 1e6:.1f} MB in total over the links) -> row blocks; output left sharded"}
+            except Exception as e:          # e.g. a backend without all-to-all on GPU tensors (gloo smoke runs)
+                extras["offaxis_one_clip"] = {"error": str(e)[:200]}
         try:
             B5, T5, C5, H5, W5 = 8, 4, 256, 96, 96
             layer5, _, src5, pos5 = make_workload(B5, T5, C5, H5, W5, seed=100 + rank)

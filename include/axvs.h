@@ -104,6 +104,16 @@ int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const v
                          int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
                          float* h_attn, float* w_attn, void* stream);
 
+/* One axial pass of the layer on a LOCAL block of the token grid -- the building block of off-axis sharding of a single clip over
+ * GPUs (SURVEY 8e option ii: the height pass mixes tokens along H only, so it runs on any block of columns; the width pass, norm1,
+ * FFN and norm2 run on any block of rows; between the two the blocks are exchanged with one all-to-all):
+ *   pass 0: out = src + height_attn(q = k = src + pos, v = src)                     (WC/temporal_attention.py:197-204)
+ *   pass 1: out = norm2(FFN(norm1(src + width_attn(q = k = src + pos, v = src))))   (:206-218)
+ * src / pos / out: fp32 [B,T,H,W,C] contiguous blocks (pos: the matching block of the full embedding).  Workspace:
+ * axvs_axial_layer_workspace_bytes_ex(B,T,H,W,C,heads,d_ffn,0,0). */
+int axvs_axial_pass_fwd(const float* src, const float* pos, float* out, const void* packed, int pass, int B, int T, int H, int W,
+                        int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same layer with `pos` given as a SPECIFICATION instead of a tensor: pos = PositionEmbeddingSine3D(num_pos_feats = C/2,
  * temperature, normalize, scale)(x, fmt) in channels-last form (WC/pos_embeddings.py:86-130, mask = None) plus an optional
  * per-channel vector (the decoder's level_embed_3d[lvl], WC/msdeformattn.py:112-115).  This is what every caller of the layer

@@ -155,6 +155,22 @@ def axial_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8, want_attn:
     return x, h_attn, w_attn
 
 
+def axial_pass(x: Tensor, pos: Tensor, w: Weights, which: int, heads: int = 8) -> Tensor:
+    """One axial pass of the layer on a block [B,T,H,W,C] of the token grid (the two halves of `axial_layer`, for the off-axis
+    sharding tests): which = 0 -> x + height_attn (WC/temporal_attention.py:197-204); 1 -> width_attn + norm1 + FFN + norm2 (:206-218)."""
+    B, T, H, W, C = x.shape
+    if which == 0:
+        xs = x.permute(0, 3, 1, 2, 4).reshape(B * W, T * H, C)
+        ps = pos.permute(0, 3, 1, 2, 4).reshape(B * W, T * H, C)
+        y, _ = trajectory_attention(xs + ps, xs + ps, xs, _sub(w, "height_attn"), T, heads, want_attn=False)
+        return (xs + y).reshape(B, W, T, H, C).permute(0, 2, 3, 1, 4).contiguous()
+    xs = x.permute(0, 2, 1, 3, 4).reshape(B * H, T * W, C)
+    ps = pos.permute(0, 2, 1, 3, 4).reshape(B * H, T * W, C)
+    y, _ = trajectory_attention(xs + ps, xs + ps, xs, _sub(w, "width_attn"), T, heads, want_attn=False)
+    z = _layer_norm((xs + y).reshape(B, H, T, W, C).permute(0, 2, 1, 3, 4), w, "norm1")
+    return _layer_norm(z + _linear(torch.relu(_linear(z, w, "linear1")), w, "linear2"), w, "norm2").contiguous()
+
+
 def temporal_encoder(src: Tensor, pos: Tensor, w: Weights, num_layers: int, heads: int = 8,
                      want_attn: bool = True):
     """WC/temporal_attention.py:90-100: layers in sequence; attention maps of the last layer."""

@@ -66,3 +66,51 @@ def test_shard_bounds():
     assert shard_bounds(64, 8) == [(8 * k, 8 * k + 8) for k in range(8)]
     assert shard_bounds(3, 2) == [(0, 2), (2, 3)]
     assert shard_bounds(1, 4) == [(0, 1), (1, 1), (1, 1), (1, 1)]
+
+
+def _offaxis_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from axial_vs_amd import dist as axd
+        B, T, C, H, W, F = 1, 2, 64, 6, 4, 128
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 8)
+        src, pos = orc.synthetic_clip(B, T, C, H, W, seed=8)
+        fn = lambda x, p, which: orc.axial_pass(x, p, w, which)
+        out = axd.offaxis_forward(fn, src, pos, gather=True)
+        rows = axd.offaxis_forward(fn, src, pos, gather=False)
+        ref = orc.axial_layer(src, pos, w, 8, want_attn=False)[0]
+        hb = H // world
+        ref_rows = ref.reshape(B, T, H, W, C)[:, :, rank * hb:(rank + 1) * hb]
+        q.put((rank, float((out - ref).abs().max()), float((rows - ref_rows).abs().max()), tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_offaxis_forward_matches_unsharded():
+    """SURVEY 8e option (ii): ONE clip over 2 ranks -- height pass on column blocks, all-to-all, width pass + FFN on row blocks.
+    The per-rank compute is the oracle's two passes (test infrastructure); under test: the block cuts, the exchange and the
+    reassembly.  (gloo has no all-to-all: `_exchange` falls back to an all-gather.)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_offaxis_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, err_rows, shape in res:
+        assert shape == (2, 24, 64)
+        assert err < 1e-5 and err_rows < 1e-5, (rank, err, err_rows)
+
+
+def test_oracle_axial_pass_composes_to_the_layer():
+    B, T, C, H, W, F = 2, 3, 64, 5, 7, 128
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 9)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, seed=9)
+    ref = orc.axial_layer(src, pos, w, 8, want_attn=False)[0]
+    y = orc.axial_pass(orc.axial_pass(src.reshape(B, T, H, W, C), pos, w, 0), pos, w, 1)
+    assert float((y.reshape(B * T, H * W, C) - ref).abs().max()) < 1e-5

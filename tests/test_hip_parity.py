@@ -582,6 +582,33 @@ def test_fp16_range_check():
         ax.disable_range_check()
 
 
+def test_offaxis_passes_real_layer():
+    """Off-axis sharding of ONE clip (SURVEY 8e option ii) with the real HIP layer, two "ranks" emulated in one process: the height
+    pass on each block of columns, the blocks re-cut into row blocks (what the all-to-all does), the width pass + FFN on each block
+    of rows.  Bit-equal to the unsharded layer: rows are computed identically however the grid is cut."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = 1, 4, 256, 32, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 71)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 71)
+    src, pos = dev(src), dev(pos)                      # a plain tensor: both paths read `pos` from HBM
+    whole = layer(src, pos)[0]
+    x = src.reshape(B, T, H, W, C)
+    G = 2
+    hb, wb = H // G, W // G
+    cols = [layer.forward_pass(x[:, :, :, r * wb:(r + 1) * wb].contiguous(), pos[:, :, :, r * wb:(r + 1) * wb].contiguous(), 0) for r in range(G)]
+    rows = []
+    for r in range(G):
+        y_rows = torch.cat([cols[i][:, :, r * hb:(r + 1) * hb] for i in range(G)], dim=3).contiguous()
+        rows.append(layer.forward_pass(y_rows, pos[:, :, r * hb:(r + 1) * hb].contiguous(), 1))
+    out = torch.cat(rows, dim=2).reshape(B * T, H * W, C)
+    assert torch.equal(out, whole)
+    from axial_vs_amd import dist as axd                # world size 1: the same two passes through the dist entry point
+    assert torch.equal(axd.offaxis_forward(layer.forward_pass, src, pos), whole)
+
+
 def test_graphed_forward_matches_eager():
     """The whole forward is capturable into a HIP graph (no allocation / sync inside the library): replay == eager, bitwise,
     also after the inputs change."""
