@@ -31,6 +31,11 @@ class AxvsAxialLayerParams(C.Structure):
                                    "norm2_w", "norm2_b")]
 
 
+class AxvsTrajLayerParams(C.Structure):
+    _fields_ = [("temporal_attn", AxvsTrajParams)] + [(n, _fp) for n in ("norm1_w", "norm1_b", "linear1_w", "linear1_b", "linear2_w",
+                                                                          "linear2_b", "norm2_w", "norm2_b")]
+
+
 class AxvsSinePos3D(C.Structure):
     _fields_ = [("temperature", C.c_float), ("normalize", C.c_int), ("scale", C.c_float), ("level_embed", _fp)]
 
@@ -86,6 +91,10 @@ SIGNATURES = {
     "axvs_traj_attn_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp] + [C.c_int] * 6 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_axial_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
+    "axvs_traj_layer_packed_bytes": (C.c_size_t, [C.c_int] * 3),
+    "axvs_traj_layer_pack": (C.c_int, [C.POINTER(AxvsTrajLayerParams), _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "axvs_traj_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "axvs_traj_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 7 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_pass_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes_ex": (C.c_size_t, [C.c_int] * 9),
     "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),

@@ -323,7 +323,15 @@ qkv_done:
     case 6: rc = launch_attn<BF, 6>(w, attn, S, N, T, L, heads, Mp, st); break;
     case 7: rc = launch_attn<BF, 7>(w, attn, S, N, T, L, heads, Mp, st); break;
     case 8: rc = launch_attn<BF, 8>(w, attn, S, N, T, L, heads, Mp, st); break;
-    default: return fail(AXVS_ERR_ARG, "axis length L=%d > 256 is not supported yet", L);
+    default: {   // more than 256 keys per frame (full T*H*W trajectory attention): chunked keys, online softmax
+      if (attn != nullptr) return fail(AXVS_ERR_ARG, "attention maps are not available for frames of more than 256 keys (L=%d)", L);
+      if (int rc2 = ensure_max_lds(reinterpret_cast<const void*>(&spatial_attn_long_kernel<BF>))) return rc2;
+      const int nwaves = (N + 31) / 32 >= 8 ? 8 : (N + 31) / 32;
+      dim3 grid((N + 32 * nwaves - 1) / (32 * nwaves), heads, S);
+      hipLaunchKernelGGL((spatial_attn_long_kernel<BF>), grid, dim3(64 * nwaves), (size_t)2 * 256 * 32 * sizeof(u16), st, w.q16, w.k16, w.v16,
+                         w.x16, N, T, L, heads, Mp);
+      rc = AXVS_OK;
+    }
   }
   if (rc != AXVS_OK) return rc;
   mark(st, nm[1]);
@@ -481,6 +489,31 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, scratch1, y16, h16, st);
   if (rc2 != AXVS_OK) return rc2;
   return last_launch_status();
+}
+
+// TemporalTrajectoryAttentionLayer (WC/temporal_attention.py:103-155): ONE trajectory attention over all T*H*W tokens of a clip
+// (frames of H*W keys), then norm1 -> FFN -> norm2.  Packed blob: TrajPacked | FFN part of LayerPacked.
+template <bool BF>
+int traj_layer_fwd_t(const float* src, const float* pos, float* out, const void* packed, int B, int T, int HW, int C, int heads, int F,
+                     void* ws, hipStream_t st) {
+  Carver pc(const_cast<void*>(packed));
+  TrajPacked pt = carve_traj(pc, C, heads);
+  LayerPacked pf = carve_ffn(pc, C, F);
+  const long long M = (long long)B * T * HW;
+  Carver wc(ws);
+  TrajWs tw = carve_traj_ws(wc, M, T, heads);
+  float* x = wc.take<float>((size_t)M * C);
+  float* tmp = wc.take<float>((size_t)M * C);
+  u16* y16 = wc.take<u16>((size_t)M * C);
+  u16* h16 = wc.take<u16>((size_t)M * F);
+  g_prof_next = 0;
+  mark(st, "begin");
+  // src [(B T), HW, C] is already the sequence order 'B (T HW) C': identity row map, T frames of HW keys
+  RowMap rm{T * HW, HW, 1, (long long)T * HW, HW, 1, 0};
+  int rc = run_traj<BF>(src, src, src, pos, src, x, nullptr, pt, tw, rm, B, T, HW, C, heads, st, 0);
+  if (rc != AXVS_OK) return rc;
+  rc = run_ffn<BF>(x, out, pf, M, C, heads, F, tmp, y16, h16, st);
+  return rc != AXVS_OK ? rc : last_launch_status();
 }
 
 // ---------------- cross-clip module ----------------
@@ -1004,6 +1037,57 @@ int axvs_axial_layer_fwd_sine3d(const float* src, const AxvsSinePos3D* pos, floa
   if (!pos) return fail(AXVS_ERR_ARG, "null pointer");
   if (!(pos->temperature > 0.f)) return fail(AXVS_ERR_ARG, "temperature must be positive");
   return axial_layer_entry(src, nullptr, pos, out, packed, B, T, H, W, C, heads, d_ffn, dtype, workspace, workspace_bytes, h_attn, w_attn, stream);
+}
+
+size_t axvs_traj_layer_packed_bytes(int C, int heads, int d_ffn) {
+  Carver c(nullptr);
+  carve_traj(c, C, heads);
+  carve_ffn(c, C, d_ffn);
+  return c.off;
+}
+
+int axvs_traj_layer_pack(const AxvsTrajLayerParams* p, void* packed, int C, int heads, int d_ffn, int dtype, void* stream) {
+  if (!p || !packed) return fail(AXVS_ERR_ARG, "null pointer");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  Carver c(packed);
+  TrajPacked t = carve_traj(c, C, heads);
+  LayerPacked l = carve_ffn(c, C, d_ffn);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) {
+    pack_traj<true>(p->temporal_attn, t, C, heads, st);
+    pack_ffn<true>(p->norm1_w, p->norm1_b, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w, p->norm2_b, l, C, d_ffn, st);
+  } else {
+    pack_traj<false>(p->temporal_attn, t, C, heads, st);
+    pack_ffn<false>(p->norm1_w, p->norm1_b, p->linear1_w, p->linear1_b, p->linear2_w, p->linear2_b, p->norm2_w, p->norm2_b, l, C, d_ffn, st);
+  }
+  return last_launch_status();
+}
+
+size_t axvs_traj_layer_workspace_bytes(int B, int T, int HW, int C, int heads, int d_ffn) {
+  const long long M = (long long)B * T * HW;
+  Carver c(nullptr);
+  carve_traj_ws(c, M, T, heads);
+  c.take<float>((size_t)M * C);
+  c.take<float>((size_t)M * C);
+  c.take<u16>((size_t)M * C);
+  c.take<u16>((size_t)M * d_ffn);
+  return c.off;
+}
+
+int axvs_traj_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int HW, int C, int heads, int d_ffn,
+                        int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!src || !pos || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || T <= 0 || HW <= 0) return fail(AXVS_ERR_ARG, "empty shape B=%d T=%d HW=%d", B, T, HW);
+  if (src == out) return fail(AXVS_ERR_ARG, "out may not alias src");
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (workspace_bytes < axvs_traj_layer_workspace_bytes(B, T, HW, C, heads, d_ffn)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16) return traj_layer_fwd_t<true>(src, pos, out, packed, B, T, HW, C, heads, d_ffn, workspace, st);
+  if (dtype == AXVS_F16) return traj_layer_fwd_t<false>(src, pos, out, packed, B, T, HW, C, heads, d_ffn, workspace, st);
+  return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
 }
 
 size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn) {

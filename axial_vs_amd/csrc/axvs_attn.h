@@ -170,4 +170,140 @@ __global__ __launch_bounds__(512) void spatial_attn_kernel(const u16* __restrict
   }
 }
 
+// ---- long frames (more than 256 keys per frame): full T*H*W trajectory attention (WC/temporal_attention.py:103-155 runs ONE
+//      sequence of T*H*W tokens per clip, H*W keys per frame).  Same orientation and layouts as spatial_attn_kernel; a frame's keys
+//      are visited in chunks of 256 (K / V of a chunk staged in LDS) with an online softmax per (query, frame): running maximum,
+//      running denominator, rescaled accumulator -- the N x N logits (8.6 GB at 64 x 64 in the reference) never exist anywhere.
+template <bool BF>
+__global__ __launch_bounds__(512) void spatial_attn_long_kernel(const u16* __restrict__ Q16, const u16* __restrict__ K16,
+                                                                const u16* __restrict__ V16, u16* __restrict__ X, int N, int T, int L,
+                                                                int heads, long long Mtot) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int NKS = 8, LP = NKS * 32, QT = 2;
+  u16* sK = smem;
+  u16* sV = smem + (size_t)LP * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int h = blockIdx.y, s = blockIdx.z;
+  const int fi = lane & 15, fg = lane >> 4;
+  const long long seq0 = (long long)s * N;
+  const u16* Kh = K16 + (long long)h * Mtot * 32;
+  const u16* Vh = V16 + (long long)h * Mtot * 32;
+  const u16* Qh = Q16 + (long long)h * Mtot * 32;
+  const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * (16 * QT);
+  int qi[QT];
+  bool qvalid[QT];
+  u16x8 qfrag[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qi[t] = min(q0 + t * 16 + fi, N - 1);
+    qvalid[t] = (q0 + t * 16 + fi) < N;
+    qfrag[t] = *reinterpret_cast<const u16x8*>(Qh + (seq0 + qi[t]) * 32 + fg * 8);
+  }
+  u16* Xh = X + (long long)h * Mtot * T * 32;
+  const bool active = q0 < N;
+  const int nch = (L + LP - 1) / LP;
+  for (int f = 0; f < T; ++f) {
+    float mrun[QT], srun[QT];
+    f32x4 xa[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      mrun[t] = -INFINITY;
+      srun[t] = 0.f;
+      xa[t][0] = xa[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = 0; c < nch; ++c) {
+      const int l0 = c * LP, nk = min(LP, L - l0);           // keys of this chunk
+      __syncthreads();                                       // every wave is done with the previous chunk
+      for (int e = tid; e < LP * 4; e += nthreads) {
+        const int row = e >> 2, g = e & 3;
+        u16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+        if (row < nk) {
+          const long long r = seq0 + (long long)f * L + l0 + row;
+          kv = *reinterpret_cast<const u16x8*>(Kh + r * 32 + g * 8);
+          vv = *reinterpret_cast<const u16x8*>(Vh + r * 32 + g * 8);
+        }
+        *reinterpret_cast<u16x8*>(sK + row * 32 + swz_chunk(row, g) * 8) = kv;
+        *reinterpret_cast<u16x8*>(sV + v_lds_off(row, g * 8)) = vv;
+      }
+      __syncthreads();
+      if (!active) continue;
+      f32x4 sc[QT][2 * NKS];
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt) {
+        const int row = kt * 16 + fi;
+        const u16x8 kf = *reinterpret_cast<const u16x8*>(sK + row * 32 + swz_chunk(row, fg) * 8);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) sc[t][kt] = H16<BF>::mfma(kf, qfrag[t], f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+      if (nk < LP) {
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt * 16 + fg * 4 + r >= nk) {
+#pragma unroll
+              for (int t = 0; t < QT; ++t) sc[t][kt][r] = -INFINITY;
+            }
+      }
+      u16x8 pf[QT][NKS];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        float mx = sc[t][0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[t][kt][r]);
+        mx = fmaxf(groups_max(mx), mrun[t]);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mx);            // 0 on the first chunk (mrun = -inf)
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sc[t][kt][r] = __builtin_amdgcn_exp2f(sc[t][kt][r] - mx);
+            sum += sc[t][kt][r];
+          }
+        srun[t] = srun[t] * alpha + groups_sum(sum);
+        mrun[t] = mx;
+        xa[t][0] *= alpha;
+        xa[t][1] *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[t][ks][j] = H16<BF>::from_f32(sc[t][2 * ks + (j >> 2)][j & 3]);
+      }
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int key0 = ks * 32 + fg * 4 + (fi >> 2);
+          const int dcol = nd * 16 + (fi & 3) * 4;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sV + v_lds_off(key0, dcol)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(sV + v_lds_off(key0 + 16, dcol)));
+          u16x8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = (u16)lo[j];
+            vf[4 + j] = (u16)hi[j];
+          }
+#pragma unroll
+          for (int t = 0; t < QT; ++t) xa[t][nd] = H16<BF>::mfma(vf, pf[t][ks], xa[t][nd]);
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        if (qvalid[t]) {
+          const float inv = 1.f / srun[t];
+          float v[8] = {xa[t][0][0] * inv, xa[t][0][1] * inv, xa[t][0][2] * inv, xa[t][0][3] * inv,
+                        xa[t][1][0] * inv, xa[t][1][1] * inv, xa[t][1][2] * inv, xa[t][1][3] * inv};
+          const long long row = (long long)f * Mtot + seq0 + qi[t];
+          *reinterpret_cast<u16x8*>(Xh + row * 32 + fg * 8) = cvt8<BF>(v);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace axvs

@@ -397,12 +397,14 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
 
 
 class TemporalTrajectoryAttentionLayer(nn.Module):
-    """Full T*H*W trajectory attention (WC/temporal_attention.py:103-155).  Unused by every shipped config
-    (all select 'axial-trajectory'); kept for state-dict compatibility, no HIP path."""
+    """Full T*H*W trajectory attention (WC/temporal_attention.py:103-155, `temporal_attn_type="trajectory"`): ONE
+    TrajectoryAttention over all tokens of a clip, then norm1 -> FFN -> norm2.  Unused by every shipped config (all select
+    'axial-trajectory'); same parameter names; returns (src', None, None) like the reference."""
 
-    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, attn_drop=0.0, activation="relu", n_heads=8):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.0, attn_drop=0.0, activation="relu", n_heads=8,
+                 mfma_dtype: Optional[str] = None):
         super().__init__()
-        self.temporal_attn = TrajectoryAttention(d_model, n_heads, dropout)
+        self.temporal_attn = TrajectoryAttention(d_model, n_heads, dropout, mfma_dtype)
         self.dropout1 = nn.Dropout(attn_drop)
         self.norm1 = nn.LayerNorm(d_model)
         self.linear1 = nn.Linear(d_model, d_ffn)
@@ -411,10 +413,59 @@ class TemporalTrajectoryAttentionLayer(nn.Module):
         self.linear2 = nn.Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
+        self.n_heads = n_heads
+        self.mfma_dtype = mfma_dtype
+        self._packed: Optional[Tensor] = None
+        self._packed_key = None
 
+    def _dtype(self) -> str:
+        return self.mfma_dtype or _DEFAULT_DTYPE
+
+    def _pack(self) -> Tensor:
+        dt = self._dtype()
+        key = _param_key(self, dt)
+        if self._packed is None or key != self._packed_key:
+            if self.activation != "relu":
+                raise NotImplementedError("axial_vs_amd: only activation='relu' (every shipped config) has a HIP path")
+            L = _lib.lib()
+            C_, F, dev = self.linear1.in_features, self.linear1.out_features, self.linear1.weight.device
+            keep: list = []
+            ps = _lib.AxvsTrajLayerParams()
+            ps.temporal_attn = _traj_struct(self.temporal_attn, keep)
+            for name, t in (("norm1_w", self.norm1.weight), ("norm1_b", self.norm1.bias),
+                            ("linear1_w", self.linear1.weight), ("linear1_b", self.linear1.bias),
+                            ("linear2_w", self.linear2.weight), ("linear2_b", self.linear2.bias),
+                            ("norm2_w", self.norm2.weight), ("norm2_b", self.norm2.bias)):
+                tt = _dev_f32(t.detach(), name)
+                keep.append(tt)
+                setattr(ps, name, tt.data_ptr())
+            buf = torch.empty(L.axvs_traj_layer_packed_bytes(C_, self.n_heads, F), dtype=torch.uint8, device=dev)
+            _lib.check(L.axvs_traj_layer_pack(C.byref(ps), buf.data_ptr(), C_, self.n_heads, F, _lib.DTYPES[dt], _stream(dev)),
+                       "axvs_traj_layer_pack")
+            torch.cuda.current_stream(dev).synchronize()
+            self._packed, self._packed_key = buf, key
+        return self._packed
+
+    @_guarded
     def forward(self, src: Tensor, pos: Tensor):
-        raise NotImplementedError("axial_vs_amd: temporal_attn_type='trajectory' (full T*H*W attention) has no HIP path; "
-                                  "use 'axial-trajectory' as every shipped config does")
+        """
+        :param src: tensor of shape [B*T, H*W, C]
+        :param pos: tensor of shape [B, T, H, W, C]
+        """
+        _require_eval(self)
+        B, T, H, W = pos.shape[:4]
+        s, p = _dev_f32(src, "src"), _dev_f32(pos, "pos")
+        C_ = s.shape[-1]
+        if s.numel() != B * T * H * W * C_ or p.shape[-1] != C_:
+            raise RuntimeError(f"src {tuple(src.shape)} does not match pos {tuple(pos.shape)}")
+        L = _lib.lib()
+        F = self.linear1.out_features
+        out = torch.empty_like(s)
+        packed = self._pack()
+        ws = _workspace(s.device, L.axvs_traj_layer_workspace_bytes(B, T, H * W, C_, self.n_heads, F))
+        _lib.check(L.axvs_traj_layer_fwd(s.data_ptr(), p.data_ptr(), out.data_ptr(), packed.data_ptr(), B, T, H * W, C_, self.n_heads, F,
+                                         _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(), _stream(s.device)), "axvs_traj_layer_fwd")
+        return out, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -426,7 +477,7 @@ class TemporalEncoder(nn.Module):
         super().__init__()
         if temporal_attn_type == "trajectory":
             self.temporal_layers = nn.ModuleList([TemporalTrajectoryAttentionLayer(
-                d_model, d_ffn, dropout, attn_drop, activation, n_heads) for _ in range(num_temporal_layer)])
+                d_model, d_ffn, dropout, attn_drop, activation, n_heads, mfma_dtype) for _ in range(num_temporal_layer)])
         elif temporal_attn_type == "axial-trajectory":
             self.temporal_layers = nn.ModuleList([TemporalAxialTrajectoryAttentionLayer(
                 d_model, d_ffn, dropout, attn_drop, activation, n_heads, mfma_dtype) for _ in range(num_temporal_layer)])

@@ -104,6 +104,21 @@ int axvs_axial_layer_fwd(const float* src, const float* pos, float* out, const v
                          int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
                          float* h_attn, float* w_attn, void* stream);
 
+/* ---- TemporalTrajectoryAttentionLayer.forward(src, pos)  (temporal_attn_type = "trajectory")
+ *      WC/temporal_attention.py:103-155: ONE TrajectoryAttention over all T*H*W tokens of a clip (q = k = src + pos, v = src,
+ *      frames of H*W keys each), residual, norm1, FFN, norm2.  src/out fp32 [(B*T), HW, C]; pos fp32 [B,T,H,W,C] (= [B, T*HW, C]).
+ *      Frames of more than 256 keys take a chunked-key attention kernel with an online softmax (the reference's N x N logits
+ *      would be 8.6 GB at 64 x 64).  No attention-map output (the reference returns None, None). */
+typedef struct AxvsTrajLayerParams {
+  AxvsTrajParams temporal_attn;
+  const float *norm1_w, *norm1_b, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
+} AxvsTrajLayerParams;
+size_t axvs_traj_layer_packed_bytes(int C, int heads, int d_ffn);
+int axvs_traj_layer_pack(const AxvsTrajLayerParams* p, void* packed, int C, int heads, int d_ffn, int dtype, void* stream);
+size_t axvs_traj_layer_workspace_bytes(int B, int T, int HW, int C, int heads, int d_ffn);
+int axvs_traj_layer_fwd(const float* src, const float* pos, float* out, const void* packed, int B, int T, int HW, int C, int heads,
+                        int d_ffn, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One axial pass of the layer on a LOCAL block of the token grid -- the building block of off-axis sharding of a single clip over
  * GPUs (SURVEY 8e option ii: the height pass mixes tokens along H only, so it runs on any block of columns; the width pass, norm1,
  * FFN and norm2 run on any block of rows; between the two the blocks are exchanged with one all-to-all):

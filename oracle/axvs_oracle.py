@@ -171,6 +171,18 @@ def axial_pass(x: Tensor, pos: Tensor, w: Weights, which: int, heads: int = 8) -
     return _layer_norm(z + _linear(torch.relu(_linear(z, w, "linear1")), w, "linear2"), w, "norm2").contiguous()
 
 
+def trajectory_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8) -> Tensor:
+    """TemporalTrajectoryAttentionLayer.forward, WC/temporal_attention.py:133-155: one trajectory attention over all T*H*W tokens
+    of a clip (q = k = src + pos, v = src), residual, norm1, FFN, norm2.  src [(B T), HW, C], pos [B,T,H,W,C]."""
+    B, T = pos.shape[:2]
+    C = src.shape[-1]
+    x = src.reshape(B, -1, C)
+    kq = x + pos.reshape(B, -1, C)
+    y, _ = trajectory_attention(kq, kq, x, _sub(w, "temporal_attn"), T, heads, want_attn=False)
+    z = _layer_norm((x + y).reshape(src.shape), w, "norm1")
+    return _layer_norm(z + _linear(torch.relu(_linear(z, w, "linear1")), w, "linear2"), w, "norm2")
+
+
 def temporal_encoder(src: Tensor, pos: Tensor, w: Weights, num_layers: int, heads: int = 8,
                      want_attn: bool = True):
     """WC/temporal_attention.py:90-100: layers in sequence; attention maps of the last layer."""

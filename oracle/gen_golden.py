@@ -128,7 +128,7 @@ def main():
     ta, pe, cc = load_reference()
 
     # G1: TrajectoryAttention (q/k/v flavour)
-    for (S, T, L, C) in [(3, 2, 7, 64), (2, 5, 6, 64), (2, 1, 9, 64), (4, 4, 16, 256)]:
+    for (S, T, L, C) in ([] if "--traj-layer-only" in sys.argv else [(3, 2, 7, 64), (2, 5, 6, 64), (2, 1, 9, 64), (4, 4, 16, 256)]):
         m = ta.TrajectoryAttention(C, num_heads=8).eval()
         seed = 1000 + S * 100 + T * 10 + L
         shapes, w = load_random(m, seed)
@@ -141,9 +141,10 @@ def main():
              attn_stride=np.int64(1 if attn.numel() < 300000 else 4), attn_checks=checks(attn))
 
     # G2/G3: axial layer + positional embedding; G4: encoder
-    for (B, T, C, H, W, dffn, full) in [(1, 2, 128, 32, 32, 1024, True), (2, 3, 64, 5, 7, 256, True),
-                                        (1, 5, 64, 6, 4, 256, True), (1, 4, 256, 64, 64, 1024, False),
-                                        (1, 1, 64, 4, 5, 128, True)]:
+    for (B, T, C, H, W, dffn, full) in ([] if "--traj-layer-only" in sys.argv else
+                                        [(1, 2, 128, 32, 32, 1024, True), (2, 3, 64, 5, 7, 256, True),
+                                         (1, 5, 64, 6, 4, 256, True), (1, 4, 256, 64, 64, 1024, False),
+                                         (1, 1, 64, 4, 5, 128, True)]):
         layer = ta.TemporalAxialTrajectoryAttentionLayer(d_model=C, d_ffn=dffn, n_heads=8).eval()
         seed = 2000 + B * 1000 + T * 100 + H
         shapes, w = load_random(layer, seed)
@@ -162,6 +163,22 @@ def main():
         else:
             arrs.update(h_attn=ha[::64, ::16], w_attn=wa[::64, ::16])
         save(f"g2_axial_B{B}_T{T}_C{C}_H{H}_W{W}", **arrs)
+
+    # G2b: the full T*H*W trajectory layer (temporal_attn_type="trajectory", WC/temporal_attention.py:103-155)
+    for (B, T, C, H, W, dffn) in [(1, 2, 64, 6, 5, 128), (1, 3, 256, 12, 16, 512), (2, 2, 256, 20, 24, 256)]:
+        layer = ta.TemporalTrajectoryAttentionLayer(d_model=C, d_ffn=dffn, n_heads=8).eval()
+        seed = 2500 + T * 100 + H
+        shapes, w = load_random(layer, seed)
+        g = torch.Generator().manual_seed(seed + 1)
+        x = torch.randn(B, T, C, H, W, generator=g)
+        src = x.permute(0, 1, 3, 4, 2).reshape(B * T, H * W, C).contiguous()
+        pos = pe.PositionEmbeddingSine3D(C // 2, normalize=True)(x, fmt="btchw").permute(0, 1, 3, 4, 2).contiguous()
+        out, _, _ = layer(src, pos)
+        stride = 1 if out.numel() < 200000 else 3
+        save(f"g2b_traj_layer_B{B}_T{T}_C{C}_H{H}_W{W}", meta=meta(B=B, T=T, C=C, H=H, W=W, d_ffn=dffn, heads=8, seed=seed, shapes=shapes, stride=stride),
+             wsum=np.float64(wsum(w)), out=out[:, ::stride], out_checks=checks(out))
+    if "--traj-layer-only" in sys.argv:
+        return
 
     B, T, C, H, W = 2, 2, 64, 6, 5
     enc = ta.TemporalEncoder(d_model=C, d_ffn=128, n_heads=8, temporal_attn_type="axial-trajectory", num_temporal_layer=2).eval()

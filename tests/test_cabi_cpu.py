@@ -92,6 +92,10 @@ def test_no_cpu_fallback_and_forward_only():
         ax.TemporalAxialTrajectoryAttentionLayer(64, 128, activation="swish")
     enc = ax.TemporalEncoder(64, 128, temporal_attn_type="axial_trajectory")   # the reference's default-string gotcha
     assert not hasattr(enc, "temporal_layers")
+    full = ax.TemporalEncoder(64, 128, temporal_attn_type="trajectory", num_temporal_layer=1).eval()    # full T*H*W attention (a7)
+    assert sorted(k for k in full.state_dict() if k.endswith(".q.weight")) == ["temporal_layers.0.temporal_attn.q.weight"]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        full(src, pos)
 
 
 @pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2"])

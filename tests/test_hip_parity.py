@@ -76,6 +76,48 @@ def test_axial_layer_golden(name, dtype, tol):
             assert rel_err(ha[::64, ::16], t(z["h_attn"])) < TOL_ATTN_MAP and rel_err(wa[::64, ::16], t(z["w_attn"])) < TOL_ATTN_MAP
 
 
+from golden_util import TRAJ_LAYER  # noqa: E402
+
+
+@pytest.mark.parametrize("name", TRAJ_LAYER)
+def test_full_trajectory_layer_golden(name):
+    """TemporalTrajectoryAttentionLayer (`temporal_attn_type="trajectory"`, WC/temporal_attention.py:103-155): ONE
+    trajectory attention over all T*H*W tokens of a clip.  Frames of 30 keys (C = 64, generic kernels), 192 keys (LDS-resident
+    K / V) and 480 keys (chunked keys with an online softmax) against the reference class."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    layer = ax.TemporalTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    out, ha, wa = layer(dev(src), dev(pos))
+    assert ha is None and wa is None
+    e, e2 = rel_err(out.cpu()[:, ::m["stride"]], t(z["out"])), rel_l2(out.cpu()[:, ::m["stride"]], t(z["out"]))
+    print(f"{name}: max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < TOL_F16 and e2 < TOL_F16
+    np.testing.assert_allclose(checks(out.cpu())[1:], z["out_checks"][1:], rtol=2e-3)
+    enc = ax.TemporalEncoder(m["C"], m["d_ffn"], n_heads=8, temporal_attn_type="trajectory", num_temporal_layer=1).eval()
+    enc.temporal_layers[0].load_state_dict(w, strict=True)
+    assert torch.equal(enc.cuda()(dev(src), dev(pos))[0], out)          # the reference's default encoder type dispatches here
+
+
+def test_full_trajectory_layer_long_frames_vs_oracle():
+    """64 x 48 = 3072 keys per frame, T = 2 (the reference would materialise 8 x 6144^2 logits): fp64 oracle."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = 1, 2, 256, 64, 48, 512
+    w = orc.random_weights({k.replace("height_attn", "temporal_attn"): v for k, v in orc.axial_layer_param_shapes(C, F).items()
+                            if "width_attn" not in k}, 81)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 81)
+    ref = orc.trajectory_layer(src.double(), pos.double(), {k: v.double() for k, v in w.items()}, 8)
+    layer = ax.TemporalTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    out = layer.cuda()(dev(src), dev(pos))[0]
+    e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
+    print(f"full trajectory layer, {H * W} keys per frame: max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < TOL_F16 and e2 < TOL_F16
+
+
 def test_encoder_golden():
     import axial_vs_amd as ax
     z, m = load("g4_encoder_B2_T2_C64_H6_W5")

@@ -216,3 +216,18 @@ def test_pixel_decoder_full_size():
                                                "s1_temporal_res4"]
     for tag, _, y in trace[1:]:
         assert rel_err(y[:, ::37, ::4], t(z["tr_" + tag])) < 2e-5, tag
+
+
+from golden_util import TRAJ_LAYER, axial_inputs  # noqa: E402
+
+
+@pytest.mark.parametrize("name", TRAJ_LAYER)
+def test_full_trajectory_layer(name):
+    """TemporalTrajectoryAttentionLayer (temporal_attn_type="trajectory"): one attention over all T*H*W tokens of a
+    clip, against the reference class (frames of 30, 192 and 480 keys)."""
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    out = orc.trajectory_layer(src, pos, w, 8)
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
+    assert rel_err(out[:, ::m["stride"]], t(z["out"])) < 2e-5
