@@ -95,6 +95,12 @@ SIGNATURES = {
     "axvs_traj_layer_pack": (C.c_int, [C.POINTER(AxvsTrajLayerParams), _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "axvs_traj_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "axvs_traj_layer_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 7 + [_fp, C.c_size_t, _fp]),
+    "axvs_axial_layer_train_saved_bytes": (C.c_size_t, [C.c_int] * 7),
+    "axvs_axial_layer_train_scratch_bytes": (C.c_size_t, [C.c_int] * 8),
+    "axvs_axial_layer_train_fwd": (C.c_int, [_fp, _fp, _fp, C.POINTER(AxvsAxialLayerParams)] + [C.c_int] * 7 +
+                                   [C.c_float, C.c_float, C.c_uint, _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
+    "axvs_axial_layer_train_bwd": (C.c_int, [_fp, _fp, _fp, C.POINTER(AxvsAxialLayerParams), C.POINTER(AxvsAxialLayerParams), _fp, _fp] +
+                                   [C.c_int] * 7 + [C.c_float, C.c_float, C.c_uint, C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
     "axvs_axial_pass_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes_ex": (C.c_size_t, [C.c_int] * 9),
     "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),

@@ -1,0 +1,547 @@
+// Training tier of the axial-trajectory attention layer: fp32 activations in natural [B,T,H,W] row order, the
+// attention / softmax / dropout / LayerNorm kernels here, the Linear layers' plain GEMMs (forward, dgrad, wgrad) through rocBLAS
+// (axvs_train.hip).  Nothing here is on the inference path; that stays on the fused 16-bit MFMA kernels (axvs_fused.h).
+//
+// Reference semantics (WC/temporal_attention.py): TrajectoryAttention.forward :35-76 (dropout on the spatial attention map :55),
+// TemporalAxialTrajectoryAttentionLayer.forward :187-220 (dropout1 on each pass output :204, :213; dropout2 / dropout3 in the
+// FFN :182-183).  Dropout masks come from a counter-based hash of (seed, site, element index) so that the backward pass (and the
+// recomputed forward, and the CPU oracle in the tests) regenerate them instead of storing them.
+#pragma once
+#include "axvs_common.h"
+
+namespace axvs {
+namespace tr {
+
+__host__ __device__ __forceinline__ unsigned fmix32(unsigned h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// keep element `idx` of dropout site `site` iff (hash >> 8) >= thr, thr = floor(p * 2^24)
+struct Drop {
+  unsigned seed, site, thr;
+  float scale;   // 1 / (1 - p)
+};
+
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned site, unsigned long long idx) {
+  unsigned h = seed ^ (site * 0x9E3779B9u);
+  h = fmix32(h ^ (unsigned)idx);
+  h = fmix32(h ^ (unsigned)(idx >> 32));
+  return h;
+}
+
+__device__ __forceinline__ float drop_keep(const Drop& d, unsigned long long idx) {   // 0 or 1/(1-p)
+  if (d.thr == 0) return 1.f;
+  return (drop_hash(d.seed, d.site, idx) >> 8) >= d.thr ? d.scale : 0.f;
+}
+
+template <int D>
+__device__ __forceinline__ void load_row(float (&r)[D], const float* p) {
+#pragma unroll
+  for (int i = 0; i < D; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + i);
+    r[i] = v.x; r[i + 1] = v.y; r[i + 2] = v.z; r[i + 3] = v.w;
+  }
+}
+template <int D>
+__device__ __forceinline__ void store_row(float* p, const float (&r)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; i += 4) *reinterpret_cast<float4*>(p + i) = make_float4(r[i], r[i + 1], r[i + 2], r[i + 3]);
+}
+template <int D>
+__device__ __forceinline__ float dot_lds(const float (&a)[D], const float* s) {   // s: LDS row (all lanes the same row: broadcast)
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(s + i);
+    acc += a[i] * v.x + a[i + 1] * v.y + a[i + 2] * v.z + a[i + 3] * v.w;
+  }
+  return acc;
+}
+template <int D>
+__device__ __forceinline__ void axpy_lds(float (&acc)[D], float a, const float* s) {
+#pragma unroll
+  for (int i = 0; i < D; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(s + i);
+    acc[i] += a * v.x; acc[i + 1] += a * v.y; acc[i + 2] += a * v.z; acc[i + 3] += a * v.w;
+  }
+}
+
+// the rows of frame f of sequence s, head h: global [.., C] -> LDS [L][D]
+template <int D>
+__device__ __forceinline__ void stage_frame(float* dst, const float* src, const RowMap& rm, int s, int f, int h, int C, int tid) {
+  constexpr int V = D / 4;
+  for (int i = tid; i < rm.L * V; i += 256) {
+    const int n = i / V, c4 = i - n * V;
+    const long long row = nat_row(rm, s * rm.N + f * rm.L + n);
+    *reinterpret_cast<float4*>(dst + n * D + c4 * 4) = *reinterpret_cast<const float4*>(src + row * C + h * D + c4 * 4);
+  }
+}
+
+// ---- spatial half, forward (WC/temporal_attention.py:47-58): x[q, f, :] = sum_n drop(softmax_n(scale q.k_{f,n})) v_{f,n}
+//      one workgroup per (sequence, head), one thread per query, K_f / V_f of the frame in LDS.  x: [M, T, C] by natural row.
+//      dropout index of P[(s h), q, f, n] is its offset in the reference's tensor: (((s heads + h) N + q) T + f) L + n.
+template <int D>
+__global__ __launch_bounds__(256) void tr_spatial_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, float* __restrict__ x, RowMap rm, int T, int C,
+                                                              int heads, float scale, Drop dr) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  float* ks = smem;
+  float* vs = smem + L * D;
+  for (int q0 = 0; q0 < N; q0 += 256) {
+    const int qn = q0 + tid;
+    const bool act = qn < N;
+    const long long mq = nat_row(rm, s * N + (act ? qn : 0));
+    float qr[D];
+    load_row<D>(qr, q + mq * C + h * D);
+#pragma unroll
+    for (int i = 0; i < D; ++i) qr[i] *= scale;
+    for (int f = 0; f < T; ++f) {
+      __syncthreads();
+      stage_frame<D>(ks, k, rm, s, f, h, C, tid);
+      stage_frame<D>(vs, v, rm, s, f, h, C, tid);
+      __syncthreads();
+      if (!act) continue;
+      float mx = -INFINITY;
+      for (int n = 0; n < L; ++n) mx = fmaxf(mx, dot_lds<D>(qr, ks + n * D));
+      float sum = 0.f, acc[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) acc[i] = 0.f;
+      const unsigned long long base = ((((unsigned long long)s * heads + h) * N + qn) * T + f) * L;
+      for (int n = 0; n < L; ++n) {
+        const float p = __expf(dot_lds<D>(qr, ks + n * D) - mx);
+        sum += p;
+        const float kp = drop_keep(dr, base + n);
+        if (kp != 0.f) axpy_lds<D>(acc, p * kp, vs + n * D);
+      }
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int i = 0; i < D; ++i) acc[i] *= inv;
+      store_row<D>(x + (mq * T + f) * C + h * D, acc);
+    }
+  }
+}
+
+// ---- spatial half, backward, part 1 (one thread per query): the softmax statistics (max, 1/sum, D = sum_n P dP) of every
+//      (query, frame) and dq.  dP_n = keep_n (dx_f . v_n),  dS_n = P_n (dP_n - D),  dq = scale sum_{f,n} dS_n k_n.
+//      stats: [(s heads + h), N, T, 3].
+template <int D>
+__global__ __launch_bounds__(256) void tr_spatial_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, const float* __restrict__ dx,
+                                                                float* __restrict__ dq, float* __restrict__ stats, RowMap rm, int T, int C,
+                                                                int heads, float scale, Drop dr) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  float* ks = smem;
+  float* vs = smem + L * D;
+  for (int q0 = 0; q0 < N; q0 += 256) {
+    const int qn = q0 + tid;
+    const bool act = qn < N;
+    const long long mq = nat_row(rm, s * N + (act ? qn : 0));
+    float qr[D], dqr[D];
+    load_row<D>(qr, q + mq * C + h * D);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      qr[i] *= scale;
+      dqr[i] = 0.f;
+    }
+    for (int f = 0; f < T; ++f) {
+      __syncthreads();
+      stage_frame<D>(ks, k, rm, s, f, h, C, tid);
+      stage_frame<D>(vs, v, rm, s, f, h, C, tid);
+      __syncthreads();
+      if (!act) continue;
+      float dxr[D];
+      load_row<D>(dxr, dx + (mq * T + f) * C + h * D);
+      float mx = -INFINITY;
+      for (int n = 0; n < L; ++n) mx = fmaxf(mx, dot_lds<D>(qr, ks + n * D));
+      const unsigned long long base = ((((unsigned long long)s * heads + h) * N + qn) * T + f) * L;
+      float sum = 0.f, pd = 0.f;
+      for (int n = 0; n < L; ++n) {
+        const float p = __expf(dot_lds<D>(qr, ks + n * D) - mx);
+        sum += p;
+        const float kp = drop_keep(dr, base + n);
+        if (kp != 0.f) pd += p * kp * dot_lds<D>(dxr, vs + n * D);
+      }
+      const float inv = 1.f / sum, Dsum = pd * inv;
+      for (int n = 0; n < L; ++n) {
+        const float P = __expf(dot_lds<D>(qr, ks + n * D) - mx) * inv;
+        const float kp = drop_keep(dr, base + n);
+        const float dP = kp != 0.f ? kp * dot_lds<D>(dxr, vs + n * D) : 0.f;
+        axpy_lds<D>(dqr, P * (dP - Dsum), ks + n * D);
+      }
+      float* st = stats + ((((size_t)s * heads + h) * N + qn) * T + f) * 3;
+      st[0] = mx;
+      st[1] = inv;
+      st[2] = Dsum;
+    }
+    if (act) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) dqr[i] *= scale;
+      store_row<D>(dq + mq * C + h * D, dqr);
+    }
+  }
+}
+
+// ---- spatial half, backward, part 2 (one thread per key): dk = scale sum_q dS q,  dv = sum_q keep P dx_f, with P rebuilt from
+//      the statistics of part 1.  Queries are staged QC at a time (scaled q, dx of all T frames, statistics).
+template <int D>
+__global__ __launch_bounds__(256) void tr_spatial_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                 const float* __restrict__ v, const float* __restrict__ dx,
+                                                                 const float* __restrict__ stats, float* __restrict__ dk,
+                                                                 float* __restrict__ dv, RowMap rm, int T, int C, int heads, float scale,
+                                                                 Drop dr, int QC) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  float* qs = smem;                  // [QC][D]
+  float* dxs = qs + QC * D;          // [QC][T][D]
+  float* sts = dxs + QC * T * D;     // [QC][T][3]
+  constexpr int V = D / 4;
+  for (int k0 = 0; k0 < N; k0 += 256) {
+    const int kn = k0 + tid;
+    const bool act = kn < N;
+    const int f = act ? kn / L : 0, n = act ? kn - f * L : 0;
+    const long long mk = nat_row(rm, s * N + (act ? kn : 0));
+    float kr[D], vr[D], dkr[D], dvr[D];
+    load_row<D>(kr, k + mk * C + h * D);
+    load_row<D>(vr, v + mk * C + h * D);
+#pragma unroll
+    for (int i = 0; i < D; ++i) dkr[i] = dvr[i] = 0.f;
+    for (int q0 = 0; q0 < N; q0 += QC) {
+      const int nq = min(QC, N - q0);
+      __syncthreads();
+      for (int i = tid; i < nq * V; i += 256) {
+        const int qi = i / V, c4 = i - qi * V;
+        const long long mq = nat_row(rm, s * N + q0 + qi);
+        float4 t = *reinterpret_cast<const float4*>(q + mq * C + h * D + c4 * 4);
+        t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+        *reinterpret_cast<float4*>(qs + qi * D + c4 * 4) = t;
+      }
+      for (int i = tid; i < nq * T * V; i += 256) {
+        const int qi = i / (T * V), r = i - qi * (T * V), ff = r / V, c4 = r - ff * V;
+        const long long mq = nat_row(rm, s * N + q0 + qi);
+        *reinterpret_cast<float4*>(dxs + (qi * T + ff) * D + c4 * 4) = *reinterpret_cast<const float4*>(dx + (mq * T + ff) * C + h * D + c4 * 4);
+      }
+      for (int i = tid; i < nq * T * 3; i += 256) sts[i] = stats[((((size_t)s * heads + h) * N + q0) * T) * 3 + i];
+      __syncthreads();
+      if (!act) continue;
+      for (int qi = 0; qi < nq; ++qi) {
+        const float* st = sts + (qi * T + f) * 3;
+        const float P = __expf(dot_lds<D>(kr, qs + qi * D) - st[0]) * st[1];
+        const float kp = drop_keep(dr, ((((unsigned long long)s * heads + h) * N + q0 + qi) * T + f) * L + n);
+        const float* dxr = dxs + (qi * T + f) * D;
+        const float dP = kp != 0.f ? kp * dot_lds<D>(vr, dxr) : 0.f;
+        axpy_lds<D>(dkr, P * (dP - st[2]), qs + qi * D);      // qs is scale * q: the factor `scale` of dk rides along
+        if (kp != 0.f) axpy_lds<D>(dvr, P * kp, dxr);
+      }
+    }
+    if (act) {
+      store_row<D>(dk + mk * C + h * D, dkr);
+      store_row<D>(dv + mk * C + h * D, dvr);
+    }
+  }
+}
+
+// ---- temporal half (WC/temporal_attention.py:69-73), one thread per (token, head):
+//      logits_f = q2 . k2_f, a = softmax_f, o = sum_f a_f v2_f.   q2 [M,C] (already scaled), kv2 [M*T, 2C] = (k2 | v2), T <= 8.
+template <int D>
+__global__ __launch_bounds__(256) void tr_temporal_fwd_kernel(const float* __restrict__ q2, const float* __restrict__ kv2,
+                                                               float* __restrict__ o, long long M, int T, int C, int heads) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * heads) return;
+  const long long m = i / heads;
+  const int h = (int)(i - m * heads);
+  float qr[D], acc[D], lg[8];
+  load_row<D>(qr, q2 + m * C + h * D);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      float kr[D];
+      load_row<D>(kr, kv2 + (m * T + f) * 2 * C + h * D);
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) a += qr[c] * kr[c];
+      lg[f] = a;
+      mx = fmaxf(mx, a);
+    }
+  float sum = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      lg[f] = __expf(lg[f] - mx);
+      sum += lg[f];
+    }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      float vr[D];
+      load_row<D>(vr, kv2 + (m * T + f) * 2 * C + C + h * D);
+      const float a = lg[f] * inv;
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] += a * vr[c];
+    }
+  store_row<D>(o + m * C + h * D, acc);
+}
+
+// backward: d_o -> dq2 [M,C], dkv2 [M*T, 2C]
+template <int D>
+__global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __restrict__ q2, const float* __restrict__ kv2,
+                                                               const float* __restrict__ d_o, float* __restrict__ dq2,
+                                                               float* __restrict__ dkv2, long long M, int T, int C, int heads) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * heads) return;
+  const long long m = i / heads;
+  const int h = (int)(i - m * heads);
+  float qr[D], gr[D], lg[8], da[8];
+  load_row<D>(qr, q2 + m * C + h * D);
+  load_row<D>(gr, d_o + m * C + h * D);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      float kr[D], vr[D];
+      load_row<D>(kr, kv2 + (m * T + f) * 2 * C + h * D);
+      load_row<D>(vr, kv2 + (m * T + f) * 2 * C + C + h * D);
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        a += qr[c] * kr[c];
+        b += gr[c] * vr[c];
+      }
+      lg[f] = a;
+      da[f] = b;
+      mx = fmaxf(mx, a);
+    }
+  float sum = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      lg[f] = __expf(lg[f] - mx);
+      sum += lg[f];
+    }
+  const float inv = 1.f / sum;
+  float dot = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      lg[f] *= inv;
+      dot += lg[f] * da[f];
+    }
+  float dqr[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) dqr[c] = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+    if (f < T) {
+      const float dl = lg[f] * (da[f] - dot);
+      float kr[D], t0[D], t1[D];
+      load_row<D>(kr, kv2 + (m * T + f) * 2 * C + h * D);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        dqr[c] += dl * kr[c];
+        t0[c] = dl * qr[c];
+        t1[c] = lg[f] * gr[c];
+      }
+      store_row<D>(dkv2 + (m * T + f) * 2 * C + h * D, t0);
+      store_row<D>(dkv2 + (m * T + f) * 2 * C + C + h * D, t1);
+    }
+  store_row<D>(dq2 + m * C + h * D, dqr);
+}
+
+// ---- LayerNorm over the channel dimension, one wave per row; eps 1e-5 (nn.LayerNorm default, WC/temporal_attention.py:167,175)
+__device__ __forceinline__ float wave_total(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void tr_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                         float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                         long long M, int C) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= M) return;
+  const float* xr = x + r * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mu = wave_total(s) / C;
+  float vs = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] - mu;
+    vs += d * d;
+  }
+  const float rs = rsqrtf(wave_total(vs) / C + 1e-5f);
+  for (int c = lane; c < C; c += 64) y[r * C + c] = (xr[c] - mu) * rs * g[c] + b[c];
+  if (lane == 0) {
+    mean[r] = mu;
+    rstd[r] = rs;
+  }
+}
+
+// dx = rstd (g dy - mean_c(g dy) - xhat mean_c(g dy xhat))
+__global__ __launch_bounds__(256) void tr_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         float* __restrict__ dx, long long M, int C) {
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= M) return;
+  const float mu = mean[r], rs = rstd[r];
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float w = dy[r * C + c] * g[c], xh = (x[r * C + c] - mu) * rs;
+    a += w;
+    b += w * xh;
+  }
+  a = wave_total(a) / C;
+  b = wave_total(b) / C;
+  for (int c = lane; c < C; c += 64) {
+    const float w = dy[r * C + c] * g[c], xh = (x[r * C + c] - mu) * rs;
+    dx[r * C + c] = rs * (w - a - xh * b);
+  }
+}
+
+// ---- column sums over rows (bias / LayerNorm parameter gradients), two deterministic stages.
+//      part_a[blk][c] = sum_r dy[r][c];  with x: part_b[blk][c] = sum_r dy[r][c] * xhat[r][c]
+__global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ part_a,
+                                                         float* __restrict__ part_b, long long M, int C, int rows_per_blk) {
+  const long long r0 = (long long)blockIdx.x * rows_per_blk;
+  const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+      const float d = dy[r * C + c];
+      a += d;
+      if (x) b += d * (x[r * C + c] - mean[r]) * rstd[r];
+    }
+    part_a[(size_t)blockIdx.x * C + c] = a;
+    if (x) part_b[(size_t)blockIdx.x * C + c] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int i = 0; i < nblk; ++i) a += part[(size_t)i * C + c];
+  out[c] = a;
+}
+
+// ---- elementwise pieces -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tr_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 u = reinterpret_cast<const float4*>(a)[i], w = reinterpret_cast<const float4*>(b)[i];
+  reinterpret_cast<float4*>(y)[i] = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+}
+
+// y = relu?((y + bias) * mul), then dropout by element index r * N + c (site: dropout2 of the FFN)
+__global__ __launch_bounds__(256) void tr_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, long long M, int N, float mul,
+                                                           int relu, Drop dr) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+  const int n4 = N / 4;
+  if (i >= (size_t)M * n4) return;
+  const int c = (int)(i % n4) * 4;
+  float4 v = reinterpret_cast<float4*>(y)[i];
+  const float4 b = *reinterpret_cast<const float4*>(bias + c);
+  float t[4] = {(v.x + b.x) * mul, (v.y + b.y) * mul, (v.z + b.z) * mul, (v.w + b.w) * mul};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (relu) t[e] = fmaxf(t[e], 0.f);
+    t[e] *= drop_keep(dr, (unsigned long long)i * 4 + e);
+  }
+  reinterpret_cast<float4*>(y)[i] = make_float4(t[0], t[1], t[2], t[3]);
+}
+
+// out[row] = res[row] + drop(y[row] + bias), rows visited in SEQUENCE order mp (row = nat_row(rm, mp)): the dropout index of the
+// reference's [(B Loff), (T L), C] tensor is mp * C + c.  With rm = identity this is the FFN's dropout3 + residual.
+__global__ __launch_bounds__(256) void tr_bias_drop_res_kernel(const float* __restrict__ y, const float* __restrict__ bias,
+                                                                const float* __restrict__ res, float* __restrict__ out, RowMap rm, long long M,
+                                                                int C, Drop dr) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = C / 4;
+  if (i >= (size_t)M * n4) return;
+  const long long mp = (long long)(i / n4);
+  const int c = (int)(i - (size_t)mp * n4) * 4;
+  const long long row = nat_row(rm, (int)mp);
+  const float4 v = *reinterpret_cast<const float4*>(y + row * C + c), b = *reinterpret_cast<const float4*>(bias + c);
+  const float4 r = *reinterpret_cast<const float4*>(res + row * C + c);
+  const unsigned long long e = (unsigned long long)mp * C + c;
+  *reinterpret_cast<float4*>(out + row * C + c) =
+      make_float4(r.x + (v.x + b.x) * drop_keep(dr, e), r.y + (v.y + b.y) * drop_keep(dr, e + 1), r.z + (v.z + b.z) * drop_keep(dr, e + 2),
+                  r.w + (v.w + b.w) * drop_keep(dr, e + 3));
+}
+
+// dy[row] = keep * dout[row]  (same indexing as tr_bias_drop_res_kernel)
+__global__ __launch_bounds__(256) void tr_drop_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dy, RowMap rm, long long M, int C,
+                                                           Drop dr) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = C / 4;
+  if (i >= (size_t)M * n4) return;
+  const long long mp = (long long)(i / n4);
+  const int c = (int)(i - (size_t)mp * n4) * 4;
+  const long long row = nat_row(rm, (int)mp);
+  const float4 v = *reinterpret_cast<const float4*>(dout + row * C + c);
+  const unsigned long long e = (unsigned long long)mp * C + c;
+  *reinterpret_cast<float4*>(dy + row * C + c) =
+      make_float4(v.x * drop_keep(dr, e), v.y * drop_keep(dr, e + 1), v.z * drop_keep(dr, e + 2), v.w * drop_keep(dr, e + 3));
+}
+
+// r = dropout2(relu(h)) was stored: d_h = (r > 0) ? scale * d_r : 0   (a dropped or clipped element has r == 0 and no gradient)
+__global__ __launch_bounds__(256) void tr_relu_drop_bwd_kernel(float* __restrict__ dr_, const float* __restrict__ r, size_t n4, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 d = reinterpret_cast<float4*>(dr_)[i];
+  const float4 a = reinterpret_cast<const float4*>(r)[i];
+  d.x = a.x > 0.f ? d.x * scale : 0.f;
+  d.y = a.y > 0.f ? d.y * scale : 0.f;
+  d.z = a.z > 0.f ? d.z * scale : 0.f;
+  d.w = a.w > 0.f ? d.w * scale : 0.f;
+  reinterpret_cast<float4*>(dr_)[i] = d;
+}
+
+// xd[m] = x[m, t(m)], t(m) = (m / HW) % T: the own-frame slot of every token (torch.diagonal, WC/temporal_attention.py:62-64)
+__global__ __launch_bounds__(256) void tr_diag_gather_kernel(const float* __restrict__ x, float* __restrict__ xd, long long M, int T, long long HW,
+                                                              int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = C / 4;
+  if (i >= (size_t)M * n4) return;
+  const long long m = (long long)(i / n4);
+  const int c4 = (int)(i - (size_t)m * n4);
+  const int t = (int)((m / HW) % T);
+  reinterpret_cast<float4*>(xd)[i] = reinterpret_cast<const float4*>(x)[((size_t)m * T + t) * n4 + c4];
+}
+
+// dx[m, t(m)] += mul * dxd[m]
+__global__ __launch_bounds__(256) void tr_diag_scatter_add_kernel(float* __restrict__ dx, const float* __restrict__ dxd, long long M, int T,
+                                                                   long long HW, int C) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = C / 4;
+  if (i >= (size_t)M * n4) return;
+  const long long m = (long long)(i / n4);
+  const int c4 = (int)(i - (size_t)m * n4);
+  const int t = (int)((m / HW) % T);
+  float4* p = reinterpret_cast<float4*>(dx) + ((size_t)m * T + t) * n4 + c4;
+  const float4 a = *p, b = reinterpret_cast<const float4*>(dxd)[i];
+  *p = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+__global__ __launch_bounds__(256) void tr_scale_kernel(float* __restrict__ y, size_t n4, float mul) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(y)[i];
+  v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+
+}  // namespace tr
+}  // namespace axvs

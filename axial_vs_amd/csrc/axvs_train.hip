@@ -1,0 +1,457 @@
+// Training tier of TemporalAxialTrajectoryAttentionLayer behind the C ABI: forward that keeps the activations,
+// and the backward pass.  Kernels: axvs_train.h.  The Linear layers (forward, input gradient, weight gradient) are plain fp32
+// GEMMs and go to rocBLAS, resolved at first use with dlopen so that inference-only users of libaxvs.so never load it.
+#include <dlfcn.h>
+#include <rocblas/rocblas.h>
+
+#include "axvs_host.h"
+#include "axvs_train.h"
+
+namespace axvs {
+namespace {
+
+using namespace tr;
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct Bump {   // bump allocator over a caller-owned buffer (nullptr: size only)
+  char* base;
+  size_t off = 0;
+  explicit Bump(void* p) : base(static_cast<char*>(p)) {}
+  float* f(size_t n) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off = align256(off + n * sizeof(float));
+    return p;
+  }
+};
+
+// ---- rocBLAS, late bound ---------------------------------------------------------------------------------------------------
+struct Blas {
+  decltype(&rocblas_create_handle) create = nullptr;
+  decltype(&rocblas_set_stream) set_stream = nullptr;
+  decltype(&rocblas_set_atomics_mode) set_atomics = nullptr;
+  decltype(&rocblas_sgemm) sgemm = nullptr;
+  bool ok = false;
+};
+
+const Blas& blas() {
+  static const Blas b = [] {
+    Blas r;
+    void* h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return r;
+    r.create = reinterpret_cast<decltype(r.create)>(dlsym(h, "rocblas_create_handle"));
+    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(h, "rocblas_set_stream"));
+    r.set_atomics = reinterpret_cast<decltype(r.set_atomics)>(dlsym(h, "rocblas_set_atomics_mode"));
+    r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(h, "rocblas_sgemm"));
+    r.ok = r.create && r.set_stream && r.set_atomics && r.sgemm;
+    return r;
+  }();
+  return b;
+}
+
+struct Gemm {   // one rocBLAS handle per (thread, device), bound to the call's stream
+  rocblas_handle h = nullptr;
+  int init(hipStream_t st) {
+    const Blas& b = blas();
+    if (!b.ok) return fail(AXVS_ERR_LAUNCH, "the training tier needs rocBLAS (librocblas.so.5 could not be loaded)");
+    constexpr int kMaxDev = 16;
+    static thread_local rocblas_handle handles[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return fail(AXVS_ERR_LAUNCH, "hipGetDevice failed");
+    if (!handles[dev]) {
+      if (b.create(&handles[dev]) != rocblas_status_success) return fail(AXVS_ERR_LAUNCH, "rocblas_create_handle failed");
+      b.set_atomics(handles[dev], rocblas_atomics_not_allowed);   // deterministic reductions
+    }
+    h = handles[dev];
+    if (b.set_stream(h, st) != rocblas_status_success) return fail(AXVS_ERR_LAUNCH, "rocblas_set_stream failed");
+    return AXVS_OK;
+  }
+  int call(rocblas_operation ta, rocblas_operation tb, long long m, long long n, long long k, const float* A, long long lda, const float* B,
+           long long ldb, float beta, float* C, long long ldc) const {
+    const float alpha = 1.f;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return fail(AXVS_ERR_ARG, "GEMM dimension exceeds rocblas_int");
+    if (blas().sgemm(h, ta, tb, (int)m, (int)n, (int)k, &alpha, A, (int)lda, B, (int)ldb, &beta, C, (int)ldc) != rocblas_status_success)
+      return fail(AXVS_ERR_LAUNCH, "rocblas_sgemm failed");
+    return AXVS_OK;
+  }
+  // row-major:  Y[M,N] = X[M,K] W[N,K]^T
+  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K) const {
+    return call(rocblas_operation_transpose, rocblas_operation_none, N, M, K, W, K, X, K, 0.f, Y, N);
+  }
+  // dX[M,K] = beta dX + dY[M,N] W[N,K]
+  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta) const {
+    return call(rocblas_operation_none, rocblas_operation_none, K, M, N, W, K, dY, N, beta, dX, K);
+  }
+  // dW[N,K] = dY[M,N]^T X[M,K]
+  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K) const {
+    return call(rocblas_operation_none, rocblas_operation_transpose, K, N, M, X, K, dY, N, 0.f, dW, K);
+  }
+};
+
+// ---- shapes and buffers ----------------------------------------------------------------------------------------------------
+struct Dims {
+  int B, T, H, W, C, heads, F, D;
+  long long M, HW;
+};
+
+int make_dims(Dims& d, int B, int T, int H, int W, int C, int heads, int F) {
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || F <= 0) return fail(AXVS_ERR_ARG, "non-positive dimension");
+  if (C % heads) return fail(AXVS_ERR_ARG, "C=%d must be a multiple of heads=%d", C, heads);
+  const int D = C / heads;
+  if (D != 8 && D != 16 && D != 32) return fail(AXVS_ERR_ARG, "training tier: head_dim=%d not built (8, 16, 32)", D);
+  if (F % 4) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a multiple of 4", F);
+  if (T > 8) return fail(AXVS_ERR_ARG, "training tier: T=%d > 8 frames per clip not built", T);
+  const long long M = (long long)B * T * H * W;
+  if (M * (long long)(T > 1 ? T : 1) > INT32_MAX) return fail(AXVS_ERR_ARG, "training tier: B*T*H*W*T exceeds 2^31 rows");
+  if ((size_t)2 * (H > W ? H : W) * D * sizeof(float) > 160 * 1024) return fail(AXVS_ERR_ARG, "training tier: axis length too long for LDS");
+  d = Dims{B, T, H, W, C, heads, F, D, M, (long long)H * W};
+  return AXVS_OK;
+}
+
+struct PassSaved {
+  float *q, *k, *v, *x, *xd, *q2, *kv2, *o;
+};
+struct Saved {
+  PassSaved p[2];
+  float *buf1, *buf2, *mean1, *rstd1, *z, *r, *u, *mean2, *rstd2;
+};
+
+Saved carve_saved(Bump& b, const Dims& d) {
+  Saved s{};
+  const size_t MC = (size_t)d.M * d.C;
+  for (int i = 0; i < 2; ++i) {
+    PassSaved& p = s.p[i];
+    p.q = b.f(MC);
+    p.k = b.f(MC);
+    p.v = b.f(MC);
+    p.x = b.f(MC * d.T);
+    p.xd = b.f(MC);
+    p.q2 = b.f(MC);
+    p.kv2 = b.f(MC * d.T * 2);
+    p.o = b.f(MC);
+  }
+  s.buf1 = b.f(MC);
+  s.buf2 = b.f(MC);
+  s.mean1 = b.f(d.M);
+  s.rstd1 = b.f(d.M);
+  s.z = b.f(MC);
+  s.r = b.f((size_t)d.M * d.F);
+  s.u = b.f(MC);
+  s.mean2 = b.f(d.M);
+  s.rstd2 = b.f(d.M);
+  return s;
+}
+
+constexpr int kColsumBlocks = 512;
+
+struct Scratch {
+  float *a, *t0, *d_o, *dq2, *dkv2, *dx, *dxd, *dq, *dk, *dv, *da, *stats, *g0, *g1, *dr, *part_a, *part_b;
+};
+
+Scratch carve_scratch(Bump& b, const Dims& d, bool backward) {
+  Scratch s{};
+  const size_t MC = (size_t)d.M * d.C;
+  s.a = b.f(MC);
+  s.t0 = b.f(MC);
+  if (!backward) return s;
+  s.d_o = b.f(MC);
+  s.dq2 = b.f(MC);
+  s.dkv2 = b.f(MC * d.T * 2);
+  s.dx = b.f(MC * d.T);
+  s.dxd = b.f(MC);
+  s.dq = b.f(MC);
+  s.dk = b.f(MC);
+  s.dv = b.f(MC);
+  s.da = b.f(MC);
+  s.stats = b.f((size_t)d.M * d.heads * d.T * 3);
+  s.g0 = b.f(MC);
+  s.g1 = b.f(MC);
+  s.dr = b.f((size_t)d.M * d.F);
+  const size_t wide = (size_t)(2 * d.C > d.F ? 2 * d.C : d.F);
+  s.part_a = b.f(kColsumBlocks * wide);
+  s.part_b = b.f(kColsumBlocks * wide);
+  return s;
+}
+
+Drop make_drop(float p, unsigned seed, unsigned site) {
+  Drop d{seed, site, 0u, 1.f};
+  if (p > 0.f) {
+    d.thr = (unsigned)((double)p * 16777216.0);
+    d.scale = 1.f / (1.f - p);
+  }
+  return d;
+}
+
+inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+#define AXVS_D_SWITCH(D_, ...)                       \
+  switch (D_) {                                      \
+    case 8: { constexpr int kD = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int kD = 16; __VA_ARGS__; } break; \
+    default: { constexpr int kD = 32; __VA_ARGS__; } break; \
+  }
+
+struct Ctx {
+  Dims d;
+  Gemm g;
+  hipStream_t st;
+  float scale;
+  Scratch sc;
+
+  void add(const float* a, const float* b, float* y, size_t n) const {
+    hipLaunchKernelGGL(tr_add_kernel, dim3(blocks(n / 4)), dim3(256), 0, st, a, b, y, n / 4);
+  }
+  void bias_act(float* y, const float* bias, long long rows, int N, float mul, int relu, Drop dr) const {
+    hipLaunchKernelGGL(tr_bias_act_kernel, dim3(blocks((size_t)rows * N / 4)), dim3(256), 0, st, y, bias, rows, N, mul, relu, dr);
+  }
+  // bias / LayerNorm parameter gradients: out_a[c] = sum_r dy[r][c]; with x: out_b[c] = sum_r dy[r][c] xhat[r][c]
+  void colsum(const float* dy, long long rows, int N, float* out_a, const float* x = nullptr, const float* mean = nullptr,
+              const float* rstd = nullptr, float* out_b = nullptr) const {
+    long long rpb = (rows + kColsumBlocks - 1) / kColsumBlocks;
+    if (rpb < 64) rpb = 64;
+    const int nblk = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(tr_colsum_kernel, dim3(nblk), dim3(256), 0, st, dy, x, mean, rstd, sc.part_a, sc.part_b, rows, N, (int)rpb);
+    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N)), dim3(256), 0, st, (const float*)sc.part_a, nblk, N, out_a);
+    if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N)), dim3(256), 0, st, (const float*)sc.part_b, nblk, N, out_b);
+  }
+  int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn, (int)bytes) : AXVS_OK; }
+};
+
+// one axial pass, forward: xout = xin + dropout1(TrajectoryAttention(q = k = xin + pos, v = xin))   WC/temporal_attention.py:35-76
+int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, const AxvsTrajParams& w, const PassSaved& s, RowMap rm, int S,
+             Drop attn_drop, Drop drop1) {
+  const Dims& d = c.d;
+  const long long M = d.M;
+  const int C = d.C;
+  const Drop none = make_drop(0.f, 0, 0);
+  int rc;
+  c.add(xin, pos, c.sc.a, (size_t)M * C);
+  if ((rc = c.g.fwd(c.sc.a, w.q_w, s.q, M, C, C)) != AXVS_OK) return rc;
+  c.bias_act(s.q, w.q_b, M, C, 1.f, 0, none);
+  if ((rc = c.g.fwd(c.sc.a, w.k_w, s.k, M, C, C)) != AXVS_OK) return rc;
+  c.bias_act(s.k, w.k_b, M, C, 1.f, 0, none);
+  if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C)) != AXVS_OK) return rc;
+  c.bias_act(s.v, w.v_b, M, C, 1.f, 0, none);
+  const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
+  AXVS_D_SWITCH(d.D, {
+    if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_fwd_kernel<kD>), lds)) != AXVS_OK) return rc;
+    hipLaunchKernelGGL(tr_spatial_fwd_kernel<kD>, dim3(S * d.heads), dim3(256), lds, c.st, (const float*)s.q, (const float*)s.k,
+                       (const float*)s.v, s.x, rm, d.T, C, d.heads, c.scale, attn_drop);
+  })
+  hipLaunchKernelGGL(tr_diag_gather_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)s.x, s.xd, M, d.T, d.HW, C);
+  if ((rc = c.g.fwd(s.xd, w.proj_q_w, s.q2, M, C, C)) != AXVS_OK) return rc;
+  c.bias_act(s.q2, w.proj_q_b, M, C, c.scale, 0, none);
+  if ((rc = c.g.fwd(s.x, w.proj_kv_w, s.kv2, M * d.T, 2 * C, C)) != AXVS_OK) return rc;
+  c.bias_act(s.kv2, w.proj_kv_b, M * d.T, 2 * C, 1.f, 0, none);
+  AXVS_D_SWITCH(d.D, {
+    hipLaunchKernelGGL(tr_temporal_fwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
+                       (const float*)s.kv2, s.o, M, d.T, C, d.heads);
+  })
+  if ((rc = c.g.fwd(s.o, w.proj_w, c.sc.t0, M, C, C)) != AXVS_OK) return rc;
+  hipLaunchKernelGGL(tr_bias_drop_res_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)c.sc.t0, w.proj_b, xin, xout, rm,
+                     M, C, drop1);
+  return AXVS_OK;
+}
+
+// backward of one axial pass.  d_out: gradient of the pass output; d_in: gradient of the pass input (written); d_pos: nullable,
+// written when `pos_first`, accumulated otherwise.
+int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* pos, const AxvsTrajParams& w, const AxvsTrajGrads& gw,
+             const PassSaved& s, RowMap rm, int S, Drop attn_drop, Drop drop1, float* d_in, float* d_pos, bool pos_first) {
+  const Dims& d = c.d;
+  const long long M = d.M;
+  const int C = d.C, T = d.T;
+  const Scratch& sc = c.sc;
+  const size_t MC = (size_t)M * C;
+  int rc;
+  // proj and dropout1
+  hipLaunchKernelGGL(tr_drop_bwd_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, d_out, sc.t0, rm, M, C, drop1);
+  c.colsum(sc.t0, M, C, gw.proj_b);
+  if ((rc = c.g.wgrad(sc.t0, s.o, gw.proj_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.t0, w.proj_w, sc.d_o, M, C, C, 0.f)) != AXVS_OK) return rc;
+  // temporal half
+  AXVS_D_SWITCH(d.D, {
+    hipLaunchKernelGGL(tr_temporal_bwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
+                       (const float*)s.kv2, (const float*)sc.d_o, sc.dq2, sc.dkv2, M, T, C, d.heads);
+  })
+  c.colsum(sc.dkv2, M * T, 2 * C, gw.proj_kv_b);
+  if ((rc = c.g.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.dkv2, w.proj_kv_w, sc.dx, M * T, 2 * C, C, 0.f)) != AXVS_OK) return rc;
+  hipLaunchKernelGGL(tr_scale_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dq2, MC / 4, c.scale);   // q2 = scale (proj_q(xd))
+  c.colsum(sc.dq2, M, C, gw.proj_q_b);
+  if ((rc = c.g.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.dq2, w.proj_q_w, sc.dxd, M, C, C, 0.f)) != AXVS_OK) return rc;
+  hipLaunchKernelGGL(tr_diag_scatter_add_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dx, (const float*)sc.dxd, M, T, d.HW, C);
+  // spatial half
+  const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
+  constexpr int QC = 32;
+  const size_t lds2 = (size_t)(QC * d.D + QC * T * d.D + QC * T * 3) * sizeof(float);
+  AXVS_D_SWITCH(d.D, {
+    if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_q_kernel<kD>), lds)) != AXVS_OK) return rc;
+    hipLaunchKernelGGL(tr_spatial_bwd_q_kernel<kD>, dim3(S * d.heads), dim3(256), lds, c.st, (const float*)s.q, (const float*)s.k,
+                       (const float*)s.v, (const float*)sc.dx, sc.dq, sc.stats, rm, T, C, d.heads, c.scale, attn_drop);
+    hipLaunchKernelGGL(tr_spatial_bwd_kv_kernel<kD>, dim3(S * d.heads), dim3(256), lds2, c.st, (const float*)s.q, (const float*)s.k,
+                       (const float*)s.v, (const float*)sc.dx, (const float*)sc.stats, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop, QC);
+  })
+  // q / k / v projections
+  c.add(xin, pos, sc.a, MC);
+  c.colsum(sc.dq, M, C, gw.q_b);
+  if ((rc = c.g.wgrad(sc.dq, sc.a, gw.q_w, M, C, C)) != AXVS_OK) return rc;
+  c.colsum(sc.dk, M, C, gw.k_b);
+  if ((rc = c.g.wgrad(sc.dk, sc.a, gw.k_w, M, C, C)) != AXVS_OK) return rc;
+  c.colsum(sc.dv, M, C, gw.v_b);
+  if ((rc = c.g.wgrad(sc.dv, xin, gw.v_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.dq, w.q_w, sc.da, M, C, C, 0.f)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.dk, w.k_w, sc.da, M, C, C, 1.f)) != AXVS_OK) return rc;
+  // d_in = d_out (residual) + dv Wv + da;   d_pos (+)= da
+  if (hipMemcpyAsync(d_in, d_out, MC * sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
+  if ((rc = c.g.dgrad(sc.dv, w.v_w, d_in, M, C, C, 1.f)) != AXVS_OK) return rc;
+  c.add(d_in, sc.da, d_in, MC);
+  if (d_pos) {
+    if (pos_first) {
+      if (hipMemcpyAsync(d_pos, sc.da, MC * sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
+    } else {
+      c.add(d_pos, sc.da, d_pos, MC);
+    }
+  }
+  return AXVS_OK;
+}
+
+int check_ptrs(const AxvsAxialLayerParams* p) {
+  const float* const* f = reinterpret_cast<const float* const*>(p);
+  for (size_t i = 0; i < sizeof(AxvsAxialLayerParams) / sizeof(float*); ++i)
+    if (!f[i]) return fail(AXVS_ERR_ARG, "null parameter pointer (field %zu of AxvsAxialLayerParams)", i);
+  return AXVS_OK;
+}
+
+int status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AXVS_ERR_LAUNCH, "HIP launch failed: %s", hipGetErrorString(e));
+  return AXVS_OK;
+}
+
+int forward(const Ctx& c, const float* src, const float* pos, float* out, const AxvsAxialLayerParams& p, const Saved& s, float p_drop,
+            float p_attn, unsigned seed) {
+  const Dims& d = c.d;
+  const long long M = d.M, sB = (long long)d.T * d.H * d.W, sT = (long long)d.H * d.W;
+  const int C = d.C;
+  int rc;
+  // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
+  const RowMap rmh{d.T * d.H, d.H, d.W, sB, sT, d.W, 1};
+  if ((rc = pass_fwd(c, src, pos, s.buf1, p.height_attn, s.p[0], rmh, d.B * d.W, make_drop(p_drop, seed, 1), make_drop(p_attn, seed, 2))) != AXVS_OK)
+    return rc;
+  // width pass: sequences (b, h), tokens (t, w)         :206-213
+  const RowMap rmw{d.T * d.W, d.W, d.H, sB, sT, 1, d.W};
+  if ((rc = pass_fwd(c, s.buf1, pos, s.buf2, p.width_attn, s.p[1], rmw, d.B * d.H, make_drop(p_drop, seed, 3), make_drop(p_attn, seed, 4))) != AXVS_OK)
+    return rc;
+  // norm1 -> FFN -> norm2                               :181-185, :217-218
+  hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.buf2, p.norm1_w, p.norm1_b, s.z, s.mean1, s.rstd1, M, C);
+  if ((rc = c.g.fwd(s.z, p.linear1_w, s.r, M, d.F, C)) != AXVS_OK) return rc;
+  c.bias_act(s.r, p.linear1_b, M, d.F, 1.f, 1, make_drop(p_drop, seed, 5));
+  if ((rc = c.g.fwd(s.r, p.linear2_w, c.sc.t0, M, C, d.F)) != AXVS_OK) return rc;
+  const RowMap id{(int)(M > INT32_MAX ? INT32_MAX : M), (int)(M > INT32_MAX ? INT32_MAX : M), 1, M, M, 1, 0};
+  hipLaunchKernelGGL(tr_bias_drop_res_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)c.sc.t0, p.linear2_b, (const float*)s.z,
+                     s.u, id, M, C, make_drop(p_drop, seed, 6));
+  hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.u, p.norm2_w, p.norm2_b, out, s.mean2, s.rstd2, M, C);
+  return status();
+}
+
+}  // namespace
+}  // namespace axvs
+
+using namespace axvs;
+
+extern "C" {
+
+size_t axvs_axial_layer_train_saved_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
+  Dims d;
+  if (make_dims(d, B, T, H, W, C, heads, d_ffn) != AXVS_OK) return 0;
+  Bump b(nullptr);
+  carve_saved(b, d);
+  return b.off;
+}
+
+size_t axvs_axial_layer_train_scratch_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn, int backward) {
+  Dims d;
+  if (make_dims(d, B, T, H, W, C, heads, d_ffn) != AXVS_OK) return 0;
+  Bump b(nullptr);
+  carve_scratch(b, d, backward != 0);
+  return b.off;
+}
+
+int axvs_axial_layer_train_fwd(const float* src, const float* pos, float* out, const AxvsAxialLayerParams* params, int B, int T, int H,
+                               int W, int C, int heads, int d_ffn, float p_dropout, float p_attn_drop, unsigned seed, void* saved,
+                               size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!src || !pos || !out || !params || !saved || !scratch) return fail(AXVS_ERR_ARG, "null pointer");
+  if (!(p_dropout >= 0.f && p_dropout < 1.f) || !(p_attn_drop >= 0.f && p_attn_drop < 1.f)) return fail(AXVS_ERR_ARG, "dropout probability outside [0, 1)");
+  Ctx c{};
+  int rc;
+  if ((rc = make_dims(c.d, B, T, H, W, C, heads, d_ffn)) != AXVS_OK || (rc = check_ptrs(params)) != AXVS_OK) return rc;
+  Bump sb(saved), cb(scratch);
+  const Saved s = carve_saved(sb, c.d);
+  c.sc = carve_scratch(cb, c.d, false);
+  if (sb.off > saved_bytes || cb.off > scratch_bytes) return fail(AXVS_ERR_WORKSPACE, "training buffers too small: saved %zu < %zu or scratch %zu < %zu", saved_bytes, sb.off, scratch_bytes, cb.off);
+  c.st = static_cast<hipStream_t>(stream);
+  c.scale = 1.f / sqrtf((float)c.d.D);
+  if ((rc = c.g.init(c.st)) != AXVS_OK) return rc;
+  return forward(c, src, pos, out, *params, s, p_dropout, p_attn_drop, seed);
+}
+
+int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float* pos, const AxvsAxialLayerParams* params,
+                               const AxvsAxialLayerGrads* grads, float* d_src, float* d_pos, int B, int T, int H, int W, int C, int heads,
+                               int d_ffn, float p_dropout, float p_attn_drop, unsigned seed, int recompute, void* saved, size_t saved_bytes,
+                               void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d_out || !src || !pos || !params || !grads || !d_src || !saved || !scratch) return fail(AXVS_ERR_ARG, "null pointer");
+  if (!(p_dropout >= 0.f && p_dropout < 1.f) || !(p_attn_drop >= 0.f && p_attn_drop < 1.f)) return fail(AXVS_ERR_ARG, "dropout probability outside [0, 1)");
+  Ctx c{};
+  int rc;
+  if ((rc = make_dims(c.d, B, T, H, W, C, heads, d_ffn)) != AXVS_OK || (rc = check_ptrs(params)) != AXVS_OK ||
+      (rc = check_ptrs(reinterpret_cast<const AxvsAxialLayerParams*>(grads))) != AXVS_OK)
+    return rc;
+  Bump sb(saved), cb(scratch);
+  const Saved s = carve_saved(sb, c.d);
+  c.sc = carve_scratch(cb, c.d, true);
+  if (sb.off > saved_bytes || cb.off > scratch_bytes) return fail(AXVS_ERR_WORKSPACE, "training buffers too small: saved %zu < %zu or scratch %zu < %zu", saved_bytes, sb.off, scratch_bytes, cb.off);
+  c.st = static_cast<hipStream_t>(stream);
+  c.scale = 1.f / sqrtf((float)c.d.D);
+  if ((rc = c.g.init(c.st)) != AXVS_OK) return rc;
+  const Dims& d = c.d;
+  const AxvsAxialLayerParams& p = *params;
+  const AxvsAxialLayerGrads& g = *grads;
+  const Scratch& sc = c.sc;
+  const long long M = d.M, sB = (long long)d.T * d.H * d.W, sT = (long long)d.H * d.W;
+  const size_t MC = (size_t)M * C, MF = (size_t)M * d.F;
+  if (recompute) {   // rebuild the activations from (src, pos, seed) instead of having kept them since the forward pass
+    if ((rc = forward(c, src, pos, sc.g0, p, s, p_dropout, p_attn_drop, seed)) != AXVS_OK) return rc;
+  }
+  // norm2                                                                       WC/temporal_attention.py:184
+  c.colsum(d_out, M, C, g.norm2_b, s.u, s.mean2, s.rstd2, g.norm2_w);
+  hipLaunchKernelGGL(tr_ln_bwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, d_out, (const float*)s.u, p.norm2_w, (const float*)s.mean2,
+                     (const float*)s.rstd2, sc.g0, M, C);                                 // g0 = d u
+  // FFN: u = z + dropout3(linear2(r)), r = dropout2(relu(linear1(z)))             :181-183
+  const RowMap id{(int)M, (int)M, 1, M, M, 1, 0};
+  hipLaunchKernelGGL(tr_drop_bwd_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, (const float*)sc.g0, sc.t0, id, M, C, make_drop(p_dropout, seed, 6));
+  c.colsum(sc.t0, M, C, g.linear2_b);
+  if ((rc = c.g.wgrad(sc.t0, s.r, g.linear2_w, M, C, d.F)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.t0, p.linear2_w, sc.dr, M, C, d.F, 0.f)) != AXVS_OK) return rc;
+  hipLaunchKernelGGL(tr_relu_drop_bwd_kernel, dim3(blocks(MF / 4)), dim3(256), 0, c.st, sc.dr, (const float*)s.r, MF / 4, make_drop(p_dropout, seed, 5).scale);
+  c.colsum(sc.dr, M, d.F, g.linear1_b);
+  if ((rc = c.g.wgrad(sc.dr, s.z, g.linear1_w, M, d.F, C)) != AXVS_OK) return rc;
+  if ((rc = c.g.dgrad(sc.dr, p.linear1_w, sc.g0, M, d.F, C, 1.f)) != AXVS_OK) return rc;   // g0 = d z = d u + d r W1
+  // norm1                                                                       :217
+  c.colsum(sc.g0, M, C, g.norm1_b, s.buf2, s.mean1, s.rstd1, g.norm1_w);
+  hipLaunchKernelGGL(tr_ln_bwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)sc.g0, (const float*)s.buf2, p.norm1_w,
+                     (const float*)s.mean1, (const float*)s.rstd1, sc.g1, M, C);          // g1 = d buf2
+  // width pass, then height pass
+  const RowMap rmw{d.T * d.W, d.W, d.H, sB, sT, 1, d.W};
+  if ((rc = pass_bwd(c, sc.g1, s.buf1, pos, p.width_attn, g.width_attn, s.p[1], rmw, d.B * d.H, make_drop(p_dropout, seed, 3),
+                     make_drop(p_attn_drop, seed, 4), sc.g0, d_pos, true)) != AXVS_OK)
+    return rc;
+  const RowMap rmh{d.T * d.H, d.H, d.W, sB, sT, d.W, 1};
+  if ((rc = pass_bwd(c, sc.g0, src, pos, p.height_attn, g.height_attn, s.p[0], rmh, d.B * d.W, make_drop(p_dropout, seed, 1),
+                     make_drop(p_attn_drop, seed, 2), d_src, d_pos, false)) != AXVS_OK)
+    return rc;
+  return status();
+}
+
+}  // extern "C"

@@ -304,6 +304,8 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         self.mfma_dtype = mfma_dtype
         self.return_attn = False
         self.use_generated_pos = True   # a `pos` made by PositionEmbeddingSine3D is evaluated in-kernel instead of read (SineTag)
+        self.recompute = True           # train() mode: backward rebuilds the activations instead of keeping them (training.py)
+        self.dropout_seed: Optional[int] = None   # train() mode: fixed dropout seed (tests); None = drawn from torch's CPU generator
         self._packed: Optional[Tensor] = None
         self._packed_key = None
 
@@ -343,8 +345,15 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         :param src: tensor of shape [B*T, H*W, C]
         :param pos: tensor of shape [B, T, H, W, C]
         :return: (src', height_traj_attn, width_traj_attn); the maps are None unless ``return_attn`` is set
+
+        ``train()`` mode: the differentiable training tier (dropout active, fp32, `axial_vs_amd.training`); ``eval()`` mode: the
+        fused 16-bit MFMA inference tier (no autograd graph).
         """
-        _require_eval(self)
+        if self.training:
+            if self.return_attn:
+                raise NotImplementedError("axial_vs_amd: attention maps are an eval-mode output (visualize_attn)")
+            from .training import axial_layer_train
+            return axial_layer_train(self, src, pos, recompute=self.recompute), None, None
         B, T, H, W = pos.shape[:4]
         s, p = _dev_f32(src, "src"), _dev_f32(pos, "pos")
         C_ = s.shape[-1]

@@ -337,6 +337,40 @@ int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature,
 int axvs_scaled_residual(const float* a, const float* b, const float* gamma, float* out, size_t n, int C,
                          void* stream);
 
+/* =====================================================================================================
+ * Training tier of the layer: forward that keeps its activations + backward.
+ * Semantics: TemporalAxialTrajectoryAttentionLayer.forward in train() mode, WC/temporal_attention.py:187-220 under autograd:
+ * dropout(p_dropout) on the spatial attention maps (:32, :55 -- the layer passes `dropout` as the attention's attn_drop, :164-165),
+ * dropout1(p_attn_drop) on both pass outputs (:166, :204, :213), dropout2 / dropout3(p_dropout) in the FFN (:172-174, :182-183).
+ * fp32 activations in natural [B,T,H,W,C] order; GEMMs through rocBLAS (loaded on first use); head_dim in {8,16,32}; T <= 8.
+ * Dropout masks are a pure function of (seed, site, element offset in the reference's tensor at that site):
+ *   h = seed ^ (site * 0x9E3779B9);  h = fmix32(h ^ lo32(idx));  h = fmix32(h ^ hi32(idx));  keep iff (h >> 8) >= floor(p * 2^24)
+ *   (fmix32 = MurmurHash3's finaliser); sites: 1 height attention map [(B W) heads, T H, T, H], 2 height pass output [(B W), T H, C],
+ *   3 width attention map [(B H) heads, T W, T, W], 4 width pass output [(B H), T W, C], 5 FFN hidden [M, F], 6 FFN output [M, C].
+ * so backward (and a recomputed forward, and a CPU oracle) regenerate them: nothing but `seed` is kept.
+ * ===================================================================================================== */
+typedef struct AxvsTrajGrads {
+  float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *proj_q_w, *proj_q_b, *proj_kv_w, *proj_kv_b, *proj_w, *proj_b;
+} AxvsTrajGrads;
+typedef struct AxvsAxialLayerGrads {   /* same field order as AxvsAxialLayerParams; every buffer is WRITTEN (not accumulated) */
+  AxvsTrajGrads height_attn, width_attn;
+  float *norm1_w, *norm1_b, *linear1_w, *linear1_b, *linear2_w, *linear2_b, *norm2_w, *norm2_b;
+} AxvsAxialLayerGrads;
+/* `saved`: the activations backward needs (kept between the two calls, or rebuilt by backward when recompute != 0: then any
+ * buffer of that size will do); `scratch`: temporaries of one call (backward != 0: size for axvs_axial_layer_train_bwd). */
+size_t axvs_axial_layer_train_saved_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn);
+size_t axvs_axial_layer_train_scratch_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn, int backward);
+/* src fp32 [(B T),(H W),C]; pos fp32 [B,T,H,W,C]; out like src.  params: the fp32 nn.Parameter storages themselves. */
+int axvs_axial_layer_train_fwd(const float* src, const float* pos, float* out, const AxvsAxialLayerParams* params, int B, int T, int H,
+                               int W, int C, int heads, int d_ffn, float p_dropout, float p_attn_drop, unsigned seed, void* saved,
+                               size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+/* d_out: gradient of `out`.  Writes d_src, d_pos (NULL: not wanted) and every buffer of `grads`.  recompute != 0: `saved` is
+ * rebuilt from (src, pos, params, seed) first -- the forward pass then only has to keep its inputs. */
+int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float* pos, const AxvsAxialLayerParams* params,
+                               const AxvsAxialLayerGrads* grads, float* d_src, float* d_pos, int B, int T, int H, int W, int C, int heads,
+                               int d_ffn, float p_dropout, float p_attn_drop, unsigned seed, int recompute, void* saved, size_t saved_bytes,
+                               void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,7 @@ def _sub(w: Weights, prefix: str) -> Weights:
 # (a2)+(a3) trajectory attention, q/k/v flavour (WC) and fused-qkv flavour (CC)
 # --------------------------------------------------------------------------------------
 def _trajectory_core(q: Tensor, k: Tensor, v: Tensor, w: Weights, num_frames: int, heads: int,
-                     want_attn: bool) -> Tuple[Tensor, Optional[Tensor]]:
+                     want_attn: bool, attn_keep: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
     """Shared by both flavours once q,k,v [S, N, C] are projected.
 
     Spatial half   WC/temporal_attention.py:46-57   (CC/...:103-113)
@@ -86,6 +86,8 @@ def _trajectory_core(q: Tensor, k: Tensor, v: Tensor, w: Weights, num_frames: in
         p = torch.softmax(logits, dim=-1)
         if want_attn:
             attn_maps[:, :, :, f] = p
+        if attn_keep is not None:                                 # train mode: self.attn_drop(space_attn), :55
+            p = p * attn_keep[:, :, :, f]
         xf = torch.matmul(p, vf)                                  # [S,h,N,d]
         x[:, :, f] = xf.permute(0, 2, 1, 3).reshape(S, N, C)
 
@@ -109,12 +111,14 @@ def _trajectory_core(q: Tensor, k: Tensor, v: Tensor, w: Weights, num_frames: in
 
 
 def trajectory_attention(query: Tensor, key: Tensor, value: Tensor, w: Weights, num_frames: int,
-                         heads: int = 8, want_attn: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
-    """WC/temporal_attention.py:35-76 (TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:667-708)."""
+                         heads: int = 8, want_attn: bool = True, attn_keep: Optional[Tensor] = None
+                         ) -> Tuple[Tensor, Optional[Tensor]]:
+    """WC/temporal_attention.py:35-76 (TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:667-708).
+    attn_keep [S, heads, N, T, L]: train-mode dropout factors (0 or 1/(1-p)) of the spatial attention map."""
     q = _linear(query, w, "q")
     k = _linear(key, w, "k")
     v = _linear(value, w, "v")
-    return _trajectory_core(q, k, v, w, num_frames, heads, want_attn)
+    return _trajectory_core(q, k, v, w, num_frames, heads, want_attn, attn_keep)
 
 
 def cc_trajectory_attention(x: Tensor, w: Weights, seq_len: int, num_frames: int, heads: int = 8) -> Tensor:
@@ -169,6 +173,61 @@ def axial_pass(x: Tensor, pos: Tensor, w: Weights, which: int, heads: int = 8) -
     y, _ = trajectory_attention(xs + ps, xs + ps, xs, _sub(w, "width_attn"), T, heads, want_attn=False)
     z = _layer_norm((xs + y).reshape(B, H, T, W, C).permute(0, 2, 1, 3, 4), w, "norm1")
     return _layer_norm(z + _linear(torch.relu(_linear(z, w, "linear1")), w, "linear2"), w, "norm2").contiguous()
+
+
+def dropout_keep(seed: int, site: int, count: int, p: float, dtype=torch.float64) -> Tensor:
+    """The training tier's dropout factors (include/axvs.h): element `idx` of site `site` is kept iff
+    (fmix32(fmix32(seed ^ site * 0x9E3779B9 ^ lo32(idx)) ^ hi32(idx)) >> 8) >= floor(p * 2^24); kept elements are scaled by
+    1 / (1 - p).  Returns the flat factor vector [count] (0 or 1/(1-p)); p == 0 -> ones."""
+    if p <= 0:
+        return torch.ones(count, dtype=dtype)
+    import numpy as np
+
+    def fmix(h):
+        h = h ^ (h >> np.uint32(16))
+        h = h * np.uint32(0x85EBCA6B)
+        h = h ^ (h >> np.uint32(13))
+        h = h * np.uint32(0xC2B2AE35)
+        return h ^ (h >> np.uint32(16))
+
+    idx = np.arange(count, dtype=np.uint64)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    h0 = np.uint32((int(seed) ^ ((int(site) * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    h = fmix(fmix(h0 ^ lo) ^ hi)
+    keep = (h >> np.uint32(8)) >= np.uint32(int(float(p) * 16777216.0))
+    return torch.from_numpy(keep).to(dtype) / (1.0 - float(p))
+
+
+def axial_layer_train(src: Tensor, pos: Tensor, w: Weights, heads: int, p_dropout: float, p_attn_drop: float, seed: int) -> Tensor:
+    """TemporalAxialTrajectoryAttentionLayer.forward in train() mode (WC/temporal_attention.py:187-220) with the dropout factors
+    of `dropout_keep` in place of torch's RNG: `dropout` (p_dropout) on the spatial attention maps (:55, :164-165) and in the
+    FFN (dropout2 / dropout3, :182-183), `dropout1` (p_attn_drop) on both pass outputs (:204, :213).  Differentiable torch code:
+    the gradient oracle of the training tier (tests call autograd on it)."""
+    B, T, H, W, C = pos.shape
+    dt = src.dtype
+    x = src.reshape(B, T, H, W, C)
+
+    def one_pass(xs, ps, name, site_attn, site_out):
+        S, N, _ = xs.shape
+        L = N // T
+        keep = dropout_keep(seed, site_attn, S * heads * N * T * L, p_dropout, dt).reshape(S, heads, N, T, L) if p_dropout > 0 else None
+        kq = xs + ps
+        o, _ = trajectory_attention(kq, kq, xs, _sub(w, name), T, heads, want_attn=False, attn_keep=keep)
+        return xs + o * dropout_keep(seed, site_out, S * N * C, p_attn_drop, dt).reshape(S, N, C)
+
+    xs = one_pass(x.permute(0, 3, 1, 2, 4).reshape(B * W, T * H, C), pos.permute(0, 3, 1, 2, 4).reshape(B * W, T * H, C).to(dt),
+                  "height_attn", 1, 2)
+    x = xs.reshape(B, W, T, H, C).permute(0, 2, 3, 1, 4)
+    xs = one_pass(x.permute(0, 2, 1, 3, 4).reshape(B * H, T * W, C), pos.permute(0, 2, 1, 3, 4).reshape(B * H, T * W, C).to(dt),
+                  "width_attn", 3, 4)
+    x = xs.reshape(B, H, T, W, C).permute(0, 2, 1, 3, 4).reshape(B * T, H * W, C)
+    z = _layer_norm(x, w, "norm1")
+    F_ = w["linear1.weight"].shape[0]
+    M = B * T * H * W
+    r = torch.relu(_linear(z, w, "linear1")) * dropout_keep(seed, 5, M * F_, p_dropout, dt).reshape(B * T, H * W, F_)
+    ff = _linear(r, w, "linear2") * dropout_keep(seed, 6, M * C, p_dropout, dt).reshape(B * T, H * W, C)
+    return _layer_norm(z + ff, w, "norm2")
 
 
 def trajectory_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8) -> Tensor:

@@ -162,3 +162,36 @@ def tl_plugin_case(z, m, C=256):
     ref = torch.cat(refs, 0)[None, :, None].repeat(bs, 1, len(shapes), 1)
     mask = (torch.rand(bs, nq, generator=g) < 0.1) if m["mask"] else None
     return w, query, query_pos, pos3d, ref, mask
+
+
+TRAIN = ["g10_train_B1_T2_C64_H5_W6", "g10_train_B2_T3_C64_H4_W5", "g10_train_B1_T2_C256_H8_W8", "g10_train_B1_T4_C128_H6_W3"]
+
+
+def train_inputs(meta, dtype=torch.float64):
+    """(src, pos, d_out) of a g10 fixture (oracle/gen_golden_train.py)."""
+    g = torch.Generator().manual_seed(meta["seed"] + 1)
+    B, T, C, H, W = (meta[k] for k in "BTCHW")
+    x = torch.randn(B, T, C, H, W, generator=g)
+    src = x.permute(0, 1, 3, 4, 2).reshape(B * T, H * W, C).contiguous().to(dtype)
+    pos = orc.pos_embed_sine_3d(B, T, H, W, C // 2).to(dtype)
+    d_out = torch.randn(B * T, H * W, C, generator=g).to(dtype)
+    return src, pos, d_out
+
+
+def train_grad_errors(z, grads):
+    """Error of every parameter gradient {name: tensor} against a g10 fixture (full arrays, or every 5th element + checksums):
+    |got - ref|_2 / max(|ref|_2, 1e-3 * the largest gradient norm of the layer).  The floor matters for k.bias only: the key bias
+    cancels in the softmax, its true gradient is 0 and both sides hold rounding noise."""
+    names = list(grads)
+    refs = {k: t(z["grad." + k]).double() for k in names}
+    floor = 1e-3 * max(float(np.sqrt(np.asarray(z["gradchk." + k])[1])) for k in names)
+    errs = {}
+    for k in names:
+        ref = refs[k]
+        got = grads[k].detach().cpu().double()
+        if ref.numel() != got.numel():
+            refc = np.asarray(z["gradchk." + k])
+            errs[k + ":sumsq"] = abs(checks(got)[1] - refc[1]) / max(refc[1], floor * floor)
+            got = got.reshape(-1)[::5]
+        errs[k] = float((got.reshape(-1) - ref.reshape(-1)).norm() / max(float(ref.norm()), floor))
+    return errs

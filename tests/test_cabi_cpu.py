@@ -83,8 +83,10 @@ def test_no_cpu_fallback_and_forward_only():
     import axial_vs_amd as ax
     layer = ax.TemporalAxialTrajectoryAttentionLayer(64, 128, n_heads=8)
     src, pos = torch.zeros(2, 12, 64), torch.zeros(1, 2, 3, 4, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(src, pos)                       # training mode: the training tier (tests/test_hip_training.py), GPU only as well
     with pytest.raises(NotImplementedError):
-        layer(src, pos)                       # training mode
+        ax.TemporalTrajectoryAttentionLayer(64, 128, n_heads=8)(src, pos)     # the full T*H*W layer has no training tier
     layer.eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         layer(src, pos)
@@ -196,3 +198,27 @@ def test_packed_weight_key_sees_replaced_parameters_and_modules():
     assert k3 != k2 and _param_key(layer, "f16") == k3
     layer.load_state_dict(layer.state_dict())                                 # copy_ into the same Parameters
     assert _param_key(layer, "f16") != k3
+
+
+def test_training_tier_has_no_cpu_fallback():
+    """train() mode routes to the training tier, which refuses CPU tensors instead of falling back to torch."""
+    import axial_vs_amd as ax
+    import axvs_oracle as orc
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(64, 128, dropout=0.1, attn_drop=0.1, n_heads=8).train()
+    src, pos = orc.synthetic_clip(1, 2, 64, 4, 4, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(src, pos)
+    from axial_vs_amd.training import layer_parameters
+    names = [k for k, _ in layer.named_parameters()]
+    assert len(layer_parameters(layer)) == len(names) == 32        # AxvsAxialLayerParams field order covers every parameter
+
+
+def test_training_buffer_sizes_and_argument_checks():
+    from axial_vs_amd import _lib
+    L = _lib.lib()
+    saved = L.axvs_axial_layer_train_saved_bytes(1, 4, 64, 64, 256, 8, 1024)
+    M, C, T, F = 4 * 64 * 64, 256, 4, 1024
+    assert saved >= 4 * (2 * (6 + 3 * T) * M * C + 4 * M * C + M * F)          # per pass q,k,v,xd,q2,o + x + kv2; pass outputs, z, u; r
+    assert L.axvs_axial_layer_train_scratch_bytes(1, 4, 64, 64, 256, 8, 1024, 1) > L.axvs_axial_layer_train_scratch_bytes(1, 4, 64, 64, 256, 8, 1024, 0)
+    assert L.axvs_axial_layer_train_saved_bytes(1, 4, 8, 8, 512, 8, 1024) == 0 and b"head_dim" in L.axvs_last_error()
+    assert L.axvs_axial_layer_train_saved_bytes(1, 9, 8, 8, 256, 8, 1024) == 0 and b"T=9" in L.axvs_last_error()

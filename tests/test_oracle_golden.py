@@ -231,3 +231,32 @@ def test_full_trajectory_layer(name):
     out = orc.trajectory_layer(src, pos, w, 8)
     np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
     assert rel_err(out[:, ::m["stride"]], t(z["out"])) < 2e-5
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").TRAIN)
+def test_training_oracle_against_reference_autograd(name):
+    """orc.axial_layer_train under autograd == the reference layer in train() mode (float64, its nn.Dropout modules
+    replaced by the hash-generated factors): output, d_src, d_pos and every parameter gradient."""
+    from golden_util import train_grad_errors, train_inputs
+    z, m = load(name)
+    w = {k: v.double().requires_grad_(True) for k, v in weights(z, m).items()}
+    src, pos, d_out = train_inputs(m)
+    src.requires_grad_(True)
+    pos.requires_grad_(True)
+    out = orc.axial_layer_train(src, pos, w, m["heads"], m["p_dropout"], m["p_attn_drop"], m["dropout_seed"])
+    out.backward(d_out)
+    assert rel_err(out.detach(), t(z["out"])) < 1e-6           # the fixture is stored in fp32
+    assert rel_err(src.grad, t(z["d_src"])) < 1e-6
+    assert rel_err(pos.grad, t(z["d_pos"])) < 1e-6
+    errs = train_grad_errors(z, {k: v.grad for k, v in w.items()})
+    assert max(errs.values()) < 1e-6, errs
+
+
+def test_dropout_hash_statistics_and_determinism():
+    for p in (0.1, 0.25, 0.5):
+        k = orc.dropout_keep(77, 3, 400000, p)
+        assert abs(float((k > 0).double().mean()) - (1 - p)) < 4e-3
+        assert torch.equal(k, orc.dropout_keep(77, 3, 400000, p))
+        assert not torch.equal(k, orc.dropout_keep(77, 4, 400000, p))     # sites are independent streams
+        assert not torch.equal(k, orc.dropout_keep(78, 3, 400000, p))
+    assert torch.equal(orc.dropout_keep(1, 1, 10, 0.0), torch.ones(10, dtype=torch.float64))
