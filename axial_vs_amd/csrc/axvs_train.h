@@ -410,30 +410,69 @@ __global__ __launch_bounds__(256) void tr_ln_bwd_kernel(const float* __restrict_
 }
 
 // ---- column sums over rows (bias / LayerNorm parameter gradients), two deterministic stages.
-//      part_a[blk][c] = sum_r dy[r][c];  with x: part_b[blk][c] = sum_r dy[r][c] * xhat[r][c]
+//      stage 1: a block sums `rows_per_blk` rows; its 256 threads are `lanes` float4 columns x 256 / lanes row groups, reduced
+//      through LDS:  part_a[blk][c] = sum_r dy[r][c];  with x: part_b[blk][c] = sum_r dy[r][c] * xhat[r][c]
 __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ part_a,
                                                          float* __restrict__ part_b, long long M, int C, int rows_per_blk) {
+  __shared__ float4 red[2][256];
+  const int n4 = C / 4, lanes = n4 < 256 ? n4 : 256, rg = 256 / lanes;
+  const int col = threadIdx.x % lanes, g = threadIdx.x / lanes;
   const long long r0 = (long long)blockIdx.x * rows_per_blk;
   const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f, b = 0.f;
-    for (long long r = r0; r < r1; ++r) {
-      const float d = dy[r * C + c];
-      a += d;
-      if (x) b += d * (x[r * C + c] - mean[r]) * rstd[r];
+  for (int c0 = 0; c0 < n4; c0 += lanes) {        // (more than one trip only when C > 1024; uniform trip count: barriers inside)
+    const int c4 = c0 + col;
+    const bool valid = c4 < n4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (g < rg && valid) {
+      for (long long r = r0 + g; r < r1; r += rg) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c4 * 4);
+        a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+        if (x) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c4 * 4);
+          const float mu = mean[r], rs = rstd[r];
+          b.x += d.x * (xv.x - mu) * rs; b.y += d.y * (xv.y - mu) * rs; b.z += d.z * (xv.z - mu) * rs; b.w += d.w * (xv.w - mu) * rs;
+        }
+      }
     }
-    part_a[(size_t)blockIdx.x * C + c] = a;
-    if (x) part_b[(size_t)blockIdx.x * C + c] = b;
+    __syncthreads();
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (g == 0 && valid) {
+      for (int j = 1; j < rg; ++j) {
+        const float4 u = red[0][j * lanes + col], w = red[1][j * lanes + col];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += w.x; b.y += w.y; b.z += w.z; b.w += w.w;
+      }
+      *reinterpret_cast<float4*>(part_a + (size_t)blockIdx.x * C + c4 * 4) = a;
+      if (x) *reinterpret_cast<float4*>(part_b + (size_t)blockIdx.x * C + c4 * 4) = b;
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+// stage 2 (also the reduction of split-K weight-gradient partials): out[c] = sum_i part[i][c]; 64 columns x 4 partial groups / block
+__global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, size_t C, float* __restrict__ out) {
+  __shared__ float red[256];
+  const size_t c = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
   float a = 0.f;
-  for (int i = 0; i < nblk; ++i) a += part[(size_t)i * C + c];
-  out[c] = a;
+  if (c < C)
+    for (int i = g; i < nblk; i += 4) a += part[(size_t)i * C + c];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (g == 0 && c < C) out[c] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+}
+
+// Wt[K][N] = W[N][K]^T (32 x 32 tiles through LDS): the input-gradient GEMMs then run in the same (fast) form as the forward ones
+__global__ __launch_bounds__(256) void tr_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (n0 + j < N && k0 + tx < K) tile[j][tx] = w[(size_t)(n0 + j) * K + k0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (k0 + j < K && n0 + tx < N) wt[(size_t)(k0 + j) * N + n0 + tx] = tile[tx][j];
 }
 
 // ---- elementwise pieces -------------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ struct Blas {
   decltype(&rocblas_set_stream) set_stream = nullptr;
   decltype(&rocblas_set_atomics_mode) set_atomics = nullptr;
   decltype(&rocblas_sgemm) sgemm = nullptr;
+  decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
   bool ok = false;
 };
 
@@ -44,7 +45,8 @@ const Blas& blas() {
     r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(h, "rocblas_set_stream"));
     r.set_atomics = reinterpret_cast<decltype(r.set_atomics)>(dlsym(h, "rocblas_set_atomics_mode"));
     r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(h, "rocblas_sgemm"));
-    r.ok = r.create && r.set_stream && r.set_atomics && r.sgemm;
+    r.sgemm_sb = reinterpret_cast<decltype(r.sgemm_sb)>(dlsym(h, "rocblas_sgemm_strided_batched"));
+    r.ok = r.create && r.set_stream && r.set_atomics && r.sgemm && r.sgemm_sb;
     return r;
   }();
   return b;
@@ -75,17 +77,33 @@ struct Gemm {   // one rocBLAS handle per (thread, device), bound to the call's 
       return fail(AXVS_ERR_LAUNCH, "rocblas_sgemm failed");
     return AXVS_OK;
   }
-  // row-major:  Y[M,N] = X[M,K] W[N,K]^T
-  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K) const {
-    return call(rocblas_operation_transpose, rocblas_operation_none, N, M, K, W, K, X, K, 0.f, Y, N);
+  // row-major:  Y[M,N] = beta Y + X[M,K] W[N,K]^T
+  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K, float beta = 0.f) const {
+    return call(rocblas_operation_transpose, rocblas_operation_none, N, M, K, W, K, X, K, beta, Y, N);
   }
-  // dX[M,K] = beta dX + dY[M,N] W[N,K]
-  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta) const {
-    return call(rocblas_operation_none, rocblas_operation_none, K, M, N, W, K, dY, N, beta, dX, K);
-  }
-  // dW[N,K] = dY[M,N]^T X[M,K]
-  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K) const {
-    return call(rocblas_operation_none, rocblas_operation_transpose, K, N, M, X, K, dY, N, 0.f, dW, K);
+  // dW[N,K] = dY[M,N]^T X[M,K]: the reduction runs over the M rows and the output is small, so it is split kSplit ways over
+  // the rows as a strided-batched GEMM into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).
+  static constexpr int kSplit = 64;
+  int wgrad_partials(const float* dY, const float* X, float* part, long long M, int N, int K, int* nparts) const {
+    const float alpha = 1.f, beta = 0.f;
+    const long long chunk = M / kSplit;
+    int np = 0;
+    if (chunk > 0) {
+      if (chunk > INT32_MAX) return fail(AXVS_ERR_ARG, "GEMM dimension exceeds rocblas_int");
+      if (blas().sgemm_sb(h, rocblas_operation_none, rocblas_operation_transpose, K, N, (int)chunk, &alpha, X, K, chunk * K, dY, N, chunk * N,
+                          &beta, part, K, (long long)N * K, kSplit) != rocblas_status_success)
+        return fail(AXVS_ERR_LAUNCH, "rocblas_sgemm_strided_batched failed");
+      np = kSplit;
+    }
+    const long long done = chunk * kSplit;
+    if (done < M) {
+      int rc = call(rocblas_operation_none, rocblas_operation_transpose, K, N, M - done, X + done * K, K, dY + done * N, N, 0.f,
+                    part + (size_t)np * N * K, K);
+      if (rc != AXVS_OK) return rc;
+      ++np;
+    }
+    *nparts = np;
+    return AXVS_OK;
   }
 };
 
@@ -146,7 +164,7 @@ Saved carve_saved(Bump& b, const Dims& d) {
 constexpr int kColsumBlocks = 512;
 
 struct Scratch {
-  float *a, *t0, *d_o, *dq2, *dkv2, *dx, *dxd, *dq, *dk, *dv, *da, *stats, *g0, *g1, *dr, *part_a, *part_b;
+  float *a, *t0, *d_o, *dq2, *dkv2, *dx, *dxd, *dq, *dk, *dv, *da, *stats, *g0, *g1, *dr, *part_a, *part_b, *wpart, *wt;
 };
 
 Scratch carve_scratch(Bump& b, const Dims& d, bool backward) {
@@ -171,6 +189,9 @@ Scratch carve_scratch(Bump& b, const Dims& d, bool backward) {
   const size_t wide = (size_t)(2 * d.C > d.F ? 2 * d.C : d.F);
   s.part_a = b.f(kColsumBlocks * wide);
   s.part_b = b.f(kColsumBlocks * wide);
+  const size_t wmax = (size_t)d.C * (2 * d.C > d.F ? 2 * d.C : d.F);     // largest weight: proj_kv [2C, C] or linear1/2 [F, C]
+  s.wpart = b.f((Gemm::kSplit + 1) * wmax);
+  s.wt = b.f(wmax);
   return s;
 }
 
@@ -212,8 +233,22 @@ struct Ctx {
     if (rpb < 64) rpb = 64;
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(tr_colsum_kernel, dim3(nblk), dim3(256), 0, st, dy, x, mean, rstd, sc.part_a, sc.part_b, rows, N, (int)rpb);
-    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N)), dim3(256), 0, st, (const float*)sc.part_a, nblk, N, out_a);
-    if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N)), dim3(256), 0, st, (const float*)sc.part_b, nblk, N, out_b);
+    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 64)), dim3(256), 0, st, (const float*)sc.part_a, nblk, (size_t)N, out_a);
+    if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 64)), dim3(256), 0, st, (const float*)sc.part_b, nblk, (size_t)N, out_b);
+  }
+  // dW[N,K] = dY[M,N]^T X[M,K]
+  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K) const {
+    int np = 0;
+    int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np);
+    if (rc != AXVS_OK) return rc;
+    const size_t n = (size_t)N * K;
+    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 64)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
+    return AXVS_OK;
+  }
+  // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
+  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta) const {
+    hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, sc.wt, N, K);
+    return g.fwd(dY, sc.wt, dX, M, K, N, beta);
   }
   int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn, (int)bytes) : AXVS_OK; }
 };
@@ -267,20 +302,20 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   // proj and dropout1
   hipLaunchKernelGGL(tr_drop_bwd_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, d_out, sc.t0, rm, M, C, drop1);
   c.colsum(sc.t0, M, C, gw.proj_b);
-  if ((rc = c.g.wgrad(sc.t0, s.o, gw.proj_w, M, C, C)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.t0, w.proj_w, sc.d_o, M, C, C, 0.f)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.t0, s.o, gw.proj_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.t0, w.proj_w, sc.d_o, M, C, C, 0.f)) != AXVS_OK) return rc;
   // temporal half
   AXVS_D_SWITCH(d.D, {
     hipLaunchKernelGGL(tr_temporal_bwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
                        (const float*)s.kv2, (const float*)sc.d_o, sc.dq2, sc.dkv2, M, T, C, d.heads);
   })
   c.colsum(sc.dkv2, M * T, 2 * C, gw.proj_kv_b);
-  if ((rc = c.g.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.dkv2, w.proj_kv_w, sc.dx, M * T, 2 * C, C, 0.f)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dkv2, w.proj_kv_w, sc.dx, M * T, 2 * C, C, 0.f)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_scale_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dq2, MC / 4, c.scale);   // q2 = scale (proj_q(xd))
   c.colsum(sc.dq2, M, C, gw.proj_q_b);
-  if ((rc = c.g.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.dq2, w.proj_q_w, sc.dxd, M, C, C, 0.f)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dq2, w.proj_q_w, sc.dxd, M, C, C, 0.f)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_diag_scatter_add_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dx, (const float*)sc.dxd, M, T, d.HW, C);
   // spatial half
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
@@ -296,16 +331,16 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   // q / k / v projections
   c.add(xin, pos, sc.a, MC);
   c.colsum(sc.dq, M, C, gw.q_b);
-  if ((rc = c.g.wgrad(sc.dq, sc.a, gw.q_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dq, sc.a, gw.q_w, M, C, C)) != AXVS_OK) return rc;
   c.colsum(sc.dk, M, C, gw.k_b);
-  if ((rc = c.g.wgrad(sc.dk, sc.a, gw.k_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dk, sc.a, gw.k_w, M, C, C)) != AXVS_OK) return rc;
   c.colsum(sc.dv, M, C, gw.v_b);
-  if ((rc = c.g.wgrad(sc.dv, xin, gw.v_w, M, C, C)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.dq, w.q_w, sc.da, M, C, C, 0.f)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.dk, w.k_w, sc.da, M, C, C, 1.f)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dv, xin, gw.v_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dq, w.q_w, sc.da, M, C, C, 0.f)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dk, w.k_w, sc.da, M, C, C, 1.f)) != AXVS_OK) return rc;
   // d_in = d_out (residual) + dv Wv + da;   d_pos (+)= da
   if (hipMemcpyAsync(d_in, d_out, MC * sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
-  if ((rc = c.g.dgrad(sc.dv, w.v_w, d_in, M, C, C, 1.f)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dv, w.v_w, d_in, M, C, C, 1.f)) != AXVS_OK) return rc;
   c.add(d_in, sc.da, d_in, MC);
   if (d_pos) {
     if (pos_first) {
@@ -432,12 +467,12 @@ int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float
   const RowMap id{(int)M, (int)M, 1, M, M, 1, 0};
   hipLaunchKernelGGL(tr_drop_bwd_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, (const float*)sc.g0, sc.t0, id, M, C, make_drop(p_dropout, seed, 6));
   c.colsum(sc.t0, M, C, g.linear2_b);
-  if ((rc = c.g.wgrad(sc.t0, s.r, g.linear2_w, M, C, d.F)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.t0, p.linear2_w, sc.dr, M, C, d.F, 0.f)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.t0, s.r, g.linear2_w, M, C, d.F)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.t0, p.linear2_w, sc.dr, M, C, d.F, 0.f)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_relu_drop_bwd_kernel, dim3(blocks(MF / 4)), dim3(256), 0, c.st, sc.dr, (const float*)s.r, MF / 4, make_drop(p_dropout, seed, 5).scale);
   c.colsum(sc.dr, M, d.F, g.linear1_b);
-  if ((rc = c.g.wgrad(sc.dr, s.z, g.linear1_w, M, d.F, C)) != AXVS_OK) return rc;
-  if ((rc = c.g.dgrad(sc.dr, p.linear1_w, sc.g0, M, d.F, C, 1.f)) != AXVS_OK) return rc;   // g0 = d z = d u + d r W1
+  if ((rc = c.wgrad(sc.dr, s.z, g.linear1_w, M, d.F, C)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dr, p.linear1_w, sc.g0, M, d.F, C, 1.f)) != AXVS_OK) return rc;   // g0 = d z = d u + d r W1
   // norm1                                                                       :217
   c.colsum(sc.g0, M, C, g.norm1_b, s.buf2, s.mean1, s.rstd1, g.norm1_w);
   hipLaunchKernelGGL(tr_ln_bwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)sc.g0, (const float*)s.buf2, p.norm1_w,

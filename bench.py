@@ -194,7 +194,7 @@ def main():
         out_bytes = layers_cc * (Q * Tc * V * Hc * Wc * 4 + 128 * Tc * V * Hc * Wc * 4)     # masks written + features read, per layer
         return {"us_per_forward": round(us, 1), "unit": "us", "layers": layers_cc, "frames_per_s": round(Tc * V / (us * 1e-6), 1),
                 "shape": {"clip_query": [1, Q, Tc, 256], "panoptic_features": [1, 128, Tc * V, Hc, Wc]},
-                "launch": "hipGraph replay" if graph else "python, 1 library call per forward, heads on an auxiliary stream",
+                "launch": "hipGraph replay" if graph else "python, 1 library call per forward",
                 "algorithmic_mbytes": round(out_bytes / 1e6, 1),
                 "hbm_gbs": round(out_bytes / (us * 1e-6) / 1e9, 1), "hbm_frac": round(out_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "what": "BASELINE config 4: CrossClipTrackingModule.forward, 4 clips x 4 frames, 64x64, 4 layers; per-layer masks "
@@ -398,6 +398,34 @@ def main():
                 extras["cc_cfg4"] = measure_cc()
             except RuntimeError as e:
                 extras["cc_cfg4"] = {"error": str(e)[:200]}
+
+        # ---- one training step (forward + backward, dropout 0.1, recompute) of the same layer at the same size ----
+        if not args.no_extras and world == 1:
+            try:
+                tl = ax.TemporalAxialTrajectoryAttentionLayer(C, F, dropout=0.1, attn_drop=0.1, n_heads=heads)
+                tl.load_state_dict(w, strict=True)
+                tl = tl.to(dev).train()
+                s_t = src.detach().clone().requires_grad_(True)
+                g_t = torch.ones_like(s_t)
+
+                def train_step():
+                    tl(s_t, pos)[0].backward(g_t)
+                for _ in range(2):
+                    train_step()
+                torch.cuda.synchronize(dev)
+                n_t = 5
+                t_tr = time.perf_counter()
+                for _ in range(n_t):
+                    train_step()
+                torch.cuda.synchronize(dev)
+                el = (time.perf_counter() - t_tr) / n_t
+                extras["train_step"] = {"ms_per_step": round(el * 1e3, 3), "value": round(B * T / el, 1), "unit": "frames/s",
+                                        "what": "forward + backward of one layer through the fp32 training tier (axvs_axial_layer_train_fwd/_bwd), "
+                                                "dropout 0.1 / attn_drop 0.1, activations recomputed in backward",
+                                        "dtype": "f32"}
+                del tl, s_t, g_t
+            except RuntimeError as e:
+                extras["train_step"] = {"error": str(e)[:200]}
 
         # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would just wait)

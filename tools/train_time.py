@@ -1,0 +1,37 @@
+"""Training step (forward + backward) of one layer at BASELINE config 2 through the training tier: ms per step, frames/s."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import axvs_oracle as orc
+import axial_vs_amd as ax
+
+B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for recompute in (True, False):
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, dropout=0.1, attn_drop=0.1, n_heads=8)
+    layer.load_state_dict(orc.random_weights(orc.axial_layer_param_shapes(C, F), 1), strict=True)
+    layer = layer.cuda().train()
+    layer.recompute = recompute
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 1)
+    s, p = src.cuda().requires_grad_(True), pos.cuda()
+    g = torch.randn_like(s)
+    def step():
+        out = layer(s, p)[0]
+        out.backward(g)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    # forward only
+    t0 = time.perf_counter()
+    for _ in range(n):
+        with torch.no_grad():
+            layer(s, p)
+    torch.cuda.synchronize()
+    df = (time.perf_counter() - t0) / n
+    print(f"recompute={recompute}: fwd+bwd {dt*1e3:.2f} ms/step ({B*T/dt:.0f} frames/s), forward alone {df*1e3:.2f} ms")
