@@ -147,6 +147,7 @@ SIGNATURES = {
     "axvs_tl_heads_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "axvs_tl_heads_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_pos3d": (C.c_int, [_fp] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, _fp]),
+    "axvs_pos3d_masked": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_float, _fp]),
     "axvs_scaled_residual": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]),
 }
 

@@ -33,6 +33,8 @@ thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use t
 thread_local int g_spatial_only = 0;     // option "spatial_only": the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
+thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN activation is exact GELU (F.gelu) instead of ReLU -- set by the
+                                         // host module around its calls for activation="gelu" (WC/temporal_attention.py:9-17); unfused FFN path
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
@@ -192,8 +194,8 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn) {
   return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 5 && !want_attn && L >= 16 && L <= 128;
 }
-bool can_fuse_ffn_into_pass(int T, int F) { return !g_no_ffn_fusion && T <= 4 && F % 256 == 0 && F <= 4096; }
-bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
+bool can_fuse_ffn_into_pass(int T, int F) { return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096; }
+bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && !g_ffn_gelu && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
 
 // what one axial layer's launch sequence touches in the workspace (the same predicates run_traj / run_ffn dispatch on)
 struct LayerPlan {
@@ -378,7 +380,7 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
   hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, X, p.g1, p.be1, tmp, y16, M, C, 1e-5f);
   mark(st, "norm1");
   ALoadBlocked<BF> ay{y16, M, (int)M, 0, 1, 1};
-  launch_gemm<BF>(ay, p.w1, EpiBlocked16<BF>{h16, M, p.b1, 1.f, 0, 1}, (int)M, F, C, st);
+  launch_gemm<BF>(ay, p.w1, EpiBlocked16<BF>{h16, M, p.b1, 1.f, 0, g_ffn_gelu ? 2 : 1}, (int)M, F, C, st);
   mark(st, "ffn.linear1");
   ALoadBlocked<BF> ah{h16, M, (int)M, 0, 1, 1};
   launch_gemm<BF>(ah, p.w2, EpiRowsF32{X, tmp, p.b2, identity_map(M), C, 1.f}, (int)M, C, F, st);
@@ -880,6 +882,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "attn_waves")) { g_attn_waves = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
+  if (key && !strcmp(key, "ffn_gelu")) { g_ffn_gelu = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
@@ -1699,6 +1702,16 @@ int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature,
   if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 2) return fail(AXVS_ERR_ARG, "bad shape");
   long long total = (long long)T * H * W * C;
   hipLaunchKernelGGL(pos3d_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
+                     B, T, H, W, C, temperature, normalize, scale);
+  return last_launch_status();
+}
+
+int axvs_pos3d_masked(float* pos, const unsigned char* mask, int B, int T, int H, int W, int C, float temperature, int normalize,
+                      float scale, void* stream) {
+  if (!pos || !mask) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 2) return fail(AXVS_ERR_ARG, "bad shape");
+  long long total = (long long)B * T * H * W * C;
+  hipLaunchKernelGGL(pos3d_masked_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pos, mask,
                      B, T, H, W, C, temperature, normalize, scale);
   return last_launch_status();
 }

@@ -136,7 +136,7 @@ struct EpiBlocked16 {
   const float* bias;  // [Nout]
   float scale;        // applied to channels < nscale after the bias (softmax scale folded into q)
   int nscale;
-  int relu;
+  int relu;           // activation: 0 none, 1 ReLU, 2 exact GELU
   const float* mul = nullptr;   // optional per-channel multiplier applied to the accumulator before the bias (folded BN)
   int n_off = 0;                // column offset in Y (concatenating several GEMMs along channels)
   const unsigned char* zero_rows = nullptr;   // optional: rows with a non-zero flag are written as zeros (padding masks)
@@ -149,9 +149,12 @@ struct EpiBlocked16 {
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     n += n_off;
     if (n < nscale) v *= scale;
-    if (relu) {
+    if (relu == 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (relu == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gelu_exact(v[i]);
     }
     if (zero_rows && zero_rows[m]) v = f32x4{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<u16x4*>(Y + blk_off(R, m, n)) = cvt4<BF>(v);

@@ -190,6 +190,55 @@ __global__ void pos3d_kernel(float* __restrict__ pos, int B, int T, int H, int W
   for (int b = 0; b < B; ++b) pos[(long long)b * total + idx] = v;
 }
 
+// The same embedding with a padding mask (WC/pos_embeddings.py:96-106): the coordinates are running counts of the unmasked
+// positions along t / h / w (not_mask.cumsum), normalised by the count over the whole axis.  mask: uint8 [B,T,H,W], non-zero =
+// padded.  One thread per (token, channel); the three short scans are re-done per channel (this is a set-up kernel).
+__global__ void pos3d_masked_kernel(float* __restrict__ pos, const unsigned char* __restrict__ mask, int B, int T, int H, int W, int C,
+                                    float temperature, int normalize, float scale) {
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long total = (long long)B * T * H * W * C;
+  if (idx >= total) return;
+  int c = idx % C;
+  long long r = idx / C;
+  int w = r % W; r /= W;
+  int h = r % H; r /= H;
+  int t = r % T;
+  int b = r / T;
+  const unsigned char* mb = mask + (long long)b * T * H * W;
+  int zc = 0, zt = 0, yc = 0, yt = 0, xc = 0, xt = 0;
+  for (int i = 0; i < T; ++i) {
+    const int nm = mb[((long long)i * H + h) * W + w] == 0;
+    zt += nm;
+    if (i <= t) zc += nm;
+  }
+  for (int i = 0; i < H; ++i) {
+    const int nm = mb[((long long)t * H + i) * W + w] == 0;
+    yt += nm;
+    if (i <= h) yc += nm;
+  }
+  for (int i = 0; i < W; ++i) {
+    const int nm = mb[((long long)t * H + h) * W + i] == 0;
+    xt += nm;
+    if (i <= w) xc += nm;
+  }
+  float z = (float)zc, y = (float)yc, x = (float)xc;
+  if (normalize) {
+    const float eps = 1e-6f;
+    z = z / ((float)zt + eps) * scale;
+    y = y / ((float)yt + eps) * scale;
+    x = x / ((float)xt + eps) * scale;
+  }
+  const int n = C / 2;
+  int cc = c < n ? c : c - n;
+  float dim_t = powf(temperature, 2.f * (float)(cc / 2) / (float)n);
+  float a = (c < n ? y : x) / dim_t;
+  float v = (cc & 1) ? cosf(a) : sinf(a);
+  float dim_z = powf(temperature, 2.f * (float)(c / 2) / (float)C);
+  float az = z / dim_z;
+  v += (c & 1) ? cosf(az) : sinf(az);
+  pos[idx] = v;
+}
+
 __global__ void scaled_residual_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                        const float* __restrict__ gamma, float* __restrict__ out, size_t n, int C) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

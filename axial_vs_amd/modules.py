@@ -133,6 +133,13 @@ def _guarded(fn):
     streams / per-device kernel attributes belong to it): tensors on cuda:1 while cuda:0 is current must not launch on 0."""
     @functools.wraps(fn)
     def wrapper(*args, **kw):
+        act = getattr(args[0], "activation", "relu") if args and isinstance(args[0], nn.Module) else "relu"
+        if act != "relu":           # the layer's FFN activation travels as a thread-local option around the library calls
+            with _ffn_activation(act):
+                return guarded(*args, **kw)
+        return guarded(*args, **kw)
+
+    def guarded(*args, **kw):
         for a in args:
             if isinstance(a, Tensor) and a.is_cuda:
                 with _on(a.device):
@@ -274,6 +281,26 @@ class TrajectoryAttention(nn.Module):
         return out, attn
 
 
+class _ffn_activation:
+    """Context: tells the library which activation the layer's FFN uses (thread-local option; ReLU is the default and the only
+    one the fused FFN kernels implement -- GELU takes the unfused LayerNorm / GEMM / GEMM / LayerNorm path)."""
+
+    def __init__(self, name: str):
+        if name == "glu":
+            raise NotImplementedError("axial_vs_amd: activation='glu' halves the hidden width, which the reference's own linear2 "
+                                      "(d_ffn inputs) cannot consume either (WC/temporal_attention.py:126,182)")
+        self.gelu = name == "gelu"
+
+    def __enter__(self):
+        if self.gelu:
+            _lib.lib().axvs_set_option(b"ffn_gelu", 1)
+
+    def __exit__(self, *exc):
+        if self.gelu:
+            _lib.lib().axvs_set_option(b"ffn_gelu", 0)
+        return False
+
+
 def _get_activation_name(activation):
     if activation in ("relu", "gelu", "glu"):
         return activation
@@ -316,8 +343,6 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         dt = self._dtype()
         key = _param_key(self, dt)
         if self._packed is None or key != self._packed_key:
-            if self.activation != "relu":
-                raise NotImplementedError("axial_vs_amd: only activation='relu' (every shipped config) has a HIP path")
             if abs(self.norm1.eps - 1e-5) > 0 or abs(self.norm2.eps - 1e-5) > 0:
                 raise NotImplementedError("axial_vs_amd: LayerNorm eps must be 1e-5")
             L = _lib.lib()
@@ -434,8 +459,6 @@ class TemporalTrajectoryAttentionLayer(nn.Module):
         dt = self._dtype()
         key = _param_key(self, dt)
         if self._packed is None or key != self._packed_key:
-            if self.activation != "relu":
-                raise NotImplementedError("axial_vs_amd: only activation='relu' (every shipped config) has a HIP path")
             L = _lib.lib()
             C_, F, dev = self.linear1.in_features, self.linear1.out_features, self.linear1.weight.device
             keep: list = []
@@ -557,8 +580,6 @@ class PositionEmbeddingSine3D(nn.Module):
     @torch.no_grad()
     def forward(self, x, mask=None, fmt="btchw"):
         assert x.dim() == 5, f"{x.shape} should be a 5-dimensional Tensor, got {x.dim()}-dimensional Tensor instead"
-        if mask is not None:
-            raise NotImplementedError("axial_vs_amd: PositionEmbeddingSine3D with a padding mask has no HIP path")
         if fmt == "btchw":
             B, T, _, H, W = x.shape
         elif fmt == "bcthw":
@@ -567,7 +588,17 @@ class PositionEmbeddingSine3D(nn.Module):
             raise ValueError(f"Invalid format given: {fmt})")
         if not x.is_cuda:
             raise RuntimeError("axial_vs_amd: x must be a GPU tensor; there is no CPU fallback")
-        pos = self.channels_last(B, T, H, W, x.device)
+        if mask is not None:          # padding mask [B,T,H,W], True = padded (:96-106); a plain tensor (no SineTag: not regenerable)
+            if tuple(mask.shape) != (B, T, H, W):
+                raise RuntimeError(f"mask {tuple(mask.shape)} must be [B,T,H,W] = {(B, T, H, W)}")
+            m8 = mask.to(device=x.device, dtype=torch.uint8).contiguous()
+            Cc = 2 * self.num_pos_feats
+            pos = torch.empty(B, T, H, W, Cc, dtype=torch.float32, device=x.device)
+            with _on(pos.device):
+                _lib.check(_lib.lib().axvs_pos3d_masked(pos.data_ptr(), m8.data_ptr(), B, T, H, W, Cc, float(self.temperature),
+                                                        int(self.normalize), float(self.scale), _stream(pos.device)), "axvs_pos3d_masked")
+        else:
+            pos = self.channels_last(B, T, H, W, x.device)
         return pos.permute(0, 1, 4, 2, 3) if fmt == "btchw" else pos.permute(0, 4, 1, 2, 3)
 
 

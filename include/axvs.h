@@ -333,6 +333,11 @@ int axvs_match_clips(const float* mask_embeddings, long long* indices, int V, in
 int axvs_pos3d(float* pos, int B, int T, int H, int W, int C, float temperature, int normalize, float scale,
                void* stream);
 
+/* The same with a padding mask (WC/pos_embeddings.py:96-106: coordinates = not_mask.cumsum along t / h / w, normalised by the
+ * count over the whole axis).  mask: uint8 [B,T,H,W], non-zero = padded position. */
+int axvs_pos3d_masked(float* pos, const unsigned char* mask, int B, int T, int H, int W, int C, float temperature, int normalize,
+                      float scale, void* stream);
+
 /* ---- out[i] = a[i] + gamma[i % C] * b[i]   (Tube-Link residual, TL/...pixel_decoder.py:625-627) */
 int axvs_scaled_residual(const float* a, const float* b, const float* gamma, float* out, size_t n, int C,
                          void* stream);

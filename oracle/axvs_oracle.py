@@ -133,9 +133,10 @@ def cc_trajectory_attention(x: Tensor, w: Weights, seq_len: int, num_frames: int
 # --------------------------------------------------------------------------------------
 # (a4) axial layer, (a5) encoder, (a8) Tube-Link gamma wrapper
 # --------------------------------------------------------------------------------------
-def axial_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8, want_attn: bool = True
+def axial_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8, want_attn: bool = True, activation: str = "relu"
                 ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
-    """WC/temporal_attention.py:187-220.  src [(B T),(H W),C], pos [B,T,H,W,C]."""
+    """WC/temporal_attention.py:187-220.  src [(B T),(H W),C], pos [B,T,H,W,C].  activation: "relu" | "gelu" (:9-17, exact GELU)."""
+    act = torch.relu if activation == "relu" else torch.nn.functional.gelu
     B, T, H, W, C = pos.shape
     x = src.reshape(B, T, H, W, C)
     # height pass: sequences (b, w), tokens (t, h)          (:197-204)
@@ -154,7 +155,7 @@ def axial_layer(src: Tensor, pos: Tensor, w: Weights, heads: int = 8, want_attn:
     x = xs.reshape(B, H, T, W, C).permute(0, 2, 1, 3, 4).reshape(B * T, H * W, C)   # (:215)
     # norm1 + FFN + norm2                                   (:181-185, :217-218)
     x = _layer_norm(x, w, "norm1")
-    ff = _linear(torch.relu(_linear(x, w, "linear1")), w, "linear2")
+    ff = _linear(act(_linear(x, w, "linear1")), w, "linear2")
     x = _layer_norm(x + ff, w, "norm2")
     return x, h_attn, w_attn
 
@@ -261,6 +262,31 @@ def tubelink_temporal_residual(f: Tensor, pos3d: Tensor, gamma: Tensor, w: Weigh
 # --------------------------------------------------------------------------------------
 # (a6) 3-D sine positional embedding
 # --------------------------------------------------------------------------------------
+def pos_embed_sine_3d_masked(mask: Tensor, num_pos_feats: int, temperature: float = 10000.0, normalize: bool = True,
+                             scale: float = 2 * math.pi, dtype: torch.dtype = torch.float32) -> Tensor:
+    """WC/pos_embeddings.py:86-130 with a padding mask [B,T,H,W] (True = padded): the coordinates are running counts of the
+    unmasked positions (:96-100), normalised by the last count of each axis (:101-105).  Channels-last [B,T,H,W,2*num_pos_feats]."""
+    nm = (~mask.bool()).to(dtype)
+    z, y, x = nm.cumsum(1), nm.cumsum(2), nm.cumsum(3)
+    if normalize:
+        eps = 1e-6
+        z = z / (z[:, -1:] + eps) * scale
+        y = y / (y[:, :, -1:] + eps) * scale
+        x = x / (x[:, :, :, -1:] + eps) * scale
+    n = num_pos_feats
+    dim_t = torch.as_tensor(temperature, dtype=dtype) ** (2 * torch.floor(torch.arange(n, dtype=dtype) / 2) / n)
+    dim_tz = torch.as_tensor(temperature, dtype=dtype) ** (2 * torch.floor(torch.arange(2 * n, dtype=dtype) / 2) / (2 * n))
+
+    def interleave(coord: Tensor, dim: Tensor) -> Tensor:
+        a = coord[..., None] / dim
+        out = torch.empty_like(a)
+        out[..., 0::2] = a[..., 0::2].sin()
+        out[..., 1::2] = a[..., 1::2].cos()
+        return out
+
+    return torch.cat([interleave(y, dim_t), interleave(x, dim_t)], dim=-1) + interleave(z, dim_tz)
+
+
 def pos_embed_sine_3d(B: int, T: int, H: int, W: int, num_pos_feats: int, temperature: float = 10000.0,
                       normalize: bool = True, scale: float = 2 * math.pi,
                       dtype: torch.dtype = torch.float32) -> Tensor:

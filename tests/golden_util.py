@@ -195,3 +195,7 @@ def train_grad_errors(z, grads):
             got = got.reshape(-1)[::5]
         errs[k] = float((got.reshape(-1) - ref.reshape(-1)).norm() / max(float(ref.norm()), floor))
     return errs
+
+
+POS_MASK = ["g11_pos3d_mask_B2_T3_H6_W7_n16", "g11_pos3d_mask_B1_T4_H12_W9_n64", "g11_pos3d_mask_B2_T2_H5_W8_n32"]
+GELU = ["g12_axial_gelu_B1_T2_C64_H6_W5", "g12_axial_gelu_B1_T3_C256_H16_W16"]

@@ -879,3 +879,44 @@ def test_match_clips_pipeline():
             cs.append(cen[b, i][idx])
         want.append(torch.stack(cs, dim=1))
     assert torch.equal(got, torch.stack(want, 0))
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").POS_MASK)
+def test_pos3d_with_padding_mask_golden(name):
+    """PositionEmbeddingSine3D(x, mask) (WC/pos_embeddings.py:96-106; round 1 refused a mask) against the reference's output."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    mask = t(z["mask"])
+    mod = ax.PositionEmbeddingSine3D(m["n"], normalize=m["normalize"], scale=m["scale"] if m["normalize"] else None)
+    x = torch.zeros(m["B"], m["T"], 2 * m["n"], m["H"], m["W"], device="cuda")
+    pos = mod(x, mask=mask.cuda(), fmt="btchw")
+    assert tuple(pos.shape) == (m["B"], m["T"], 2 * m["n"], m["H"], m["W"])
+    e = rel_err(pos.permute(0, 1, 3, 4, 2).cpu(), t(z["pos"]))
+    print(f"{name}: {e:.2e}")
+    assert e < 2e-5
+    from axial_vs_amd.modules import _sine_tag
+    assert _sine_tag(pos.permute(0, 1, 3, 4, 2).contiguous()) is None        # a masked embedding is read, never regenerated in-kernel
+    bcthw = mod(x.permute(0, 2, 1, 3, 4), mask=mask.cuda(), fmt="bcthw")
+    assert torch.equal(bcthw.permute(0, 2, 1, 3, 4), pos)
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").GELU)
+def test_axial_layer_gelu_golden(name):
+    """activation="gelu" (round 1 refused it): the FFN leaves the fused kernels for LayerNorm / GEMM+GELU / GEMM / LayerNorm; the
+    attention passes stay fused.  The option is scoped to the call: a ReLU layer afterwards is unaffected."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=m["heads"], activation="gelu").eval()
+    layer.load_state_dict(w, strict=True)
+    out, _, _ = layer.cuda()(dev(src), dev(pos))
+    e = rel_err(out.cpu(), t(z["out"]))
+    print(f"{name}: {e:.2e}")
+    assert e < TOL_F16
+    relu = ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=m["heads"]).eval()
+    relu.load_state_dict(w, strict=True)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, m["heads"], want_attn=False)
+    assert rel_err(relu.cuda()(dev(src), dev(pos))[0].cpu(), ref) < TOL_F16
+    with pytest.raises(NotImplementedError, match="glu"):
+        ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=m["heads"], activation="glu").eval().cuda()(dev(src), dev(pos))

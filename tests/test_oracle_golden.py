@@ -260,3 +260,23 @@ def test_dropout_hash_statistics_and_determinism():
         assert not torch.equal(k, orc.dropout_keep(77, 4, 400000, p))     # sites are independent streams
         assert not torch.equal(k, orc.dropout_keep(78, 3, 400000, p))
     assert torch.equal(orc.dropout_keep(1, 1, 10, 0.0), torch.ones(10, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").POS_MASK)
+def test_pos3d_with_padding_mask(name):
+    """WC/pos_embeddings.py:96-106: PositionEmbeddingSine3D called with a mask (cumulative counts of unmasked positions)."""
+    z, m = load(name)
+    pos = orc.pos_embed_sine_3d_masked(t(z["mask"]), m["n"], normalize=m["normalize"], scale=m["scale"])
+    assert rel_err(pos, t(z["pos"])) < 1e-6
+    # mask = None is the all-false mask
+    none = orc.pos_embed_sine_3d_masked(torch.zeros(m["B"], m["T"], m["H"], m["W"], dtype=torch.bool), m["n"], normalize=m["normalize"], scale=m["scale"])
+    assert rel_err(none, orc.pos_embed_sine_3d(m["B"], m["T"], m["H"], m["W"], m["n"], normalize=m["normalize"], scale=m["scale"])) < 1e-6
+
+
+@pytest.mark.parametrize("name", __import__("golden_util").GELU)
+def test_axial_layer_gelu(name):
+    """activation="gelu" (WC/temporal_attention.py:9-17: F.gelu, the exact erf form)."""
+    z, m = load(name)
+    src, pos = axial_inputs(m)
+    out, _, _ = orc.axial_layer(src, pos, weights(z, m), m["heads"], want_attn=False, activation="gelu")
+    assert rel_err(out, t(z["out"])) < TOL
