@@ -35,3 +35,32 @@ for recompute in (True, False):
     torch.cuda.synchronize()
     df = (time.perf_counter() - t0) / n
     print(f"recompute={recompute}: fwd+bwd {dt*1e3:.2f} ms/step ({B*T/dt:.0f} frames/s), forward alone {df*1e3:.2f} ms")
+
+# reference point: the same math as plain PyTorch ops on the same GPU (autograd through the oracle's torch code, fp32, rocBLAS/MIOpen
+# kernels chosen by torch) -- what "unmodified reference on ROCm PyTorch" would cost for this layer
+if "--torch" in sys.argv:
+    orc.dropout_keep = lambda seed, site, count, p, dtype=torch.float32: torch.ones(count, dtype=dtype, device="cuda")
+    w = {k: v.cuda().requires_grad_(True) for k, v in orc.random_weights(orc.axial_layer_param_shapes(C, F), 1).items()}
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 1)
+    s, p = src.cuda().requires_grad_(True), pos.cuda()
+    g = torch.randn_like(s)
+    def tstep():
+        out = orc.axial_layer_train(s, p, w, 8, 0.0, 0.0, 0)
+        out.backward(g)
+    for _ in range(3):
+        tstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tstep()
+    torch.cuda.synchronize()
+    print(f"torch eager (oracle code on the GPU, fp32, no dropout): fwd+bwd {(time.perf_counter() - t0) / n * 1e3:.2f} ms/step")
+    with torch.autocast("cuda", dtype=torch.float16):
+        for _ in range(2):
+            tstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tstep()
+        torch.cuda.synchronize()
+    print(f"torch eager under fp16 autocast: fwd+bwd {(time.perf_counter() - t0) / n * 1e3:.2f} ms/step")
