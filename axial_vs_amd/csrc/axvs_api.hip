@@ -288,7 +288,9 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
       if (fuse_attn && L % 32 != 0 &&
           hipMemsetAsync(w.vt16, 0, (size_t)(Mp / L) * nks_fused * 8 * 1024 * sizeof(u16), st) != hipSuccess)   // pad keys must be finite
         return fail(AXVS_ERR_LAUNCH, "memset failed");
-      hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3((unsigned)((Mp + 63) / 64)), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
+      const unsigned qtiles = (unsigned)((Mp + 63) / 64);
+      // few tiles (cross-clip queries): one workgroup per (tile, q | k | v) -- a third of the weight stream each
+      hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3(qtiles, (qtiles <= 64 && !g_no_small_tiles) ? 3 : 1), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
                          p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e,
                          fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{},
                          (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0, g_status);
@@ -574,7 +576,8 @@ void fold_bn(const AxvsBN& bn, float* mul, float* add, int n, hipStream_t st) {
 }
 
 template <bool BF>
-int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q, int Tc, const int* rates, void* ws, hipStream_t st) {
+int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q, int Tc, const int* rates, void* ws, hipStream_t st,
+                   float* out2 = nullptr /* optional second copy of the output rows */) {
   Carver pc(const_cast<void*>(packed));
   CCLayerPacked p = carve_cc_layer(pc);
   const long long R = (long long)B * Q * Tc;
@@ -612,7 +615,7 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   ALoadBlocked<BF> ac{w.cat16, R, (int)R, 0, 1, 1};
   launch_gemm<BF>(ac, p.aspp_proj, EpiRowsF32{w.y, nullptr, nullptr, identity_map(R), 256, 1.f}, (int)R, 256, 768, st);
   mark(st, "cc.aspp");
-  hipLaunchKernelGGL(cc_aspp_post_kernel, dim3(lnblocks), dim3(256), 0, st, w.y, w.t2, p.an_w, p.an_b, p.cn_w, p.cn_b, out, R);
+  hipLaunchKernelGGL(cc_aspp_post_kernel, dim3(lnblocks), dim3(256), 0, st, w.y, w.t2, p.an_w, p.an_b, p.cn_w, p.cn_b, out, R, out2);
   mark(st, "cc.aspp_post");
   return last_launch_status();
 }
@@ -846,13 +849,12 @@ int run_cc_module(const float* clip_query, const void* const* packed_layers, int
   const float* cur = clip_query;
   for (int i = 0; i < layers; ++i) {
     float* nxt = w.q + (size_t)i * R * 256;
-    int rc = dtype == AXVS_BF16 ? cc_layer_fwd_t<true>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st)
-                                : cc_layer_fwd_t<false>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st);
+    float* also = i == layers - 1 ? last_query : nullptr;      // the caller's copy of the last layer's queries
+    int rc = dtype == AXVS_BF16 ? cc_layer_fwd_t<true>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st, also)
+                                : cc_layer_fwd_t<false>(cur, nxt, packed_layers[i], B, Q, Tc, rates, w.chain, st, also);
     if (rc != AXVS_OK) return rc;
     cur = nxt;
   }
-  if (hipMemcpyAsync(last_query, cur, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return fail(AXVS_ERR_LAUNCH, "copy failed");
   if (int rc = heads(st)) return rc;
   return last_launch_status();
 }

@@ -33,7 +33,8 @@ __global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restr
 __global__ __launch_bounds__(256) void cc_aspp_post_kernel(const float* __restrict__ Y, const float* __restrict__ Xin,
                                                            const float* __restrict__ ga, const float* __restrict__ ba,
                                                            const float* __restrict__ gn, const float* __restrict__ bn,
-                                                           float* __restrict__ out, long long M) {
+                                                           float* __restrict__ out, long long M,
+                                                           float* __restrict__ out2 = nullptr /* optional second copy of the rows */) {
   constexpr int C = 256;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -51,8 +52,9 @@ __global__ __launch_bounds__(256) void cc_aspp_post_kernel(const float* __restri
   d0 = z0 - mu2; d1 = z1 - mu2; d2 = z2 - mu2; d3 = z3 - mu2;
   const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
   const float4 g2 = *reinterpret_cast<const float4*>(gn + lane * 4), b2 = *reinterpret_cast<const float4*>(bn + lane * 4);
-  *reinterpret_cast<float4*>(out + row * C + lane * 4) =
-      float4{d0 * rstd2 * g2.x + b2.x, d1 * rstd2 * g2.y + b2.y, d2 * rstd2 * g2.z + b2.z, d3 * rstd2 * g2.w + b2.w};
+  const float4 o = float4{d0 * rstd2 * g2.x + b2.x, d1 * rstd2 * g2.y + b2.y, d2 * rstd2 * g2.z + b2.z, d3 * rstd2 * g2.w + b2.w};
+  *reinterpret_cast<float4*>(out + row * C + lane * 4) = o;
+  if (out2) *reinterpret_cast<float4*>(out2 + row * C + lane * 4) = o;
 }
 
 // Class head of MaXTronCCPredictor (CC/...:48-52): per query q, softmax over ALL (b, clip) entries of a 256->1 activation

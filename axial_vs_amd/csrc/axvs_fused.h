@@ -893,8 +893,12 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
   QSTAMP_DECL;
   QSTAMP(0);
   const WtBuf wq(Q16), wk(K16), wvt(VT16);
+  // gridDim.y == 3 (few row tiles: the cross-clip modules' 512 clip queries): workgroup (tile, part) computes only q, k or v, so
+  // each one streams a third of the weights -- with 8 tiles the chip is empty and the per-CU weight stream is the whole cost
+  const bool split = gridDim.y == 3;
+  const int part = split ? (int)blockIdx.y : 0;
   u16x8 wf[2][8];
-  load_wfrags<2, 8>(wf, Wq, C, 0, wave * 32, fi, fg);
+  load_wfrags<2, 8>(wf, part == 0 ? Wq : part == 1 ? Wk : Wv, C, 0, wave * 32, fi, fg);
   float bias3[3];                        // biases requested now, parked in LDS behind the row gather
   if (tid < C) {
     bias3[0] = bq[tid]; bias3[1] = bk[tid]; bias3[2] = bv[tid];
@@ -961,12 +965,14 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
   // q, k from the (src+pos) tile, v from the src tile; each sweep refills the fragment set for the next one
 #pragma unroll
   for (int which = 0; which < 3; ++which) {
+    if (split && which != part) continue;
     f32x4 acc[2][MT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (which == 0) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wk, C, wave * 32, fi, fg);
+    if (split && which < 2) sweep8<BF, MT, false>(acc, wf, tqk, bb, KBS, Wk, C, 0, fi, fg);        // no refill: nothing follows
+    else if (which == 0) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wk, C, wave * 32, fi, fg);
     else if (which == 1) sweep8<BF, MT, true>(acc, wf, tqk, bb, KBS, Wv, C, wave * 32, fi, fg);
     else if (VT16 == nullptr) sweep8<BF, MT, false>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);
     else sweep8<BF, MT, false, true>(acc, wf, tv, bb, KBS, Wv, C, 0, fi, fg);          // tokens on D rows
