@@ -35,18 +35,22 @@ struct ALoadRowsF32 {
   const float* add;   // nullable: added element-wise (positional embedding)
   RowMap rm;
   int M, K;
-  __device__ __forceinline__ u16x8 load(int m, int k) const {
+  __device__ __forceinline__ u16x8 load(int m, int k) const { return conv(fetch(m, k)); }
+  struct raw_t { float4 a, b, c, d; };      // row words and (optional) positional words, summed and rounded at the point of use
+  __device__ __forceinline__ raw_t fetch(int m, int k) const {
     m = min(m, M - 1);
     long long off = nat_row(rm, m) * K + k;
     const float4* p = reinterpret_cast<const float4*>(src + off);
-    float4 a = p[0], b = p[1];
+    raw_t r{p[0], p[1], float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}};
     if (add) {
       const float4* q = reinterpret_cast<const float4*>(add + off);
-      float4 c = q[0], d = q[1];
-      a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
-      b.x += d.x; b.y += d.y; b.z += d.z; b.w += d.w;
+      r.c = q[0];
+      r.d = q[1];
     }
-    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return r;
+  }
+  static __device__ __forceinline__ u16x8 conv(const raw_t& r) {
+    float v[8] = {r.a.x + r.c.x, r.a.y + r.c.y, r.a.z + r.c.z, r.a.w + r.c.w, r.b.x + r.d.x, r.b.y + r.d.y, r.b.z + r.d.z, r.b.w + r.d.w};
     return cvt8<BF>(v);
   }
 };
@@ -238,11 +242,13 @@ __device__ __forceinline__ void gemm64_body(const ALoad& al, const u16* __restri
   // module: -12 %); loaders that do split-precision arithmetic on fp32 rows are throughput-bound on big grids and lose
   // occupancy to the extra registers, they declare kPrefetch = 1
   constexpr int PF = ALoad::kPrefetch;
-  u16x8 rx[PF], rw[PF];
+  typedef RawOf<ALoad> Raw;                 // fp32-source loaders keep the raw words in flight and convert when staging
+  typename Raw::type rx[PF];
+  u16x8 rw[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
     const int k = min(u, nkb - 1) * 32 + lg * 8;
-    rx[u] = al.load(m0 + lrow, k);
+    rx[u] = Raw::fetch(al, m0 + lrow, k);
     rw[u] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, k));
   }
   for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
@@ -252,12 +258,12 @@ __device__ __forceinline__ void gemm64_body(const ALoad& al, const u16* __restri
       if (kb < nkb) {                       // uniform
         u16* bx = sX[kb & 1];
         u16* bw = sW[kb & 1];
-        *reinterpret_cast<u16x8*>(bx + st_off) = rx[u];
+        *reinterpret_cast<u16x8*>(bx + st_off) = Raw::conv(rx[u]);
         *reinterpret_cast<u16x8*>(bw + st_off) = rw[u];
         __syncthreads();                    // also orders these writes after the reads of this buffer two steps ago
         {
           const int k = min(kb + PF, nkb - 1) * 32 + lg * 8;   // unconditional (clamped) prefetch keeps vmcnt bookkeeping simple
-          rx[u] = al.load(m0 + lrow, k);
+          rx[u] = Raw::fetch(al, m0 + lrow, k);
           rw[u] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, k));
         }
         u16x8 fx[2], fw[2];
