@@ -285,7 +285,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&qkv_fused_kernel<BF>))) return rc;
     // the fused kernel reads the value rows from the same tensor as the q/k rows (+ optional additive term)
     if (vsrc == qsrc) {
-      if (fuse_attn && L % 32 != 0 &&
+      if (fuse_attn && L % 16 != 0 &&      // (L % 16 == 0: the kernel clears the padding half-steps itself)
           hipMemsetAsync(w.vt16, 0, (size_t)(Mp / L) * nks_fused * 8 * 1024 * sizeof(u16), st) != hipSuccess)   // pad keys must be finite
         return fail(AXVS_ERR_LAUNCH, "memset failed");
       const unsigned qtiles = (unsigned)((Mp + 63) / 64);
@@ -1613,8 +1613,11 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
     else launch_gemm<false>(ALoadTokensSplit3<false>{x, (int)M, Cin, HW, in_batch_stride, in_ld}, w, ey, (int)M, Cout, 3 * Cin, st);
   }
   mark(st, "glue.conv1x1");
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nblk, N), dim3(256), 2 * (size_t)Cout * sizeof(float), st, y, partial, HW, Cout, groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((N * groups + 255) / 256)), dim3(256), 0, st, partial, stats, nblk, groups, N * groups);
+  {
+    const int n4 = Cout / 4, lanes = n4 < 256 ? n4 : 256, rg = 256 / lanes;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nblk, N), dim3(256), 2 * (size_t)rg * Cout * sizeof(float), st, y, partial, HW, Cout, groups);
+  }
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((N * groups + 3) / 4)), dim3(256), 0, st, partial, stats, nblk, groups, N * groups);
   const dim3 ag((unsigned)((HW + 63) / 64), (unsigned)((Cout + 63) / 64), N);
   if (out_layout == 0) hipLaunchKernelGGL((gn_apply_kernel<true>), ag, dim3(256), 0, st, y, stats, g, be, out, HW, Cout, groups, eps, (long long)0, (long long)Cout * HW);
   else hipLaunchKernelGGL((gn_apply_kernel<false>), ag, dim3(256), 0, st, y, stats, g, be, out, HW, Cout, groups, eps, out_ld, out_batch_stride);

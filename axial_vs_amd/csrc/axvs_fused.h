@@ -1042,6 +1042,9 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
             v[0] += b; v[1] += b; v[2] += b; v[3] += b;
             if (wt) wvt.store8((unsigned)(d * 2), cvt4<BF>(v));
             else *reinterpret_cast<u16x4*>(VT16 + d) = cvt4<BF>(v);
+            // frame length an odd multiple of 16: the frame's last 16-key tile also clears the other (padding) half of its
+            // 32-key step -- pad keys get probability 0 but must hold finite values (this replaces a memset per pass)
+            if (L % 32 != 0 && (int)(mt0 - sf * L) + 16 == L) *reinterpret_cast<u16x4*>(VT16 + (d ^ 4)) = u16x4{0, 0, 0, 0};
           }
         }
       }

@@ -57,41 +57,58 @@ struct ALoadTokensSplit3 {
 // sample, thread = 4 consecutive channels -> per-channel sums in LDS -> per-group partials [N][nblk][G][2] in channel order.
 // Stage 2 (gn_finalize_kernel): partials summed in block order -> stats [N][G][2] = (sum, sum of squares).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ y, float* __restrict__ partial, int HW, int C, int G) {
-  extern __shared__ float chs[];                        // [C] sums | [C] sums of squares
-  float* chq = chs + C;
+  extern __shared__ float chs[];                        // [RG][C] sums | [RG][C] sums of squares (RG row groups)
   const int n = blockIdx.y, r0 = blockIdx.x * 64, tid = threadIdx.x;
   const int rows = min(64, HW - r0);
-  for (int c = tid * 4; c < C; c += 1024) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < rows; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(y + ((long long)n * HW + r0 + r) * C + c);
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
+  // threads = `lanes` float4 columns x RG row groups (C = 256: 64 x 4, 16 rows each, loads independent of one another): the
+  // serial 64-row loop of round 1 made this kernel a 18 us latency chain whatever the problem size
+  const int n4 = C / 4, lanes = n4 < 256 ? n4 : 256, RG = 256 / lanes;
+  const int col = tid % lanes, g = tid / lanes;
+  float* chq = chs + RG * C;
+  for (int c0 = 0; c0 < n4; c0 += lanes) {
+    const int c4 = c0 + col;
+    float4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (g < RG && c4 < n4) {
+#pragma unroll 4
+      for (int r = g; r < rows; r += RG) {
+        const float4 v = *reinterpret_cast<const float4*>(y + ((long long)n * HW + r0 + r) * C + c4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+      }
+      *reinterpret_cast<float4*>(chs + g * C + c4 * 4) = s;
+      *reinterpret_cast<float4*>(chq + g * C + c4 * 4) = q;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { chs[c + i] = s[i]; chq[c + i] = q[i]; }
   }
   __syncthreads();
   const int cg = C / G;
-  for (int g = tid; g < G; g += 256) {
+  for (int gg = tid; gg < G; gg += 256) {
     float s = 0.f, q = 0.f;
-    for (int c = g * cg; c < (g + 1) * cg; ++c) { s += chs[c]; q += chq[c]; }
-    float* o = partial + (((long long)n * gridDim.x + blockIdx.x) * G + g) * 2;
+    for (int j = 0; j < RG; ++j)                          // fixed order: row groups, then channels
+      for (int c = gg * cg; c < (gg + 1) * cg; ++c) { s += chs[j * C + c]; q += chq[j * C + c]; }
+    float* o = partial + (((long long)n * gridDim.x + blockIdx.x) * G + gg) * 2;
     o[0] = s; o[1] = q;
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int G, int NG) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (n, g)
+// one wave per (n, g): lanes stride over the blocks, then a fixed-order butterfly
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int G, int NG) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // (n, g)
   if (i >= NG) return;
   const int n = i / G, g = i - n * G;
   float s = 0.f, q = 0.f;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     const float* p = partial + (((long long)n * nblk + b) * G + g) * 2;
     s += p[0]; q += p[1];
   }
-  stats[(long long)i * 2] = s;
-  stats[(long long)i * 2 + 1] = q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) {
+    stats[(long long)i * 2] = s;
+    stats[(long long)i * 2 + 1] = q;
+  }
 }
 
 // GroupNorm apply: out = (y - mean_g) * rstd_g * gamma_c + beta_c; token rows in, token rows (in place allowed) or NCHW out.
