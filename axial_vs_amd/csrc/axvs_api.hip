@@ -194,7 +194,12 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn) {
   return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 5 && !want_attn && L >= 16 && L <= 128;
 }
-bool can_fuse_ffn_into_pass(int T, int F) { return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096; }
+// The FFN rides in the width-pass kernel only when that kernel fills at least half the chip: with fewer 64-row tiles every
+// workgroup's private 1 MB FFN weight stream is pure latency (43 us per pass whether 16 or 64 workgroups run), and a 16-row
+// trajectory kernel (4x the workgroups) + the stand-alone FFN kernel is faster (BASELINE config 3: res4 / res5 levels).
+bool can_fuse_ffn_into_pass(int T, int F, long long M) {
+  return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096 && (M >= 128 * 64 || g_no_small_tiles);
+}
 bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && !g_ffn_gelu && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
 
 // what one axial layer's launch sequence touches in the workspace (the same predicates run_traj / run_ffn dispatch on)
@@ -203,10 +208,10 @@ struct LayerPlan {
   bool need_buf2;     // the width pass writes rows for a separate FFN launch
   bool need_ffn_tmp;  // generic FFN (LayerNorm / GEMM / GEMM / LayerNorm): fp32 scratch + 16-bit y and h
 };
-LayerPlan plan_layer(int T, int H, int W, int C, int heads, int F, bool want_attn) {
+LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool want_attn) {
   LayerPlan p;
   p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn) && can_fuse_attn(C, heads, T, W, want_attn);
-  p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn) && can_fuse_ffn_into_pass(T, F));
+  p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn) && can_fuse_ffn_into_pass(T, F, (long long)B * T * H * W));
   p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
   return p;
 }
@@ -308,7 +313,7 @@ qkv_done:
   mark(st, nm[0]);
   if (fuse_attn) {
     // the layer's FFN can ride along (64-row tiles, LDS budget): `out` then receives norm2(FFN(norm1(...)))
-    const bool with_ffn = ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F);
+    const bool with_ffn = ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F, Mp);
     int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr);
     if (rc != AXVS_OK) return rc;
     if (with_ffn) *ffn_done = true;
@@ -438,7 +443,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   LayerPacked p = carve_layer(pc, C, heads, F);
   const long long M = (long long)B * T * H * W;
   Carver wc(ws);
-  const LayerPlan plan = plan_layer(T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
+  const LayerPlan plan = plan_layer(B, T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
   TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
   float* buf1 = wc.take<float>((size_t)M * C);
   float* const scratch1 = buf1;                // fp32 scratch of the generic FFN path (free once the width pass has read the rows)
@@ -975,7 +980,7 @@ int axvs_traj_attn_fwd(const float* query, const float* key, const float* value,
 size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, int heads, int d_ffn, int want_attn_maps, int sine_pos) {
   const long long M = (long long)B * T * H * W;
   Carver c(nullptr);
-  const LayerPlan plan = plan_layer(T, H, W, C, heads, d_ffn, want_attn_maps != 0);
+  const LayerPlan plan = plan_layer(B, T, H, W, C, heads, d_ffn, want_attn_maps != 0);
   carve_traj_ws(c, M, T, heads, plan.lean_traj);
   c.take<float>((size_t)M * C);
   if (plan.need_buf2) c.take<float>((size_t)M * C);

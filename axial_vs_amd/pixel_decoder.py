@@ -197,6 +197,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self.mfma_dtype = mfma_dtype
         self._packed = None
         self._packed_key = None
+        self._pos_cache = None          # (key, pos 2-D tokens, [pos 3-D per temporal level]) of the last shapes seen
 
     def _dtype(self) -> str:
         from . import modules
@@ -251,22 +252,31 @@ class MSDeformAttnPixelDecoder(nn.Module):
         pin, pout = self._pack_projs()
         spatial = self.transformer.num_spatial_layers > 0
         src = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev)
-        pos = torch.empty(BT, S, Cd, dtype=torch.float32, device=dev) if spatial else None
         wsb = max(L.axvs_conv1x1_gn_workspace_bytes(BT, hw, max(Cd, x.shape[1]), 32) for hw, x in zip(sizes, xs))
         ws = _workspace(dev, wsb)
-        lvl2d = _dev_f32(self.transformer.level_embed_2d.detach(), "level_embed_2d") if spatial else None
-        pos_3d = []
+        # The position embeddings (+ level embeddings) are functions of the shapes and of two small parameters: they are built once
+        # per (shapes, parameter version) instead of once per forward (the reference recomputes them, WC/msdeformattn.py:104-118;
+        # 7 launches / 55 us of a 1.3 ms forward at BASELINE config 3).  Nothing downstream writes into them.
+        lvl2d_p = self.transformer.level_embed_2d if spatial else None       # (the temporal-only decoder has no 2-D level embedding)
+        lvl3d_p = getattr(self.transformer, "level_embed_3d", None)
+        pkey = (str(dev), B, T, tuple(shapes), spatial) + tuple(v for p_ in (lvl2d_p, lvl3d_p) if p_ is not None for v in (p_.data_ptr(), p_._version))
+        cached = self._pos_cache if self._pos_cache is not None and self._pos_cache[0] == pkey else None
+        pos, pos_3d = (cached[1], cached[2]) if cached else (torch.empty(BT, S, Cd, dtype=torch.float32, device=dev) if spatial else None, [])
+        lvl2d = _dev_f32(lvl2d_p.detach(), "level_embed_2d") if spatial and not cached else None
         row0 = 0
         for idx, (f, x) in enumerate(zip(order, xs)):
             H, W = shapes[idx]
             _lib.check(L.axvs_conv1x1_gn_fwd(x.data_ptr(), 0, 0, 0, src.data_ptr() + row0 * Cd * 4, 1, S * Cd, Cd, pin[idx].data_ptr(), BT,
                                              H * W, x.shape[1], Cd, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
-            if spatial:
-                self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
-            if self.transformer_temporal_layers > 0 and f in self.transformer_temporal_in_features:
-                lvl3d = _dev_f32(self.transformer.level_embed_3d.detach(), "level_embed_3d")
-                pos_3d.append(self.pe_layer_3d.channels_last_with_level(B, T, H, W, lvl3d[len(pos_3d)]))
+            if not cached:
+                if spatial:
+                    self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
+                if self.transformer_temporal_layers > 0 and f in self.transformer_temporal_in_features:
+                    lvl3d = _dev_f32(lvl3d_p.detach(), "level_embed_3d")
+                    pos_3d.append(self.pe_layer_3d.channels_last_with_level(B, T, H, W, lvl3d[len(pos_3d)]))
             row0 += H * W
+        if not cached:
+            self._pos_cache = (pkey, pos, pos_3d)
         if spatial:
             y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, pos, None, pos_3d)
         else:                                                           # temporal-only decoder (WC/msdeformattn.py:152-170)

@@ -53,7 +53,7 @@ def layer_bytes(B, T, H, W, C, F, e=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--shape", default="1,4,256,64,64", help="B,T,C,H,W per rank")
@@ -398,6 +398,42 @@ def main():
                 extras["cc_cfg4"] = measure_cc()
             except RuntimeError as e:
                 extras["cc_cfg4"] = {"error": str(e)[:200]}
+
+        # ---- BASELINE config 3: the whole within-clip tracking module at ConvNeXt-T size, T = 4 (launch / latency bound: ms per forward) ----
+        if not args.no_extras and world == 1:
+            try:
+                class _Shape:
+                    def __init__(self, c, s_):
+                        self.channels, self.stride = c, s_
+                chans, sizes3 = {"res3": 192, "res4": 384, "res5": 768}, {"res3": (64, 64), "res4": (32, 32), "res5": (16, 16)}
+                wc = ax.WithinClipTrackingModule(
+                    {k: _Shape(c, st_) for (k, c), st_ in zip(chans.items(), (8, 16, 32))}, transformer_dropout=0.0, transformer_attn_drop=0.0,
+                    transformer_nheads=8, transformer_dim_feedforward=1024, transformer_num_stages=2, transformer_spatial_layers=2,
+                    transformer_temporal_layers=4, transformer_temporal_attn_type="axial-trajectory", transformer_conv_dims=256,
+                    transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
+                    num_clip_frames=4, cross_clip_training=True).eval()
+                sd3 = wc.within_clip_tracking_module.state_dict()
+                sd3.update(orc.random_weights({k: tuple(v.shape) for k, v in sd3.items() if v.dtype.is_floating_point}, 3))
+                wc.within_clip_tracking_module.load_state_dict(sd3, strict=True)
+                wc = wc.to(dev)
+                g3 = torch.Generator(device=dev).manual_seed(3)
+                feats3 = {k: torch.randn(4, chans[k], *sizes3[k], device=dev, generator=g3) for k in chans}
+                with torch.no_grad():
+                    for _ in range(5):
+                        wc.forward_features(dict(feats3))
+                    torch.cuda.synchronize(dev)
+                    n3 = 30
+                    t3 = time.perf_counter()
+                    for _ in range(n3):
+                        wc.forward_features(dict(feats3))
+                    torch.cuda.synchronize(dev)
+                el = (time.perf_counter() - t3) / n3
+                extras["wc_cfg3"] = {"ms_per_forward": round(el * 1e3, 3), "value": round(4 / el, 1), "unit": "frames/s",
+                                     "what": "BASELINE config 3: WithinClipTrackingModule.forward_features, res3/4/5 = [4,192,64,64] / [4,384,32,32] / "
+                                             "[4,768,16,16], 2 stages x (1 deformable spatial layer + 2 axial-trajectory layers on res5 and res4)"}
+                del wc, feats3
+            except RuntimeError as e:
+                extras["wc_cfg3"] = {"error": str(e)[:200]}
 
         # ---- one training step (forward + backward, dropout 0.1, recompute) of the same layer at the same size ----
         if not args.no_extras and world == 1:

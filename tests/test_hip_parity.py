@@ -310,7 +310,9 @@ def test_ragged_axis_lengths_take_the_fused_tier(shape):
     layer = layer.cuda()
     out, _, _ = layer(dev(src), dev(pos))
     names = _stage_names()
-    assert "h.traj_fused" in names and ("w.traj_fused+ffn" in names if T <= 4 else "w.traj_fused" in names), names
+    # the FFN rides in the width-pass kernel when that kernel has >= 128 row tiles (half the chip); below that it is its own launch
+    ffn_rides = T <= 4 and B * T * H * W >= 128 * 64
+    assert "h.traj_fused" in names and ("w.traj_fused+ffn" in names if ffn_rides else "w.traj_fused" in names), names
     assert not any("spatial_attn" in n for n in names), names
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
     print(f"{shape}: {names[1:]} max/max {e:.2e} relL2 {e2:.2e}")
@@ -957,3 +959,29 @@ def test_conv1x1_groupnorm_unit(N, HW, Cin, Cout):
     e2 = rel_err(nchw.cpu(), ref)
     print(f"conv1x1+GN N={N} HW={HW} {Cin}->{Cout}: {e1:.2e} {e2:.2e}")
     assert e1 < 2e-5 and e2 < 2e-5      # split-precision operands: fp32-grade projections
+
+
+def test_decoder_position_cache_follows_parameter_updates():
+    """The pixel decoder builds its position (+ level) embeddings once per (shapes, parameter version): an in-place update of a
+    level embedding (optimizer step, load_state_dict) must be seen by the next forward."""
+    from test_cabi_cpu import _decoder_from_meta
+    z, m = load("g8_pixel_decoder_T3_S1")
+    w = weights(z, m)
+    mod = _decoder_from_meta(m).eval()
+    mod.within_clip_tracking_module.load_state_dict(w, strict=True)
+    mod = mod.cuda()
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    feats = {k: torch.randn(m["B"] * m["T"], m["chans"][k], *m["sizes"][k], generator=g).cuda() for k in m["chans"]}
+    a = {k: v.clone() for k, v in mod.forward_features(dict(feats))[0].items()}
+    b = mod.forward_features(dict(feats))[0]
+    assert all(torch.equal(a[k], b[k]) for k in a)                       # cached embeddings: same results
+    tr = mod.within_clip_tracking_module.transformer
+    with torch.no_grad():
+        tr.level_embed_3d.add_(0.25)
+        tr.level_embed_2d.mul_(-1.0)
+    c = mod.forward_features(dict(feats))[0]
+    assert not any(torch.equal(a[k], c[k]) for k in a)
+    fresh = _decoder_from_meta(m).eval()
+    fresh.within_clip_tracking_module.load_state_dict(mod.within_clip_tracking_module.state_dict(), strict=True)
+    d = fresh.cuda().forward_features(dict(feats))[0]
+    assert all(torch.equal(c[k], d[k]) for k in c)
