@@ -18,12 +18,15 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   cfg5_share  BASELINE config 5's per-GPU share [8,4,256,96,96] (batch-sharded layer), frames/s over all ranks
                   offaxis_one_clip  (N > 1) ONE clip sharded over the ranks with an all-to-all between the passes ("strong" scaling)
                   cc_cfg4     BASELINE config 4: CrossClipTrackingModule forward, us per forward and output GB/s (N = 1)
+                  wc_cfg3     BASELINE config 3: the whole within-clip tracking module at ConvNeXt-T size, ms per forward (N = 1)
+                  train_step  forward + backward of the layer through the fp32 training tier, ms per step (N = 1)
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
 import json
+import math
 import os
 import statistics
 import sys
@@ -116,8 +119,27 @@ def main():
         dist.barrier()
     import axial_vs_amd as ax
     from axial_vs_amd import _lib
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import axvs_oracle as orc
+
+    def random_weights(shapes, seed):
+        """Random-init weights of the benchmarked modules (no checkpoints here): xavier-uniform matrices, small uniform biases,
+        norm gains around 1, BatchNorm variances around 1.  Deterministic in (shapes, seed).  (Own generator: the oracle under
+        oracle/ is imported by the cpu_baseline leg only.)"""
+        g = torch.Generator().manual_seed(seed)
+        out = {}
+        for name, shp in shapes.items():
+            if len(shp) >= 2:
+                rf = 1
+                for d_ in shp[2:]:
+                    rf *= d_
+                bound = math.sqrt(6.0 / ((shp[0] + shp[1]) * rf))
+                out[name] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+            elif name.endswith("running_var"):
+                out[name] = torch.rand(shp, generator=g) * 0.5 + 0.75
+            elif "norm" in name and name.endswith("weight"):
+                out[name] = 1.0 + (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+            else:
+                out[name] = (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+        return out
     L = _lib.lib()
     for kv in args.opt:
         k, v = kv.split("=")
@@ -154,8 +176,8 @@ def main():
         """Synthetic workload (SURVEY.md 8d recipe); every rank gets its own clips.  `pos` as the reference's callers make it
         (WC/msdeformattn.py:108-115): PositionEmbeddingSine3D on the device -- the tensor carries its specification, so the layer
         evaluates the embedding in the q/k loaders instead of reading it; --tensor-pos passes an untagged copy."""
-        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 0)
         layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=heads, mfma_dtype=args.dtype).eval()
+        w = random_weights({k: tuple(v.shape) for k, v in layer.state_dict().items()}, 0)
         layer.load_state_dict(w, strict=True)
         layer = layer.to(dev)
         g = torch.Generator(device=dev).manual_seed(seed)
@@ -171,7 +193,7 @@ def main():
         cc = ax.CrossClipTrackingModule(num_layers=layers_cc, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
                                         atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V, mfma_dtype=args.dtype).eval()
         sd = cc.state_dict()
-        sd.update(orc.random_weights({k: tuple(v.shape) for k, v in sd.items() if v.dtype.is_floating_point}, 4))
+        sd.update(random_weights({k: tuple(v.shape) for k, v in sd.items() if v.dtype.is_floating_point}, 4))
         cc.load_state_dict(sd, strict=True)
         cc = cc.to(dev)
         cc.eval_outputs_on_cpu = False          # time the device path (the reference's eval branch copies to the host afterwards)
@@ -413,7 +435,7 @@ def main():
                     transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
                     num_clip_frames=4, cross_clip_training=True).eval()
                 sd3 = wc.within_clip_tracking_module.state_dict()
-                sd3.update(orc.random_weights({k: tuple(v.shape) for k, v in sd3.items() if v.dtype.is_floating_point}, 3))
+                sd3.update(random_weights({k: tuple(v.shape) for k, v in sd3.items() if v.dtype.is_floating_point}, 3))
                 wc.within_clip_tracking_module.load_state_dict(sd3, strict=True)
                 wc = wc.to(dev)
                 g3 = torch.Generator(device=dev).manual_seed(3)
@@ -467,6 +489,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would just wait)
             ncpu = os.cpu_count() or 1
             src_cpu, pos_cpu = src.cpu(), pos.cpu()
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import axvs_oracle as orc          # the CPU restatement of the reference: the baseline being timed, nothing else
             fwd = lambda: orc.axial_layer(src_cpu, pos_cpu, w, heads, want_attn=False)
             with torch.no_grad():
                 # torch's CPU kernels stop scaling (and thrash) far below a big host's core count: probe a few
