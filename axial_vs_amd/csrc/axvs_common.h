@@ -55,9 +55,16 @@ __device__ __forceinline__ float dot8_acc(f32x4 a_lo, f32x4 a_hi, u16x8 x, float
     acc = __builtin_amdgcn_fdot2(a2, xs.v[2], acc, false);
     acc = __builtin_amdgcn_fdot2(a3, xs.v[3], acc, false);
     return acc;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc += a_lo[i] * H16<BF>::to_f32(x[i]) + a_hi[i] * H16<BF>::to_f32(x[4 + i]);
+  } else {     // v_dot2c_f32_bf16 (gfx950): the multiplier is rounded to bf16 like the f16 path rounds it to f16
+    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+    struct B2x4 { b16x2 v[4]; };
+    const B2x4 xs = __builtin_bit_cast(B2x4, x);
+    const b16x2 a0 = {(__bf16)a_lo[0], (__bf16)a_lo[1]}, a1 = {(__bf16)a_lo[2], (__bf16)a_lo[3]};
+    const b16x2 a2 = {(__bf16)a_hi[0], (__bf16)a_hi[1]}, a3 = {(__bf16)a_hi[2], (__bf16)a_hi[3]};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(a0, xs.v[0], acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(a1, xs.v[1], acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(a2, xs.v[2], acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(a3, xs.v[3], acc, false);
     return acc;
   }
 }
