@@ -169,3 +169,30 @@ def test_unsupported_training_shapes_fail_loudly():
     src, pos = orc.synthetic_clip(1, 2, 512, 4, 4, 1)
     with pytest.raises(RuntimeError, match="head_dim"):
         layer(src.cuda(), pos.cuda())
+
+
+def test_training_random_shapes_sweep():
+    """Seeded sweep over small shapes (head_dim 8 / 16 / 32, T = 1 .. 6, ragged axes, several dropout settings): output and all
+    gradients against autograd on the float64 oracle."""
+    import random
+    rng = random.Random(77)
+    worst = 0.0
+    for i in range(8):
+        C = rng.choice([64, 128, 256])
+        T, H, W, B = rng.randint(1, 6), rng.randint(1, 12), rng.randint(1, 12), rng.randint(1, 2)
+        F = rng.choice([64, 128, 256])
+        p_drop, p_attn = rng.choice([0.0, 0.1, 0.3]), rng.choice([0.0, 0.2])
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 900 + i)
+        src, pos = orc.synthetic_clip(B, T, C, H, W, 900 + i)
+        d_out = torch.randn(B * T, H * W, C, generator=torch.Generator().manual_seed(i))
+        wd = {k: v.double().requires_grad_(True) for k, v in w.items()}
+        sd, pd = src.double().requires_grad_(True), pos.double().requires_grad_(True)
+        ref = orc.axial_layer_train(sd, pd, wd, 8, p_drop, p_attn, 5000 + i)
+        ref.backward(d_out.double())
+        out, d_src, d_pos, grads = run(make_layer(C, F, w, p_drop, p_attn, 5000 + i), src, pos, d_out)
+        scale = max(float(v.grad.norm()) for v in wd.values())
+        errs = [rel_err(out, ref.detach()), rel_err(d_src, sd.grad), rel_err(d_pos, pd.grad)] + \
+               [float((grads[k].double() - wd[k].grad).norm() / max(float(wd[k].grad.norm()), 1e-3 * scale)) for k in wd]
+        worst = max(worst, max(errs))
+        assert max(errs) < TOL, (B, T, C, H, W, F, p_drop, p_attn, max(errs))
+    print(f"8 random training shapes: worst error {worst:.2e}")
