@@ -890,6 +890,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_gelu")) { g_ffn_gelu = value; return AXVS_OK; }
+  if (key && !strcmp(key, "train_valu")) { g_train_valu = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }

@@ -13,6 +13,10 @@
 namespace axvs {
 
 inline thread_local char g_err[512] = "";
+// axvs_set_option("train_valu", 1): keep the spatial attention of the training tier on the fp32 VALU kernels (the head_dim 8 / 16
+// path) instead of the fp32 MFMA ones -- A/B comparisons and tests of both.  Process-wide, not per thread: autograd runs the
+// backward call on its own thread and forward / backward must agree on the kernel family (the statistics travel between them).
+inline int g_train_valu = 0;
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

@@ -127,6 +127,294 @@ __global__ __launch_bounds__(256) void tr_spatial_fwd_kernel(const float* __rest
   }
 }
 
+// ---- the same forward on the matrix cores, head_dim 32: v_mfma_f32_16x16x4_f32 (fp32 operands: the tier stays fp32) ----
+// One workgroup per (sequence, head), K_f / V_f of the frame in LDS (row stride 36 floats), 4 waves that each take 16-query tiles.
+// Per (query tile, 16-key tile): S^T = K Q^T as 8 MFMAs (lane (j, g) supplies d = 8 g + t at step t for key / query j: the
+// contraction order over d is free), flash-style running max / sum per query (the 4 lane groups of a query reduce with two
+// xor-shuffles), then X^T += V^T P^T as 4 x 2 MFMAs where step r contracts keys {4 g + r}: exactly the keys lane group g holds in
+// register r of the score tile, so probabilities feed the B operand without leaving their registers.
+constexpr int kTrLd = 36;   // LDS row stride (floats) of the staged K / V rows
+
+__device__ __forceinline__ float xor_max16_32(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xor_sum16_32(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// rows of frame f of (sequence s, head h) -> LDS [ceil16(L)][kTrLd], rows past L zero
+__device__ __forceinline__ void stage_frame36(float* dst, const float* src, const RowMap& rm, int s, int f, int h, int C, int tid) {
+  const int Lp = (rm.L + 15) & ~15;
+  for (int i = tid; i < Lp * 8; i += 256) {
+    const int n = i >> 3, c4 = i & 7;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < rm.L) v = *reinterpret_cast<const float4*>(src + nat_row(rm, s * rm.N + f * rm.L + n) * C + h * 32 + c4 * 4);
+    *reinterpret_cast<float4*>(dst + n * kTrLd + c4 * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_spatial_fwd_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, float* __restrict__ x,
+                                                                   float* __restrict__ stats /* [(s heads + h), N, T, 3]: max, 1 / sum, - */,
+                                                                   RowMap rm, int T, int C, int heads, float scale, Drop dr) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  const int Lp = (L + 15) & ~15, nkt = Lp >> 4, nqt = (N + 15) >> 4;
+  float* ks = smem;
+  float* vs = smem + Lp * kTrLd;
+  for (int f = 0; f < T; ++f) {
+    __syncthreads();
+    stage_frame36(ks, k, rm, s, f, h, C, tid);
+    stage_frame36(vs, v, rm, s, f, h, C, tid);
+    __syncthreads();
+    for (int qt = wave; qt < nqt; qt += 4) {
+      const int qn = qt * 16 + j;
+      const long long mq = nat_row(rm, s * N + min(qn, N - 1));
+      float qr[8];
+      {
+        const float4 a = *reinterpret_cast<const float4*>(q + mq * C + h * 32 + 8 * g), b = *reinterpret_cast<const float4*>(q + mq * C + h * 32 + 8 * g + 4);
+        qr[0] = a.x * scale; qr[1] = a.y * scale; qr[2] = a.z * scale; qr[3] = a.w * scale;
+        qr[4] = b.x * scale; qr[5] = b.y * scale; qr[6] = b.z * scale; qr[7] = b.w * scale;
+      }
+      float m = -INFINITY, sum = 0.f;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const unsigned long long base = ((((unsigned long long)s * heads + h) * N + min(qn, N - 1)) * T + f) * L;
+      for (int kt = 0; kt < nkt; ++kt) {
+        const float* kp = ks + (kt * 16 + j) * kTrLd + 8 * g;
+        const float4 ka = *reinterpret_cast<const float4*>(kp), kb = *reinterpret_cast<const float4*>(kp + 4);
+        const float kr[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[t], qr[t], sc, 0, 0, 0);
+        const int n0 = kt * 16 + 4 * g;             // my 4 keys: n0 .. n0 + 3
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n0 + r >= L) sc[r] = -INFINITY;
+          tmax = fmaxf(tmax, sc[r]);
+        }
+        const float mn = fmaxf(m, xor_max16_32(tmax));
+        const float alpha = __expf(m - mn);
+        float p[4], ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = __expf(sc[r] - mn);
+          ps += p[r];
+          if (n0 + r < L) p[r] *= drop_keep(dr, base + n0 + r);
+        }
+        sum = sum * alpha + xor_sum16_32(ps);
+        m = mn;
+        acc[0] *= alpha;
+        acc[1] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vp = vs + (n0 + r) * kTrLd + j;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[0], p[r], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[16], p[r], acc[1], 0, 0, 0);
+        }
+      }
+      if (qn < N) {
+        const float inv = 1.f / sum;
+        float* xo = x + (mq * T + f) * C + h * 32 + 4 * g;        // lane (query j, group g): channels dt * 16 + 4 g + r
+        *reinterpret_cast<float4*>(xo) = float4{acc[0][0] * inv, acc[0][1] * inv, acc[0][2] * inv, acc[0][3] * inv};
+        *reinterpret_cast<float4*>(xo + 16) = float4{acc[1][0] * inv, acc[1][1] * inv, acc[1][2] * inv, acc[1][3] * inv};
+        if (g == 0) {                                 // softmax statistics of (query, frame): the backward kernels rebuild P from them
+          float* st = stats + ((((size_t)s * heads + h) * N + qn) * T + f) * 3;
+          st[0] = m;
+          st[1] = inv;
+        }
+      }
+    }
+  }
+}
+
+// ---- backward on the matrix cores, part 1 (queries): D = dx . x (= sum_n P keep dP, the flash-attention identity), then per
+//      16-key tile  S^T = K Q^T,  dP^T = V dX^T  (8 + 8 MFMAs),  dS = P (keep dP - D) with P rebuilt from the forward's (max, 1/sum),
+//      dq^T += K^T dS^T (4 x 2 MFMAs, keys {4 g + r} per step as in the forward).  dq accumulates over the frames in global memory
+//      (first frame writes).  Writes D into stats[.., 2] for part 2.
+__global__ __launch_bounds__(256) void tr_spatial_bwd_q_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                     const float* __restrict__ v, const float* __restrict__ x,
+                                                                     const float* __restrict__ dx, float* __restrict__ dq,
+                                                                     float* __restrict__ stats, RowMap rm, int T, int C, int heads, float scale,
+                                                                     Drop dr) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  const int Lp = (L + 15) & ~15, nkt = Lp >> 4, nqt = (N + 15) >> 4;
+  float* ks = smem;
+  float* vs = smem + Lp * kTrLd;
+  for (int f = 0; f < T; ++f) {
+    __syncthreads();
+    stage_frame36(ks, k, rm, s, f, h, C, tid);
+    stage_frame36(vs, v, rm, s, f, h, C, tid);
+    __syncthreads();
+    for (int qt = wave; qt < nqt; qt += 4) {
+      const int qn = qt * 16 + j, qc = min(qn, N - 1);
+      const long long mq = nat_row(rm, s * N + qc);
+      float qr[8], dxr[8];
+      float dsum;
+      {
+        const float* qp = q + mq * C + h * 32 + 8 * g;
+        const float* gp = dx + (mq * T + f) * C + h * 32 + 8 * g;
+        const float* xp = x + (mq * T + f) * C + h * 32 + 8 * g;
+        const float4 a = *reinterpret_cast<const float4*>(qp), b = *reinterpret_cast<const float4*>(qp + 4);
+        const float4 c = *reinterpret_cast<const float4*>(gp), d = *reinterpret_cast<const float4*>(gp + 4);
+        const float4 e = *reinterpret_cast<const float4*>(xp), e2 = *reinterpret_cast<const float4*>(xp + 4);
+        qr[0] = a.x * scale; qr[1] = a.y * scale; qr[2] = a.z * scale; qr[3] = a.w * scale;
+        qr[4] = b.x * scale; qr[5] = b.y * scale; qr[6] = b.z * scale; qr[7] = b.w * scale;
+        dxr[0] = c.x; dxr[1] = c.y; dxr[2] = c.z; dxr[3] = c.w; dxr[4] = d.x; dxr[5] = d.y; dxr[6] = d.z; dxr[7] = d.w;
+        dsum = xor_sum16_32(c.x * e.x + c.y * e.y + c.z * e.z + c.w * e.w + d.x * e2.x + d.y * e2.y + d.z * e2.z + d.w * e2.w);
+      }
+      float* st = stats + ((((size_t)s * heads + h) * N + qc) * T + f) * 3;
+      const float m = st[0], inv = st[1];
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      const unsigned long long base = ((((unsigned long long)s * heads + h) * N + qc) * T + f) * L;
+      for (int kt = 0; kt < nkt; ++kt) {
+        const float* kp = ks + (kt * 16 + j) * kTrLd + 8 * g;
+        const float* vp = vs + (kt * 16 + j) * kTrLd + 8 * g;
+        const float4 ka = *reinterpret_cast<const float4*>(kp), kb = *reinterpret_cast<const float4*>(kp + 4);
+        const float4 va = *reinterpret_cast<const float4*>(vp), vb = *reinterpret_cast<const float4*>(vp + 4);
+        const float kr[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+        const float vr[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          sc = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[t], qr[t], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[t], dxr[t], dp, 0, 0, 0);
+        }
+        const int n0 = kt * 16 + 4 * g;
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = n0 + r < L;
+          const float P = valid ? __expf(sc[r] - m) * inv : 0.f;
+          const float kp_ = valid ? drop_keep(dr, base + n0 + r) : 0.f;
+          ds[r] = P * (kp_ * dp[r] - dsum);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* kt_ = ks + (n0 + r) * kTrLd + j;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt_[0], ds[r], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt_[16], ds[r], acc[1], 0, 0, 0);
+        }
+      }
+      if (qn < N) {
+        float* o = dq + mq * C + h * 32 + 4 * g;
+        float4 o0 = float4{acc[0][0] * scale, acc[0][1] * scale, acc[0][2] * scale, acc[0][3] * scale};
+        float4 o1 = float4{acc[1][0] * scale, acc[1][1] * scale, acc[1][2] * scale, acc[1][3] * scale};
+        if (f > 0) {
+          const float4 p0 = *reinterpret_cast<const float4*>(o), p1 = *reinterpret_cast<const float4*>(o + 16);
+          o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+          o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        }
+        *reinterpret_cast<float4*>(o) = o0;
+        *reinterpret_cast<float4*>(o + 16) = o1;
+        if (g == 0) st[2] = dsum;
+      }
+    }
+  }
+}
+
+// ---- backward on the matrix cores, part 2 (keys): per frame the queries' scaled q, dx and statistics sit in LDS; a wave owns a
+//      16-key tile and walks all query tiles:  S = Q K^T, dP = dX V^T (queries on the D rows: lane (key j, group g) holds queries
+//      4 g + r),  dv^T += dX^T (P keep),  dk^T += (scale Q)^T dS  (4 x 2 MFMAs each, queries {4 g + r} per step).
+__global__ __launch_bounds__(256) void tr_spatial_bwd_kv_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                      const float* __restrict__ v, const float* __restrict__ dx,
+                                                                      const float* __restrict__ stats, float* __restrict__ dk,
+                                                                      float* __restrict__ dv, RowMap rm, int T, int C, int heads, float scale,
+                                                                      Drop dr) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  const int Np = (N + 15) & ~15, nqt = Np >> 4, nkt = (L + 15) >> 4;
+  float* qs = smem;                      // [Np][kTrLd] scale * q
+  float* gs = qs + Np * kTrLd;           // [Np][kTrLd] dx of the frame
+  float* ss = gs + Np * kTrLd;           // [Np][4]     max, 1/sum, D of (query, frame)
+  for (int i = tid; i < Np * 8; i += 256) {            // scaled q once
+    const int n = i >> 3, c4 = i & 7;
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+      t = *reinterpret_cast<const float4*>(q + nat_row(rm, s * N + n) * C + h * 32 + c4 * 4);
+      t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+    }
+    *reinterpret_cast<float4*>(qs + n * kTrLd + c4 * 4) = t;
+  }
+  for (int f = 0; f < T; ++f) {
+    __syncthreads();
+    for (int i = tid; i < Np * 8; i += 256) {
+      const int n = i >> 3, c4 = i & 7;
+      float4 t = {0.f, 0.f, 0.f, 0.f};
+      if (n < N) t = *reinterpret_cast<const float4*>(dx + (nat_row(rm, s * N + n) * T + f) * C + h * 32 + c4 * 4);
+      *reinterpret_cast<float4*>(gs + n * kTrLd + c4 * 4) = t;
+    }
+    for (int n = tid; n < Np; n += 256) {
+      const float* st = stats + ((((size_t)s * heads + h) * N + min(n, N - 1)) * T + f) * 3;
+      // padding queries: 1/sum = 0 makes their probabilities vanish
+      *reinterpret_cast<float4*>(ss + n * 4) = float4{st[0], n < N ? st[1] : 0.f, st[2], 0.f};
+    }
+    __syncthreads();
+    for (int kt = wave; kt < nkt; kt += 4) {
+      const int kn = kt * 16 + j, kc = min(kn, L - 1);                  // key index within the frame
+      const long long mk = nat_row(rm, s * N + f * L + kc);
+      float kr[8], vr[8];
+      {
+        const float* kp = k + mk * C + h * 32 + 8 * g;
+        const float* vp = v + mk * C + h * 32 + 8 * g;
+        const float4 a = *reinterpret_cast<const float4*>(kp), b = *reinterpret_cast<const float4*>(kp + 4);
+        const float4 c = *reinterpret_cast<const float4*>(vp), d = *reinterpret_cast<const float4*>(vp + 4);
+        kr[0] = a.x; kr[1] = a.y; kr[2] = a.z; kr[3] = a.w; kr[4] = b.x; kr[5] = b.y; kr[6] = b.z; kr[7] = b.w;
+        vr[0] = c.x; vr[1] = c.y; vr[2] = c.z; vr[3] = c.w; vr[4] = d.x; vr[5] = d.y; vr[6] = d.z; vr[7] = d.w;
+      }
+      f32x4 dka[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dva[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      for (int qt = 0; qt < nqt; ++qt) {
+        const float* qp = qs + (qt * 16 + j) * kTrLd + 8 * g;
+        const float* gp = gs + (qt * 16 + j) * kTrLd + 8 * g;
+        const float4 qa = *reinterpret_cast<const float4*>(qp), qb = *reinterpret_cast<const float4*>(qp + 4);
+        const float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
+        const float qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        const float gr[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {                 // D[i = query 4 g' + r][j = key]: A = query rows, B = key rows
+          sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[t], kr[t], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[t], vr[t], dp, 0, 0, 0);
+        }
+        const int q0 = qt * 16 + 4 * g;               // my 4 queries: q0 .. q0 + 3
+        float pk[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float4 st = *reinterpret_cast<const float4*>(ss + (q0 + r) * 4);
+          const float P = __expf(sc[r] - st.x) * st.y;
+          const float kp_ = (q0 + r < N && kn < L)
+                                ? drop_keep(dr, ((((unsigned long long)s * heads + h) * N + q0 + r) * T + f) * L + kn) : 0.f;
+          pk[r] = P * kp_;
+          ds[r] = P * (kp_ * dp[r] - st.z);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* gq = gs + (q0 + r) * kTrLd + j;      // A: dx^T (resp. q^T) of query q0 + r, channels j and 16 + j
+          const float* qq = qs + (q0 + r) * kTrLd + j;
+          dva[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[0], pk[r], dva[0], 0, 0, 0);
+          dva[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[16], pk[r], dva[1], 0, 0, 0);
+          dka[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[0], ds[r], dka[0], 0, 0, 0);
+          dka[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[16], ds[r], dka[1], 0, 0, 0);
+        }
+      }
+      if (kn < L) {                                    // lane (key j, group g): channels dt * 16 + 4 g + r
+        float* ok = dk + mk * C + h * 32 + 4 * g;
+        float* ov = dv + mk * C + h * 32 + 4 * g;
+        *reinterpret_cast<float4*>(ok) = float4{dka[0][0], dka[0][1], dka[0][2], dka[0][3]};
+        *reinterpret_cast<float4*>(ok + 16) = float4{dka[1][0], dka[1][1], dka[1][2], dka[1][3]};
+        *reinterpret_cast<float4*>(ov) = float4{dva[0][0], dva[0][1], dva[0][2], dva[0][3]};
+        *reinterpret_cast<float4*>(ov + 16) = float4{dva[1][0], dva[1][1], dva[1][2], dva[1][3]};
+      }
+    }
+  }
+}
+
 // ---- spatial half, backward, part 1 (one thread per query): the softmax statistics (max, 1/sum, D = sum_n P dP) of every
 //      (query, frame) and dq.  dP_n = keep_n (dx_f . v_n),  dS_n = P_n (dP_n - D),  dq = scale sum_{f,n} dS_n k_n.
 //      stats: [(s heads + h), N, T, 3].

@@ -14,6 +14,7 @@ using namespace tr;
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+
 struct Bump {   // bump allocator over a caller-owned buffer (nullptr: size only)
   char* base;
   size_t off = 0;
@@ -129,6 +130,7 @@ int make_dims(Dims& d, int B, int T, int H, int W, int C, int heads, int F) {
 
 struct PassSaved {
   float *q, *k, *v, *x, *xd, *q2, *kv2, *o;
+  float* st;   // softmax statistics of the spatial half [(s heads + h), N, T, 3]: max, 1 / sum (forward), D (backward part 1)
 };
 struct Saved {
   PassSaved p[2];
@@ -148,6 +150,7 @@ Saved carve_saved(Bump& b, const Dims& d) {
     p.q2 = b.f(MC);
     p.kv2 = b.f(MC * d.T * 2);
     p.o = b.f(MC);
+    p.st = b.f((size_t)d.M * d.heads * d.T * 3);
   }
   s.buf1 = b.f(MC);
   s.buf2 = b.f(MC);
@@ -164,7 +167,7 @@ Saved carve_saved(Bump& b, const Dims& d) {
 constexpr int kColsumBlocks = 512;
 
 struct Scratch {
-  float *a, *t0, *d_o, *dq2, *dkv2, *dx, *dxd, *dq, *dk, *dv, *da, *stats, *g0, *g1, *dr, *part_a, *part_b, *wpart, *wt;
+  float *a, *t0, *d_o, *dq2, *dkv2, *dx, *dxd, *dq, *dk, *dv, *da, *g0, *g1, *dr, *part_a, *part_b, *wpart, *wt;
 };
 
 Scratch carve_scratch(Bump& b, const Dims& d, bool backward) {
@@ -182,7 +185,6 @@ Scratch carve_scratch(Bump& b, const Dims& d, bool backward) {
   s.dk = b.f(MC);
   s.dv = b.f(MC);
   s.da = b.f(MC);
-  s.stats = b.f((size_t)d.M * d.heads * d.T * 3);
   s.g0 = b.f(MC);
   s.g1 = b.f(MC);
   s.dr = b.f((size_t)d.M * d.F);
@@ -253,6 +255,14 @@ struct Ctx {
   int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn, (int)bytes) : AXVS_OK; }
 };
 
+// The spatial half runs on the fp32 MFMA kernels (forward and both backward parts, or none of them: the backward reads the
+// statistics the forward leaves) when head_dim is 32 and a sequence's scaled q + dx rows fit in LDS.
+bool mfma_spatial(const Dims& d, const RowMap& rm) {
+  const size_t lds_q = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
+  const size_t lds_kv = (size_t)((rm.N + 15) / 16 * 16) * (2 * kTrLd + 4) * sizeof(float);
+  return d.D == 32 && !g_train_valu && lds_q <= 160 * 1024 && lds_kv <= 160 * 1024;
+}
+
 // one axial pass, forward: xout = xin + dropout1(TrajectoryAttention(q = k = xin + pos, v = xin))   WC/temporal_attention.py:35-76
 int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, const AxvsTrajParams& w, const PassSaved& s, RowMap rm, int S,
              Drop attn_drop, Drop drop1) {
@@ -269,6 +279,12 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C)) != AXVS_OK) return rc;
   c.bias_act(s.v, w.v_b, M, C, 1.f, 0, none);
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
+  const size_t lds_mfma = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
+  if (mfma_spatial(d, rm)) {                                            // head_dim 32 (every shipped config): fp32 MFMA kernels
+    if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_fwd_mfma_kernel), lds_mfma)) != AXVS_OK) return rc;
+    hipLaunchKernelGGL(tr_spatial_fwd_mfma_kernel, dim3(S * d.heads), dim3(256), lds_mfma, c.st, (const float*)s.q, (const float*)s.k,
+                       (const float*)s.v, s.x, s.st, rm, d.T, C, d.heads, c.scale, attn_drop);
+  } else
   AXVS_D_SWITCH(d.D, {
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_fwd_kernel<kD>), lds)) != AXVS_OK) return rc;
     hipLaunchKernelGGL(tr_spatial_fwd_kernel<kD>, dim3(S * d.heads), dim3(256), lds, c.st, (const float*)s.q, (const float*)s.k,
@@ -321,12 +337,22 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
   constexpr int QC = 32;
   const size_t lds2 = (size_t)(QC * d.D + QC * T * d.D + QC * T * 3) * sizeof(float);
+  const size_t lds_q = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
+  const size_t lds_kv = (size_t)((rm.N + 15) / 16 * 16) * (2 * kTrLd + 4) * sizeof(float);
+  if (mfma_spatial(d, rm)) {       // the forward was the MFMA kernel too: (max, 1 / sum) are in s.st
+    if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_q_mfma_kernel), lds_q)) != AXVS_OK) return rc;
+    if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_kv_mfma_kernel), lds_kv)) != AXVS_OK) return rc;
+    hipLaunchKernelGGL(tr_spatial_bwd_q_mfma_kernel, dim3(S * d.heads), dim3(256), lds_q, c.st, (const float*)s.q, (const float*)s.k,
+                       (const float*)s.v, (const float*)s.x, (const float*)sc.dx, sc.dq, s.st, rm, T, C, d.heads, c.scale, attn_drop);
+    hipLaunchKernelGGL(tr_spatial_bwd_kv_mfma_kernel, dim3(S * d.heads), dim3(256), lds_kv, c.st, (const float*)s.q, (const float*)s.k,
+                       (const float*)s.v, (const float*)sc.dx, (const float*)s.st, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop);
+  } else
   AXVS_D_SWITCH(d.D, {
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_q_kernel<kD>), lds)) != AXVS_OK) return rc;
     hipLaunchKernelGGL(tr_spatial_bwd_q_kernel<kD>, dim3(S * d.heads), dim3(256), lds, c.st, (const float*)s.q, (const float*)s.k,
-                       (const float*)s.v, (const float*)sc.dx, sc.dq, sc.stats, rm, T, C, d.heads, c.scale, attn_drop);
+                       (const float*)s.v, (const float*)sc.dx, sc.dq, s.st, rm, T, C, d.heads, c.scale, attn_drop);
     hipLaunchKernelGGL(tr_spatial_bwd_kv_kernel<kD>, dim3(S * d.heads), dim3(256), lds2, c.st, (const float*)s.q, (const float*)s.k,
-                       (const float*)s.v, (const float*)sc.dx, (const float*)sc.stats, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop, QC);
+                       (const float*)s.v, (const float*)sc.dx, (const float*)s.st, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop, QC);
   })
   // q / k / v projections
   c.add(xin, pos, sc.a, MC);

@@ -55,11 +55,16 @@ def test_training_tier_against_reference_autograd(name, recompute):
         assert p.grad.shape == p.shape and p.grad.dtype == p.dtype
 
 
+@pytest.mark.parametrize("valu", [0, 1])
 @pytest.mark.parametrize("shape,p_drop,p_attn", [((1, 4, 256, 32, 32, 1024), 0.1, 0.1), ((2, 5, 128, 7, 9, 256), 0.2, 0.0),
-                                                 ((1, 3, 256, 25, 43, 512), 0.0, 0.0)])
-def test_training_tier_vs_float64_oracle_autograd(shape, p_drop, p_attn):
+                                                 ((1, 3, 256, 25, 43, 512), 0.0, 0.0), ((2, 2, 256, 16, 5, 256), 0.3, 0.1)])
+def test_training_tier_vs_float64_oracle_autograd(shape, p_drop, p_attn, valu, request):
     """Sizes the fixtures do not hold (BASELINE channel counts, ragged axis lengths): gradients against torch.autograd on the
-    float64 oracle with the same hash-generated dropout factors."""
+    float64 oracle with the same hash-generated dropout factors.  head_dim 32 runs the spatial half on the fp32 MFMA kernels;
+    `train_valu` = 1 keeps it on the VALU kernels (the head_dim 8 / 16 path): both are checked."""
+    from axial_vs_amd import _lib
+    _lib.check(_lib.lib().axvs_set_option(b"train_valu", valu), "axvs_set_option")
+    request.addfinalizer(lambda: _lib.lib().axvs_set_option(b"train_valu", 0))
     B, T, C, H, W, F = shape
     w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 51)
     src, pos = orc.synthetic_clip(B, T, C, H, W, 51)
@@ -70,6 +75,7 @@ def test_training_tier_vs_float64_oracle_autograd(shape, p_drop, p_attn):
     ref = orc.axial_layer_train(sd, pd, wd, 8, p_drop, p_attn, seed)
     ref.backward(d_out.double())
     layer = make_layer(C, F, w, p_drop, p_attn, seed)
+    layer.recompute = bool(valu)        # (and the kept-activations mode on the MFMA kernels, recompute on the VALU ones)
     out, d_src, d_pos, grads = run(layer, src, pos, d_out)
     e = dict(out=rel_err(out, ref.detach()), d_src=rel_err(d_src, sd.grad), d_pos=rel_err(d_pos, pd.grad),
              out_l2=rel_l2(out, ref.detach()), d_src_l2=rel_l2(d_src, sd.grad))
