@@ -739,17 +739,26 @@ __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict_
   }
 }
 
-// stage 2 (also the reduction of split-K weight-gradient partials): out[c] = sum_i part[i][c]; 64 columns x 4 partial groups / block
+// stage 2 (also the reduction of split-K weight-gradient partials): out[c] = sum_i part[i][c].  A block = 64 float4 columns x 4
+// partial groups (1 KiB contiguous per wave and partial row), joined through LDS in a fixed order; C % 4 == 0.
 __global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, size_t C, float* __restrict__ out) {
-  __shared__ float red[256];
-  const size_t c = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  __shared__ float4 red[256];
+  const size_t c4 = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), n4 = C / 4;
   const int g = threadIdx.x >> 6;
-  float a = 0.f;
-  if (c < C)
-    for (int i = g; i < nblk; i += 4) a += part[(size_t)i * C + c];
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < n4) {
+#pragma unroll 4
+    for (int i = g; i < nblk; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)i * C + c4 * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
   red[threadIdx.x] = a;
   __syncthreads();
-  if (g == 0 && c < C) out[c] = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+  if (g == 0 && c4 < n4) {
+    const float4 b = red[threadIdx.x + 64], c = red[threadIdx.x + 128], d = red[threadIdx.x + 192];
+    *reinterpret_cast<float4*>(out + c4 * 4) = float4{a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w};
+  }
 }
 
 // Wt[K][N] = W[N][K]^T (32 x 32 tiles through LDS): the input-gradient GEMMs then run in the same (fast) form as the forward ones

@@ -235,8 +235,8 @@ struct Ctx {
     if (rpb < 64) rpb = 64;
     const int nblk = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(tr_colsum_kernel, dim3(nblk), dim3(256), 0, st, dy, x, mean, rstd, sc.part_a, sc.part_b, rows, N, (int)rpb);
-    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 64)), dim3(256), 0, st, (const float*)sc.part_a, nblk, (size_t)N, out_a);
-    if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 64)), dim3(256), 0, st, (const float*)sc.part_b, nblk, (size_t)N, out_b);
+    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_a, nblk, (size_t)N, out_a);
+    if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_b, nblk, (size_t)N, out_b);
   }
   // dW[N,K] = dY[M,N]^T X[M,K]
   int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K) const {
@@ -244,7 +244,7 @@ struct Ctx {
     int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np);
     if (rc != AXVS_OK) return rc;
     const size_t n = (size_t)N * K;
-    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 64)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
+    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
     return AXVS_OK;
   }
   // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
