@@ -153,9 +153,16 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(step, steps, warmup):
-        """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over ranks (s)."""
+    def timed(step, steps, warmup, settle_ms=0.0):
+        """[`settle_ms` of untimed steady running -- the secondary measurements start after host-side set-up gaps in which the GPU
+        clocks drop --,] `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over
+        ranks (s)."""
         out = None
+        t_set = time.perf_counter()
+        while (time.perf_counter() - t_set) * 1e3 < settle_ms:
+            for _ in range(5):
+                out = step()
+            torch.cuda.synchronize(dev)
         for _ in range(max(warmup, 1)):
             out = step()
         torch.cuda.synchronize(dev)
@@ -325,7 +332,7 @@ def main():
                     s2 = torch.randn(2 * 4, 64 * 64, 256, device=dev, generator=g2)
                     p2 = ax.PositionEmbeddingSine3D(128, normalize=True).channels_last(2, 4, 64, 64, dev)
                     st2 = max(20, min(args.steps // 2, 200))
-                    el2, o2 = timed(lambda: l2(s2, p2)[0], st2, 5)
+                    el2, o2 = timed(lambda: l2(s2, p2)[0], st2, 5, settle_ms=min(args.settle_ms, 100.0))
                     assert torch.isfinite(o2).all()
                     ex2[dt2] = {"value": round(2 * 4 * st2 / el2, 1), "unit": "frames/s", "ms_per_step": round(el2 / st2 * 1e3, 5),
                                 "mfma_frac": round(layer_flops(2, 4, 64, 64, 256, F) / (el2 / st2) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
@@ -338,7 +345,7 @@ def main():
             B5, T5, C5, H5, W5 = 8, 4, 256, 96, 96
             layer5, _, src5, pos5 = make_workload(B5, T5, C5, H5, W5, seed=100 + rank)
             steps5 = max(10, min(args.steps // 4, 50))
-            el, o5 = timed(lambda: layer5(src5, pos5)[0], steps5, 3)
+            el, o5 = timed(lambda: layer5(src5, pos5)[0], steps5, 3, settle_ms=min(args.settle_ms, 100.0))
             assert torch.isfinite(o5).all()
             fl5 = layer_flops(B5, T5, H5, W5, C5, F)
             extras["cfg5_share"] = {"value": round(world * B5 * T5 * steps5 / el, 1), "unit": "frames/s", "ms_per_step": round(el / steps5 * 1e3, 4),
@@ -464,9 +471,11 @@ def main():
                 g3 = torch.Generator(device=dev).manual_seed(3)
                 feats3 = {k: torch.randn(4, chans[k], *sizes3[k], device=dev, generator=g3) for k in chans}
                 with torch.no_grad():
-                    for _ in range(5):
-                        wc.forward_features(dict(feats3))
-                    torch.cuda.synchronize(dev)
+                    t_set3 = time.perf_counter()
+                    while (time.perf_counter() - t_set3) * 1e3 < min(args.settle_ms, 100.0):      # clocks back up after the set-up gap
+                        for _ in range(5):
+                            wc.forward_features(dict(feats3))
+                        torch.cuda.synchronize(dev)
                     n3 = 30
                     t3 = time.perf_counter()
                     for _ in range(n3):
@@ -491,10 +500,10 @@ def main():
 
                 def train_step():
                     tl(s_t, pos)[0].backward(g_t)
-                for _ in range(2):
+                for _ in range(10):
                     train_step()
                 torch.cuda.synchronize(dev)
-                n_t = 5
+                n_t = 10
                 t_tr = time.perf_counter()
                 for _ in range(n_t):
                     train_step()
