@@ -65,7 +65,8 @@ def _dev_f32(t: Tensor, what: str) -> Tensor:
 
 def _require_eval(m: nn.Module) -> None:
     if m.training:
-        raise NotImplementedError("axial_vs_amd: forward-only HIP path -- call .eval() (training/autograd is out of scope)")
+        raise NotImplementedError("axial_vs_amd: this module has a forward-only HIP path -- call .eval() (the training tier covers "
+                                  "TemporalAxialTrajectoryAttentionLayer / TemporalEncoder('axial-trajectory'), axial_vs_amd/training.py)")
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
