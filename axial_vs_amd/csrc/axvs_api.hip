@@ -33,6 +33,7 @@ thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use t
 thread_local int g_spatial_only = 0;     // option "spatial_only": the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
+thread_local int g_no_reassoc = 0;       // option "no_reassoc": generic tier computes k2, v2 = proj_kv(x) for every frame slot (the reference's form)
 thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN activation is exact GELU (F.gelu) instead of ReLU -- set by the
                                          // host module around its calls for activation="gelu" (WC/temporal_attention.py:9-17); unfused FFN path
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
@@ -75,6 +76,8 @@ TrajPacked carve_traj(Carver& c, int C, int heads) {
   t.wpq = c.take<u16>(Cp * Cp);
   t.wpkv = c.take<u16>(2 * Cp * Cp);
   t.wk2t = c.take<u16>(Cp * Cp);
+  t.wk2n = c.take<u16>(Cp * Cp);
+  t.wv2h = c.take<u16>(Cp * Cp);
   t.wp = c.take<u16>((size_t)C * Cp);
   t.bq = c.take<float>(Cp);
   t.bk = c.take<float>(Cp);
@@ -161,7 +164,12 @@ void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, h
   pack_w<BF>(p.v_w, t.wv, headC, plainC, st);
   pack_w<BF>(p.proj_q_w, t.wpq, headC, headCp, st);
   pack_w<BF>(p.proj_kv_w, t.wpkv, head2C, headCp, st);
-  if (d == 32) hipLaunchKernelGGL((pack_wk2t_kernel<BF>), dim3((unsigned)(((long long)heads * C * 32 + 255) / 256)), dim3(256), 0, st, p.proj_kv_w, t.wk2t, C, heads);
+  if (d == 32) {
+    const dim3 pg((unsigned)(((long long)heads * C * 32 + 255) / 256));
+    hipLaunchKernelGGL((pack_wk2t_kernel<BF>), pg, dim3(256), 0, st, p.proj_kv_w, t.wk2t, C, heads);
+    hipLaunchKernelGGL((pack_wk2n_kernel<BF>), pg, dim3(256), 0, st, p.proj_kv_w, t.wk2n, C, heads);
+    hipLaunchKernelGGL((pack_wv2h_kernel<BF>), pg, dim3(256), 0, st, p.proj_kv_w, t.wv2h, C, heads);
+  }
   pack_w<BF>(p.proj_w, t.wp, plainC, headC, st);
   pack_b(p.q_b, t.bq, headC, st);
   pack_b(p.k_b, t.bk, headC, st);
@@ -184,7 +192,8 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
   w.x16 = c.take<u16>(Cp * Mp * T);
   w.o16 = c.take<u16>(Cp * Mp);
   w.q2 = c.take<float>(Cp * Mp);
-  w.kv2 = c.take<float>(2 * Cp * Mp * T);
+  // (k2 | v2) of every frame slot, or -- reassociated temporal half, T > 5 -- u and z: [Mp][heads * Cp] fp32 each
+  w.kv2 = c.take<float>(((size_t)2 * Cp * T > (size_t)2 * heads * Cp ? (size_t)2 * Cp * T : (size_t)2 * heads * Cp) * Mp);
   return w;
 }
 
@@ -355,6 +364,36 @@ qkv_done:
   ALoadBlocked<BF> adiag{w.x16, Mp * T, M, T, N, L};
   launch_gemm<BF>(adiag, p.wpq, EpiRowsF32{w.q2, nullptr, p.bpq, identity_map(Mp), Cp, scale}, M, Cp, Cp, st);
   mark(st, nm[2]);
+  if (!g_generic_only && !g_no_reassoc && C == 256 && heads == 8 && T >= 12) {   // (below ~12 frames the per-head GEMMs cost more than they save)
+    // Reassociated (see temporal_fused_kernel): proj_kv is applied to u_h = Wk2_h^T q2_h and z_h = sum_f a_f x_f instead of to
+    // every frame slot of x -- 2 C^2 instead of 2 T C^2 MACs per token, and no [T*M, 2C] tensor.  Whole-video cross-clip
+    // inference runs T = number of clips (tens): this is what keeps the temporal half linear in T.
+    float* U = w.kv2;
+    float* Z = w.kv2 + (size_t)Mp * heads * Cp;
+    {
+      GemmBatch<ALoadRowsLd<BF>, EpiRowsF32, 8> gb;
+      for (int h = 0; h < 8; ++h) {
+        gb.al[h] = ALoadRowsLd<BF>{w.q2, Cp, h * 32, M};
+        gb.W[h] = p.wk2n + (size_t)h * Cp * 32;
+        gb.epi[h] = EpiRowsF32{U + h * Cp, nullptr, nullptr, identity_map(Mp), heads * Cp, 1.f};
+      }
+      launch_gemm_batched<BF>(gb, M, Cp, 32, st);
+    }
+    hipLaunchKernelGGL((temporal_stream_kernel<BF>), dim3((unsigned)((Mp + 3) / 4)), dim3(256), 0, st, (const float*)U, (const u16*)w.x16, Z,
+                       (long long)M, Mp, T);
+    mark(st, nm[3]);
+    {
+      GemmBatch<ALoadRowsLd<BF>, EpiBlocked16<BF>, 8> gb;
+      for (int h = 0; h < 8; ++h) {
+        gb.al[h] = ALoadRowsLd<BF>{Z, heads * Cp, h * Cp, M};
+        gb.W[h] = p.wv2h + (size_t)h * Cp * 32;
+        gb.epi[h] = EpiBlocked16<BF>{w.o16, Mp, p.bpkv + Cp + h * 32, 1.f, 0, 0};
+        gb.epi[h].n_off = h * 32;
+      }
+      launch_gemm_batched<BF>(gb, M, 32, Cp, st);
+    }
+    mark(st, nm[4]);
+  } else {
   ALoadBlocked<BF> aall{w.x16, Mp * T, M * T, 0, 1, 1};
   launch_gemm<BF>(aall, p.wpkv, EpiRowsF32{w.kv2, nullptr, p.bpkv, identity_map(Mp * T), 2 * Cp, 1.f}, M * T, 2 * Cp, Cp, st);
   mark(st, nm[3]);
@@ -364,6 +403,7 @@ qkv_done:
                        w.o16, Mp, T, heads);
   }
   mark(st, nm[4]);
+  }
   ALoadBlocked<BF> ao{w.o16, Mp, M, 0, 1, 1};
   launch_gemm<BF>(ao, p.wp, EpiRowsF32{out, res, p.bp, rm, C, 1.f}, M, C, Cp, st);
   mark(st, nm[5]);
@@ -890,6 +930,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_attn_fusion")) { g_no_attn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_ffn_fusion")) { g_no_ffn_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_gelu")) { g_ffn_gelu = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_reassoc")) { g_no_reassoc = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_valu")) { g_train_valu = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }

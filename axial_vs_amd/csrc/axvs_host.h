@@ -45,6 +45,7 @@ inline int ensure_max_lds(const void* fn, int bytes = 160 * 1024) {
 
 struct TrajPacked {  // pointers into the packed blob
   u16 *wq, *wk, *wv, *wpq, *wpkv, *wp, *wk2t;     // wk2t: transposed k half of proj_kv (fused temporal kernel, C = 256)
+  u16 *wk2n, *wv2h;                               // per-head copies for the reassociated generic temporal half (axvs_misc.h)
   float *bq, *bk, *bv, *bpq, *bpkv, *bp;
   const float *post_ln_g = nullptr, *post_ln_b = nullptr;   // optional LayerNorm on (residual + attention) in the kernel epilogue (not in the blob)
 };

@@ -81,6 +81,84 @@ __global__ void pack_wk2t_kernel(const float* __restrict__ W, u16* __restrict__ 
   out[idx] = H16<BF>::from_f32(W[(long long)(h * 32 + perm32(p)) * C + c]);
 }
 
+// Per-head weight copies for the REASSOCIATED temporal half of the shape-generic tier (any T; d = 32, C = heads * 32):
+//   wk2n [heads][C positions n][32 d]:  Wk2[h*32 + d][channel of stored position n]  -- u_h = Wk2_h^T q2_h as a K = 32 GEMM per head
+//   wv2h [heads][C/32 kb][32 r][32]:    Wv2[h*32 + r][channel of stored position kb*32 + kk] -- o_h = Wv2_h z_h as an N = 32 GEMM per head
+// "stored position": x is stored with the 32 channels of every head block in perm32 order (see pack_traj).
+template <bool BF>
+__global__ void pack_wk2n_kernel(const float* __restrict__ W, u16* __restrict__ out, int C, int heads) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)heads * C * 32) return;
+  const int d = idx & 31;
+  const long long r = idx >> 5;
+  const int n = (int)(r % C), h = (int)(r / C);
+  const int ch = (n & ~31) + perm32(n & 31);
+  out[idx] = H16<BF>::from_f32(W[(long long)(h * 32 + d) * C + ch]);
+}
+template <bool BF>
+__global__ void pack_wv2h_kernel(const float* __restrict__ W, u16* __restrict__ out, int C, int heads) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)heads * C * 32) return;
+  const int kk = idx & 31;
+  long long t = idx >> 5;
+  const int r = (int)(t & 31);
+  t >>= 5;
+  const int KB = C / 32, kb = (int)(t % KB), h = (int)(t / KB);
+  out[idx] = H16<BF>::from_f32(W[(long long)(C + h * 32 + r) * C + kb * 32 + perm32(kk)]);
+}
+
+// Reassociated temporal attention over any number of frames (WC/temporal_attention.py:66-73 with proj_kv applied once instead
+// of once per frame):  logit_f = u_h . x_f,  a = softmax_f,  z_h = sum_f a_f x_f   (u_h = Wk2_h^T q2_h; the k2 bias drops out of
+// the softmax).  U, Z: fp32 [M][heads * C] (head-major); X16: blocked [C/32][T*Mp][32], row f*Mp + m.  One wave per token:
+// lane = (head, 32-channel block) -- the 8 lanes of a head reduce with three xor-shuffles --, online softmax over the frames,
+// x read once per frame (64 bytes per lane, the 8 heads share the lines).  C = 256, 8 heads.
+template <bool BF>
+__global__ __launch_bounds__(256) void temporal_stream_kernel(const float* __restrict__ U, const u16* __restrict__ X16, float* __restrict__ Z,
+                                                              long long M, long long Mp, int T) {
+  constexpr int C = 256, HC = 8 * C;
+  const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int lane = threadIdx.x & 63, h = lane >> 3, sub = lane & 7;
+  float u[32], z[32];
+  {
+    const float* up = U + m * HC + h * C + sub * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(up + i);
+      u[i] = v.x; u[i + 1] = v.y; u[i + 2] = v.z; u[i + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) z[i] = 0.f;
+  float mx = -INFINITY, sum = 0.f;
+  const long long R = Mp * T;
+  for (int f = 0; f < T; ++f) {
+    const u16* xp = X16 + blk_off(R, (long long)f * Mp + m, sub * 32);
+    u16x8 xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const u16x8*>(xp + i * 8);
+    float x[32], p = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      x[i] = H16<BF>::to_f32(xv[i >> 3][i & 7]);
+      p += u[i] * x[i];
+    }
+    p += __shfl_xor(p, 1, 64);
+    p += __shfl_xor(p, 2, 64);
+    p += __shfl_xor(p, 4, 64);
+    const float nm = fmaxf(mx, p);
+    const float corr = __expf(mx - nm), e = __expf(p - nm);
+    sum = sum * corr + e;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) z[i] = z[i] * corr + e * x[i];
+    mx = nm;
+  }
+  const float inv = 1.f / sum;
+  float* zp = Z + m * HC + h * C + sub * 32;
+#pragma unroll
+  for (int i = 0; i < 32; i += 4) *reinterpret_cast<float4*>(zp + i) = float4{z[i] * inv, z[i + 1] * inv, z[i + 2] * inv, z[i + 3] * inv};
+}
+
 __global__ void pack_bias_kernel(const float* __restrict__ b, float* __restrict__ out, PackDim nd) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nd.padded) return;

@@ -1033,3 +1033,28 @@ def test_random_shapes_sweep():
         worst = max(worst, e)
         assert e < TOL_F16, (B, T, C, H, W, F, e)
     print(f"24 random shapes: worst max/max {worst:.2e}")
+
+
+def test_many_frames_both_temporal_forms():
+    """T >= 12 on the shape-generic tier: the temporal half applies proj_kv once per token (u = Wk2^T q2, z = sum_f a_f x_f) instead
+    of once per frame slot.  Both forms against the float64 oracle, and against each other."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    B, T, C, H, W, F = 1, 14, 256, 9, 6, 256
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 43)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 43)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    outs = {}
+    for flag in (0, 1):
+        _lib.check(_lib.lib().axvs_set_option(b"no_reassoc", flag), "axvs_set_option")
+        try:
+            outs[flag] = layer(dev(src), dev(pos))[0].cpu()
+        finally:
+            _lib.lib().axvs_set_option(b"no_reassoc", 0)
+        e = rel_err(outs[flag], ref)
+        print(f"T=14, no_reassoc={flag}: {e:.2e}")
+        assert e < TOL_F16
+    assert not torch.equal(outs[0], outs[1]) and rel_err(outs[0], outs[1]) < TOL_F16
