@@ -39,9 +39,10 @@ def test_size_queries_need_no_gpu():
     L = _lib.lib()
     C, h, F = 256, 8, 1024
     packed = L.axvs_axial_layer_packed_bytes(C, h, F)
-    # 2 x (7 C^2) 16-bit attention weights + 2 C F 16-bit FFN weights, plus fp32 biases / norms
-    assert packed >= 2 * (2 * 7 * C * C) + 2 * (2 * C * F)
-    assert packed < 1.1 * (2 * (2 * 7 * C * C) + 2 * (2 * C * F)) + 65536
+    # 2 x (7 C^2) 16-bit attention weights (+ 3 C^2 of per-head copies of the proj_kv halves for the reassociated temporal forms)
+    # + 2 C F 16-bit FFN weights, plus fp32 biases / norms
+    assert packed >= 2 * (2 * 10 * C * C) + 2 * (2 * C * F)
+    assert packed < 1.1 * (2 * (2 * 10 * C * C) + 2 * (2 * C * F)) + 65536
     ws = L.axvs_axial_layer_workspace_bytes(1, 4, 64, 64, C, h, F)
     assert ws > 0
     assert L.axvs_traj_attn_workspace_bytes(4, 4, 16, C, h) > 0
