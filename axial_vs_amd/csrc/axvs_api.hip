@@ -201,7 +201,7 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 // output, 16..128 keys per frame (L >= 16: the 32-key padding of V^T stays within 2x).  Any axis length: row tiles are cut
 // per sequence, partial key tiles are masked.
 bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn) {
-  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 5 && !want_attn && L >= 16 && L <= 128;
+  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 8 && !want_attn && L >= 16 && L <= 128;
 }
 // The FFN rides in the width-pass kernel only when that kernel fills at least half the chip: with fewer 64-row tiles every
 // workgroup's private 1 MB FFN weight stream is pure latency (43 us per pass whether 16 or 64 workgroups run), and a 16-row
@@ -260,6 +260,9 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
       case 3: return launch_temporal_n<BF, 3, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       case 4: return launch_temporal_n<BF, 4, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       case 5: return launch_temporal_n<BF, 5, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 6: return launch_temporal_n<BF, 6, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 7: return launch_temporal_n<BF, 7, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 8: return launch_temporal_n<BF, 8, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       default: break;
     }
   }
@@ -269,7 +272,10 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
     case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
     case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
     case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 5");
+    case 6: return launch_temporal_n<BF, 6, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);     // x tile: T * 16 KiB of LDS
+    case 7: return launch_temporal_n<BF, 7, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 8: return launch_temporal_n<BF, 8, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 8");
   }
 }
 
@@ -355,7 +361,7 @@ qkv_done:
   mark(st, nm[1]);
 
   // temporal half + output projection + residual
-  if (!g_generic_only && C == 256 && heads == 8 && T <= 5) {
+  if (!g_generic_only && C == 256 && heads == 8 && T <= 8) {
     rc = launch_temporal<BF>(w, p, res, out, rm, Mp, N, L, T, scale, st);
     if (rc != AXVS_OK) return rc;
     mark(st, nm[6]);
@@ -633,8 +639,8 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   // trajectory attention over (t q) tokens of each video, read in place from [B,Q,Tc,C]:  row (b; t,q) -> b*Q*Tc + q*Tc + t
   RowMap rm{Tc * Q, Q, 1, (long long)Q * Tc, 1, Tc, 0};
   const unsigned lnblocks = (unsigned)((R + 3) / 4);
-  // the post-norm LayerNorm(x + attn(x)) rides in the trajectory kernel's row-wise epilogue when a fused kernel runs (T <= 5)
-  const bool ln_in_kernel = !g_generic_only && Tc <= 5;
+  // the post-norm LayerNorm(x + attn(x)) rides in the trajectory kernel's row-wise epilogue when a fused kernel runs (T <= 8)
+  const bool ln_in_kernel = !g_generic_only && Tc <= 8;
   if (ln_in_kernel) {
     p.t.post_ln_g = p.norm_w;
     p.t.post_ln_b = p.norm_b;

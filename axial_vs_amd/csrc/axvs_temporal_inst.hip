@@ -1,13 +1,13 @@
 // One translation unit per (operand type, frame count): the instantiations of temporal_fused_kernel are what dominates the
 // build (5 key-step counts x {with, without FFN} large kernels each), so __graft_entry__.build() compiles them in parallel:
-//   hipcc -c axvs_temporal_inst.hip -DAXVS_INST_BF=<0|1> -DAXVS_INST_T=<1..5>
+//   hipcc -c axvs_temporal_inst.hip -DAXVS_INST_BF=<0|1> -DAXVS_INST_T=<1..8>
 #include "axvs_host.h"
 #include "axvs_fused.h"
 
 #if !defined(AXVS_INST_BF) || !defined(AXVS_INST_T)
 #error "compile with -DAXVS_INST_BF=<0|1> -DAXVS_INST_T=<frames> [-DAXVS_INST_MT=<16-row tiles per workgroup>]"
 #endif
-#ifndef AXVS_INST_MT   // default tile: 64 rows (32 for T = 5); MT = 1 (16 rows) units serve problems with few rows (cross-clip queries)
+#ifndef AXVS_INST_MT   // default tile: 64 rows (32 for T >= 5: the x tile takes T * 16 KiB of LDS per 32 rows); MT = 1 (16 rows) units serve problems with few rows (cross-clip queries)
 #define AXVS_INST_MT (AXVS_INST_T <= 4 ? 4 : 2)
 #endif
 

@@ -294,7 +294,9 @@ def _stage_names():
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 256, 25, 43, 1024), (1, 4, 256, 49, 85, 1024), (2, 2, 256, 49, 85, 1024), (1, 5, 256, 25, 43, 512),
-                                   (1, 3, 256, 17, 127, 256), (1, 4, 256, 23, 40, 1024)])
+                                   (1, 3, 256, 17, 127, 256), (1, 4, 256, 23, 40, 1024),
+                                   # 6 .. 8 frames per clip (fused since the end of round 2: 32-row tiles, x tile T * 16 KiB)
+                                   (1, 6, 256, 32, 48, 512), (1, 7, 256, 25, 43, 256), (1, 8, 256, 64, 16, 1024), (2, 8, 256, 17, 40, 256)])
 def test_ragged_axis_lengths_take_the_fused_tier(shape):
     """The real VIPSeg pyramid sizes (res4 49x85 / res5 25x43; T = 2 in Video-kMaX, up to 5 in Tube-Link) have axis
     lengths that are not multiples of 16 and sequences that are not multiples of the 64-row tile.  They stay on the fully fused
