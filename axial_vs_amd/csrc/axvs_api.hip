@@ -1715,6 +1715,12 @@ int axvs_linear_sum_assignment(const float* cost, long long* col4row, int batch,
   return launch_lsap(cost, col4row, batch, n, static_cast<hipStream_t>(stream));
 }
 
+static int cost_tile_lds(int C) {     // two 16-row panels of C + 1 floats
+  const size_t bytes = (size_t)2 * 16 * (C + 1) * sizeof(float);
+  if (bytes > 160 * 1024) return fail(AXVS_ERR_ARG, "embedding width C=%d too large for the cost kernel's LDS panels", C);
+  return bytes > 64 * 1024 ? ensure_max_lds(reinterpret_cast<const void*>(&cost_tile_kernel), (int)bytes) : AXVS_OK;
+}
+
 size_t axvs_match_embds_workspace_bytes(int Q, int C) { return ((size_t)Q * Q + 2 * (size_t)Q * C) * sizeof(float); }
 
 int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* indices, int Q, int C, void* workspace,
@@ -1725,8 +1731,10 @@ int axvs_match_embds(const float* tgt_embds, const float* cur_embds, long long* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* cost = static_cast<float*>(workspace);
   float* nrm = cost + (size_t)Q * Q;
+  if (int rc = cost_tile_lds(C)) return rc;
   hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((2 * Q + 3) / 4)), dim3(256), 0, st, tgt_embds, cur_embds, nrm, Q, C);
-  hipLaunchKernelGGL(cosine_cost_kernel, dim3((unsigned)((Q * Q + 255) / 256)), dim3(256), 0, st, nrm, cost, Q, C);
+  hipLaunchKernelGGL(cost_tile_kernel, dim3((Q + 15) / 16, (Q + 15) / 16, 1), dim3(256), (size_t)2 * 16 * (C + 1) * sizeof(float), st, (const float*)nrm,
+                     cost, 0, Q, C);
   return launch_lsap(cost, indices, 1, Q, st);
 }
 
@@ -1743,9 +1751,11 @@ int axvs_match_clips(const float* mask_embeddings, long long* indices, int V, in
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* nrm = static_cast<float*>(workspace);
   float* cost = nrm + (size_t)V * Tc * Q * C;
-  const long long R = (long long)V * Tc * Q, total = (long long)V * (Tc - 1) * Q * Q;
+  const long long R = (long long)V * Tc * Q;
+  if (int rc = cost_tile_lds(C)) return rc;
   hipLaunchKernelGGL(normalize_rows1_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, mask_embeddings, nrm, R, C);
-  hipLaunchKernelGGL(pair_cost_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nrm, cost, Tc, Q, C, total);
+  hipLaunchKernelGGL(cost_tile_kernel, dim3((Q + 15) / 16, (Q + 15) / 16, (unsigned)(V * (Tc - 1))), dim3(256), (size_t)2 * 16 * (C + 1) * sizeof(float), st,
+                     (const float*)nrm, cost, Tc, Q, C);
   return launch_lsap(cost, indices, V, Q, st, Tc - 1);
 }
 

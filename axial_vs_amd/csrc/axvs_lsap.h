@@ -24,16 +24,38 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
   for (int c = lane; c < C; c += 64) out[(long long)row * C + c] = x[c] / nrm;
 }
 
-// cost[t][j] = 1 - <tgt_t / |tgt_t|, cur_j / |cur_j|>   (rows = target queries, columns = current queries: C^T of the reference)
-__global__ __launch_bounds__(256) void cosine_cost_kernel(const float* __restrict__ nrm, float* __restrict__ cost, int Q, int C) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Q * Q) return;
-  const int t = idx / Q, j = idx - t * Q;
-  const float* a = nrm + (long long)t * C;
-  const float* b = nrm + (long long)(Q + j) * C;
+// cost[z][t][j] = 1 - <a_t, b_j> on row-normalised embeddings (rows = target queries, columns = current queries: C^T of the
+// reference).  Problem z: Tc == 0 -> a = nrm rows 0..Q-1, b = rows Q..2Q-1 (one pair); Tc > 1 -> video z / (Tc-1), clips i and
+// i + 1 of e [V][Tc][Q][C] (i = z % (Tc-1)).  A workgroup computes a 16 x 16 tile from two 16-row panels staged in LDS (row stride
+// C + 1: conflict-free); every dot is still the plain sequential fp32 sum over c = 0..C-1, so the values are bit-identical to the
+// one-thread-per-entry kernel of round 1 (33 us at Q = 128 because every lane streamed its own row from L2).
+__global__ __launch_bounds__(256) void cost_tile_kernel(const float* __restrict__ nrm, float* __restrict__ cost, int Tc, int Q, int C) {
+  extern __shared__ float cst[];
+  const int ld = C + 1, tid = threadIdx.x, z = blockIdx.z;
+  float* sa = cst;
+  float* sb = cst + 16 * ld;
+  const float *A, *B;
+  if (Tc > 1) {
+    const long long vid = z / (Tc - 1), i = z - vid * (Tc - 1);
+    A = nrm + ((vid * Tc + i) * Q) * C;
+    B = A + (long long)Q * C;
+  } else {
+    A = nrm;
+    B = nrm + (long long)Q * C;
+  }
+  const int t0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  for (int i = tid; i < 16 * C; i += 256) {
+    const int r = i / C, c = i - r * C;
+    sa[r * ld + c] = t0 + r < Q ? A[(long long)(t0 + r) * C + c] : 0.f;
+    sb[r * ld + c] = j0 + r < Q ? B[(long long)(j0 + r) * C + c] : 0.f;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  const float* a = sa + ty * ld;
+  const float* b = sb + tx * ld;
   float dot = 0.f;
   for (int c = 0; c < C; ++c) dot += b[c] * a[c];
-  cost[idx] = 1.f - dot;
+  if (t0 + ty < Q && j0 + tx < Q) cost[((long long)z * Q + t0 + ty) * Q + j0 + tx] = 1.f - dot;
 }
 
 // candidate of the column scan: (shortest path cost, tie key).  The sequential rule
@@ -242,25 +264,6 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
       for (int r = lane; r < n; r += 64) rowperm[r] = col4row[r];
     }
   }
-}
-
-// raw pair-wise cosine costs of consecutive clips: cost[v][i][s][j] = 1 - <e[v][i][s], e[v][i+1][j]> on row-normalised embeddings
-// e [V][Tc][Q][C]; the same sequential fp32 dot as cosine_cost_kernel (so the values equal the per-pair path's bit for bit)
-__global__ __launch_bounds__(256) void pair_cost_kernel(const float* __restrict__ nrm, float* __restrict__ cost, int Tc, int Q, int C,
-                                                        long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int j = (int)(idx % Q);
-  long long r = idx / Q;
-  const int s = (int)(r % Q);
-  r /= Q;
-  const int i = (int)(r % (Tc - 1));
-  const long long vid = r / (Tc - 1);
-  const float* a = nrm + ((vid * Tc + i) * Q + s) * C;
-  const float* b = nrm + ((vid * Tc + i + 1) * Q + j) * C;
-  float dot = 0.f;
-  for (int c = 0; c < C; ++c) dot += b[c] * a[c];
-  cost[idx] = 1.f - dot;
 }
 
 // rows of x [R][C] divided by their norm (`x / x.norm(dim=1)[:, None]`), one wave per row
