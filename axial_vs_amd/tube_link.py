@@ -118,6 +118,7 @@ class MultiScaleDeformableAxialTrajectoryAttention(nn.Module):
         first) temporal level; reference_points (bs, num_query, num_levels, 2 | 4); spatial_shapes (num_levels, 2) = (h, w).
         Returns the tensor in the layout of `query`."""
         _require_eval(self)
+        v_is_q, id_is_q = value is None or value is query, identity is None or identity is query     # TL:567-570 defaults
         if value is None:
             value = query
         if identity is None:
@@ -126,7 +127,9 @@ class MultiScaleDeformableAxialTrajectoryAttention(nn.Module):
             query, value, identity = query.permute(1, 0, 2), value.permute(1, 0, 2), identity.permute(1, 0, 2)
             if query_pos is not None:
                 query_pos = query_pos.permute(1, 0, 2)
-        q, v, ident = _dev_f32(query, "query"), _dev_f32(value, "value"), _dev_f32(identity, "identity")
+        q = _dev_f32(query, "query")                   # (one layout copy for the three roles when they are the same tensor)
+        v = q if v_is_q else _dev_f32(value, "value")
+        ident = q if id_is_q else _dev_f32(identity, "identity")
         qp = _dev_f32(query_pos, "query_pos") if query_pos is not None else None
         ref = _dev_f32(reference_points, "reference_points")
         bs, nq, Cq = q.shape
