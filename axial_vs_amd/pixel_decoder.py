@@ -94,10 +94,13 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         for i, spatial_layer in enumerate(self.spatial_layers):
             output = spatial_layer(output, pos, self._ref, spatial_shapes, level_start_index, padding_mask)
             if self.transformer_num_temporal_feature_levels > 0:
-                parts = list(torch.split(output, sizes, dim=1))
+                # the temporal levels (the coarsest, first in the buffer) are replaced in place; the reference's split / cat
+                # (WC/msdeformattn.py:258-264) would also copy the large level that passes through
+                start = 0
                 for j in range(self.transformer_num_temporal_feature_levels):
-                    parts[j], h_attn, w_attn = self.temporal_layers[i](src=parts[j].contiguous(), pos=pos_3d[j])
-                output = torch.cat(parts, dim=1)
+                    lvl, h_attn, w_attn = self.temporal_layers[i](src=output[:, start:start + sizes[j]].contiguous(), pos=pos_3d[j])
+                    output[:, start:start + sizes[j]] = lvl
+                    start += sizes[j]
         return output, h_attn, w_attn
 
 
@@ -113,12 +116,18 @@ class TemporalTransformerEncoder(nn.Module):
     @_guarded
     def forward(self, src, spatial_shapes, pos_3d):
         sizes = [h * w for h, w in spatial_shapes]
-        parts = list(torch.split(src, sizes, dim=1))
+        nt = self.transformer_num_temporal_feature_levels
+        parts = [p.contiguous() for p in torch.split(src, sizes, dim=1)[:nt]]
         h_attn = w_attn = None
         for temporal_layer in self.temporal_layers:
-            for j in range(self.transformer_num_temporal_feature_levels):
-                parts[j], h_attn, w_attn = temporal_layer(src=parts[j].contiguous(), pos=pos_3d[j])
-        return torch.cat(parts, dim=1), h_attn, w_attn
+            for j in range(nt):
+                parts[j], h_attn, w_attn = temporal_layer(src=parts[j], pos=pos_3d[j])
+        out = src.clone()                               # (the caller's buffer is left alone)
+        start = 0
+        for j in range(nt):
+            out[:, start:start + sizes[j]] = parts[j]
+            start += sizes[j]
+        return out, h_attn, w_attn
 
 
 class MSDeformAttnTransformerEncoderOnly(nn.Module):
