@@ -305,9 +305,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&qkv_fused_kernel<BF>))) return rc;
     // the fused kernel reads the value rows from the same tensor as the q/k rows (+ optional additive term)
     if (vsrc == qsrc) {
-      if (fuse_attn && L % 16 != 0 &&      // (L % 16 == 0: the kernel clears the padding half-steps itself)
-          hipMemsetAsync(w.vt16, 0, (size_t)(Mp / L) * nks_fused * 8 * 1024 * sizeof(u16), st) != hipSuccess)   // pad keys must be finite
-        return fail(AXVS_ERR_LAUNCH, "memset failed");
+      // (the V^T padding keys of frames that are not multiples of 32 keys are cleared by the kernel itself)
       const unsigned qtiles = (unsigned)((Mp + 63) / 64);
       // few tiles (cross-clip queries): one workgroup per (tile, q | k | v) -- a third of the weight stream each
       hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3(qtiles, (qtiles <= 64 && !g_no_small_tiles) ? 3 : 1), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,

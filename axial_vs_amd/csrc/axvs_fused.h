@@ -1021,6 +1021,16 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                 const long long d = ((((long long)wave * heads_sf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
                 VT16[d] = H16<BF>::from_f32(acc[nt][mt][r] + sbias[2 * C + wave * 32 + nt * 16 + fi]);
               }
+              // the frame's last key also clears the padding keys L .. 32 NKS - 1 of its d rows (they get probability 0 but must be
+              // finite): no memset of the V^T buffer per pass
+              if (l == L - 1) {
+                for (int l2 = L; l2 < NKS * 32; ++l2) {
+                  const int k2 = l2 & 31, p2 = ((k2 >> 2) & 3) * 8 + (k2 >> 4) * 4 + (k2 & 3);
+#pragma unroll
+                  for (int nt = 0; nt < 2; ++nt)
+                    VT16[((((long long)wave * heads_sf + sf) * NKS + (l2 >> 5)) * 2 + nt) * 512 + fi * 32 + p2] = 0;
+                }
+              }
             }
             ++tok;
             if (++l == L) { l = 0; ++sf; }

@@ -989,10 +989,12 @@ def test_decoder_position_cache_follows_parameter_updates():
     assert all(torch.equal(c[k], d[k]) for k in c)
 
 
-@pytest.mark.parametrize("shape", [(1, 4, 256, 48, 80, 1024), (1, 2, 256, 112, 16, 512), (2, 3, 256, 16, 48, 256), (1, 5, 256, 80, 112, 512)])
-def test_axis_lengths_that_are_odd_multiples_of_16(shape):
-    """L % 32 == 16: the frame's last 32-key step is half padding, which the QKV kernel clears itself (no memset).  The workspace is
-    poisoned with NaN bit patterns first: a padding half-step that is not cleared would put NaN into the attention output."""
+@pytest.mark.parametrize("shape", [(1, 4, 256, 48, 80, 1024), (1, 2, 256, 112, 16, 512), (2, 3, 256, 16, 48, 256), (1, 5, 256, 80, 112, 512),
+                                   (1, 2, 256, 49, 85, 1024), (2, 3, 256, 25, 43, 512), (1, 4, 256, 17, 127, 256), (1, 7, 256, 33, 97, 256)])
+def test_padding_keys_are_cleared_in_kernel(shape):
+    """Frames that are not multiples of 32 keys (L % 32 == 16, and any L % 16 != 0): the last 32-key step is partly padding, which
+    the QKV kernel clears itself (no memset).  The workspace is poisoned with NaN bit patterns first: a padding key that is not
+    cleared would put NaN into the attention output."""
     import axial_vs_amd as ax
     from axial_vs_amd import modules
     B, T, C, H, W, F = shape
