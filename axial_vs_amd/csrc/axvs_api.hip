@@ -200,8 +200,11 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 // Full fusion (spatial half inside the temporal kernel, x never leaves LDS) needs: the fused kernels, no attention-map
 // output, 16..128 keys per frame (L >= 16: the 32-key padding of V^T stays within 2x).  Any axis length: row tiles are cut
 // per sequence, partial key tiles are masked.
-bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn) {
-  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && T <= 8 && !want_attn && L >= 16 && L <= 128;
+// Frame counts the fused trajectory kernels exist for: T <= 8 (64- / 32-row tiles), and 9 .. 12 on 16-row tiles (x tile T * 8 KiB)
+// for problems with few rows -- whole-video cross-clip inference with up to 12 clips (Q * Tc rows per video).
+bool fused_frames(int T, long long rows) { return T <= 8 || (T <= 12 && rows < 128 * 64 && !g_no_small_tiles); }
+bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn, long long rows) {
+  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && fused_frames(T, rows) && !want_attn && L >= 16 && L <= 128;
 }
 // The FFN rides in the width-pass kernel only when that kernel fills at least half the chip: with fewer 64-row tiles every
 // workgroup's private 1 MB FFN weight stream is pure latency (43 us per pass whether 16 or 64 workgroups run), and a 16-row
@@ -219,8 +222,9 @@ struct LayerPlan {
 };
 LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool want_attn) {
   LayerPlan p;
-  p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn) && can_fuse_attn(C, heads, T, W, want_attn);
-  p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn) && can_fuse_ffn_into_pass(T, F, (long long)B * T * H * W));
+  const long long rows = (long long)B * T * H * W;
+  p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn, rows) && can_fuse_attn(C, heads, T, W, want_attn, rows);
+  p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn, rows) && can_fuse_ffn_into_pass(T, F, rows));
   p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
   return p;
 }
@@ -253,7 +257,7 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
   const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? 2 : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? (Mp / N) * ((N + 63) / 64) : (Mp + 63) / 64;
-  if (fa == nullptr && tiles64 < 128 && !g_no_small_tiles) {
+  if (fa == nullptr && (tiles64 < 128 || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
     switch (T) {
       case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
@@ -263,6 +267,10 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
       case 6: return launch_temporal_n<BF, 6, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       case 7: return launch_temporal_n<BF, 7, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       case 8: return launch_temporal_n<BF, 8, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 9: return launch_temporal_n<BF, 9, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 10: return launch_temporal_n<BF, 10, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 11: return launch_temporal_n<BF, 11, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 12: return launch_temporal_n<BF, 12, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
       default: break;
     }
   }
@@ -298,7 +306,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const float scale = 1.0f / sqrtf((float)d);
   const float kLog2e = 1.4426950408889634f;
 
-  const bool fuse_attn = qsrc == ksrc && vsrc == qsrc && can_fuse_attn(C, heads, T, L, attn != nullptr);
+  const bool fuse_attn = qsrc == ksrc && vsrc == qsrc && can_fuse_attn(C, heads, T, L, attn != nullptr, Mp);
   const int nks_fused = (L + 31) / 32;
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
   if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
@@ -359,7 +367,7 @@ qkv_done:
   mark(st, nm[1]);
 
   // temporal half + output projection + residual
-  if (!g_generic_only && C == 256 && heads == 8 && T <= 8) {
+  if (!g_generic_only && C == 256 && heads == 8 && fused_frames(T, Mp)) {
     rc = launch_temporal<BF>(w, p, res, out, rm, Mp, N, L, T, scale, st);
     if (rc != AXVS_OK) return rc;
     mark(st, nm[6]);
@@ -637,8 +645,8 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   // trajectory attention over (t q) tokens of each video, read in place from [B,Q,Tc,C]:  row (b; t,q) -> b*Q*Tc + q*Tc + t
   RowMap rm{Tc * Q, Q, 1, (long long)Q * Tc, 1, Tc, 0};
   const unsigned lnblocks = (unsigned)((R + 3) / 4);
-  // the post-norm LayerNorm(x + attn(x)) rides in the trajectory kernel's row-wise epilogue when a fused kernel runs (T <= 8)
-  const bool ln_in_kernel = !g_generic_only && Tc <= 8;
+  // the post-norm LayerNorm(x + attn(x)) rides in the trajectory kernel's row-wise epilogue when a fused kernel runs
+  const bool ln_in_kernel = !g_generic_only && fused_frames(Tc, R);
   if (ln_in_kernel) {
     p.t.post_ln_g = p.norm_w;
     p.t.post_ln_b = p.norm_b;

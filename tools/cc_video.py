@@ -11,10 +11,10 @@ mod = ax.CrossClipTrackingModule(num_layers=4, num_classes=124, attn_drop=0.0, a
 shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
 sd = mod.state_dict(); sd.update(orc.random_weights(shapes, 0)); mod.load_state_dict(sd)
 mod = mod.cuda(); mod.eval_outputs_on_cpu = False
-for Tc in [4, 8, 16, 24, 40]:
+for Tc in [4, 8, 10, 12, 16, 24, 40]:
     cq = torch.randn(1, 128, Tc, 256, device="cuda")
     pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * 2, 64, 64, device="cuda"), dim=1)
-    for _ in range(3): mod(cq, pf)
+    for _ in range(10): mod(cq, pf)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 20
     for _ in range(n): mod(cq, pf)
