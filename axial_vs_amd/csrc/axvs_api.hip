@@ -13,6 +13,7 @@
 #include "axvs_lsap.h"
 #include "axvs_common.h"
 #include "axvs_fused.h"
+#include "axvs_ffn_split.h"
 #include "axvs_gemm.h"
 #include "axvs_misc.h"
 
@@ -213,12 +214,18 @@ bool can_fuse_ffn_into_pass(int T, int F, long long M) {
   return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096 && (M >= 128 * 64 || g_no_small_tiles);
 }
 bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && !g_ffn_gelu && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
+// few rows: one workgroup per (64-row tile, 256-unit chunk of the hidden layer) + a row-wise finishing kernel (axvs_ffn_split.h);
+// bit-identical to the one-workgroup-per-tile kernels, so the row count may decide
+bool ffn_split_applies(int C, int heads, int F, long long M) {
+  return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < 128 * 64;
+}
 
 // what one axial layer's launch sequence touches in the workspace (the same predicates run_traj / run_ffn dispatch on)
 struct LayerPlan {
   bool lean_traj;     // both passes fully fused
   bool need_buf2;     // the width pass writes rows for a separate FFN launch
   bool need_ffn_tmp;  // generic FFN (LayerNorm / GEMM / GEMM / LayerNorm): fp32 scratch + 16-bit y and h
+  bool need_ffn_part; // chunk-per-workgroup FFN for few rows: [F/256][M][256] fp32 partial outputs
 };
 LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool want_attn) {
   LayerPlan p;
@@ -226,6 +233,7 @@ LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool w
   p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn, rows) && can_fuse_attn(C, heads, T, W, want_attn, rows);
   p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn, rows) && can_fuse_ffn_into_pass(T, F, rows));
   p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
+  p.need_ffn_part = p.need_buf2 && ffn_split_applies(C, heads, F, rows);
   return p;
 }
 
@@ -425,7 +433,16 @@ qkv_done:
 // norm1 -> linear1 -> ReLU -> linear2 -> +residual -> norm2 on fp32 rows X[M][C] (X is clobbered by the generic path)
 template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
-            hipStream_t st) {
+            hipStream_t st, float* part = nullptr /* [F/256][M][256] fp32: enables the chunk-per-workgroup form for few rows */) {
+  if (part != nullptr && ffn_split_applies(C, heads, F, M)) {
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF>))) return rc;
+    hipLaunchKernelGGL((ffn_split_kernel<BF>), dim3((unsigned)((M + kRows - 1) / kRows), F / 256), dim3(512), kFfnSplitLds, st, (const float*)X, p.w1,
+                       p.b1, p.w2, p.g1, p.be1, part, M, F);
+    hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
+                       p.g2, p.be2, out, M, F / 256);
+    mark(st, "norm1+ffn+norm2");
+    return AXVS_OK;
+  }
   if (ffn_kernel_is_fused(C, heads, F)) {
     const size_t lds = ffn_lds_bytes(F);
     if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "d_ffn=%d too large for the fused FFN kernel", F);
@@ -502,6 +519,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   float* buf2 = plan.need_buf2 ? wc.take<float>((size_t)M * C) : nullptr;
   u16* y16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * C) : nullptr;
   u16* h16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * F) : nullptr;
+  float* ffn_part = plan.need_ffn_part ? wc.take<float>((size_t)(F / 256) * M * C) : nullptr;
   const long long sB = (long long)T * H * W, sT = (long long)H * W;
 
   g_prof_next = 0;
@@ -547,7 +565,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
   // norm1 -> FFN -> norm2                               :181-185, :217-218
-  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, scratch1, y16, h16, st);
+  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, scratch1, y16, h16, st, ffn_part);
   if (rc2 != AXVS_OK) return rc2;
   return last_launch_status();
 }
@@ -1042,6 +1060,7 @@ size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, in
     c.take<u16>((size_t)M * C);
     c.take<u16>((size_t)M * d_ffn);
   }
+  if (plan.need_ffn_part) c.take<float>((size_t)(d_ffn / 256) * M * C);
   if (sine_pos && !sine_in_kernel(C, heads)) c.take<float>((size_t)M * C);     // materialised positions (tiers without in-kernel evaluation)
   return c.off;
 }

@@ -232,9 +232,21 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     if (ci == 0) FSTAMP(4);
     __syncthreads();
     if (ci == 0) FSTAMP(5);
-    // ---- linear2 partial: += W2[my 32 channels, chunk] . h ; meanwhile fetch the next chunk's linear1 fragments
-    //      (unconditional: the last iteration re-loads its own chunk, which keeps the vmcnt bookkeeping branch-free) ----
-    gemm_phase_pf<BF, 2, 4, KB, 2>(acc2, w2f, l.htile, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
+    // ---- linear2 partial: W2[my 32 channels, chunk] . h, accumulated from zero and then added to the running sum (so the
+    //      result is the ordered sum of per-chunk partials: exactly what the chunk-per-workgroup variant for few rows,
+    //      ffn_split_kernel + ffn_finish_kernel, produces -- the choice between them depends on the row count and must not
+    //      change a single bit); meanwhile fetch the next chunk's linear1 fragments (unconditional: the last iteration
+    //      re-loads its own chunk, which keeps the vmcnt bookkeeping branch-free) ----
+    f32x4 part[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) part[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_phase_pf<BF, 2, 4, KB, 2>(part, w2f, l.htile, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc2[a][b] = ci == 0 ? part[a][b] : acc2[a][b] + part[a][b];
     if (ci == 0) FSTAMP(6);
     if (ci == 1) FSTAMP(7);
     if (ci == 2) FSTAMP(8);

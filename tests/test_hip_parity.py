@@ -1062,3 +1062,31 @@ def test_many_frames_both_temporal_forms():
         print(f"T=14, no_reassoc={flag}: {e:.2e}")
         assert e < TOL_F16
     assert not torch.equal(outs[0], outs[1]) and rel_err(outs[0], outs[1]) < TOL_F16
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 256, 32, 32, 1024), (1, 2, 256, 25, 43, 512), (2, 3, 256, 16, 20, 2048), (1, 4, 256, 16, 16, 1024)])
+def test_small_problem_kernels_are_bit_identical_to_the_large_problem_ones(shape):
+    """Few rows switch the layer to 16-row trajectory tiles and to the chunk-per-workgroup FFN (ffn_split_kernel + ffn_finish_kernel);
+    the row count decides, so the results have to be the same bits as with the 64-row kernels (option no_small_tiles) -- otherwise a
+    clip's output would depend on the batch it is sharded out of."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 71)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 71)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    out_small = layer(dev(src), dev(pos))[0].clone()
+    names_small = _stage_names()
+    _lib.check(_lib.lib().axvs_set_option(b"no_small_tiles", 1), "axvs_set_option")
+    try:
+        out_big = layer(dev(src), dev(pos))[0].clone()
+        names_big = _stage_names()
+    finally:
+        _lib.lib().axvs_set_option(b"no_small_tiles", 0)
+    print(f"{shape}: {names_small[1:]} vs {names_big[1:]}: max/max {rel_err(out_small.cpu(), ref):.2e}")
+    assert "norm1+ffn+norm2" in names_small and "w.traj_fused+ffn" in names_big
+    assert torch.equal(out_small, out_big)
+    assert rel_err(out_small.cpu(), ref) < TOL_F16
