@@ -1720,7 +1720,7 @@ static int launch_lsap(const float* cost, long long* col4row, int batch, int n, 
 #define AXVS_LSAP(CPL)                                                                                                        \
   do {                                                                                                                        \
     if (lds) {                                                                                                                \
-      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<CPL, true>), 128 * 1024)) return rc;             \
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&lsap_kernel<CPL, true>))) return rc;             \
       hipLaunchKernelGGL((lsap_kernel<CPL, true>), dim3(batch), dim3(64), bytes, st, cost, col4row, n, chain);                \
     } else {                                                                                                                  \
       hipLaunchKernelGGL((lsap_kernel<CPL, false>), dim3(batch), dim3(64), 0, st, cost, col4row, n, chain);                   \
@@ -1743,7 +1743,7 @@ int axvs_linear_sum_assignment(const float* cost, long long* col4row, int batch,
 static int cost_tile_lds(int C) {     // two 16-row panels of C + 1 floats
   const size_t bytes = (size_t)2 * 16 * (C + 1) * sizeof(float);
   if (bytes > 160 * 1024) return fail(AXVS_ERR_ARG, "embedding width C=%d too large for the cost kernel's LDS panels", C);
-  return bytes > 64 * 1024 ? ensure_max_lds(reinterpret_cast<const void*>(&cost_tile_kernel), (int)bytes) : AXVS_OK;
+  return bytes > 64 * 1024 ? ensure_max_lds(reinterpret_cast<const void*>(&cost_tile_kernel)) : AXVS_OK;
 }
 
 size_t axvs_match_embds_workspace_bytes(int Q, int C) { return ((size_t)Q * Q + 2 * (size_t)Q * C) * sizeof(float); }

@@ -27,8 +27,11 @@ inline int fail(int code, const char* fmt, ...) {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember (device, kernel) pairs that have
-// been raised (by default to the full 160 KiB) so a second device in the same process is configured too.
-inline int ensure_max_lds(const void* fn, int bytes = 160 * 1024) {
+// been raised so a second device in the same process is configured too.  The attribute is always raised to the full 160 KiB,
+// never to the size of the launch at hand: the cache below remembers only THAT a kernel was configured, so a shape-dependent
+// size would pin the first (possibly smaller) request and fail a later, larger launch.
+inline int ensure_max_lds(const void* fn) {
+  constexpr int bytes = 160 * 1024;
   constexpr int kCap = 256;
   struct Entry { int dev; const void* fn; };
   static thread_local Entry seen[kCap];

@@ -252,7 +252,7 @@ struct Ctx {
     hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, sc.wt, N, K);
     return g.fwd(dY, sc.wt, dX, M, K, N, beta);
   }
-  int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn, (int)bytes) : AXVS_OK; }
+  int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn) : AXVS_OK; }
 };
 
 // The spatial half runs on the fp32 MFMA kernels (forward and both backward parts, or none of them: the backward reads the

@@ -92,18 +92,19 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
 
 def _exchange(blocks: List[Tensor], group=None) -> List[Tensor]:
     """all-to-all of equally shaped blocks: blocks[j] goes to rank j, the result's entry i came from rank i.  RCCL / MPI:
-    `all_to_all_single`; backends without it (gloo, used by the CPU tests): an all-gather of everything, keeping my column."""
+    `all_to_all_single`; gloo (the CPU tests) has no all-to-all: an all-gather of everything, keeping my column (world times the
+    bytes).  The path is chosen from the backend up front -- a failing collective propagates instead of being retried on a
+    communicator that other ranks may still be using."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     send = torch.stack(blocks, 0).contiguous()
-    try:
+    if str(dist.get_backend(group)).lower() != "gloo":
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=group)
         return list(recv.unbind(0))
-    except (RuntimeError, NotImplementedError):
-        every = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(every, send, group=group)
-        return [every[i][rank] for i in range(world)]
+    every = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(every, send, group=group)
+    return [every[i][rank] for i in range(world)]
 
 
 def offaxis_forward(pass_fn: Callable[[Tensor, Tensor, int], Tensor], src: Tensor, pos: Tensor, group=None, gather: bool = True) -> Tensor:

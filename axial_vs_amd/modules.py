@@ -16,7 +16,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import math
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -144,6 +144,7 @@ def _guarded(fn):
         for a in args:
             if isinstance(a, Tensor) and a.is_cuda:
                 with _on(a.device):
+                    _select_status_word(a.device)
                     return fn(*args, **kw)
         return fn(*args, **kw)
     return wrapper
@@ -172,6 +173,22 @@ def _sine_tag(pos: Tensor) -> Optional[SineTag]:
 
 
 _status_words: Dict[str, Tensor] = {}
+_status_current: List[Optional[str]] = [None]      # device whose word the library currently holds (it keeps ONE pointer per thread)
+
+
+def _select_status_word(device: torch.device) -> None:
+    """The library holds a single status pointer; with range checks enabled on several devices, hand it the word of the device
+    the next call launches on (a word of another device would be a cross-device atomic: a fault without peer access, and the
+    flag would land on the wrong device).  A device without a registered word gets none."""
+    if not _status_words:
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = f"cuda:{idx}"
+    if _status_current[0] == key:
+        return
+    w = _status_words.get(key)
+    _lib.check(_lib.lib().axvs_set_status_buffer(w.data_ptr() if w is not None else None), "axvs_set_status_buffer")
+    _status_current[0] = key
 
 
 def enable_range_check(device="cuda") -> None:
@@ -184,6 +201,7 @@ def enable_range_check(device="cuda") -> None:
     if w is None:
         w = _status_words[str(dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().axvs_set_status_buffer(w.data_ptr()), "axvs_set_status_buffer")
+    _status_current[0] = str(dev)
 
 
 def range_check_report(device="cuda", reset: bool = True) -> bool:
@@ -201,6 +219,8 @@ def range_check_report(device="cuda", reset: bool = True) -> bool:
 
 
 def disable_range_check() -> None:
+    _status_words.clear()
+    _status_current[0] = None
     _lib.check(_lib.lib().axvs_set_status_buffer(None), "axvs_set_status_buffer")
 
 

@@ -126,7 +126,8 @@ class _AxialLayerTrain(torch.autograd.Function):
                                                     d_pos.data_ptr() if want_pos else None, B, T, H, W, C_, heads, F, p_dropout, p_attn_drop,
                                                     seed, int(recompute), saved_ptr, nsaved, scratch_ptr, nscr, _stream(dev)),
                        "axvs_axial_layer_train_bwd")
-        ctx.saved_buf = None
+        # (the saved activations stay with ctx until autograd releases it: a second backward through the same graph --
+        #  retain_graph=True, shared subgraphs -- finds them again)
         sd, pd, wd = ctx.in_dtypes
         out_grads = [gr.to(dt) for gr, dt in zip(grads, wd)]
         return (d_src.view(ctx.shapes[0]).to(sd), d_pos.view(ctx.shapes[1]).to(pd) if want_pos else None, None, None, None, None, None,
