@@ -7,6 +7,8 @@
 // exactly one wave, so weights go L2 -> VGPR directly (1 KiB coalesced loads from the blocked layout), a whole GEMM
 // phase ahead of their use, and never touch LDS.  MFMA orientation is D[channel][token] (weights = A operand).
 #pragma once
+#include <type_traits>
+
 #include "axvs_common.h"
 
 namespace axvs {
@@ -510,24 +512,29 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
     AXVS_STAMP(11);
     stage_small();                       // behind the cold Q / K loads of the first frame instead of in front of the barrier
-#pragma unroll 2
-    for (int f = 0; f < T; ++f) {
+    // One frame.  PAR = f & 1 as a compile-time constant (the K fragment sets alternate; register arrays need static indices).
+    // LAST: the sequence's last frame -- no K prefetch for a next one, and the first GEMM phase's weight fragments (Wpq rows of
+    // my head) are requested as soon as the score registers are free, so their L2 latency hides behind the last AV products and
+    // the barrier instead of following them.
+    auto frame = [&](const int f, auto par_tag, auto last_tag) {
+      constexpr int PAR = decltype(par_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
       vp += NKS * 1024;
-      if (f + 1 < T) {
+      if constexpr (!LAST) {
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
-      }
 #pragma unroll
-      for (int kt = 0; kt < 2 * NKS; ++kt) kb[(f + 1) & 1][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+        for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+      }
       f32x4 sc[MT][2 * NKS];
 #pragma unroll
       for (int kt = 0; kt < 2 * NKS; ++kt) {
 #pragma unroll
-        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kb[f & 1][kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
+        for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kb[PAR][kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
       }
       if (ragged) {
 #pragma unroll
@@ -547,8 +554,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
-        mx = groups_max(mx);
+          for (int r = 0; r < 4; ++r) mx = fmaximum(mx, sc[qt][kt][r]);      // v_maximum3_f32: no NaN-quieting copies
+        mx = groups_maximum(mx);
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 mx2 = {mx, mx};
 #pragma unroll
@@ -568,6 +575,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int ks = 0; ks < NKS; ++ks) ssum = H16<BF>::mfma(ones, pf[qt][ks], ssum);
         inv[qt] = __builtin_amdgcn_rcpf(ssum[0]);   // 1 ulp; the result is rounded to 16 bits right after
       }
+      if constexpr (LAST) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
       f32x4 xa[MT][2];
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) {
@@ -591,9 +599,20 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #ifdef AXVS_STAMPS
       if (f == 0) { AXVS_STAMP(12); } else if (f == 1) { AXVS_STAMP(13); } else if (f == 2) { AXVS_STAMP(14); } else { AXVS_STAMP(15); }
 #endif
+    };
+    {
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      int f = 0;
+#pragma nounroll
+      for (; f + 2 <= T - 1; f += 2) {
+        frame(f, I0{}, std::false_type{});
+        frame(f + 1, I1{}, std::false_type{});
+      }
+      if constexpr (((T - 1) & 1) != 0) frame(T - 2, I0{}, std::false_type{});
+      frame(T - 1, std::integral_constant<int, (T - 1) & 1>{}, std::true_type{});
     }
     if (spatial_only) return;            // bench.py times QK^T / softmax / AV alone with this (nothing is written)
-    load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
   } else {
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
   {
@@ -950,8 +969,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
         *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{a[i].x, a[i].y, a[i].z, a[i].w});
         *reinterpret_cast<u16x4*>(tqk + o) = cvt4<BF>(f32x4{a[i].x + p[i].x, a[i].y + p[i].y, a[i].z + p[i].z, a[i].w + p[i].w});
         if (!BF) {     // fp16 operands: remember the largest magnitude that gets rounded (range check below)
-          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[i].x), fabsf(a[i].y)), fmaxf(fabsf(a[i].z), fabsf(a[i].w))));
-          amax = fmaxf(amax, fmaxf(fmaxf(fabsf(a[i].x + p[i].x), fabsf(a[i].y + p[i].y)), fmaxf(fabsf(a[i].z + p[i].z), fabsf(a[i].w + p[i].w))));
+          amax = fmaximum(amax, fmaximum(fmaximum(fabsf(a[i].x), fabsf(a[i].y)), fmaximum(fabsf(a[i].z), fabsf(a[i].w))));
+          amax = fmaximum(amax, fmaximum(fmaximum(fabsf(a[i].x + p[i].x), fabsf(a[i].y + p[i].y)), fmaximum(fabsf(a[i].z + p[i].z), fabsf(a[i].w + p[i].w))));
         }
       }
       lds_fence();

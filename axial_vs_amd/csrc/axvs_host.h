@@ -31,7 +31,6 @@ inline int fail(int code, const char* fmt, ...) {
 // never to the size of the launch at hand: the cache below remembers only THAT a kernel was configured, so a shape-dependent
 // size would pin the first (possibly smaller) request and fail a later, larger launch.
 inline int ensure_max_lds(const void* fn) {
-  constexpr int bytes = 160 * 1024;
   constexpr int kCap = 256;
   struct Entry { int dev; const void* fn; };
   static thread_local Entry seen[kCap];
@@ -40,6 +39,10 @@ inline int ensure_max_lds(const void* fn) {
   if (hipGetDevice(&dev) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipGetDevice failed");
   for (int i = 0; i < nseen; ++i)
     if (seen[i].fn == fn && seen[i].dev == dev) return AXVS_OK;
+  // the dynamic part may use what the kernel's static __shared__ objects leave of the CU's 160 KiB
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipFuncGetAttributes failed");
+  const int bytes = 160 * 1024 - (int)((fa.sharedSizeBytes + 255) / 256 * 256);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
     return fail(AXVS_ERR_LAUNCH, "hipFuncSetAttribute failed");
   if (nseen < kCap) seen[nseen++] = Entry{dev, fn};

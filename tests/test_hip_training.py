@@ -202,3 +202,26 @@ def test_training_random_shapes_sweep():
         worst = max(worst, max(errs))
         assert max(errs) < TOL, (B, T, C, H, W, F, p_drop, p_attn, max(errs))
     print(f"8 random training shapes: worst error {worst:.2e}")
+
+
+def test_lds_attribute_is_not_pinned_to_the_first_shape():
+    """The spatial-attention kernels of the training tier size their LDS by T * max(H, W); above 64 KiB the per-kernel
+    attribute has to be raised.  It used to be raised to the size of the FIRST such launch and cached, so a later, larger
+    shape in the same process (multi-scale training) -- or the height pass of a clip with H > W, which follows the smaller
+    width pass inside one backward -- failed to launch.  Two shapes with 304 * ceil16(T * L) > 64 KiB, in increasing order."""
+    worst = 0.0
+    for i, (B, T, C, H, W, F) in enumerate([(1, 4, 256, 8, 56, 256), (1, 4, 256, 96, 60, 256)]):
+        # (seed 300 at the first shape puts one linear1 pre-activation within fp32 rounding of zero: the fp32 tier and the float64
+        #  oracle then disagree about that unit's ReLU mask and d_src moves by 1e-2 at one token -- a tie, not an error)
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 310 + i)
+        src, pos = orc.synthetic_clip(B, T, C, H, W, 310 + i)
+        d_out = torch.randn(B * T, H * W, C, generator=torch.Generator().manual_seed(i))
+        wd = {k: v.double().requires_grad_(True) for k, v in w.items()}
+        sd, pd = src.double().requires_grad_(True), pos.double().requires_grad_(True)
+        ref = orc.axial_layer_train(sd, pd, wd, 8, 0.0, 0.0, 1)
+        ref.backward(d_out.double())
+        out, d_src, d_pos, grads = run(make_layer(C, F, w, 0.0, 0.0, 1), src, pos, d_out)
+        errs = [rel_err(out, ref.detach()), rel_err(d_src, sd.grad), rel_err(d_pos, pd.grad)]
+        worst = max(worst, max(errs))
+        assert max(errs) < TOL, (H, W, errs)
+    print(f"two LDS sizes above 64 KiB in one process: worst error {worst:.2e}")

@@ -1,0 +1,42 @@
+#!/bin/bash
+# tools/ab_run.sh [rounds] -- per-kernel averages (rocprofv3 --kernel-trace --stats) of bench.py for every tools/ab/*.so, interleaved
+# `rounds` times on this box; summary in gpurun_out/ab_summary.txt
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+ROUNDS=${1:-2}
+shift
+OUT=$R/gpurun_out/ab
+rm -rf $OUT; mkdir -p $OUT
+for r in $(seq 1 $ROUNDS); do
+  for so in $R/tools/ab/*.so; do
+    n=$(basename $so .so)
+    AXVS_LIB_PATH=$so rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${n}_$r -- python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extras "$@" > $OUT/${n}_$r.log 2>&1
+    cp $OUT/${n}_$r/*/*kernel_stats.csv $OUT/${n}_$r.stats.csv; rm -rf $OUT/${n}_$r
+  done
+done
+python3 - <<PY > $R/gpurun_out/ab_summary.txt
+import csv, glob, collections, json, os
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob("$OUT/*.stats.csv")):
+    n = os.path.basename(f)[:-len(".stats.csv")].rsplit("_", 1)[0]
+    rows = [r for r in csv.DictReader(open(f)) if "axvs" in r["Name"] and int(r["Calls"]) >= 100]
+    per_step = min(int(r["Calls"]) for r in rows)          # the least-launched kernel runs once per forward
+    for r in rows:
+        k = r["Name"].replace("void axvs::", "").split("(")[0][:52]
+        res[n][k].append(float(r["AverageNs"]) / 1e3 * round(int(r["Calls"]) / per_step))
+for f in sorted(glob.glob("$OUT/*.log")):
+    n = os.path.basename(f).rsplit("_", 1)[0]
+    for l in open(f):
+        if l.startswith("{"):
+            res[n]["ms_per_step(us)"].append(json.loads(l)["ms_per_step"] * 1e3)
+kernels = sorted({k for v in res.values() for k in v})
+for k in kernels:
+    print(k)
+    for n in sorted(res):
+        v = res[n].get(k, [])
+        if v: print(f"    {n:24s} " + " ".join(f"{x:8.2f}" for x in v) + f"   | min {min(v):8.2f}")
+print("kernel sum per step (min over rounds):")
+for n in sorted(res):
+    print(f"    {n:24s} {sum(min(v) for k, v in res[n].items() if k != 'ms_per_step(us)'):8.2f}")
+PY
+cat $R/gpurun_out/ab_summary.txt
