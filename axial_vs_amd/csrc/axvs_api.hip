@@ -37,6 +37,8 @@ thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN
 thread_local int g_no_reassoc = 0;       // option "no_reassoc": generic tier computes k2, v2 = proj_kv(x) for every frame slot (the reference's form)
 thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN activation is exact GELU (F.gelu) instead of ReLU -- set by the
                                          // host module around its calls for activation="gelu" (WC/temporal_attention.py:9-17); unfused FFN path
+thread_local int g_no_vrow = 0;          // option "no_vrow": the 64-row fused kernels read V block-transposed (V^T from the QKV kernel) also where the row form applies
+thread_local int g_no_qkv_fusion = 0;    // option "no_qkv_fusion": the width pass's q/k/v come from their own qkv_fused_kernel launch instead of the height-pass kernel
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
@@ -220,8 +222,18 @@ bool ffn_split_applies(int C, int heads, int F, long long M) {
   return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < 128 * 64;
 }
 
+// 64-row tiles (MT = 4) of the fused trajectory kernel: T <= 4, and either the FFN rides along or there are enough tiles to
+// fill the chip (few tiles take 16-row tiles: 4x the workgroups) -- the choice launch_temporal makes
+bool traj_mt4(int T, long long tiles64, bool with_ffn) { return T <= 4 && (with_ffn || tiles64 >= 128 || g_no_small_tiles); }
+long long traj_tiles64(long long Mp, int N) { return (Mp / N) * ((N + 63) / 64); }
+// V in row form (K's layout; staged through the x tile and read back transposed): 64-row tiles, at most 64 keys per frame
+bool can_vrow(int T, int L, long long Mp, bool with_ffn) {
+  return !g_no_vrow && L <= 64 && traj_mt4(T, traj_tiles64(Mp, T * L), with_ffn);
+}
+
 // what one axial layer's launch sequence touches in the workspace (the same predicates run_traj / run_ffn dispatch on)
 struct LayerPlan {
+  bool fuse_qkv;      // the width pass's q/k/v are produced by the height-pass kernel (second q/k/v set in the workspace)
   bool lean_traj;     // both passes fully fused
   bool need_buf2;     // the width pass writes rows for a separate FFN launch
   bool need_ffn_tmp;  // generic FFN (LayerNorm / GEMM / GEMM / LayerNorm): fp32 scratch + 16-bit y and h
@@ -232,6 +244,9 @@ LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool w
   const long long rows = (long long)B * T * H * W;
   p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn, rows) && can_fuse_attn(C, heads, T, W, want_attn, rows);
   p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn, rows) && can_fuse_ffn_into_pass(T, F, rows));
+  // height-pass kernel on 64-row tiles without the FFN, width pass on the row-form kernels
+  p.fuse_qkv = p.lean_traj && !g_no_qkv_fusion && traj_mt4(T, traj_tiles64(rows, T * H), false) &&
+               can_vrow(T, W, rows, can_fuse_ffn_into_pass(T, F, rows));
   p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
   p.need_ffn_part = p.need_buf2 && ffn_split_applies(C, heads, F, rows);
   return p;
@@ -260,37 +275,38 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
 // nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel
 template <bool BF>
 int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
-                    float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr) {
+                    float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr, int vrow = 0, const NextQkv* nq = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
   const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? 2 : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
-  const long long tiles64 = nks > 0 ? (Mp / N) * ((N + 63) / 64) : (Mp + 63) / 64;
+  const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
+  if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
   if (fa == nullptr && (tiles64 < 128 || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
     switch (T) {
-      case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 3: return launch_temporal_n<BF, 3, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 4: return launch_temporal_n<BF, 4, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 5: return launch_temporal_n<BF, 5, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 6: return launch_temporal_n<BF, 6, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 7: return launch_temporal_n<BF, 7, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 8: return launch_temporal_n<BF, 8, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 9: return launch_temporal_n<BF, 9, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 10: return launch_temporal_n<BF, 10, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 11: return launch_temporal_n<BF, 11, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-      case 12: return launch_temporal_n<BF, 12, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+      case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 3: return launch_temporal_n<BF, 3, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 4: return launch_temporal_n<BF, 4, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 5: return launch_temporal_n<BF, 5, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 6: return launch_temporal_n<BF, 6, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 7: return launch_temporal_n<BF, 7, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 8: return launch_temporal_n<BF, 8, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 9: return launch_temporal_n<BF, 9, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 10: return launch_temporal_n<BF, 10, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 11: return launch_temporal_n<BF, 11, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 12: return launch_temporal_n<BF, 12, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
       default: break;
     }
   }
   switch (T) {
-    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 6: return launch_temporal_n<BF, 6, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);     // x tile: T * 16 KiB of LDS
-    case 7: return launch_temporal_n<BF, 7, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 8: return launch_temporal_n<BF, 8, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 6: return launch_temporal_n<BF, 6, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);     // x tile: T * 16 KiB of LDS
+    case 7: return launch_temporal_n<BF, 7, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 8: return launch_temporal_n<BF, 8, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
     default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 8");
   }
 }
@@ -301,7 +317,8 @@ template <bool BF>
 int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const float* qk_add, const float* res, float* out,
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
              hipStream_t st, int pass = 0, const FfnArgs* ffn = nullptr, float* ffn_out = nullptr, bool* ffn_done = nullptr,
-             const PosGen* posgen = nullptr) {
+             const PosGen* posgen = nullptr, const NextQkv* nq = nullptr /* the kernel also emits q, k, v of the next pass */,
+             bool have_qkv = false /* w.q16 / k16 / vt16 already hold q, k and row-form v (written by the previous pass's kernel) */) {
   static const char* const kNames[3][8] = {
       {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused", "traj_fused"},
       {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused", "h.traj_fused"},
@@ -316,6 +333,12 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
 
   const bool fuse_attn = qsrc == ksrc && vsrc == qsrc && can_fuse_attn(C, heads, T, L, attn != nullptr, Mp);
   const int nks_fused = (L + 31) / 32;
+  const bool with_ffn = fuse_attn && ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F, Mp);
+  // row-form V (K's layout, 16-byte stores from any producer) on the 64-row fused kernels with at most 64 keys per frame
+  const bool vrow = fuse_attn && can_vrow(T, L, Mp, with_ffn);
+  if ((have_qkv || nq) && !vrow && !(nq && fuse_attn && traj_mt4(T, traj_tiles64(Mp, N), with_ffn)))
+    return fail(AXVS_ERR_ARG, "internal: fused q/k/v hand-over outside the 64-row fused tier");
+  if (have_qkv) goto qkv_done;
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
   if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&qkv_fused_kernel<BF>))) return rc;
@@ -325,9 +348,9 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
       const unsigned qtiles = (unsigned)((Mp + 63) / 64);
       // few tiles (cross-clip queries): one workgroup per (tile, q | k | v) -- a third of the weight stream each
       hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3(qtiles, (qtiles <= 64 && !g_no_small_tiles) ? 3 : 1), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
-                         p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, w.v16, Mp, scale * kLog2e,
-                         fuse_attn ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{},
-                         (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0, g_status);
+                         p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, vrow ? w.vt16 : w.v16, Mp, scale * kLog2e,
+                         (fuse_attn && !vrow) ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{},
+                         (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0, g_status, vrow ? 1 : 0);
       goto qkv_done;
     }
   }
@@ -339,14 +362,14 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
     launch_gemm<BF>(av, p.wv, EpiBlocked16<BF>{w.v16, Mp, p.bv, 1.f, 0, 0}, M, Cp, C, st);
   }
 qkv_done:
-  mark(st, nm[0]);
+  if (!have_qkv) mark(st, nm[0]);
   if (fuse_attn) {
     // the layer's FFN can ride along (64-row tiles, LDS budget): `out` then receives norm2(FFN(norm1(...)))
-    const bool with_ffn = ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F, Mp);
-    int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr);
+    int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr,
+                                 vrow ? 1 : 0, nq);
     if (rc != AXVS_OK) return rc;
     if (with_ffn) *ffn_done = true;
-    mark(st, with_ffn ? "w.traj_fused+ffn" : nm[7]);
+    mark(st, with_ffn ? "w.traj_fused+ffn" : nq ? "h.traj_fused+w.qkv" : nm[7]);
     return AXVS_OK;
   }
 
@@ -514,6 +537,9 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   Carver wc(ws);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
   TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
+  // second q / k / v set: the height-pass kernel writes the width pass's operands while other tiles still read its own
+  const bool fuse_qkv = plan.fuse_qkv && which == 0;
+  TrajWs tw2 = plan.fuse_qkv ? carve_traj_ws(wc, M, T, heads, true) : tw;
   float* buf1 = wc.take<float>((size_t)M * C);
   float* const scratch1 = buf1;                // fp32 scratch of the generic FFN path (free once the width pass has read the rows)
   float* buf2 = plan.need_buf2 ? wc.take<float>((size_t)M * C) : nullptr;
@@ -549,8 +575,17 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   // height pass: sequences (b, w), tokens (t, h)        WC/temporal_attention.py:197-204
   RowMap rmh{T * H, H, W, sB, sT, W, 1};
   int rc = AXVS_OK;
+  // the width pass's q, k, v from the height-pass kernel (its output rows are in LDS there): WC/temporal_attention.py:206-212
+  NextQkv nq{};
+  if (fuse_qkv) {
+    const float kLog2e = 1.4426950408889634f;
+    nq = NextQkv{p.tw.wq, p.tw.wk, p.tw.wv, p.tw.bq, p.tw.bk, p.tw.bv, tw2.q16, tw2.k16, tw2.vt16, ph ? nullptr : pos, ph ? pgh : PosGen{},
+                 kLog2e / sqrtf((float)(C / heads)), (!g_no_wt_stores && 2 * (long long)heads * 32 * M * 2 < (1ll << 32)) ? 1 : 0, g_status};
+    nq.pg.l_is_h = 1;
+  }
   if (which != 2) {
-    rc = run_traj<BF>(src, src, src, pos, src, which == 1 ? out : buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1, nullptr, nullptr, nullptr, ph);
+    rc = run_traj<BF>(src, src, src, pos, src, which == 1 ? out : buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1, nullptr, nullptr, nullptr, ph,
+                      fuse_qkv ? &nq : nullptr);
     if (rc != AXVS_OK) return rc;
     if (which == 1) return last_launch_status();
   } else {
@@ -560,7 +595,8 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   RowMap rmw{T * W, W, H, sB, sT, 1, W};
   const FfnArgs fa{p.w1, p.w2, p.b1, p.b2, p.g1, p.be1, p.g2, p.be2, F};
   bool ffn_done = false;
-  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, tw, rmw, B * H, T, W, C, heads, st, 2, &fa, out, &ffn_done, pw);
+  rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, fuse_qkv ? tw2 : tw, rmw, B * H, T, W, C, heads, st, 2, &fa, out, &ffn_done, pw,
+                    nullptr, fuse_qkv);
   if (rc != AXVS_OK) return rc;
   if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
@@ -965,6 +1001,8 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_vrow")) { g_no_vrow = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_qkv_fusion")) { g_no_qkv_fusion = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }
@@ -1054,6 +1092,7 @@ size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, in
   Carver c(nullptr);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, d_ffn, want_attn_maps != 0);
   carve_traj_ws(c, M, T, heads, plan.lean_traj);
+  if (plan.fuse_qkv) carve_traj_ws(c, M, T, heads, true);
   c.take<float>((size_t)M * C);
   if (plan.need_buf2) c.take<float>((size_t)M * C);
   if (plan.need_ffn_tmp) {

@@ -275,25 +275,27 @@ struct WtBuf {
 
 // ---- in-kernel phase stamps: diagnostic builds only (-DAXVS_STAMPS); the shipped library contains none ----
 #ifdef AXVS_STAMPS
-static __device__ unsigned long long g_stamps[32 * 64];   // per translation unit; g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]
+static __device__ unsigned long long g_stamps[64 * 64];   // per translation unit; g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]
 // Stamps stay in SGPRs until AXVS_STAMP_FLUSH at the end of the kernel: no VGPR cost where registers are tight
 // (a first version that stored each stamp immediately pushed a 250-VGPR kernel into spills and mis-measured it).
-#define AXVS_STAMP_DECL unsigned long long st_[16] = {}
+#define AXVS_STAMP_DECL unsigned long long st_[24] = {}
 #define AXVS_STAMP(slot)                                                                      \
   do {                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_[slot])::"memory");      \
     __builtin_amdgcn_sched_barrier(0);                                                        \
   } while (0)
-#define AXVS_STAMP_FLUSH(n)                                                                   \
+#define AXVS_STAMP_FLUSH_AT(base, n)                                                          \
   do {                                                                                        \
     if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)                                            \
-      for (int i_ = 0; i_ < (n); ++i_) ::axvs::g_stamps[i_ * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = st_[i_]; \
+      for (int i_ = 0; i_ < (n); ++i_) ::axvs::g_stamps[((base) + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = st_[i_]; \
   } while (0)
+#define AXVS_STAMP_FLUSH(n) AXVS_STAMP_FLUSH_AT(0, n)
 #else
 #define AXVS_STAMP_DECL
 #define AXVS_STAMP(slot)
 #define AXVS_STAMP_FLUSH(n)
+#define AXVS_STAMP_FLUSH_AT(base, n)
 #endif
 
 // lgkmcnt is a 4-bit counter.  hipcc (ROCm 7.2) will happily leave 16 or more LDS/SMEM operations in flight before one

@@ -357,18 +357,34 @@ namespace axvs {
 // Each wave streams exactly its own weight rows L2 -> VGPR (Wpq_h, Wk2_h, Wv2_h, Wp[32w..]: 64 KiB), one 64-VGPR fragment
 // set that is refilled in place, slot by slot, right after a slot's last use.
 // =====================================================================================================
-template <int T, int MT, bool FFN = false>
+template <int T, int MT, bool FFN = false, bool QKVN = false>
 constexpr size_t temporal_tile_bytes() {
   // x tile, re-used as: o tile | fp32 epilogue tile [| h tile of the FFN half; its y tile takes the o tile's place]
+  //                    [| value tile of the next pass's q/k/v projections (QKVN); their (rows + pos) tile takes the o tile's place]
   size_t xt = (size_t)T * 8 * MT * 16 * 32 * sizeof(u16);
   size_t epi = (size_t)8 * MT * 16 * 32 * sizeof(u16) + (size_t)MT * 16 * kEpiLd * sizeof(float);
-  if (FFN) epi += (size_t)8 * MT * 16 * 32 * sizeof(u16);
+  if (FFN || QKVN) epi += (size_t)8 * MT * 16 * 32 * sizeof(u16);
   return xt > epi ? xt : epi;
 }
-template <int T, int MT, bool FFN = false>
+template <int T, int MT, bool FFN = false, bool QKVN = false>
 constexpr size_t temporal_lds_bytes(int F = 0) {   // tiles | bpq, bv2, bp | FFN parameters
-  return temporal_tile_bytes<T, MT, FFN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0);
+  return temporal_tile_bytes<T, MT, FFN, QKVN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0);
 }
+
+// QKVN: what the trajectory kernel of one pass needs to emit q, k, v of the NEXT pass from its own output rows (they are in LDS
+// anyway), instead of a separate qkv_fused_kernel launch that gathers the same rows from HBM again: packed weights / biases of
+// the next pass's q, k, v Linear layers, its blocked 16-bit outputs ([8][Mp][32], 32 channels of a head in perm32 order, V too),
+// the positional term (generated or read), and the fp16 range-check word.
+struct NextQkv {
+  const u16 *Wq, *Wk, *Wv;
+  const float *bq, *bk, *bv;
+  u16 *Q16, *K16, *V16;
+  const float* pos;       // nullable; read when pg.mode == 0
+  PosGen pg;              // pg.l_is_h refers to THIS pass's row map (the coordinates are taken from it)
+  float qscale;
+  int wt;                 // write-through stores (byte offsets < 4 GiB)
+  int* status;
+};
 
 template <int MT>
 __device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // element offset in the x tile
@@ -414,7 +430,13 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
 //          the T-expanded tensor never touches HBM.  Needs the tile inside one sequence (N % (16*MT) == 0), L % 16 == 0.
 // FFN: the rows do not go back to HBM after the residual; norm1 -> FFN -> norm2 (ffn_body) runs on them right here and `out`
 //      receives the layer output (MT = 4 only).
-template <bool BF, int T, int MT, int NKS = 0, bool FFN = false>
+// VROW: V arrives row-major, [8 heads][Mp][32 channels in perm32 order] -- the layout of K -- instead of block-transposed.  A frame's
+//       rows (L <= 64: 4 KiB per head) are staged in the wave's own, not yet written, block of the x tile and read back with the
+//       transposing LDS load (ds_read_b64_tr_b16) as the A operand of the AV products.  This is what lets a producer store V with
+//       16-byte rows from any tile shape (QKVN below); MT = 4, NKS <= 2 only.
+// QKVN: after the residual, q / k / v of the NEXT pass are computed from the 64 output rows still in LDS (NextQkv) and stored in
+//       that pass's sequence order.
+template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, bool VROW = false, bool QKVN = false>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
                                                              const u16* __restrict__ Wpq, const float* __restrict__ bpq,
                                                              const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
@@ -427,12 +449,14 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */,
                                                              int spatial_only = 0 /* measurement: stop after the QK^T / AV half */,
                                                              const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
-                                                             const float* __restrict__ ln_b = nullptr) {
+                                                             const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{}) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
+  static_assert(!VROW || (MT == 4 && NKS >= 1 && NKS <= 2), "row-major V is staged in a 64-row x-tile block: 64 keys per frame at most");
+  static_assert(!QKVN || (MT == 4 && !FFN && NKS > 0), "the next pass's q/k/v ride in the 64-row kernel without the FFN");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
-  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN>());   // bpq | bv2 | bp
+  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN, QKVN>());   // bpq | bv2 | bp
   FfnLds fl;
   if constexpr (FFN) {
     fl.ytile = xt;
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const u16* Qh = Q16 + (long long)wave * Mp * 32;
     const u16* Kh = K16 + (long long)wave * Mp * 32;
     const long long nsf = Mp / L;                               // frame slots (sequences x frames)
-    const u16* Vh = VT16 + (long long)wave * nsf * NKS * 1024;
+    const u16* Vh = VROW ? VT16 + (long long)wave * Mp * 32 : VT16 + (long long)wave * nsf * NKS * 1024;
     u16x8 qf[MT];
 #pragma unroll
     for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + min(qt * 16 + fi, nvalid - 1)) * 32 + fg * 8);
@@ -508,6 +532,26 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] = Kh + (seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8;
     const u16* vp = Vh + (seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8;
     const int kstep = L * 32;
+    // VROW: the frame's V rows go global -> registers -> the wave's own block [f][wave] of the x tile (free until the frame's x is
+    // stored there) -> transposed back into A fragments.  16-byte load n of a lane covers the 16 rows
+    // {32 (n >> 1) + 8 a + 4 (n & 1) + b : a, b = 0..3} of the frame (chunk = lane & 3): all of them have the same bit 2, so the
+    // bank swizzle of the LDS image -- the two 8-byte halves of a chunk swapped in rows with bit 2 set, which makes the
+    // transposed reads conflict-free (rows r and r + 4 would share banks) -- is a compile-time register permutation.
+    constexpr int NVL = VROW ? 2 * NKS : 1;
+    const u16* vrp[NVL];
+    int vwo[NVL], vtr[2];
+    if constexpr (VROW) {
+#pragma unroll
+      for (int n = 0; n < NVL; ++n) {
+        const int row = 32 * (n >> 1) + 8 * (lane >> 4) + 4 * (n & 1) + ((lane >> 2) & 3);
+        vrp[n] = Vh + (seq0 + min(row, L - 1)) * 32 + (lane & 3) * 8;
+        vwo[n] = row * 32 + (lane & 3) * 8;
+      }
+      // transposed read of fragment (nd, ks), key half hj: lane (fi, fg) supplies row 32 ks + 16 hj + 4 fg + (fi >> 2), positions
+      // 8 (fi & 3) + 4 nd .. + 3 and receives channel 16 nd + fi of the 4 keys 32 ks + 16 hj + 4 fg + (0..3)
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd) vtr[nd] = (4 * fg + (fi >> 2)) * 32 + 8 * (fi & 3) + 4 * (nd ^ (fg & 1));
+    }
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
     AXVS_STAMP(11);
@@ -519,11 +563,20 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     auto frame = [&](const int f, auto par_tag, auto last_tag) {
       constexpr int PAR = decltype(par_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;
+      u16x8 vr[NVL];
+      if constexpr (VROW) {
 #pragma unroll
-      for (int nd = 0; nd < 2; ++nd)
+        for (int n = 0; n < NVL; ++n) {
+          vr[n] = *reinterpret_cast<const u16x8*>(vrp[n]);
+          vrp[n] += kstep;
+        }
+      } else {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
-      vp += NKS * 1024;
+        for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
+        vp += NKS * 1024;
+      }
       if constexpr (!LAST) {
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
@@ -574,6 +627,26 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) ssum = H16<BF>::mfma(ones, pf[qt][ks], ssum);
         inv[qt] = __builtin_amdgcn_rcpf(ssum[0]);   // 1 ulp; the result is rounded to 16 bits right after
+      }
+      if constexpr (VROW) {
+        u16* vblk = xt + ((f * 8 + wave) * ROWS) * 32;
+#pragma unroll
+        for (int n = 0; n < NVL; ++n)
+          *reinterpret_cast<u16x8*>(vblk + vwo[n]) =
+              (n & 1) ? __builtin_shufflevector(vr[n], vr[n], 4, 5, 6, 7, 0, 1, 2, 3) : vr[n];
+        asm volatile("" ::: "memory");      // the transposed reads below are an intrinsic: keep them behind the stores
+#pragma unroll
+        for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+              typedef short s16x4v __attribute__((ext_vector_type(4)));
+              const s16x4v t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (s16x4v __attribute__((address_space(3)))*)(vblk + vtr[nd] + (32 * ks + 16 * hj) * 32));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) vf[nd][ks][4 * hj + e] = (u16)t4[e];
+            }
       }
       if constexpr (LAST) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
       f32x4 xa[MT][2];
@@ -822,10 +895,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   long long roff[RPW];
   // RowMap arithmetic (integer divisions) once per wave, lane i computing row i of the wave's RPW rows, then broadcast with
   // v_readlane -- instead of RPW unrolled copies of the same ~75-instruction sequence
+  int rcoords = 0;                                  // QKVN: (t, h, w) of the wave's row (lane % RPW), packed (nat_row_coords)
   {
     const int myrow = wave * RPW + (lane % RPW);
     const int mym = (int)m0 + min(myrow, nvalid - 1);
-    const long long myoff = nat_row(rm, mym) * C;
+    const long long myoff = (QKVN ? nat_row_coords(rm, mym, nq.pg.l_is_h, &rcoords) : nat_row(rm, mym)) * C;
     const int lo = (int)(myoff & 0xffffffffll), hi = (int)(myoff >> 32);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -837,6 +911,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // with the FFN half following, the sweep leaves the first linear1 fragment set behind
   constexpr int crot = 0;                          // fixed chunk order: results do not depend on the tile index (see ffn_fused_kernel)
   if constexpr (FFN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, fa.W1, fa.F, crot * 256 + wave * 32, fi, fg);
+  else if constexpr (QKVN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, nq.Wq, C, wave * 32, fi, fg);       // leaves the next pass's Wq rows of my head behind
   else sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
   AXVS_STAMP(7);
   // ---- row-wise epilogue: accumulators (+bias) -> LDS fp32 tile (behind the o tile) -> whole rows: + residual -> out ----
@@ -850,11 +925,35 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       epi_put(etile, mt * 16 + fi, n, f32x4{po[nt][mt][0] + b.x, po[nt][mt][1] + b.y, po[nt][mt][2] + b.z, po[nt][mt][3] + b.w});
   }
   __syncthreads();
+  // QKVN: the output rows also become the two 16-bit operand tiles of the next pass's projections -- (rows + pos) for q and k in
+  // the o tile's place (every wave is past the projection sweep), rows for v behind the fp32 tile; same image as qkv_fused_kernel's
+  u16* const tqk = xt;
+  u16* const tv = reinterpret_cast<u16*>(etile + ROWS * kEpiLd);
+  PosGenLane npl;
+  float namax = 0.f;
+  if constexpr (QKVN) {
+    if (nq.pg.mode) npl.init(nq.pg, lane * 4);
+  }
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int row = wave * RPW + i;
     const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
     float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
+    if constexpr (QKVN) {
+      float4 pp = float4{0.f, 0.f, 0.f, 0.f};
+      if (nq.pg.mode) pp = npl.eval(nq.pg, __builtin_amdgcn_readlane(rcoords, i));
+      else if (nq.pos) pp = *reinterpret_cast<const float4*>(nq.pos + roff[i]);
+      const int n = lane * 4, kb = n >> 5, kk = n & 31;
+      const int o = (kb * ROWS + row) * 32 + swz_chunk(row, kk >> 3) * 8 + (kk & 7);
+      const f32x4 yq = {y.x + pp.x, y.y + pp.y, y.z + pp.z, y.w + pp.w};
+      *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{y.x, y.y, y.z, y.w});
+      *reinterpret_cast<u16x4*>(tqk + o) = cvt4<BF>(yq);
+      if (!BF) {
+        namax = fmaximum(namax, fmaximum(fmaximum(fabsf(y.x), fabsf(y.y)), fmaximum(fabsf(y.z), fabsf(y.w))));
+        namax = fmaximum(namax, fmaximum(fmaximum(fabsf(yq[0]), fabsf(yq[1])), fmaximum(fabsf(yq[2]), fabsf(yq[3]))));
+      }
+      if (i == 3) lds_fence();
+    }
     if constexpr (!FFN) {
       if (ln_g) {      // post-norm layer (cross-clip TrajectoryAttentionLayer.forward_post, CC/...:156-161): LayerNorm(x + attn(x)), eps 1e-5
         const float mu = wave_sum(y.x + y.y + y.z + y.w) * (1.f / C);
@@ -871,6 +970,61 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
   AXVS_STAMP(8);
+  if constexpr (QKVN) {
+    // ---- q, k, v of the NEXT pass (WC/temporal_attention.py:42-44 on this pass's output, :206-212): three sweeps over the tiles
+    //      just written; each refills the fragment set for the one after it.  Outputs in the next pass's sequence order: with
+    //      this pass's decomposition m' = ((b Loff + o) T + t) L + l of a row, the next pass (axes swapped: its on-axis
+    //      coordinate is o, its sequences are (b, l)) has m'' = ((b L + l) T + t) Loff + o.
+    if (!BF && nq.status != nullptr && !(namax <= 65504.f)) atomicOr(nq.status, 1);
+    lds_fence();
+    __syncthreads();
+    AXVS_STAMP(16);
+    int mnext;
+    {
+      const int m = (int)m0 + min(lane, nvalid - 1);
+      const int sq = m / rm.N, n = m - sq * rm.N;
+      const int b = sq / rm.Loff, o = sq - b * rm.Loff;
+      const int t = n / rm.L, l = n - t * rm.L;
+      mnext = ((b * rm.L + l) * T + t) * rm.Loff + o;
+    }
+    int mn[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mn[mt] = __builtin_amdgcn_ds_bpermute((mt * 16 + fi) * 4, mnext);
+    const WtBuf wq(nq.Q16), wk(nq.K16), wv(nq.V16);
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+      f32x4 acc[2][MT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (which == 0) sweep8<BF, MT, true>(acc, wf, tqk, bo, KBS, nq.Wk, C, wave * 32, fi, fg);
+      else if (which == 1) sweep8<BF, MT, true>(acc, wf, tqk, bo, KBS, nq.Wv, C, wave * 32, fi, fg);
+      else sweep8<BF, MT, false>(acc, wf, tv, bo, KBS, nq.Wv, C, 0, fi, fg);
+#ifdef AXVS_STAMPS
+      if (which == 0) { AXVS_STAMP(17); } else if (which == 1) { AXVS_STAMP(19); } else { AXVS_STAMP(21); }
+#endif
+      const float* bias = which == 0 ? nq.bq : which == 1 ? nq.bk : nq.bv;
+      const float sc_ = which == 0 ? nq.qscale : 1.f;
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + wave * 32 + fg * 4);
+      const float4 b1 = *reinterpret_cast<const float4*>(bias + wave * 32 + 16 + fg * 4);
+      u16* dst = which == 0 ? nq.Q16 : which == 1 ? nq.K16 : nq.V16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt * 16 + fi < nvalid) {   // stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r (perm32): 16 contiguous bytes per lane
+          float v8[8] = {(acc[0][mt][0] + b0.x) * sc_, (acc[0][mt][1] + b0.y) * sc_, (acc[0][mt][2] + b0.z) * sc_,
+                         (acc[0][mt][3] + b0.w) * sc_, (acc[1][mt][0] + b1.x) * sc_, (acc[1][mt][1] + b1.y) * sc_,
+                         (acc[1][mt][2] + b1.z) * sc_, (acc[1][mt][3] + b1.w) * sc_};
+          const long long d = ((long long)wave * Mp + mn[mt]) * 32 + fg * 8;
+          if (nq.wt) (which == 0 ? wq : which == 1 ? wk : wv).store16((unsigned)(d * 2), cvt8<BF>(v8));
+          else *reinterpret_cast<u16x8*>(dst + d) = cvt8<BF>(v8);
+        }
+      }
+#ifdef AXVS_STAMPS
+      if (which == 0) { AXVS_STAMP(18); } else if (which == 1) { AXVS_STAMP(20); } else { AXVS_STAMP(22); }
+#endif
+    }
+  }
   if constexpr (FFN) {
     lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
     ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
@@ -878,7 +1032,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   AXVS_STAMP(10);
 #if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)
-  AXVS_STAMP_FLUSH(16);
+  if constexpr (QKVN) AXVS_STAMP_FLUSH_AT(32, 24);      // the height-pass kernel's stamps: slots 32 .. 55 (the width pass's stay in 0 .. 15)
+  else AXVS_STAMP_FLUSH(16);
 #endif
 }
 
@@ -911,7 +1066,8 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                                                         u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
                                                         long long Mp, float qscale, u16* __restrict__ VT16, int N, int L, int T,
                                                         int NKS, PosGen pg, int wt /* write-through q/k/V^T stores (offsets < 4 GiB) */,
-                                                        int* __restrict__ status /* nullable: bit 0 <- an operand left the fp16 range */) {
+                                                        int* __restrict__ status /* nullable: bit 0 <- an operand left the fp16 range */,
+                                                        int vrow = 0 /* V16 <- v in K's layout (perm32 channel order): the VROW trajectory kernels */) {
   constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* tqk = smem;                       // (src + pos) tile [8][64][32]
@@ -923,7 +1079,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
 
   QSTAMP_DECL;
   QSTAMP(0);
-  const WtBuf wq(Q16), wk(K16), wvt(VT16);
+  const WtBuf wq(Q16), wk(K16), wvt(VT16), wvr(V16);
   // gridDim.y == 3 (few row tiles: the cross-clip modules' 512 clip queries): workgroup (tile, part) computes only q, k or v, so
   // each one streams a third of the weights -- with 8 tiles the chip is empty and the per-CU weight stream is the whole cost
   const bool split = gridDim.y == 3;
@@ -1101,12 +1257,12 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
     for (int mt = 0; mt < MT; ++mt) {
       const long long m = m0 + mt * 16 + fi;
       if (m < Mp) {
-        if (which < 2) {   // q, k: stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r: 16 contiguous bytes per lane
+        if (which < 2 || vrow) {   // q, k (v in row mode): stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r: 16 contiguous bytes per lane
           float v[8] = {(acc[0][mt][0] + b0.x) * sc, (acc[0][mt][1] + b0.y) * sc, (acc[0][mt][2] + b0.z) * sc,
                         (acc[0][mt][3] + b0.w) * sc, (acc[1][mt][0] + b1.x) * sc, (acc[1][mt][1] + b1.y) * sc,
                         (acc[1][mt][2] + b1.z) * sc, (acc[1][mt][3] + b1.w) * sc};
           const long long d = ((long long)wave * Mp + m) * 32 + fg * 8;
-          if (wt) (which == 0 ? wq : wk).store16((unsigned)(d * 2), cvt8<BF>(v));
+          if (wt) (which == 0 ? wq : which == 1 ? wk : wvr).store16((unsigned)(d * 2), cvt8<BF>(v));
           else *reinterpret_cast<u16x8*>(dst + d) = cvt8<BF>(v);
         } else {           // v: natural channel order
 #pragma unroll

@@ -13,43 +13,54 @@
 
 namespace axvs {
 
+template <bool BF, int T, int MT, int NKS, bool FFN, bool VROW, bool QKVN>
+static int launch_one(unsigned grid, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
+                      float scale, hipStream_t st, const FfnArgs* fa, int wt, const NextQkv* nq) {
+  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, VROW, QKVN>;
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern))) return rc;
+  const size_t lds = temporal_lds_bytes<T, MT, FFN, QKVN>(FFN ? fa->F : 0);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale,
+                     w.q16, w.k16, w.vt16, FFN ? *fa : FfnArgs{}, p.wk2t, wt & 1, wt >> 1, FFN ? nullptr : p.post_ln_g,
+                     FFN ? nullptr : p.post_ln_b, QKVN ? *nq : NextQkv{});
+  return AXVS_OK;
+}
+
 template <bool BF, int T, int MT, int NKS>
 static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                             float scale, hipStream_t st, const FfnArgs* fa, int wt) {
+                             float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq) {
   // with the spatial half in the kernel every sequence gets its own ceil(N / rows) tiles (see temporal_fused_kernel)
   const unsigned grid = NKS > 0 ? (unsigned)((Mp / N) * ((N + MT * 16 - 1) / (MT * 16))) : (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
   if constexpr (NKS > 0 && MT == 4) {
-    if (fa) {                                    // trajectory attention + FFN in one kernel
-      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS, true>))) return rc;
-      const size_t lds_ffn = temporal_lds_bytes<T, MT, true>(fa->F);
-      hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS, true>), dim3(grid), dim3(512), lds_ffn, st, w.x16, p.wpq, p.bpq, p.wpkv,
-                         p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, *fa, p.wk2t, wt & 1, wt >> 1);
-      return AXVS_OK;
+    if constexpr (NKS <= 2) {           // V in row form (staged in the x tile: 64 keys per frame at most)
+      if (vrow && fa) return launch_one<BF, T, MT, NKS, true, true, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
+      if (vrow && nq) return launch_one<BF, T, MT, NKS, false, true, true>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
+      if (vrow) return launch_one<BF, T, MT, NKS, false, true, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
     }
+    if (vrow) return fail(AXVS_ERR_ARG, "internal: row-major V needs nks <= 2");
+    if (fa) return launch_one<BF, T, MT, NKS, true, false, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);   // trajectory attention + FFN
+    if (nq) return launch_one<BF, T, MT, NKS, false, false, true>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);   // + next pass's q/k/v
   }
   if (fa) return fail(AXVS_ERR_ARG, "internal: FFN fusion needs the in-kernel spatial half and 64-row tiles");
-  constexpr size_t lds = temporal_lds_bytes<T, MT>();
-  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&temporal_fused_kernel<BF, T, MT, NKS>))) return rc;
-  hipLaunchKernelGGL((temporal_fused_kernel<BF, T, MT, NKS>), dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv,
-                     p.wp, p.bp, res, out, rm, Mp, N, L, scale, w.q16, w.k16, w.vt16, FfnArgs{}, p.wk2t, wt & 1, wt >> 1, p.post_ln_g, p.post_ln_b);
-  return AXVS_OK;
+  if (vrow || nq) return fail(AXVS_ERR_ARG, "internal: row-major V / next-pass q,k,v need the in-kernel spatial half and 64-row tiles");
+  return launch_one<BF, T, MT, NKS, false, false, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
 }
 
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt) {
+                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq) {
   switch (nks) {
-    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
-    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
+    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
     default: return fail(AXVS_ERR_ARG, "bad nks");
   }
 }
 
 template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, AXVS_INST_MT>(
-    int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int);
+    int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int, int,
+    const NextQkv*);
 
 }  // namespace axvs
 

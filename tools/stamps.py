@@ -18,9 +18,9 @@ p = pos.cuda() if os.environ.get("AXVS_TENSOR_POS") else ax.PositionEmbeddingSin
 for _ in range(3): layer(s, p)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * (64 * 32))()
-raw.axvs_debug_read_stamps(buf, 64 * 32)
-a = np.array(buf, dtype=np.uint64).reshape(32, 64).astype(np.int64)
+buf = (ctypes.c_ulonglong * (64 * 64))()
+raw.axvs_debug_read_stamps(buf, 64 * 64)
+a = np.array(buf, dtype=np.uint64).reshape(64, 64).astype(np.int64)
 order = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(nslots))
 a = a[order]; nslots = len(order)
 d = np.diff(a, axis=0)
