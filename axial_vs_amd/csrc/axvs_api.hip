@@ -37,8 +37,11 @@ thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN
 thread_local int g_no_reassoc = 0;       // option "no_reassoc": generic tier computes k2, v2 = proj_kv(x) for every frame slot (the reference's form)
 thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN activation is exact GELU (F.gelu) instead of ReLU -- set by the
                                          // host module around its calls for activation="gelu" (WC/temporal_attention.py:9-17); unfused FFN path
-thread_local int g_no_vrow = 0;          // option "no_vrow": the 64-row fused kernels read V block-transposed (V^T from the QKV kernel) also where the row form applies
-thread_local int g_no_qkv_fusion = 0;    // option "no_qkv_fusion": the width pass's q/k/v come from their own qkv_fused_kernel launch instead of the height-pass kernel
+// Two round-3 variants that are bit-identical to the default path and measured NOT faster on MI355X (the
+// kernel that emits the next pass's q/k/v ends in a 42 MB write burst with nothing to overlap it; 101.7 vs 101.3 us at B = 1, 870 vs
+// 838 us at B = 8) -- kept selectable, off by default:
+thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kernels read V in K's row layout (staged through the x tile, ds_read_b64_tr_b16) instead of V^T
+thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
@@ -227,8 +230,8 @@ bool ffn_split_applies(int C, int heads, int F, long long M) {
 bool traj_mt4(int T, long long tiles64, bool with_ffn) { return T <= 4 && (with_ffn || tiles64 >= 128 || g_no_small_tiles); }
 long long traj_tiles64(long long Mp, int N) { return (Mp / N) * ((N + 63) / 64); }
 // V in row form (K's layout; staged through the x tile and read back transposed): 64-row tiles, at most 64 keys per frame
-bool can_vrow(int T, int L, long long Mp, bool with_ffn) {
-  return !g_no_vrow && L <= 64 && traj_mt4(T, traj_tiles64(Mp, T * L), with_ffn);
+bool can_vrow(int T, int L, long long Mp, bool with_ffn, bool forced = false) {
+  return (g_vrow || forced) && L <= 64 && traj_mt4(T, traj_tiles64(Mp, T * L), with_ffn);
 }
 
 // what one axial layer's launch sequence touches in the workspace (the same predicates run_traj / run_ffn dispatch on)
@@ -245,8 +248,8 @@ LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool w
   p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn, rows) && can_fuse_attn(C, heads, T, W, want_attn, rows);
   p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn, rows) && can_fuse_ffn_into_pass(T, F, rows));
   // height-pass kernel on 64-row tiles without the FFN, width pass on the row-form kernels
-  p.fuse_qkv = p.lean_traj && !g_no_qkv_fusion && traj_mt4(T, traj_tiles64(rows, T * H), false) &&
-               can_vrow(T, W, rows, can_fuse_ffn_into_pass(T, F, rows));
+  p.fuse_qkv = p.lean_traj && g_qkv_fusion && traj_mt4(T, traj_tiles64(rows, T * H), false) &&
+               can_vrow(T, W, rows, can_fuse_ffn_into_pass(T, F, rows), true);
   p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
   p.need_ffn_part = p.need_buf2 && ffn_split_applies(C, heads, F, rows);
   return p;
@@ -335,7 +338,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const int nks_fused = (L + 31) / 32;
   const bool with_ffn = fuse_attn && ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F, Mp);
   // row-form V (K's layout, 16-byte stores from any producer) on the 64-row fused kernels with at most 64 keys per frame
-  const bool vrow = fuse_attn && can_vrow(T, L, Mp, with_ffn);
+  const bool vrow = fuse_attn && can_vrow(T, L, Mp, with_ffn, have_qkv);
   if ((have_qkv || nq) && !vrow && !(nq && fuse_attn && traj_mt4(T, traj_tiles64(Mp, N), with_ffn)))
     return fail(AXVS_ERR_ARG, "internal: fused q/k/v hand-over outside the 64-row fused tier");
   if (have_qkv) goto qkv_done;
@@ -1001,8 +1004,8 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
-  if (key && !strcmp(key, "no_vrow")) { g_no_vrow = value; return AXVS_OK; }
-  if (key && !strcmp(key, "no_qkv_fusion")) { g_no_qkv_fusion = value; return AXVS_OK; }
+  if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
+  if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }

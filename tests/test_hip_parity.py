@@ -1094,11 +1094,12 @@ def test_small_problem_kernels_are_bit_identical_to_the_large_problem_ones(shape
 
 @pytest.mark.parametrize("shape", [(1, 4, 256, 64, 64, 1024), (2, 3, 256, 48, 40, 512), (2, 2, 256, 57, 61, 1024), (4, 1, 256, 64, 32, 256),
                                    (1, 4, 256, 96, 64, 1024), (1, 4, 256, 64, 96, 1024)])
-def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_separate_kernels(shape):
-    """Round 3: on the 64-row fused tier the width pass's q / k / v are produced by the height-pass kernel from its output rows
-    (they are in LDS there) and V travels in K's row layout, transposed back on load (ds_read_b64_tr_b16) -- instead of a second
-    qkv_fused_kernel launch that re-reads the rows, and of block-transposed V^T stores.  Same MFMA fragments, same order: the
-    outputs have to be the same bits as with `no_qkv_fusion` (separate launch, row-form V) and with `no_vrow` (V^T everywhere)."""
+def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_default_kernels(shape):
+    """Round 3 built two variants of the 64-row fused tier: `qkv_fusion` -- the width pass's q / k / v are produced by the
+    height-pass kernel from its output rows (they are in LDS there) instead of a second qkv_fused_kernel launch that re-reads
+    them from HBM -- and `vrow` -- V travels in K's row layout and is transposed back on load (staged through the x tile,
+    ds_read_b64_tr_b16) instead of block-transposed V^T stores.  Same MFMA fragments in the same order: the outputs have to be
+    the same bits as the default path.  (Measured not faster -- DESIGN.md section 4 -- so both stay opt-in.)"""
     import axial_vs_amd as ax
     from axial_vs_amd import _lib
     B, T, C, H, W, F = shape
@@ -1108,31 +1109,24 @@ def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_separate_kernels(shap
     layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
     layer.load_state_dict(w, strict=True)
     layer = layer.cuda()
-    outs, names = {}, {}
-    for opt in (None, "no_qkv_fusion", "no_vrow"):
+    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    outs, gen, names = {}, {}, {}
+    for opt in (None, "qkv_fusion", "vrow"):
         if opt:
             _lib.check(_lib.lib().axvs_set_option(opt.encode(), 1), "axvs_set_option")
         try:
-            outs[opt] = layer(dev(src), dev(pos))[0].clone()
+            outs[opt] = layer(dev(src), dev(pos))[0].clone()      # positions read from the tensor
             names[opt] = _stage_names()
+            gen[opt] = layer(dev(src), pg)[0].clone()             # positions evaluated in the loaders
         finally:
             if opt:
                 _lib.lib().axvs_set_option(opt.encode(), 0)
     e, e2 = rel_err(outs[None].cpu(), ref), rel_l2(outs[None].cpu(), ref)
-    print(f"{shape}: {names[None][1:]} | {names['no_qkv_fusion'][1:]} | max/max {e:.2e} relL2 {e2:.2e}")
+    print(f"{shape}: {names[None][1:]} | {names['qkv_fusion'][1:]} | max/max {e:.2e} relL2 {e2:.2e}")
     if W <= 64:      # (the last shape's width pass has 96 keys per frame: V^T form, separate q/k/v launch)
-        assert "h.traj_fused+w.qkv" in names[None] and "w.qkv_proj" not in names[None], names[None]
-    assert "w.qkv_proj" in names["no_qkv_fusion"] and "w.qkv_proj" in names["no_vrow"]
-    assert torch.equal(outs[None], outs["no_qkv_fusion"])
-    assert torch.equal(outs[None], outs["no_vrow"])
-    assert e < TOL_F16 and e2 < TOL_F16
-    # the same with the positions evaluated in the loaders (PositionEmbeddingSine3D specification instead of a tensor)
-    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
-    g0 = layer(dev(src), pg)[0].clone()
-    _lib.check(_lib.lib().axvs_set_option(b"no_qkv_fusion", 1), "axvs_set_option")
-    try:
-        g1 = layer(dev(src), pg)[0].clone()
-    finally:
-        _lib.lib().axvs_set_option(b"no_qkv_fusion", 0)
-    assert torch.equal(g0, g1)
-    assert rel_err(g0.cpu(), ref) < TOL_F16
+        assert "h.traj_fused+w.qkv" in names["qkv_fusion"] and "w.qkv_proj" not in names["qkv_fusion"], names["qkv_fusion"]
+    assert "w.qkv_proj" in names[None] and "w.qkv_proj" in names["vrow"]
+    for opt in ("qkv_fusion", "vrow"):
+        assert torch.equal(outs[None], outs[opt]), opt
+        assert torch.equal(gen[None], gen[opt]), opt
+    assert e < TOL_F16 and e2 < TOL_F16 and rel_err(gen[None].cpu(), ref) < TOL_F16
