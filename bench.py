@@ -246,23 +246,28 @@ def main():
     B, T, C, H, W = (int(v) for v in args.shape.split(","))
     layer, w, src, pos = make_workload(B, T, C, H, W, seed=rank)
 
-    gathered = side = None
+    gathered = gathered16 = side = None
     if world > 1 and args.backend == "nccl":
         gathered = torch.empty(world * B * T, H * W, C, device=dev)
+        gathered16 = torch.empty(world * B * T, H * W, C, device=dev, dtype=torch.float16)     # the 16-bit map: half the link bytes
         side = torch.cuda.Stream(dev)
 
     # --graph replays the 4 launches from a captured HIP graph (axial_vs_amd.GraphedForward); measured on MI355X / ROCm 7.2 it is
     # NOT faster at this size (the Python launch path keeps ahead of the GPU), so the default stays the plain path.
     graphed = ax.GraphedForward(layer, src, pos) if args.graph else None
 
-    def step(gather=args.gather):
+    def step(gather=args.gather, half=False):
         out = graphed()[0] if graphed is not None else layer(src, pos)[0]
         if gather and gathered is not None:
             # the north star's reassembly of the output map: one contiguous RCCL all-gather (dim 0 is the shard dimension), on a
             # side stream so that it overlaps the next step's kernels
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered, out)
+                if half:
+                    o16 = out.half()
+                    dist.all_gather_into_tensor(gathered16, o16)
+                else:
+                    dist.all_gather_into_tensor(gathered, out)
                 out.record_stream(side)
         return out
 
@@ -302,9 +307,18 @@ def main():
                 gsteps = min(args.steps, 300)
                 el, _ = timed(lambda: step(True), gsteps, 5)
                 torch.cuda.synchronize(dev)
+                mb32 = (world - 1) * B * T * H * W * C * 4 / 1e6          # bytes that cross the links INTO each rank per step
+                el16, _ = timed(lambda: step(True, True), gsteps, 5)
+                torch.cuda.synchronize(dev)
+                link_peak = 7 * 153.0                                      # GB/s into one GPU over its 7 xGMI links (MI355X_MICROARCH / task notes)
                 extras["gather"] = {"value": round(world * B * T * gsteps / el, 1), "unit": "frames/s", "ms_per_step": round(el / gsteps * 1e3, 5),
+                                    "inbound_MB_per_rank_per_step": round(mb32, 1), "inbound_GBs_per_rank": round(mb32 / 1e3 / (el / gsteps), 1),
+                                    "frac_of_7x153_GBs": round(mb32 / 1e3 / (el / gsteps) / link_peak, 3),
+                                    "f16_map": {"value": round(world * B * T * gsteps / el16, 1), "ms_per_step": round(el16 / gsteps * 1e3, 5),
+                                                "inbound_MB_per_rank_per_step": round(mb32 / 2, 1),
+                                                "inbound_GBs_per_rank": round(mb32 / 2e3 / (el16 / gsteps), 1)},
                                     "what": f"{gsteps} of the same steps, every step followed by one contiguous RCCL all-gather of the output maps "
-                                            f"({world * B * T * H * W * C * 4 / 1e6:.1f} MB gathered per rank per step) on a side stream"}
+                                            f"(fp32, and cast to f16: half the link bytes) on a side stream, overlapping the next step's kernels"}
             except Exception as e:
                 extras["gather"] = {"error": str(e)[:200]}
         if world > 1 and H % world == 0 and W % world == 0:

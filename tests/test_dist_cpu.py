@@ -39,6 +39,14 @@ def _worker(rank, world, port, q):
                 out = axd.sharded_forward(fn, s_loc, p_loc, gather=True, replicated_inputs=False)
             ref = fn(src, pos)
             q.put((rank, B, float((out - ref).abs().max()), tuple(out.shape)))
+        # chunked, overlapped gather (groups of clips land in their places of the full map) and the 16-bit map
+        src, pos = orc.synthetic_clip(8, T, C, H, W, seed=6)
+        ref = fn(src, pos)
+        for chunks, dt in ((2, None), (4, None), (2, torch.bfloat16), (1, torch.float16)):
+            out = axd.sharded_forward(fn, src, pos, gather=True, chunks=chunks, gather_dtype=dt)
+            want = ref if dt is None else ref.to(dt)
+            assert out.dtype == want.dtype
+            q.put((rank, 8, float((out.float() - want.float()).abs().max()), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
@@ -51,14 +59,14 @@ def test_sharded_forward_matches_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world * len(CASES))]
+    res = [q.get(timeout=300) for _ in range(world * (len(CASES) + 4))]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert len(res) == world * len(CASES)
+    assert len(res) == world * (len(CASES) + 4)
     for rank, B, err, shape in res:
         assert shape == (B * 2, 20, 64)
-        assert err < 1e-5, (rank, B, err)   # sharding never mixes clips
+        assert err < 1e-5, (rank, B, err)   # sharding never mixes clips (the 16-bit maps are compared with the cast reference)
 
 
 def test_shard_bounds():
