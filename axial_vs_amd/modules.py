@@ -28,9 +28,10 @@ _DEFAULT_DTYPE = "f16"
 
 
 def set_default_dtype(name: str) -> None:
-    """MFMA operand type used by modules that were not given an explicit ``mfma_dtype``: 'f16' | 'bf16'."""
+    """MFMA operand type used by modules that were not given an explicit ``mfma_dtype``: 'f16' | 'bf16' | 'f32' (the last one
+    only exists for TemporalAxialTrajectoryAttentionLayer / TemporalEncoder: see TemporalAxialTrajectoryAttentionLayer.forward)."""
     global _DEFAULT_DTYPE
-    if name not in _lib.DTYPES:
+    if name not in _lib.DTYPES and name != "f32":
         raise ValueError(f"unknown dtype {name!r}")
     _DEFAULT_DTYPE = name
 
@@ -400,6 +401,15 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
                 raise NotImplementedError("axial_vs_amd: attention maps are an eval-mode output (visualize_attn)")
             from .training import axial_layer_train
             return axial_layer_train(self, src, pos, recompute=self.recompute), None, None
+        if self._dtype() == "f32":
+            # fp32 tier: the training tier's forward with dropout off -- fp32 MFMA (v_mfma_f32_16x16x4_f32) attention, fp32 GEMMs, fp32
+            # everywhere (1e-6 against the float64 oracle).  ~12x the time of the 16-bit tier: for operands beyond the fp16 range
+            # (enable_range_check reports them) or callers that need more than the 1e-3 bar.  head_dim in {8, 16, 32}, T <= 8.
+            if self.return_attn:
+                raise NotImplementedError("axial_vs_amd: attention maps are an output of the 16-bit tier (mfma_dtype 'f16' / 'bf16')")
+            from .training import axial_layer_train
+            with torch.no_grad():
+                return axial_layer_train(self, src, pos, dropout=False), None, None
         B, T, H, W = pos.shape[:4]
         s, p = _dev_f32(src, "src"), _dev_f32(pos, "pos")
         C_ = s.shape[-1]

@@ -17,8 +17,10 @@ TOL_BF16 = 1.5e-2   # bf16 operands: documented as outside the 1e-3 bar (DESIGN.
 TOL_ATTN_MAP = 3e-3
 # The free-running decoder stack (6 fused layers back to back on the temporal levels, each re-normalised by a LayerNorm): every
 # stage holds TOL_F16 on its own under teacher forcing (test_within_clip_stages_teacher_forced); the independent 16-bit operand
-# roundings of the stages add up along the stack.
-TOL_STACK = 3e-3
+# roundings of the stages add up along the stack (sqrt(layers) growth, profiles/r2_error_budget.json).  Measured at BASELINE config 3's
+# full size (round 3): max-norm 0.5 .. 1.4e-3, relative L2 2.7 .. 5.7e-4 -- the bounds are those values with a margin, no longer 3e-3:
+# max-norm TOL_STACK on the temporal levels, relative L2 inside the north star's 1e-3 everywhere.
+TOL_STACK = 1.5e-3
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -45,7 +47,9 @@ def test_trajectory_attention_golden(name):
     mod = mod.cuda()
     mod.return_attn = True
     out, attn = mod(dev(q), dev(q), dev(v), num_frames=m["T"])
-    assert rel_err(out.cpu(), t(z["out"])) < TOL_F16
+    e, e2 = rel_err(out.cpu(), t(z["out"])), rel_l2(out.cpu(), t(z["out"]))
+    print(f"{name}: max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < TOL_F16 and e2 < TOL_F16
     assert rel_err(attn.cpu()[:: int(z["attn_stride"])], t(z["attn"])) < TOL_ATTN_MAP
     rows = attn.sum(-1)
     assert float((rows - 1).abs().max()) < 1e-5          # every (query, frame) softmax sums to one
@@ -64,9 +68,9 @@ def test_axial_layer_golden(name, dtype, tol):
     layer.return_attn = dtype == "f16"
     out, ha, wa = layer(dev(src), dev(pos))
     s = m["stride"]
-    e = rel_err(out.cpu()[:, ::s], t(z["out"]))
-    print(f"{name} {dtype}: rel_err {e:.2e}")
-    assert e < tol
+    e, e2 = rel_err(out.cpu()[:, ::s], t(z["out"])), rel_l2(out.cpu()[:, ::s], t(z["out"]))
+    print(f"{name} {dtype}: max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < tol and e2 < tol
     if dtype == "f16":
         np.testing.assert_allclose(checks(out.cpu())[1:], z["out_checks"][1:], rtol=2e-3)
         ha, wa = ha.cpu(), wa.cpu()
@@ -128,7 +132,9 @@ def test_encoder_golden():
     enc = enc.cuda()
     out, ha, wa = enc(dev(src), dev(pos))
     assert ha is None and wa is None
-    assert rel_err(out.cpu(), t(z["out"])) < TOL_F16
+    e, e2 = rel_err(out.cpu(), t(z["out"])), rel_l2(out.cpu(), t(z["out"]))
+    print(f"encoder ({m['layers']} layers): max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < TOL_F16 and e2 < TOL_F16
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 5, 7, 64), (2, 4, 16, 9, 256), (1, 1, 3, 3, 32)])
@@ -383,20 +389,20 @@ def test_cross_clip_module_golden(name):
     mod = mod.cuda()
     out = mod(dev(cq), dev(pf))
     assert out["pred_logits"].device.type == "cpu"          # the reference's eval branch hands back CPU tensors
-    e_l = rel_err(out["pred_logits"], t(z["pred_logits"]))
-    print(f"{name}: logits {e_l:.2e}")
-    assert e_l < TOL_F16
+    e_l, e_l2 = rel_err(out["pred_logits"], t(z["pred_logits"])), rel_l2(out["pred_logits"], t(z["pred_logits"]))
+    print(f"{name}: logits max/max {e_l:.2e} relL2 {e_l2:.2e}")
+    assert e_l < TOL_F16 and e_l2 < TOL_F16
     np.testing.assert_allclose(checks(out["pred_masks"])[1:], z["masks_checks"][1:], rtol=5e-3)
     if "aux0_logits" in z:
-        e_m = rel_err(out["pred_masks"], t(z["pred_masks"]))
-        print(f"{name}: masks {e_m:.2e}")
-        assert e_m < TOL_F16
+        e_m, e_m2 = rel_err(out["pred_masks"], t(z["pred_masks"])), rel_l2(out["pred_masks"], t(z["pred_masks"]))
+        print(f"{name}: masks max/max {e_m:.2e} relL2 {e_m2:.2e}")
+        assert e_m < TOL_F16 and e_m2 < TOL_F16
         assert rel_err(out["aux_outputs"][0]["pred_logits"], t(z["aux0_logits"])) < TOL_F16
         assert rel_err(out["aux_outputs"][0]["pred_masks"], t(z["aux0_masks"])) < TOL_F16
     else:
-        e_m = rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]))
-        print(f"{name}: masks {e_m:.2e}")
-        assert e_m < TOL_F16
+        e_m, e_m2 = rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"])), rel_l2(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]))
+        print(f"{name}: masks max/max {e_m:.2e} relL2 {e_m2:.2e}")
+        assert e_m < TOL_F16 and e_m2 < TOL_F16
 
 
 @pytest.mark.parametrize("name", ["g6_tl_cc_head_Tc3_Q16_f2_L2", "g6_tl_cc_head_Tc2_Q20_f1_L1", "g6_tl_cc_head_Tc4_Q100_f2_L4"])
@@ -689,7 +695,7 @@ def test_within_clip_module_golden(name):
     # Tolerance: every layer of the stack holds the 1e-3 per-layer bar on its own fixtures (axial layer, MSDA encoder layer,
     # projections); here 2 + 4 (resp. 1 + 2) of them run back to back on the temporal levels, each LayerNorm re-normalising
     # the stream, so the independent 16-bit operand roundings add in quadrature: measured 5e-4 on res3 (spatial layers only),
-    # 1.1e-3 .. 2.1e-3 on res4 / res5.  3e-3 is the stated bound for the whole decoder.
+    # 1.1e-3 .. 2.2e-3 on res4 / res5 of these toy maps (see the bounds below; the full-size decoder holds TOL_STACK = 1.5e-3).
     for k in m["chans"]:
         e, e2 = rel_err(out[k].cpu(), t(z["out_" + k])), rel_l2(out[k].cpu(), t(z["out_" + k]))
         print(f"{name} {k}: max/max {e:.2e} relL2 {e2:.2e}")
@@ -697,8 +703,9 @@ def test_within_clip_module_golden(name):
         # rounding upstream moves single outputs by whole 1e-3s -- the max-norm of these fixtures moves between 1.4e-3 and 3.2e-3
         # with the summation order of unrelated fp32 reductions while relL2 stays at 7e-4 .. 1.1e-3.  The bound that means
         # something here is the L2 one; the full-size decoder (test_within_clip_module_full_size_golden) holds TOL_STACK in max-norm.
-        assert e2 < (TOL_F16 if k == "res3" else 1.5e-3), k
-        assert e < (TOL_F16 if k == "res3" else 5e-3), k
+        # measured (round 3): relL2 <= 1.01e-3, max-norm <= 2.2e-3 on the temporal levels of the toy decoders
+        assert e2 < (TOL_F16 if k == "res3" else 1.3e-3), k
+        assert e < (TOL_F16 if k == "res3" else 3.5e-3), k
 
 
 def _full_size_decoder(m, w):
@@ -744,7 +751,7 @@ def test_within_clip_module_full_size_golden():
         o = out[k].cpu()
         e, e2 = rel_err(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k])), rel_l2(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]))
         print(f"full-size decoder {k}: max/max {e:.2e} relL2 {e2:.2e}")
-        assert e < (TOL_F16 if k == "res3" else TOL_STACK) and e2 < (TOL_F16 if k == "res3" else TOL_STACK), k
+        assert e < (TOL_F16 if k == "res3" else TOL_STACK) and e2 < TOL_F16, k
         np.testing.assert_allclose(checks(o)[1:], z["chk_" + k][1:], rtol=5e-3)
 
 
@@ -1130,3 +1137,30 @@ def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_default_kernels(shape
         assert torch.equal(outs[None], outs[opt]), opt
         assert torch.equal(gen[None], gen[opt]), opt
     assert e < TOL_F16 and e2 < TOL_F16 and rel_err(gen[None].cpu(), ref) < TOL_F16
+
+
+def test_f32_tier_handles_operands_beyond_the_fp16_range():
+    """`mfma_dtype="f32"`: the layer on the fp32 tier (the training tier's forward without dropout: fp32 MFMA attention, fp32 GEMMs).
+    The reference computes in fp32 and has no operand range limit (WC/temporal_attention.py:35-76); the f16 tier turns |x| > 65504
+    into inf (and says so through the range check), the bf16 tier misses the 1e-3 bar -- this tier is the <= 1e-3 path for such
+    inputs, at ~12x the time."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = 1, 3, 256, 12, 20, 512
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 33)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 33)
+    big = src * 3.0e4                                  # |src| up to ~1.4e5: beyond fp16
+    ref, _, _ = orc.axial_layer(big.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8, mfma_dtype="f32").eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    out = layer(dev(big), dev(pos))[0]
+    assert not out.requires_grad and torch.isfinite(out).all()
+    e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
+    print(f"f32 tier on operands beyond fp16: max/max {e:.2e} relL2 {e2:.2e}")
+    assert e < 1e-4 and e2 < 1e-4
+    # and on ordinary inputs it is the exact counterpart of the 16-bit tier
+    ref1, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    assert rel_err(layer(dev(src), dev(pos))[0].cpu(), ref1) < 1e-5
+    enc = ax.TemporalEncoder(C, F, n_heads=8, temporal_attn_type="axial-trajectory", num_temporal_layer=2, mfma_dtype="f32").eval().cuda()
+    o2 = enc(dev(src), dev(pos))[0]
+    assert torch.isfinite(o2).all()
