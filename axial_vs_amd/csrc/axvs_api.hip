@@ -1001,6 +1001,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "ffn_gelu")) { g_ffn_gelu = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_reassoc")) { g_no_reassoc = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_valu")) { g_train_valu = value; return AXVS_OK; }
+  if (key && !strcmp(key, "train_exact")) { g_train_exact = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }

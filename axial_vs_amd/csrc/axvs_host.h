@@ -17,6 +17,10 @@ inline thread_local char g_err[512] = "";
 // path) instead of the fp32 MFMA ones -- A/B comparisons and tests of both.  Process-wide, not per thread: autograd runs the
 // backward call on its own thread and forward / backward must agree on the kernel family (the statistics travel between them).
 inline int g_train_valu = 0;
+// The FORWARD GEMMs of the training tier split their operands into three bf16 pieces (fp32 accuracy, 6 MFMAs per product: the
+// forward decides the ReLU masks); axvs_set_option("train_exact", 0) makes them two-piece (1.5e-5 per product, 3 MFMAs) like the
+// backward ones, 2: three pieces for the input-gradient GEMMs as well -- see axvs_train_gemm.h.  Process-wide like train_valu.
+inline int g_train_exact = 1;
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

@@ -1,11 +1,9 @@
 // Training tier of TemporalAxialTrajectoryAttentionLayer behind the C ABI: forward that keeps the activations,
-// and the backward pass.  Kernels: axvs_train.h.  The Linear layers (forward, input gradient, weight gradient) are plain fp32
-// GEMMs and go to rocBLAS, resolved at first use with dlopen so that inference-only users of libaxvs.so never load it.
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>
-
+// and the backward pass.  Kernels: axvs_train.h; the Linear layers (forward, input gradient, weight gradient) run on the
+// split-precision bf16 MFMA GEMM kernels of axvs_train_gemm.h (round 3: no vendor BLAS on this path any more).
 #include "axvs_host.h"
 #include "axvs_train.h"
+#include "axvs_train_gemm.h"
 
 namespace axvs {
 namespace {
@@ -26,83 +24,37 @@ struct Bump {   // bump allocator over a caller-owned buffer (nullptr: size only
   }
 };
 
-// ---- rocBLAS, late bound ---------------------------------------------------------------------------------------------------
-struct Blas {
-  decltype(&rocblas_create_handle) create = nullptr;
-  decltype(&rocblas_set_stream) set_stream = nullptr;
-  decltype(&rocblas_set_atomics_mode) set_atomics = nullptr;
-  decltype(&rocblas_sgemm) sgemm = nullptr;
-  decltype(&rocblas_sgemm_strided_batched) sgemm_sb = nullptr;
-  bool ok = false;
-};
-
-const Blas& blas() {
-  static const Blas b = [] {
-    Blas r;
-    void* h = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return r;
-    r.create = reinterpret_cast<decltype(r.create)>(dlsym(h, "rocblas_create_handle"));
-    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(h, "rocblas_set_stream"));
-    r.set_atomics = reinterpret_cast<decltype(r.set_atomics)>(dlsym(h, "rocblas_set_atomics_mode"));
-    r.sgemm = reinterpret_cast<decltype(r.sgemm)>(dlsym(h, "rocblas_sgemm"));
-    r.sgemm_sb = reinterpret_cast<decltype(r.sgemm_sb)>(dlsym(h, "rocblas_sgemm_strided_batched"));
-    r.ok = r.create && r.set_stream && r.set_atomics && r.sgemm && r.sgemm_sb;
-    return r;
-  }();
-  return b;
-}
-
-struct Gemm {   // one rocBLAS handle per (thread, device), bound to the call's stream
-  rocblas_handle h = nullptr;
-  int init(hipStream_t st) {
-    const Blas& b = blas();
-    if (!b.ok) return fail(AXVS_ERR_LAUNCH, "the training tier needs rocBLAS (librocblas.so.5 could not be loaded)");
-    constexpr int kMaxDev = 16;
-    static thread_local rocblas_handle handles[kMaxDev] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return fail(AXVS_ERR_LAUNCH, "hipGetDevice failed");
-    if (!handles[dev]) {
-      if (b.create(&handles[dev]) != rocblas_status_success) return fail(AXVS_ERR_LAUNCH, "rocblas_create_handle failed");
-      b.set_atomics(handles[dev], rocblas_atomics_not_allowed);   // deterministic reductions
-    }
-    h = handles[dev];
-    if (b.set_stream(h, st) != rocblas_status_success) return fail(AXVS_ERR_LAUNCH, "rocblas_set_stream failed");
+// ---- the Linear layers' GEMMs: split-precision bf16 MFMA kernels (axvs_train_gemm.h) ------------------------------------------------
+struct Gemm {
+  hipStream_t st = nullptr;
+  int init(hipStream_t s) {
+    st = s;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3>))) return rc;
+    return ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel));
+  }
+  // row-major:  Y[M,N] = beta Y + epilogue(X[M,K] W[N,K]^T); epilogue (optional): + bias, * mul, ReLU, dropout by element index
+  // exact: three bf16 pieces per operand (fp32 accuracy) -- for the GEMM in front of the ReLU (see tr_gemm_nt_kernel)
+  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K, float beta = 0.f, const GemmEpi* ep = nullptr,
+          bool exact = false) const {
+    if (N % 4 || K % 4) return fail(AXVS_ERR_ARG, "training GEMM: N=%d and K=%d must be multiples of 4", N, K);
+    GemmEpi e = ep ? *ep : GemmEpi{nullptr, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, 0.f};
+    e.beta = beta;
+    const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT));
+    if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, e);
+    else hipLaunchKernelGGL(tr_gemm_nt_kernel<2>, grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, e);
     return AXVS_OK;
   }
-  int call(rocblas_operation ta, rocblas_operation tb, long long m, long long n, long long k, const float* A, long long lda, const float* B,
-           long long ldb, float beta, float* C, long long ldc) const {
-    const float alpha = 1.f;
-    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return fail(AXVS_ERR_ARG, "GEMM dimension exceeds rocblas_int");
-    if (blas().sgemm(h, ta, tb, (int)m, (int)n, (int)k, &alpha, A, (int)lda, B, (int)ldb, &beta, C, (int)ldc) != rocblas_status_success)
-      return fail(AXVS_ERR_LAUNCH, "rocblas_sgemm failed");
-    return AXVS_OK;
-  }
-  // row-major:  Y[M,N] = beta Y + X[M,K] W[N,K]^T
-  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K, float beta = 0.f) const {
-    return call(rocblas_operation_transpose, rocblas_operation_none, N, M, K, W, K, X, K, beta, Y, N);
-  }
-  // dW[N,K] = dY[M,N]^T X[M,K]: the reduction runs over the M rows and the output is small, so it is split kSplit ways over
-  // the rows as a strided-batched GEMM into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).
+  // dW[N,K] = dY[M,N]^T X[M,K]: the reduction runs over the M rows and the output is small, so the rows are split kSplit ways
+  // into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).
   static constexpr int kSplit = 64;
   int wgrad_partials(const float* dY, const float* X, float* part, long long M, int N, int K, int* nparts) const {
-    const float alpha = 1.f, beta = 0.f;
-    const long long chunk = M / kSplit;
-    int np = 0;
-    if (chunk > 0) {
-      if (chunk > INT32_MAX) return fail(AXVS_ERR_ARG, "GEMM dimension exceeds rocblas_int");
-      if (blas().sgemm_sb(h, rocblas_operation_none, rocblas_operation_transpose, K, N, (int)chunk, &alpha, X, K, chunk * K, dY, N, chunk * N,
-                          &beta, part, K, (long long)N * K, kSplit) != rocblas_status_success)
-        return fail(AXVS_ERR_LAUNCH, "rocblas_sgemm_strided_batched failed");
-      np = kSplit;
-    }
-    const long long done = chunk * kSplit;
-    if (done < M) {
-      int rc = call(rocblas_operation_none, rocblas_operation_transpose, K, N, M - done, X + done * K, K, dY + done * N, N, 0.f,
-                    part + (size_t)np * N * K, K);
-      if (rc != AXVS_OK) return rc;
-      ++np;
-    }
+    if (N % 8 || K % 8) return fail(AXVS_ERR_ARG, "training GEMM: N=%d and K=%d must be multiples of 8", N, K);
+    long long chunk = (M + kSplit - 1) / kSplit;
+    chunk = (chunk + kGK - 1) / kGK * kGK;                 // whole k-steps per split
+    const int np = (int)((M + chunk - 1) / chunk);
+    const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), (unsigned)np);
+    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk);
     *nparts = np;
     return AXVS_OK;
   }
@@ -119,7 +71,7 @@ int make_dims(Dims& d, int B, int T, int H, int W, int C, int heads, int F) {
   if (C % heads) return fail(AXVS_ERR_ARG, "C=%d must be a multiple of heads=%d", C, heads);
   const int D = C / heads;
   if (D != 8 && D != 16 && D != 32) return fail(AXVS_ERR_ARG, "training tier: head_dim=%d not built (8, 16, 32)", D);
-  if (F % 4) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a multiple of 4", F);
+  if (F % 8) return fail(AXVS_ERR_ARG, "training tier: d_ffn=%d must be a multiple of 8", F);
   if (T > 8) return fail(AXVS_ERR_ARG, "training tier: T=%d > 8 frames per clip not built", T);
   const long long M = (long long)B * T * H * W;
   if (M * (long long)(T > 1 ? T : 1) > INT32_MAX) return fail(AXVS_ERR_ARG, "training tier: B*T*H*W*T exceeds 2^31 rows");
@@ -250,7 +202,7 @@ struct Ctx {
   // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
   int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta) const {
     hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, sc.wt, N, K);
-    return g.fwd(dY, sc.wt, dX, M, K, N, beta);
+    return g.fwd(dY, sc.wt, dX, M, K, N, beta, nullptr, g_train_exact >= 2);
   }
   int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn) : AXVS_OK; }
 };
@@ -272,12 +224,12 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   const Drop none = make_drop(0.f, 0, 0);
   int rc;
   c.add(xin, pos, c.sc.a, (size_t)M * C);
-  if ((rc = c.g.fwd(c.sc.a, w.q_w, s.q, M, C, C)) != AXVS_OK) return rc;
-  c.bias_act(s.q, w.q_b, M, C, 1.f, 0, none);
-  if ((rc = c.g.fwd(c.sc.a, w.k_w, s.k, M, C, C)) != AXVS_OK) return rc;
-  c.bias_act(s.k, w.k_b, M, C, 1.f, 0, none);
-  if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C)) != AXVS_OK) return rc;
-  c.bias_act(s.v, w.v_b, M, C, 1.f, 0, none);
+  // (the biases ride in the GEMM epilogues; `ex`: option train_exact -- forward products with fp32 accuracy)
+  const bool ex = g_train_exact != 0;
+  const GemmEpi eq{w.q_b, 1.f, 0, none, 0.f}, ek{w.k_b, 1.f, 0, none, 0.f}, ev{w.v_b, 1.f, 0, none, 0.f};
+  if ((rc = c.g.fwd(c.sc.a, w.q_w, s.q, M, C, C, 0.f, &eq, ex)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(c.sc.a, w.k_w, s.k, M, C, C, 0.f, &ek, ex)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C, 0.f, &ev, ex)) != AXVS_OK) return rc;
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
   const size_t lds_mfma = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
   if (mfma_spatial(d, rm)) {                                            // head_dim 32 (every shipped config): fp32 MFMA kernels
@@ -291,15 +243,14 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
                        (const float*)s.v, s.x, rm, d.T, C, d.heads, c.scale, attn_drop);
   })
   hipLaunchKernelGGL(tr_diag_gather_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)s.x, s.xd, M, d.T, d.HW, C);
-  if ((rc = c.g.fwd(s.xd, w.proj_q_w, s.q2, M, C, C)) != AXVS_OK) return rc;
-  c.bias_act(s.q2, w.proj_q_b, M, C, c.scale, 0, none);
-  if ((rc = c.g.fwd(s.x, w.proj_kv_w, s.kv2, M * d.T, 2 * C, C)) != AXVS_OK) return rc;
-  c.bias_act(s.kv2, w.proj_kv_b, M * d.T, 2 * C, 1.f, 0, none);
+  const GemmEpi epq{w.proj_q_b, c.scale, 0, none, 0.f}, epkv{w.proj_kv_b, 1.f, 0, none, 0.f};
+  if ((rc = c.g.fwd(s.xd, w.proj_q_w, s.q2, M, C, C, 0.f, &epq, ex)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(s.x, w.proj_kv_w, s.kv2, M * d.T, 2 * C, C, 0.f, &epkv, ex)) != AXVS_OK) return rc;
   AXVS_D_SWITCH(d.D, {
     hipLaunchKernelGGL(tr_temporal_fwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
                        (const float*)s.kv2, s.o, M, d.T, C, d.heads);
   })
-  if ((rc = c.g.fwd(s.o, w.proj_w, c.sc.t0, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(s.o, w.proj_w, c.sc.t0, M, C, C, 0.f, nullptr, ex)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_bias_drop_res_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)c.sc.t0, w.proj_b, xin, xout, rm,
                      M, C, drop1);
   return AXVS_OK;
@@ -407,9 +358,11 @@ int forward(const Ctx& c, const float* src, const float* pos, float* out, const 
     return rc;
   // norm1 -> FFN -> norm2                               :181-185, :217-218
   hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.buf2, p.norm1_w, p.norm1_b, s.z, s.mean1, s.rstd1, M, C);
-  if ((rc = c.g.fwd(s.z, p.linear1_w, s.r, M, d.F, C)) != AXVS_OK) return rc;
-  c.bias_act(s.r, p.linear1_b, M, d.F, 1.f, 1, make_drop(p_drop, seed, 5));
-  if ((rc = c.g.fwd(s.r, p.linear2_w, c.sc.t0, M, C, d.F)) != AXVS_OK) return rc;
+  {   // linear1 + bias + ReLU + dropout2 in one launch
+    const GemmEpi e1{p.linear1_b, 1.f, 1, make_drop(p_drop, seed, 5), 0.f};
+    if ((rc = c.g.fwd(s.z, p.linear1_w, s.r, M, d.F, C, 0.f, &e1, g_train_exact != 0)) != AXVS_OK) return rc;
+  }
+  if ((rc = c.g.fwd(s.r, p.linear2_w, c.sc.t0, M, C, d.F, 0.f, nullptr, g_train_exact != 0)) != AXVS_OK) return rc;
   const RowMap id{(int)(M > INT32_MAX ? INT32_MAX : M), (int)(M > INT32_MAX ? INT32_MAX : M), 1, M, M, 1, 0};
   hipLaunchKernelGGL(tr_bias_drop_res_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)c.sc.t0, p.linear2_b, (const float*)s.z,
                      s.u, id, M, C, make_drop(p_drop, seed, 6));

@@ -280,3 +280,31 @@ def test_axial_layer_gelu(name):
     src, pos = axial_inputs(m)
     out, _, _ = orc.axial_layer(src, pos, weights(z, m), m["heads"], want_attn=False, activation="gelu")
     assert rel_err(out, t(z["out"])) < TOL
+
+
+def test_relu_ties_bound_fp32_gradient_parity():
+    """Why the GPU training tests pick their data seeds: with ~1e5 .. 1e6 hidden units, some draws put a linear1 pre-activation
+    within fp32 rounding of zero.  ANY fp32 forward (here: torch's own fp32 CPU ops on the oracle) then lands on the other side of
+    the ReLU than the float64 one for that unit, and the input gradient of its token moves by ~1e-2 of the gradient's scale while
+    the output moves by 4e-7.  Max-norm gradient parity at 1e-4 against float64 is therefore a property of the draw, not of the
+    arithmetic; the draw below ([1,4,256,8,56], d_ffn 256, seed 300) has such a unit, seed 310 does not."""
+    B, T, C, H, W, F = 1, 4, 256, 8, 56, 256
+    out = {}
+    for seed in (300, 310):
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), seed)
+        src, pos = orc.synthetic_clip(B, T, C, H, W, seed)
+        d_out = torch.randn(B * T, H * W, C, generator=torch.Generator().manual_seed(0))
+        g = {}
+        for dt in (torch.float64, torch.float32):
+            wd = {k: v.to(dt).requires_grad_(True) for k, v in w.items()}
+            sd, pd = src.to(dt).requires_grad_(True), pos.to(dt).requires_grad_(True)
+            y = orc.axial_layer_train(sd, pd, wd, 8, 0.0, 0.0, 1)
+            y.backward(d_out.to(dt))
+            g[dt] = (y.detach().double(), sd.grad.double())
+        e_out = float((g[torch.float32][0] - g[torch.float64][0]).abs().max() / g[torch.float64][0].abs().max())
+        e_src = float((g[torch.float32][1] - g[torch.float64][1]).abs().max() / g[torch.float64][1].abs().max())
+        out[seed] = (e_out, e_src)
+    print(out)
+    assert out[300][0] < 2e-6 and out[310][0] < 2e-6           # the forward agrees either way
+    assert out[300][1] > 1e-3                                  # one flipped mask bit
+    assert out[310][1] < 1e-5

@@ -12,8 +12,9 @@ import csv, glob
 for f in glob.glob("$OUT/*/*kernel_stats.csv"):
     rows = [r for r in csv.DictReader(open(f)) if "axvs" in r["Name"] and int(r["Calls"]) >= 100]
     tot = 0.0
+    per_step = min(int(r["Calls"]) for r in rows)          # the least-launched kernel runs once per forward (settling steps included)
     for r in sorted(rows, key=lambda r: -float(r["AverageNs"])):
-        n = int(r["Calls"]) // 220 or 1
+        n = round(int(r["Calls"]) / per_step)
         tot += float(r["AverageNs"]) * n
         print(f"  {r['Name'][:70]:70s} calls/step {n}  avg {float(r['AverageNs'])/1e3:8.2f} us")
     print(f"  kernel sum per step: {tot/1e3:.2f} us")

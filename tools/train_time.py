@@ -8,7 +8,9 @@ import axial_vs_amd as ax
 
 B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-for recompute in (True, False):
+from axial_vs_amd import _lib
+for exact, recompute in ((0, True), (0, False), (1, True), (1, False)):
+    _lib.lib().axvs_set_option(b"train_exact", exact)
     layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, dropout=0.1, attn_drop=0.1, n_heads=8)
     layer.load_state_dict(orc.random_weights(orc.axial_layer_param_shapes(C, F), 1), strict=True)
     layer = layer.cuda().train()
@@ -34,7 +36,7 @@ for recompute in (True, False):
             layer(s, p)
     torch.cuda.synchronize()
     df = (time.perf_counter() - t0) / n
-    print(f"recompute={recompute}: fwd+bwd {dt*1e3:.2f} ms/step ({B*T/dt:.0f} frames/s), forward alone {df*1e3:.2f} ms")
+    print(f"train_exact={exact} recompute={recompute}: fwd+bwd {dt*1e3:.2f} ms/step ({B*T/dt:.0f} frames/s), forward alone {df*1e3:.2f} ms")
 
 # reference point: the same math as plain PyTorch ops on the same GPU (autograd through the oracle's torch code, fp32, rocBLAS/MIOpen
 # kernels chosen by torch) -- what "unmodified reference on ROCm PyTorch" would cost for this layer
