@@ -17,6 +17,8 @@
 // Block tile 128 x 128, k-step 32, 8 waves (wave tile 64 x 32: 24 MFMAs per k-step), operand tiles double-buffered in LDS with the
 // global loads of step k+1 in flight under the MFMAs of step k, one barrier per step; two workgroups per CU (<= 128 VGPRs).
 #pragma once
+#include <type_traits>
+
 #include "axvs_train.h"
 
 namespace axvs {
@@ -98,23 +100,27 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   const float* bp = B + (long long)(n0 + (b_ok ? sr : 0)) * K + sq * 8;
   const int soff = sr * 32 + swz_chunk(sr, sq) * 8;
   const int nk = (K + kGK - 1) / kGK;
-  float4 ra[2], rb[2];
-  auto gload = [&](int ks) {
+  // global loads run TWO k-steps ahead of the MFMAs (two register slots, used alternately): with one step of lookahead a load had a
+  // single step's MFMAs (~0.3 us) to cover an L2 / HBM round trip and every step stalled at its LDS store
+  float4 ra[2][2], rb[2][2];
+  auto gload = [&](int ks, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int kk = ks * kGK + sq * 8 + 4 * h;               // K % 4 == 0: a float4 is inside or outside
       const bool kin = kk < K;
-      ra[h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
-      rb[h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto lstore = [&](int stage) {
+  auto lstore = [&](int stage, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
     u16* const base = sbuf + stage * kStage;
     u16x8 p[NS];
-    split_n<NS>(ra[0], ra[1], p);
+    split_n<NS>(ra[SL][0], ra[SL][1], p);
 #pragma unroll
     for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x8*>(base + s * kGTileElems + soff) = p[s];
-    split_n<NS>(rb[0], rb[1], p);
+    split_n<NS>(rb[SL][0], rb[SL][1], p);
 #pragma unroll
     for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x8*>(base + (NS + s) * kGTileElems + soff) = p[s];
   };
@@ -134,13 +140,13 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) gload(ks + 1);
-    const u16* const base = sbuf + cur * kStage;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // one k-step: stage `PAR` of LDS holds step ks; register slot PAR ^ 1 holds step ks + 1 (requested a step ago), slot PAR is free
+  auto kstep = [&](int ks, auto par_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    if (ks + 2 < nk) gload(ks + 2, std::integral_constant<int, PAR>{});
+    const u16* const base = sbuf + PAR * kStage;
     u16x8 bf[2][NS];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
 #pragma unroll
       for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const u16x8*>(base + s * kGTileElems + aoff[mt]);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {                        // D[n = 4 fg + r][m = fi]; pieces i + j <= NS - 1 ... (NS = 3: also 1.1)
+      for (int nt = 0; nt < 2; ++nt) {                        // D[n = 4 fg + r][m = fi]
         f32x4 c = acc[mt][nt];
         c = H16<true>::mfma(bf[nt][0], af[0], c);
         c = H16<true>::mfma(bf[nt][0], af[1], c);
@@ -165,8 +171,16 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
         acc[mt][nt] = c;
       }
     }
-    if (ks + 1 < nk) lstore(cur ^ 1);        // the other stage: every wave left its reads behind the previous barrier
+    if (ks + 1 < nk) lstore(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});   // the other stage: every wave left its reads behind the previous barrier
     __syncthreads();
+  };
+  gload(0, S0{});
+  if (nk > 1) gload(1, S1{});
+  lstore(0, S0{});
+  __syncthreads();
+  for (int ks = 0; ks < nk; ks += 2) {
+    kstep(ks, S0{});
+    if (ks + 1 < nk) kstep(ks + 1, S1{});
   }
   // ---- epilogue: accumulators -> fp32 staging tile [m][n] -> whole rows, 512 bytes per row segment ----
   float* const stg = reinterpret_cast<float*>(gsmem);
