@@ -61,6 +61,32 @@ def _conv_gn(in_channels: int, out_channels: int) -> nn.Sequential:
     return nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1), nn.GroupNorm(32, out_channels))
 
 
+_side_streams: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def _run_levels_concurrently(fns):
+    """The temporal encoder of a stage is applied to each temporal level on its own (WC/msdeformattn.py:258-264: a Python loop over
+    the levels): the levels are independent and small (res5 = 16, res4 = 64 row tiles at BASELINE config 3, on a 256-CU chip), so
+    level 0 runs on a side stream beside level 1 on the caller's stream -- fork / join with events, no host synchronisation; each
+    stream has its own workspace (modules._workspace is keyed by stream).  Returns the results in order."""
+    if len(fns) < 2:
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    key = str(cur.device)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(cur.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        first = fns[0]()
+    rest = [f() for f in fns[1:]]
+    cur.wait_stream(side)
+    for t in first:
+        if isinstance(t, torch.Tensor):
+            t.record_stream(cur)
+    return [first] + rest
+
+
 class MSDeformAttnTransformerEncoder(nn.Module):
     def __init__(self, spatial_layer, num_stages, transformer_num_spatial_feature_levels, transformer_num_temporal_feature_levels=0,
                  temporal_layer=None):
@@ -96,11 +122,14 @@ class MSDeformAttnTransformerEncoder(nn.Module):
             if self.transformer_num_temporal_feature_levels > 0:
                 # the temporal levels (the coarsest, first in the buffer) are replaced in place; the reference's split / cat
                 # (WC/msdeformattn.py:258-264) would also copy the large level that passes through
-                start = 0
-                for j in range(self.transformer_num_temporal_feature_levels):
-                    lvl, h_attn, w_attn = self.temporal_layers[i](src=output[:, start:start + sizes[j]].contiguous(), pos=pos_3d[j])
-                    output[:, start:start + sizes[j]] = lvl
-                    start += sizes[j]
+                nt = self.transformer_num_temporal_feature_levels
+                starts = [sum(sizes[:j]) for j in range(nt)]
+                ins = [output[:, starts[j]:starts[j] + sizes[j]].contiguous() for j in range(nt)]
+                layer = self.temporal_layers[i]
+                res = _run_levels_concurrently([(lambda j=j: layer(src=ins[j], pos=pos_3d[j])) for j in range(nt)])
+                for j in range(nt):
+                    lvl, h_attn, w_attn = res[j]
+                    output[:, starts[j]:starts[j] + sizes[j]] = lvl
         return output, h_attn, w_attn
 
 
@@ -120,8 +149,9 @@ class TemporalTransformerEncoder(nn.Module):
         parts = [p.contiguous() for p in torch.split(src, sizes, dim=1)[:nt]]
         h_attn = w_attn = None
         for temporal_layer in self.temporal_layers:
+            res = _run_levels_concurrently([(lambda j=j: temporal_layer(src=parts[j], pos=pos_3d[j])) for j in range(nt)])
             for j in range(nt):
-                parts[j], h_attn, w_attn = temporal_layer(src=parts[j], pos=pos_3d[j])
+                parts[j], h_attn, w_attn = res[j]
         out = src.clone()                               # (the caller's buffer is left alone)
         start = 0
         for j in range(nt):

@@ -31,3 +31,25 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
 print(f"cfg3 within-clip module forward: {dt*1e3:.3f} ms ({m['B']*m['T']/dt:.0f} frames/s)")
+
+# the same forward replayed from a captured HIP graph (two streams inside: the temporal levels of a stage run side by side)
+keys = list(feats)
+def fn(*ts):
+    o, _, _ = mod.forward_features({k: t for k, t in zip(keys, ts)})
+    return tuple(o[k] for k in keys)
+import axial_vs_amd as ax
+class _Fn(torch.nn.Module):
+    def forward(self, *ts):
+        return fn(*ts)
+with torch.no_grad():
+    gf = ax.GraphedForward(_Fn(), *[feats[k] for k in keys])
+    for _ in range(5): gf()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gf()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    eager = fn(*[feats[k] for k in keys])
+    same = all(torch.equal(a, b) for a, b in zip(eager, gf()))
+print(f"cfg3 within-clip module forward, HIP graph replay: {dt*1e3:.3f} ms ({m['B']*m['T']/dt:.0f} frames/s), bit-equal to eager: {same}")

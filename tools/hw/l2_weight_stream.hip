@@ -49,5 +49,7 @@ int main() {
   run(stream<32, true>, "depth 32 rotated", 256);
   run(stream<16, true>, "depth 16 rotated", 256);
   run(stream<32, true>, "depth 32 rotated 2 WG/CU", 512);
+  // does the per-CU rate depend on how many CUs stream at the same time?  (a shared L2 limit would, a per-CU limit would not)
+  for (int g : {8, 32, 64, 128, 192, 256}) run(stream<16, false>, "depth 16, fewer workgroups", g);
   return 0;
 }
