@@ -48,13 +48,13 @@ struct Gemm {
   // dW[N,K] = dY[M,N]^T X[M,K]: the reduction runs over the M rows and the output is small, so the rows are split kSplit ways
   // into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).
   static constexpr int kSplit = 64;
-  int wgrad_partials(const float* dY, const float* X, float* part, long long M, int N, int K, int* nparts) const {
+  int wgrad_partials(const float* dY, const float* X, float* part, long long M, int N, int K, int* nparts, float* part_b = nullptr) const {
     if (N % 8 || K % 8) return fail(AXVS_ERR_ARG, "training GEMM: N=%d and K=%d must be multiples of 8", N, K);
     long long chunk = (M + kSplit - 1) / kSplit;
     chunk = (chunk + kGK - 1) / kGK * kGK;                 // whole k-steps per split
     const int np = (int)((M + chunk - 1) / chunk);
     const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), (unsigned)np);
-    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk);
+    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b);
     *nparts = np;
     return AXVS_OK;
   }
@@ -190,13 +190,14 @@ struct Ctx {
     hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_a, nblk, (size_t)N, out_a);
     if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_b, nblk, (size_t)N, out_b);
   }
-  // dW[N,K] = dY[M,N]^T X[M,K]
-  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K) const {
+  // dW[N,K] = dY[M,N]^T X[M,K]; db (nullable) [N] = column sums of dY -- the bias gradient rides in the same GEMM launch
+  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K, float* db = nullptr) const {
     int np = 0;
-    int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np);
+    int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np, db ? sc.part_a : nullptr);
     if (rc != AXVS_OK) return rc;
     const size_t n = (size_t)N * K;
     hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
+    if (db) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_a, np, (size_t)N, db);
     return AXVS_OK;
   }
   // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
@@ -268,20 +269,17 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   int rc;
   // proj and dropout1
   hipLaunchKernelGGL(tr_drop_bwd_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, d_out, sc.t0, rm, M, C, drop1);
-  c.colsum(sc.t0, M, C, gw.proj_b);
-  if ((rc = c.wgrad(sc.t0, s.o, gw.proj_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.t0, s.o, gw.proj_w, M, C, C, gw.proj_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.t0, w.proj_w, sc.d_o, M, C, C, 0.f)) != AXVS_OK) return rc;
   // temporal half
   AXVS_D_SWITCH(d.D, {
     hipLaunchKernelGGL(tr_temporal_bwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
                        (const float*)s.kv2, (const float*)sc.d_o, sc.dq2, sc.dkv2, M, T, C, d.heads);
   })
-  c.colsum(sc.dkv2, M * T, 2 * C, gw.proj_kv_b);
-  if ((rc = c.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C, gw.proj_kv_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dkv2, w.proj_kv_w, sc.dx, M * T, 2 * C, C, 0.f)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_scale_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dq2, MC / 4, c.scale);   // q2 = scale (proj_q(xd))
-  c.colsum(sc.dq2, M, C, gw.proj_q_b);
-  if ((rc = c.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C, gw.proj_q_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dq2, w.proj_q_w, sc.dxd, M, C, C, 0.f)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_diag_scatter_add_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dx, (const float*)sc.dxd, M, T, d.HW, C);
   // spatial half
@@ -307,12 +305,9 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   })
   // q / k / v projections
   c.add(xin, pos, sc.a, MC);
-  c.colsum(sc.dq, M, C, gw.q_b);
-  if ((rc = c.wgrad(sc.dq, sc.a, gw.q_w, M, C, C)) != AXVS_OK) return rc;
-  c.colsum(sc.dk, M, C, gw.k_b);
-  if ((rc = c.wgrad(sc.dk, sc.a, gw.k_w, M, C, C)) != AXVS_OK) return rc;
-  c.colsum(sc.dv, M, C, gw.v_b);
-  if ((rc = c.wgrad(sc.dv, xin, gw.v_w, M, C, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dq, sc.a, gw.q_w, M, C, C, gw.q_b)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dk, sc.a, gw.k_w, M, C, C, gw.k_b)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dv, xin, gw.v_w, M, C, C, gw.v_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dq, w.q_w, sc.da, M, C, C, 0.f)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dk, w.k_w, sc.da, M, C, C, 1.f)) != AXVS_OK) return rc;
   // d_in = d_out (residual) + dv Wv + da;   d_pos (+)= da
@@ -445,12 +440,10 @@ int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float
   // FFN: u = z + dropout3(linear2(r)), r = dropout2(relu(linear1(z)))             :181-183
   const RowMap id{(int)M, (int)M, 1, M, M, 1, 0};
   hipLaunchKernelGGL(tr_drop_bwd_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, (const float*)sc.g0, sc.t0, id, M, C, make_drop(p_dropout, seed, 6));
-  c.colsum(sc.t0, M, C, g.linear2_b);
-  if ((rc = c.wgrad(sc.t0, s.r, g.linear2_w, M, C, d.F)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.t0, s.r, g.linear2_w, M, C, d.F, g.linear2_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.t0, p.linear2_w, sc.dr, M, C, d.F, 0.f)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_relu_drop_bwd_kernel, dim3(blocks(MF / 4)), dim3(256), 0, c.st, sc.dr, (const float*)s.r, MF / 4, make_drop(p_dropout, seed, 5).scale);
-  c.colsum(sc.dr, M, d.F, g.linear1_b);
-  if ((rc = c.wgrad(sc.dr, s.z, g.linear1_w, M, d.F, C)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dr, s.z, g.linear1_w, M, d.F, C, g.linear1_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dr, p.linear1_w, sc.g0, M, d.F, C, 1.f)) != AXVS_OK) return rc;   // g0 = d z = d u + d r W1
   // norm1                                                                       :217
   c.colsum(sc.g0, M, C, g.norm1_b, s.buf2, s.mean1, s.rstd1, g.norm1_w);

@@ -243,8 +243,12 @@ __device__ __forceinline__ u16x8 tn_frag(const u16* tile, int col0, int fi, int 
   return r;
 }
 
+// part_b (nullable): [split][N] partial COLUMN SUMS of dY (the bias gradient of the same Linear layer), added in fp32 from the
+// staging registers by the workgroups of the first k-tile (a bias gradient can be a sum that cancels to zero -- the k bias of a
+// softmax -- so it does not go through the bf16 split) and reduced over the 32 staging rows through LDS in a fixed order.
 __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
-                                                            long long M, int N, int K, long long rows_per_split) {
+                                                            long long M, int N, int K, long long rows_per_split,
+                                                            float* __restrict__ part_b) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
   u16* const sbuf = reinterpret_cast<u16*>(gsmem);            // [2 stages][dY hi | dY lo | X hi | X lo][32 rows m][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
@@ -258,6 +262,8 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
   const bool n_ok = n0 + sc * 8 < N, k_ok = k0 + sc * 8 < K;         // N, K % 8 == 0 (host check)
   const int soff = sr * kGT + tn_chunk(sr, sc) * 8;
   const int nsteps = (int)((me - ms + kGK - 1) / kGK);
+  const bool do_bias = part_b != nullptr && k0 == 0;                 // workgroup-uniform
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // my 8 columns of dY, rows m = sr (mod 32) of the split
   float4 ra[2], rb[2];
   auto gload = [&](int s) {
     const long long m = ms + (long long)s * kGK + sr;
@@ -271,6 +277,10 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
   auto lstore = [&](int stage) {
     u16* const base = sbuf + stage * 4 * kGTileElems;
     u16x8 hi, lo;
+    if (do_bias) {
+      bsum[0] += ra[0].x; bsum[1] += ra[0].y; bsum[2] += ra[0].z; bsum[3] += ra[0].w;
+      bsum[4] += ra[1].x; bsum[5] += ra[1].y; bsum[6] += ra[1].z; bsum[7] += ra[1].w;
+    }
     split8(ra[0], ra[1], hi, lo);
     *reinterpret_cast<u16x8*>(base + soff) = hi;
     *reinterpret_cast<u16x8*>(base + kGTileElems + soff) = lo;
@@ -317,6 +327,18 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
       const int n = n0 + wn * 64 + nt * 16 + fi, k = k0 + wk * 32 + kt * 16 + 4 * fg;
       if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * K + k) = float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
     }
+  if (do_bias) {                 // (the loop's last barrier is behind every wave: the operand stages are free)
+    float* const red = reinterpret_cast<float*>(gsmem);        // [32 staging rows][128 columns]
+    *reinterpret_cast<float4*>(red + sr * kGT + sc * 8) = float4{bsum[0], bsum[1], bsum[2], bsum[3]};
+    *reinterpret_cast<float4*>(red + sr * kGT + sc * 8 + 4) = float4{bsum[4], bsum[5], bsum[6], bsum[7]};
+    __syncthreads();
+    if (tid < kGT && n0 + tid < N) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) t += red[r * kGT + tid];
+      part_b[(size_t)blockIdx.y * N + n0 + tid] = t;
+    }
+  }
 }
 
 }  // namespace tr

@@ -20,7 +20,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   offaxis_one_clip  (N > 1) ONE clip sharded over the ranks with an all-to-all between the passes ("strong" scaling)
                   cc_cfg4     BASELINE config 4: CrossClipTrackingModule forward, us per forward and output GB/s (N = 1)
                   wc_cfg3     BASELINE config 3: the whole within-clip tracking module at ConvNeXt-T size, ms per forward (N = 1)
-                  train_step  forward + backward of the layer through the fp32 training tier, ms per step (N = 1)
+                  train_step  forward + backward of the layer through the training tier, ms per step (N = 1)
 """
 from __future__ import annotations
 
@@ -518,19 +518,27 @@ def main():
 
                 def train_step():
                     tl(s_t, pos)[0].backward(g_t)
-                for _ in range(10):
-                    train_step()
-                torch.cuda.synchronize(dev)
-                n_t = 10
-                t_tr = time.perf_counter()
-                for _ in range(n_t):
-                    train_step()
-                torch.cuda.synchronize(dev)
-                el = (time.perf_counter() - t_tr) / n_t
+
+                def time_train():
+                    for _ in range(10):
+                        train_step()
+                    torch.cuda.synchronize(dev)
+                    n_t = 10
+                    t_tr = time.perf_counter()
+                    for _ in range(n_t):
+                        train_step()
+                    torch.cuda.synchronize(dev)
+                    return (time.perf_counter() - t_tr) / n_t
+                el = time_train()
+                tl.recompute = False
+                el_kept = time_train()
                 extras["train_step"] = {"ms_per_step": round(el * 1e3, 3), "value": round(B * T / el, 1), "unit": "frames/s",
-                                        "what": "forward + backward of one layer through the fp32 training tier (axvs_axial_layer_train_fwd/_bwd), "
-                                                "dropout 0.1 / attn_drop 0.1, activations recomputed in backward",
-                                        "dtype": "f32"}
+                                        "ms_per_step_activations_kept": round(el_kept * 1e3, 3),
+                                        "what": "forward + backward of one layer through the training tier (axvs_axial_layer_train_fwd/_bwd), "
+                                                "dropout 0.1 / attn_drop 0.1; ms_per_step: activations recomputed in backward (default), "
+                                                "ms_per_step_activations_kept: layer.recompute = False.  Linear layers on the library's own "
+                                                "split-precision bf16 MFMA GEMMs (fp32-accurate forward), attention on fp32 MFMA",
+                                        "dtype": "f32 (GEMM operands split into bf16 pieces, fp32 accumulate)"}
                 del tl, s_t, g_t
             except RuntimeError as e:
                 extras["train_step"] = {"error": str(e)[:200]}
