@@ -75,8 +75,14 @@ int axvs_profile_stages(void** events, int capacity);
 int axvs_profile_stage_count(void);
 const char* axvs_profile_stage_name(int i);
 
-/* ---- tuning / test switches (thread-local).  "generic_only" = 1: always use the shape-generic kernels
- *      instead of the fused C=256 ones (A/B comparisons, parity tests of both paths). */
+/* ---- tuning / test switches (thread-local unless noted).  "generic_only" = 1: always use the shape-generic kernels
+ *      instead of the fused C=256 ones (A/B comparisons, parity tests of both paths).  Others: "no_attn_fusion", "no_ffn_fusion",
+ *      "no_small_tiles", "no_reassoc", "no_wt_stores", "spatial_only" (timing), "ffn_gelu", "attn_waves";
+ *      "vrow" = 1: the 64-row fused kernels read V in K's row layout (transposed on load) instead of block-transposed V^T;
+ *      "qkv_fusion" = 1: the width pass's q/k/v are produced by the height-pass kernel (both bit-identical to the default,
+ *      measured not faster: DESIGN.md 4a);  process-wide: "train_valu" (VALU instead of fp32-MFMA attention kernels of the
+ *      training tier), "train_exact" (default 1: forward GEMMs of the training tier with fp32 accuracy; 0: two-piece bf16
+ *      products in the forward too; 2: three-piece input-gradient GEMMs as well). */
 int axvs_set_option(const char* key, int value);
 
 /* ---- weight packing (once per load_state_dict; result is opaque, device-resident) ---- */
