@@ -55,6 +55,25 @@ class AxvsCCHeadParams(C.Structure):
                 ("act_head_w", _fp), ("act_head_b", _fp), ("pixel_bn", AxvsBN)]
 
 
+class AxvsBNGrads(C.Structure):
+    _fields_ = [("w", _fp), ("b", _fp)]
+
+
+class AxvsCCHeadGrads(C.Structure):
+    _fields_ = [("class_proj_w", _fp), ("class_proj_bn", AxvsBNGrads), ("mask_proj_w", _fp), ("mask_proj_bn", AxvsBNGrads),
+                ("mask_head_w", _fp), ("mask_head_bn", AxvsBNGrads), ("class_head_w", _fp), ("class_head_b", _fp),
+                ("act_head_w", _fp), ("act_head_b", _fp), ("pixel_bn", AxvsBNGrads)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class AxvsCCTrainCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "Q", "Tc", "V", "H", "W", "K1", "num_layers")] + \
+               [("rates", C.c_int * 3), ("p_attn_drop", C.c_float), ("p_aspp_drop", C.c_float), ("seed", C.c_uint),
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p)]
+
+
 class AxvsTLHeadParams(C.Structure):
     _fields_ = [(n, _fp) for n in ("post_norm_w", "post_norm_b", "activation_proj_w", "activation_proj_b", "cls_embed_w",
                                    "cls_embed_b")] + [("mask_embed_w", _fp * 3), ("mask_embed_b", _fp * 3)]
@@ -101,6 +120,13 @@ SIGNATURES = {
                                    [C.c_float, C.c_float, C.c_uint, _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
     "axvs_axial_layer_train_bwd": (C.c_int, [_fp, _fp, _fp, C.POINTER(AxvsAxialLayerParams), C.POINTER(AxvsAxialLayerParams), _fp, _fp] +
                                    [C.c_int] * 7 + [C.c_float, C.c_float, C.c_uint, C.c_int, _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
+    "axvs_cc_module_train_saved_bytes": (C.c_size_t, [C.POINTER(AxvsCCTrainCfg)]),
+    "axvs_cc_module_train_scratch_bytes": (C.c_size_t, [C.POINTER(AxvsCCTrainCfg), C.c_int]),
+    "axvs_cc_module_train_bn_stats_floats": (C.c_size_t, [C.POINTER(AxvsCCTrainCfg)]),
+    "axvs_cc_module_train_fwd": (C.c_int, [_fp] * 5 + [C.POINTER(AxvsCCLayerParams), C.POINTER(AxvsCCHeadParams), C.POINTER(AxvsCCTrainCfg),
+                                           _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
+    "axvs_cc_module_train_bwd": (C.c_int, [_fp] * 4 + [C.POINTER(AxvsCCLayerParams), C.POINTER(AxvsCCHeadParams), C.POINTER(AxvsCCLayerParams),
+                                           C.POINTER(AxvsCCHeadGrads), _fp, C.POINTER(AxvsCCTrainCfg), _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
     "axvs_axial_pass_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes_ex": (C.c_size_t, [C.c_int] * 9),
     "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),

@@ -4,8 +4,8 @@ Reference: CC = MaXTron_Video-kMaX/maxtron_deeplab/modeling/cross_clip_tracking_
 (same classes inlined in MaXTron_Tube-Link/models/video/tube_link_vis/mask2former_video_cc_head.py:125-247).
 Same constructor, attribute names and state-dict keys as `CrossClipTrackingModule` (CC:204-331) and its parts
 (`TrajectoryAttention` CC:78-130, `TrajectoryAttentionLayer` :133-173, `ASPP` :176-201, `MaXTronCCPredictor` :30-75,
-`ConvBN` / channels-first `LayerNorm` from kmax_deeplab); forward runs in libaxvs.so.  Eval only, norm_fn='ln'
-(every shipped config), kernel sizes 3.
+`ConvBN` / channels-first `LayerNorm` from kmax_deeplab); forward runs in libaxvs.so.  norm_fn='ln' (every shipped config),
+kernel sizes 3.  eval(): the fused 16-bit inference kernels; train(): the fp32 training tier with a backward pass (cc_training.py).
 """
 from __future__ import annotations
 
@@ -190,9 +190,21 @@ class CrossClipTrackingModule(nn.Module):
         return self._packed
 
     # ---- forward (CC:275-322) ------------------------------------------------------------------------------------
+    def _forward_train(self, clip_query: Tensor, panoptic_features: Tensor):
+        """train() mode (CC:53-57 instead of :58-70): differentiable, BatchNorm on batch statistics, outputs stay on the GPU."""
+        from .cc_training import cc_module_train
+        logits, masks = cc_module_train(self, clip_query, panoptic_features)
+        nl = self.num_layers
+        cls_all = [logits[i] for i in range(nl)]
+        mask_all = [masks[i] for i in range(nl)]
+        # (_set_aux_loss resamples the auxiliary masks to the last layer's size, CC:324-331: every layer has that size already)
+        aux = [{"pred_logits": a, "pred_masks": b} for a, b in zip(cls_all[:-1], mask_all[:-1])]
+        return {"pred_logits": cls_all[-1], "pred_masks": mask_all[-1], "aux_outputs": aux}
+
     @_guarded
     def forward(self, clip_query: Tensor, panoptic_features: Tensor):
-        _require_eval(self)
+        if self.training:
+            return self._forward_train(clip_query, panoptic_features)
         cq = _dev_f32(clip_query, "clip_query")
         pf = _dev_f32(panoptic_features, "panoptic_features")
         B, Q, Tc, Cq = cq.shape

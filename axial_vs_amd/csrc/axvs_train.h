@@ -645,7 +645,8 @@ __global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __res
   store_row<D>(dq2 + m * C + h * D, dqr);
 }
 
-// ---- LayerNorm over the channel dimension, one wave per row; eps 1e-5 (nn.LayerNorm default, WC/temporal_attention.py:167,175)
+// ---- LayerNorm over the channel dimension, one wave per row; eps 1e-5 for nn.LayerNorm (WC/temporal_attention.py:167,175),
+//      1e-6 for the channels-first LayerNorm of the cross-clip ASPP
 __device__ __forceinline__ float wave_total(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -654,7 +655,7 @@ __device__ __forceinline__ float wave_total(float v) {
 
 __global__ __launch_bounds__(256) void tr_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                          float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                         long long M, int C) {
+                                                         long long M, int C, float eps) {
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (r >= M) return;
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(256) void tr_ln_fwd_kernel(const float* __restrict_
     const float d = xr[c] - mu;
     vs += d * d;
   }
-  const float rs = rsqrtf(wave_total(vs) / C + 1e-5f);
+  const float rs = rsqrtf(wave_total(vs) / C + eps);
   for (int c = lane; c < C; c += 64) y[r * C + c] = (xr[c] - mu) * rs * g[c] + b[c];
   if (lane == 0) {
     mean[r] = mu;

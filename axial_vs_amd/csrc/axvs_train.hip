@@ -4,6 +4,7 @@
 #include "axvs_host.h"
 #include "axvs_train.h"
 #include "axvs_train_gemm.h"
+#include "axvs_cc_train.h"
 
 namespace axvs {
 namespace {
@@ -35,27 +36,43 @@ struct Gemm {
   }
   // row-major:  Y[M,N] = beta Y + epilogue(X[M,K] W[N,K]^T); epilogue (optional): + bias, * mul, ReLU, dropout by element index
   // exact: three bf16 pieces per operand (fp32 accuracy) -- for the GEMM in front of the ReLU (see tr_gemm_nt_kernel)
-  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K, float beta = 0.f, const GemmEpi* ep = nullptr,
-          bool exact = false) const {
-    if (N % 4 || K % 4) return fail(AXVS_ERR_ARG, "training GEMM: N=%d and K=%d must be multiples of 4", N, K);
-    GemmEpi e = ep ? *ep : GemmEpi{nullptr, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, 0.f};
-    e.beta = beta;
-    const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT));
-    if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, e);
-    else hipLaunchKernelGGL(tr_gemm_nt_kernel<2>, grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, e);
+  // ld (optional): row strides of X, W, Y (sub-matrices of wider buffers); ld.ksteps > 0 with zsplits: split-K partials [z][M][ld.c]
+  int nt(const float* X, const float* W, float* Y, long long M, int N, int K, GemmLd ld, const GemmEpi& e, bool exact, int zsplits = 1) const {
+    if (N % 4 || K % 4 || ld.a % 4 || ld.b % 4 || ld.c % 4) return fail(AXVS_ERR_ARG, "training GEMM: N=%d, K=%d and the row strides must be multiples of 4", N, K);
+    if (M <= 0) return AXVS_OK;
+    const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT), (unsigned)zsplits);
+    if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+    else hipLaunchKernelGGL(tr_gemm_nt_kernel<2>, grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
     return AXVS_OK;
   }
+  int fwd(const float* X, const float* W, float* Y, long long M, int N, int K, float beta = 0.f, const GemmEpi* ep = nullptr,
+          bool exact = false) const {
+    GemmEpi e = ep ? *ep : GemmEpi{nullptr, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, 0.f};
+    e.beta = beta;
+    return nt(X, W, Y, M, N, K, GemmLd{K, K, N, 0}, e, exact);
+  }
   // dW[N,K] = dY[M,N]^T X[M,K]: the reduction runs over the M rows and the output is small, so the rows are split kSplit ways
-  // into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).
+  // into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).  ldy / ldx: row strides of dY / X (0: N / K).
   static constexpr int kSplit = 64;
-  int wgrad_partials(const float* dY, const float* X, float* part, long long M, int N, int K, int* nparts, float* part_b = nullptr) const {
+  int wgrad_partials(const float* dY, const float* X, float* part, long long M, int N, int K, int* nparts, float* part_b = nullptr,
+                     long long ldy = 0, long long ldx = 0) const {
     if (N % 8 || K % 8) return fail(AXVS_ERR_ARG, "training GEMM: N=%d and K=%d must be multiples of 8", N, K);
     long long chunk = (M + kSplit - 1) / kSplit;
     chunk = (chunk + kGK - 1) / kGK * kGK;                 // whole k-steps per split
     const int np = (int)((M + chunk - 1) / chunk);
     const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), (unsigned)np);
-    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b);
+    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b,
+                       GemmLd{ldy ? ldy : N, ldx ? ldx : K, K, 0});
     *nparts = np;
+    return AXVS_OK;
+  }
+  // P[N][K] (row stride ldo) = A[Mc][N]^T X[Mc][K]: the contraction over a FEW rows Mc (the 128 channels of the mask einsum,
+  // CC:55) in one split, straight into the caller's tensor
+  int tn_direct(const float* A, const float* X, float* P, int Mc, int N, int K, long long lda, long long ldx, long long ldo) const {
+    if (N % 8 || K % 8 || lda % 4 || ldx % 4 || ldo % 4) return fail(AXVS_ERR_ARG, "einsum GEMM: N=%d and K=%d must be multiples of 8", N, K);
+    const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), 1u);
+    const long long chunk = (Mc + kGK - 1) / kGK * kGK;
+    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, GemmLd{lda, ldx, ldo, 0});
     return AXVS_OK;
   }
 };
@@ -89,21 +106,25 @@ struct Saved {
   float *buf1, *buf2, *mean1, *rstd1, *z, *r, *u, *mean2, *rstd2;
 };
 
+PassSaved carve_pass(Bump& b, const Dims& d) {
+  PassSaved p{};
+  const size_t MC = (size_t)d.M * d.C;
+  p.q = b.f(MC);
+  p.k = b.f(MC);
+  p.v = b.f(MC);
+  p.x = b.f(MC * d.T);
+  p.xd = b.f(MC);
+  p.q2 = b.f(MC);
+  p.kv2 = b.f(MC * d.T * 2);
+  p.o = b.f(MC);
+  p.st = b.f((size_t)d.M * d.heads * d.T * 3);
+  return p;
+}
+
 Saved carve_saved(Bump& b, const Dims& d) {
   Saved s{};
   const size_t MC = (size_t)d.M * d.C;
-  for (int i = 0; i < 2; ++i) {
-    PassSaved& p = s.p[i];
-    p.q = b.f(MC);
-    p.k = b.f(MC);
-    p.v = b.f(MC);
-    p.x = b.f(MC * d.T);
-    p.xd = b.f(MC);
-    p.q2 = b.f(MC);
-    p.kv2 = b.f(MC * d.T * 2);
-    p.o = b.f(MC);
-    p.st = b.f((size_t)d.M * d.heads * d.T * 3);
-  }
+  for (int i = 0; i < 2; ++i) s.p[i] = carve_pass(b, d);
   s.buf1 = b.f(MC);
   s.buf2 = b.f(MC);
   s.mean1 = b.f(d.M);
@@ -191,9 +212,10 @@ struct Ctx {
     if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_b, nblk, (size_t)N, out_b);
   }
   // dW[N,K] = dY[M,N]^T X[M,K]; db (nullable) [N] = column sums of dY -- the bias gradient rides in the same GEMM launch
-  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K, float* db = nullptr) const {
+  int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K, float* db = nullptr, long long ldy = 0,
+            long long ldx = 0) const {
     int np = 0;
-    int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np, db ? sc.part_a : nullptr);
+    int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np, db ? sc.part_a : nullptr, ldy, ldx);
     if (rc != AXVS_OK) return rc;
     const size_t n = (size_t)N * K;
     hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
@@ -201,9 +223,11 @@ struct Ctx {
     return AXVS_OK;
   }
   // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
-  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta) const {
+  // exact: three-piece operands (see axvs_train_gemm.h) -- where the result feeds a sum that cancels analytically
+  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta, long long ldy = 0, bool exact = false) const {
     hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, sc.wt, N, K);
-    return g.fwd(dY, sc.wt, dX, M, K, N, beta, nullptr, g_train_exact >= 2);
+    GemmEpi e{nullptr, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, beta};
+    return g.nt(dY, sc.wt, dX, M, K, N, GemmLd{ldy ? ldy : N, N, K, 0}, e, exact || g_train_exact >= 2);
   }
   int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn) : AXVS_OK; }
 };
@@ -224,12 +248,13 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   const int C = d.C;
   const Drop none = make_drop(0.f, 0, 0);
   int rc;
-  c.add(xin, pos, c.sc.a, (size_t)M * C);
+  const float* const xa = pos ? c.sc.a : xin;           // q = k = x (+ pos): the cross-clip layer has no positional term (CC:96)
+  if (pos) c.add(xin, pos, c.sc.a, (size_t)M * C);
   // (the biases ride in the GEMM epilogues; `ex`: option train_exact -- forward products with fp32 accuracy)
   const bool ex = g_train_exact != 0;
   const GemmEpi eq{w.q_b, 1.f, 0, none, 0.f}, ek{w.k_b, 1.f, 0, none, 0.f}, ev{w.v_b, 1.f, 0, none, 0.f};
-  if ((rc = c.g.fwd(c.sc.a, w.q_w, s.q, M, C, C, 0.f, &eq, ex)) != AXVS_OK) return rc;
-  if ((rc = c.g.fwd(c.sc.a, w.k_w, s.k, M, C, C, 0.f, &ek, ex)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(xa, w.q_w, s.q, M, C, C, 0.f, &eq, ex)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(xa, w.k_w, s.k, M, C, C, 0.f, &ek, ex)) != AXVS_OK) return rc;
   if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C, 0.f, &ev, ex)) != AXVS_OK) return rc;
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
   const size_t lds_mfma = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
@@ -304,9 +329,10 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
                        (const float*)s.v, (const float*)sc.dx, (const float*)s.st, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop, QC);
   })
   // q / k / v projections
-  c.add(xin, pos, sc.a, MC);
-  if ((rc = c.wgrad(sc.dq, sc.a, gw.q_w, M, C, C, gw.q_b)) != AXVS_OK) return rc;
-  if ((rc = c.wgrad(sc.dk, sc.a, gw.k_w, M, C, C, gw.k_b)) != AXVS_OK) return rc;
+  const float* const xa = pos ? sc.a : xin;
+  if (pos) c.add(xin, pos, sc.a, MC);
+  if ((rc = c.wgrad(sc.dq, xa, gw.q_w, M, C, C, gw.q_b)) != AXVS_OK) return rc;
+  if ((rc = c.wgrad(sc.dk, xa, gw.k_w, M, C, C, gw.k_b)) != AXVS_OK) return rc;
   if ((rc = c.wgrad(sc.dv, xin, gw.v_w, M, C, C, gw.v_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dq, w.q_w, sc.da, M, C, C, 0.f)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dk, w.k_w, sc.da, M, C, C, 1.f)) != AXVS_OK) return rc;
@@ -352,7 +378,7 @@ int forward(const Ctx& c, const float* src, const float* pos, float* out, const 
   if ((rc = pass_fwd(c, s.buf1, pos, s.buf2, p.width_attn, s.p[1], rmw, d.B * d.H, make_drop(p_drop, seed, 3), make_drop(p_attn, seed, 4))) != AXVS_OK)
     return rc;
   // norm1 -> FFN -> norm2                               :181-185, :217-218
-  hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.buf2, p.norm1_w, p.norm1_b, s.z, s.mean1, s.rstd1, M, C);
+  hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.buf2, p.norm1_w, p.norm1_b, s.z, s.mean1, s.rstd1, M, C, 1e-5f);
   {   // linear1 + bias + ReLU + dropout2 in one launch
     const GemmEpi e1{p.linear1_b, 1.f, 1, make_drop(p_drop, seed, 5), 0.f};
     if ((rc = c.g.fwd(s.z, p.linear1_w, s.r, M, d.F, C, 0.f, &e1, g_train_exact != 0)) != AXVS_OK) return rc;
@@ -361,9 +387,11 @@ int forward(const Ctx& c, const float* src, const float* pos, float* out, const 
   const RowMap id{(int)(M > INT32_MAX ? INT32_MAX : M), (int)(M > INT32_MAX ? INT32_MAX : M), 1, M, M, 1, 0};
   hipLaunchKernelGGL(tr_bias_drop_res_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)c.sc.t0, p.linear2_b, (const float*)s.z,
                      s.u, id, M, C, make_drop(p_drop, seed, 6));
-  hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.u, p.norm2_w, p.norm2_b, out, s.mean2, s.rstd2, M, C);
+  hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, c.st, (const float*)s.u, p.norm2_w, p.norm2_b, out, s.mean2, s.rstd2, M, C, 1e-5f);
   return status();
 }
+
+#include "axvs_cc_train_host.h"
 
 }  // namespace
 }  // namespace axvs
@@ -459,6 +487,65 @@ int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float
                      make_drop(p_attn_drop, seed, 2), d_src, d_pos, false)) != AXVS_OK)
     return rc;
   return status();
+}
+
+// ---- cross-clip tracking module, training tier (axvs_cc_train_host.h) ---------------------------------------------------------------
+size_t axvs_cc_module_train_saved_bytes(const AxvsCCTrainCfg* cfg) {
+  CCShape s;
+  if (make_cc_shape(s, cfg) != AXVS_OK) return 0;
+  Bump b(nullptr);
+  carve_cc_saved(b, s);
+  return b.off;
+}
+
+size_t axvs_cc_module_train_scratch_bytes(const AxvsCCTrainCfg* cfg, int backward) {
+  CCShape s;
+  if (make_cc_shape(s, cfg) != AXVS_OK) return 0;
+  Bump b(nullptr);
+  carve_scratch(b, s.d, backward != 0);
+  carve_cc_scratch(b, s, backward != 0);
+  return b.off;
+}
+
+size_t axvs_cc_module_train_bn_stats_floats(const AxvsCCTrainCfg* cfg) {
+  CCShape s;
+  if (make_cc_shape(s, cfg) != AXVS_OK) return 0;
+  return (size_t)s.nl * (4 * kCcC + 2 * kCcCm + 2);
+}
+
+int axvs_cc_module_train_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks, float* bn_stats,
+                             const AxvsCCLayerParams* layers, const AxvsCCHeadParams* heads, const AxvsCCTrainCfg* cfg, void* saved,
+                             size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !bn_stats || !layers || !heads || !cfg || !saved || !scratch)
+    return fail(AXVS_ERR_ARG, "null pointer");
+  CCCtx k{};
+  CCSaved sv;
+  int rc;
+  if ((rc = cc_setup(k, cfg, scratch, scratch_bytes, saved, saved_bytes, sv, false, stream)) != AXVS_OK) return rc;
+  for (int l = 0; l < k.s.nl; ++l)
+    if ((rc = cc_check_ptrs(&layers[l], sizeof(AxvsCCLayerParams), "AxvsCCLayerParams")) != AXVS_OK) return rc;
+  if ((rc = cc_check_ptrs(heads, sizeof(AxvsCCHeadParams), "AxvsCCHeadParams")) != AXVS_OK) return rc;
+  return cc_forward(k, clip_query, panoptic_features, pred_logits, pred_masks, bn_stats, layers, *heads, sv);
+}
+
+int axvs_cc_module_train_bwd(const float* d_logits, const float* d_masks, const float* clip_query, const float* panoptic_features,
+                             const AxvsCCLayerParams* layers, const AxvsCCHeadParams* heads, const AxvsCCLayerGrads* layer_grads,
+                             const AxvsCCHeadGrads* head_grads, float* d_clip_query, const AxvsCCTrainCfg* cfg, void* saved, size_t saved_bytes,
+                             void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d_logits || !d_masks || !clip_query || !panoptic_features || !layers || !heads || !layer_grads || !head_grads || !d_clip_query || !cfg ||
+      !saved || !scratch)
+    return fail(AXVS_ERR_ARG, "null pointer");
+  CCCtx k{};
+  CCSaved sv;
+  int rc;
+  if ((rc = cc_setup(k, cfg, scratch, scratch_bytes, saved, saved_bytes, sv, true, stream)) != AXVS_OK) return rc;
+  for (int l = 0; l < k.s.nl; ++l) {
+    if ((rc = cc_check_ptrs(&layers[l], sizeof(AxvsCCLayerParams), "AxvsCCLayerParams")) != AXVS_OK) return rc;
+    if ((rc = cc_check_ptrs(&layer_grads[l], sizeof(AxvsCCLayerGrads), "AxvsCCLayerGrads")) != AXVS_OK) return rc;
+  }
+  if ((rc = cc_check_ptrs(heads, sizeof(AxvsCCHeadParams), "AxvsCCHeadParams")) != AXVS_OK) return rc;
+  if ((rc = cc_check_ptrs(head_grads, sizeof(AxvsCCHeadGrads), "AxvsCCHeadGrads")) != AXVS_OK) return rc;
+  return cc_backward(k, d_logits, d_masks, clip_query, panoptic_features, layers, *heads, layer_grads, *head_grads, d_clip_query, sv);
 }
 
 }  // extern "C"

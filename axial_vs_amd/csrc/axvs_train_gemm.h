@@ -30,6 +30,11 @@ constexpr int kGTileElems = kGT * kGK;   // one 16-bit operand tile
 constexpr int kGLd = kGT + 4;            // fp32 row stride of the epilogue staging tile
 constexpr size_t kGemmLds = (size_t)kGT * kGLd * sizeof(float);   // 67.6 KB >= 2 stages x 4 tiles x 8 KB
 
+struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps > 0: split-K, that many 32-wide k-steps per blockIdx.z
+  long long a, b, c;
+  int ksteps;
+};
+
 struct GemmEpi {
   const float* bias;   // nullable [N]: added first
   float mul;           // then multiplied
@@ -85,7 +90,7 @@ constexpr size_t gemm_nt_lds() {
 
 template <int NS>
 __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                                         float* __restrict__ C, long long M, int N, int K, GemmEpi ep) {
+                                                                         float* __restrict__ C, long long M, int N, int K, GemmLd ld, GemmEpi ep) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
   u16* const sbuf = reinterpret_cast<u16*>(gsmem);            // [2 stages][A pieces | B pieces][128 rows][32] (rows chunk-swizzled)
   constexpr int kStage = 2 * NS * kGTileElems;
@@ -96,10 +101,15 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   // staging: thread -> (tile row, 8-float chunk): 4 threads cover a 128-byte row segment
   const int sr = tid >> 2, sq = tid & 3;
   const bool a_ok = m0 + sr < M, b_ok = n0 + sr < N;
-  const float* ap = A + (m0 + (a_ok ? sr : 0)) * K + sq * 8;
-  const float* bp = B + (long long)(n0 + (b_ok ? sr : 0)) * K + sq * 8;
+  // split-K (ld.ksteps > 0): workgroup z contracts k-steps [z ksteps, (z + 1) ksteps) into the partial C + z M ldc
+  const int nk_all = (K + kGK - 1) / kGK;
+  const int ks0 = ld.ksteps > 0 ? (int)blockIdx.z * ld.ksteps : 0;
+  const int nk = ld.ksteps > 0 ? (nk_all - ks0 < ld.ksteps ? (nk_all - ks0 > 0 ? nk_all - ks0 : 0) : ld.ksteps) : nk_all;
+  const int kbase = ks0 * kGK;
+  const float* ap = A + (m0 + (a_ok ? sr : 0)) * ld.a + kbase + sq * 8;
+  const float* bp = B + (long long)(n0 + (b_ok ? sr : 0)) * ld.b + kbase + sq * 8;
+  C += (size_t)blockIdx.z * M * ld.c;
   const int soff = sr * 32 + swz_chunk(sr, sq) * 8;
-  const int nk = (K + kGK - 1) / kGK;
   // global loads run TWO k-steps ahead of the MFMAs (two register slots, used alternately): with one step of lookahead a load had a
   // single step's MFMAs (~0.3 us) to cover an L2 / HBM round trip and every step stalled at its LDS store
   float4 ra[2][2], rb[2][2];
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
     constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int kk = ks * kGK + sq * 8 + 4 * h;               // K % 4 == 0: a float4 is inside or outside
+      const int kk = kbase + ks * kGK + sq * 8 + 4 * h;       // K % 4 == 0: a float4 is inside or outside
       const bool kin = kk < K;
       ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
       rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
@@ -174,9 +184,9 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
     if (ks + 1 < nk) lstore(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});   // the other stage: every wave left its reads behind the previous barrier
     __syncthreads();
   };
-  gload(0, S0{});
+  if (nk > 0) gload(0, S0{});
   if (nk > 1) gload(1, S1{});
-  lstore(0, S0{});
+  if (nk > 0) lstore(0, S0{});
   __syncthreads();
   for (int ks = 0; ks < nk; ks += 2) {
     kstep(ks, S0{});
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
         const float4 b = *reinterpret_cast<const float4*>(ep.bias + gn);
         t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
       }
-      float* const cp = C + gm * N + gn;
+      float* const cp = C + gm * ld.c + gn;
       const unsigned long long e0 = (unsigned long long)gm * N + gn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -248,7 +258,7 @@ __device__ __forceinline__ u16x8 tn_frag(const u16* tile, int col0, int fi, int 
 // softmax -- so it does not go through the bf16 split) and reduced over the 32 staging rows through LDS in a fixed order.
 __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
                                                             long long M, int N, int K, long long rows_per_split,
-                                                            float* __restrict__ part_b) {
+                                                            float* __restrict__ part_b, GemmLd ld) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
   u16* const sbuf = reinterpret_cast<u16*>(gsmem);            // [2 stages][dY hi | dY lo | X hi | X lo][32 rows m][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
@@ -270,8 +280,8 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
     const bool m_ok = m < me;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      ra[h] = m_ok && n_ok ? *reinterpret_cast<const float4*>(dY + m * N + n0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
-      rb[h] = m_ok && k_ok ? *reinterpret_cast<const float4*>(X + m * K + k0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      ra[h] = m_ok && n_ok ? *reinterpret_cast<const float4*>(dY + m * ld.a + n0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      rb[h] = m_ok && k_ok ? *reinterpret_cast<const float4*>(X + m * ld.b + k0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&](int stage) {
@@ -319,13 +329,13 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
     __syncthreads();
   }
   // partial tile: lane (n = fi, 4 consecutive k) -> 16-byte stores into part[split][n][k]
-  float* const out = part + (size_t)blockIdx.y * N * K;
+  float* const out = part + (size_t)blockIdx.y * N * ld.c;     // (ld.c != K only with a single split: the einsum form below)
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const int n = n0 + wn * 64 + nt * 16 + fi, k = k0 + wk * 32 + kt * 16 + 4 * fg;
-      if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * K + k) = float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
+      if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * ld.c + k) = float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
     }
   if (do_bias) {                 // (the loop's last barrier is behind every wave: the operand stages are free)
     float* const red = reinterpret_cast<float*>(gsmem);        // [32 staging rows][128 columns]

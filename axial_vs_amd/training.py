@@ -3,7 +3,7 @@
 Reference: the layer in ``train()`` mode under autograd, WC/temporal_attention.py:187-220 (and TrajectoryAttention :35-76), as the
 shipped configs train it (``ATTN_DROP: 0.1``, AMP -- VK/configs/VIPSeg/.../maxtron_wc_convnext_large.yaml).  The forward and the
 backward pass both run in the library (``axvs_axial_layer_train_fwd`` / ``_bwd``: fp32 activations, hand-written attention /
-softmax / dropout / LayerNorm kernels, rocBLAS for the Linear layers' GEMMs); this file is the ``torch.autograd.Function`` that
+softmax / dropout / LayerNorm kernels, split-precision bf16 MFMA GEMMs for the Linear layers); this file is the ``torch.autograd.Function`` that
 binds them, nothing is computed here.
 
 * recompute (default): the forward pass keeps only (src, pos, seed); backward rebuilds the activations first.  ``recompute=False``

@@ -353,7 +353,8 @@ int axvs_scaled_residual(const float* a, const float* b, const float* gamma, flo
  * Semantics: TemporalAxialTrajectoryAttentionLayer.forward in train() mode, WC/temporal_attention.py:187-220 under autograd:
  * dropout(p_dropout) on the spatial attention maps (:32, :55 -- the layer passes `dropout` as the attention's attn_drop, :164-165),
  * dropout1(p_attn_drop) on both pass outputs (:166, :204, :213), dropout2 / dropout3(p_dropout) in the FFN (:172-174, :182-183).
- * fp32 activations in natural [B,T,H,W,C] order; GEMMs through rocBLAS (loaded on first use); head_dim in {8,16,32}; T <= 8.
+ * fp32 activations in natural [B,T,H,W,C] order; the Linear layers run on split-precision bf16 MFMA GEMMs (axvs_train_gemm.h,
+ * no vendor BLAS); head_dim in {8,16,32}; T <= 8.
  * Dropout masks are a pure function of (seed, site, element offset in the reference's tensor at that site):
  *   h = seed ^ (site * 0x9E3779B9);  h = fmix32(h ^ lo32(idx));  h = fmix32(h ^ hi32(idx));  keep iff (h >> 8) >= floor(p * 2^24)
  *   (fmix32 = MurmurHash3's finaliser); sites: 1 height attention map [(B W) heads, T H, T, H], 2 height pass output [(B W), T H, C],
@@ -381,6 +382,65 @@ int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float
                                const AxvsAxialLayerGrads* grads, float* d_src, float* d_pos, int B, int T, int H, int W, int C, int heads,
                                int d_ffn, float p_dropout, float p_attn_drop, unsigned seed, int recompute, void* saved, size_t saved_bytes,
                                void* scratch, size_t scratch_bytes, void* stream);
+
+/* =====================================================================================================
+ * Training tier of the cross-clip tracking module: CrossClipTrackingModule.forward in train() mode,
+ * CC/maxtron_cross_clip_tracking_module.py:275-322 under autograd -- the module the reference trains on its own with the
+ * segmenter frozen (maxtron_cc_model.py:104-108).  Per layer: TrajectoryAttentionLayer (:133-173; attention-map dropout
+ * p_attn_drop, site 10 + 2 l, index as in the layer above), ASPP (:176-201; _proj_drop p_aspp_drop, site 11 + 2 l, element
+ * index of the reference's [(B Q), 256, Tc] tensor) + residual + LayerNorm (:293-295); then for EVERY layer the embedding
+ * projections and the predictor's training branch (:300-309, :45-57) with (Sync)BatchNorm on BATCH statistics (eps 1e-3).
+ * Sizes: C = 256, 8 heads, mask channels 128, norm_fn 'ln', kernel sizes 3; Q % 8 == 0, V*H*W % 8 == 0, Tc <= 8.
+ *
+ * SyncBatchNorm: `allreduce` (NULL in a single process) is called with a device buffer of partial sums (and the row count)
+ * that it must SUM over the ranks in place, ordered on `stream` -- three times per forward and three times per backward call.
+ * The parameter gradients written are this rank's own share (like nn.SyncBatchNorm under DDP: ranks are averaged afterwards).
+ * bn_stats (forward, out): [class_proj [nl][2][256] | mask_proj [nl][2][256] | mask_head [nl][2][128] | pixel [nl][2]] = the batch
+ * mean and UNBIASED variance of each layer's call, for the caller's running-statistics update (momentum 0.01, in layer order).
+ * The running means are only read (as the shift of the variance sums); gradients are WRITTEN, not accumulated; no gradient is
+ * produced for panoptic_features (the frozen segmenter's output).
+ * ===================================================================================================== */
+typedef struct AxvsCCLayerGrads {     /* field order of AxvsCCLayerParams */
+  AxvsTrajGrads attn;
+  float *norm_w, *norm_b;
+  float *aspp_w[3], *aspp_b[3];
+  float *aspp_proj_w;
+  float *aspp_norm_w, *aspp_norm_b;
+  float *conv_norm_w, *conv_norm_b;
+} AxvsCCLayerGrads;
+typedef struct AxvsBNGrads { float *w, *b; } AxvsBNGrads;
+typedef struct AxvsCCHeadGrads {      /* field order of AxvsCCHeadParams */
+  float* class_proj_w; AxvsBNGrads class_proj_bn;
+  float* mask_proj_w;  AxvsBNGrads mask_proj_bn;
+  float* mask_head_w;  AxvsBNGrads mask_head_bn;
+  float *class_head_w, *class_head_b;
+  float *act_head_w, *act_head_b;
+  AxvsBNGrads pixel_bn;
+} AxvsCCHeadGrads;
+typedef int (*axvs_allreduce_fn)(void* user, float* device_buf, size_t n, void* stream);   /* 0 = success */
+typedef struct AxvsCCTrainCfg {
+  int B, Q, Tc, V, H, W, K1, num_layers;
+  int rates[3];
+  float p_attn_drop, p_aspp_drop;
+  unsigned seed;
+  axvs_allreduce_fn allreduce;
+  void* allreduce_user;
+} AxvsCCTrainCfg;
+size_t axvs_cc_module_train_saved_bytes(const AxvsCCTrainCfg* cfg);
+size_t axvs_cc_module_train_scratch_bytes(const AxvsCCTrainCfg* cfg, int backward);
+size_t axvs_cc_module_train_bn_stats_floats(const AxvsCCTrainCfg* cfg);
+/* clip_query fp32 [B,Q,Tc,256]; panoptic_features fp32 [B,128,Tc*V,H,W]; pred_logits fp32 [nl,1,Q,K1]; pred_masks fp32
+ * [nl,B,Q,Tc*V,H,W]; layers: array of num_layers parameter sets (the fp32 nn.Parameter storages themselves; AxvsBN.mean / .var =
+ * the running buffers). */
+int axvs_cc_module_train_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks, float* bn_stats,
+                             const AxvsCCLayerParams* layers, const AxvsCCHeadParams* heads, const AxvsCCTrainCfg* cfg, void* saved,
+                             size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+/* d_logits / d_masks: gradients of pred_logits / pred_masks (all layers: the auxiliary outputs are part of the loss, CC:311-318).
+ * `saved` as the forward call left it.  Writes d_clip_query [B,Q,Tc,256] and every buffer of layer_grads[0..nl) / head_grads. */
+int axvs_cc_module_train_bwd(const float* d_logits, const float* d_masks, const float* clip_query, const float* panoptic_features,
+                             const AxvsCCLayerParams* layers, const AxvsCCHeadParams* heads, const AxvsCCLayerGrads* layer_grads,
+                             const AxvsCCHeadGrads* head_grads, float* d_clip_query, const AxvsCCTrainCfg* cfg, void* saved, size_t saved_bytes,
+                             void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,12 +121,14 @@ def trajectory_attention(query: Tensor, key: Tensor, value: Tensor, w: Weights, 
     return _trajectory_core(q, k, v, w, num_frames, heads, want_attn, attn_keep)
 
 
-def cc_trajectory_attention(x: Tensor, w: Weights, seq_len: int, num_frames: int, heads: int = 8) -> Tensor:
-    """CC/maxtron_cross_clip_tracking_module.py:91-130 (fused qkv, no positional term)."""
+def cc_trajectory_attention(x: Tensor, w: Weights, seq_len: int, num_frames: int, heads: int = 8,
+                            attn_keep: Optional[Tensor] = None) -> Tensor:
+    """CC/maxtron_cross_clip_tracking_module.py:91-130 (fused qkv, no positional term).  attn_keep [B, heads, N, T, L]: train-mode
+    dropout factors of the spatial attention map (:106)."""
     assert x.shape[1] == seq_len * num_frames
     C = x.shape[-1]
     qkv = _linear(x, w, "qkv")
-    out, _ = _trajectory_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], w, num_frames, heads, False)
+    out, _ = _trajectory_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], w, num_frames, heads, False, attn_keep)
     return out
 
 
@@ -440,6 +442,110 @@ def cross_clip_module(clip_query: Tensor, panoptic_features: Tensor, w: Weights,
     aux = [{"pred_logits": a, "pred_masks": F.interpolate(b, size=size, mode="trilinear", align_corners=ac)}
            for a, b in zip(cls_all[:-1], mask_all[:-1])]
     return {"pred_logits": cls_all[-1], "pred_masks": mask_all[-1], "aux_outputs": aux, "clip_query": clip_query}
+
+
+# ---- the cross-clip module in train() mode: differentiable torch code, the gradient oracle of the training tier ----
+def _batch_norm_train(x: Tensor, w: Weights, name: str, eps: float = 1e-3) -> Tuple[Tensor, Tensor, Tensor]:
+    """nn.SyncBatchNorm(eps=1e-3) in train mode on one process: normalise with the BATCH mean and biased variance over every
+    dimension but the channel (dim 1).  Returns (y, batch mean, UNBIASED batch variance) -- the latter two feed the
+    running-statistics update (momentum 0.01, kmax_pixel_decoder.py:36-37)."""
+    dims = [d for d in range(x.dim()) if d != 1]
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    n = x.numel() // x.shape[1]
+    mean = x.mean(dims)
+    var = ((x - mean.reshape(shape)) ** 2).mean(dims)
+    g = w[name + ".weight"].to(x.dtype).reshape(shape)
+    b = w[name + ".bias"].to(x.dtype).reshape(shape)
+    y = (x - mean.reshape(shape)) / torch.sqrt(var.reshape(shape) + eps) * g + b
+    return y, mean.detach(), (var * n / max(n - 1, 1)).detach()
+
+
+def cc_module_param_shapes(num_layers: int, num_classes: int) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys and shapes of CrossClipTrackingModule(num_layers, num_classes, norm_fn='ln', kernel sizes 3) (CC:233-272)."""
+    C, Cm, K1 = 256, 128, num_classes + 1
+    sh: Dict[str, Tuple[int, ...]] = {}
+    for i in range(num_layers):
+        p = f"transformer_trajectory_self_attention_layers.{i}."
+        for name, out in (("qkv", 3 * C), ("proj_q", C), ("proj_kv", 2 * C), ("proj", C)):
+            sh[p + f"self_attn.{name}.weight"] = (out, C)
+            sh[p + f"self_attn.{name}.bias"] = (out,)
+        sh[p + "norm.weight"] = (C,)
+        sh[p + "norm.bias"] = (C,)
+    for i in range(num_layers):
+        p = f"conv_short_aggregate_layers.{i}."
+        for k in range(3):
+            sh[p + f"_aspp_conv{k}.weight"] = (C, C, 3)
+            sh[p + f"_aspp_conv{k}.bias"] = (C,)
+        sh[p + "_proj_conv_bn_act.conv.weight"] = (C, 3 * C, 1)
+        sh[p + "_proj_conv_bn_act.norm.weight"] = (C,)
+        sh[p + "_proj_conv_bn_act.norm.bias"] = (C,)
+    for i in range(num_layers):
+        sh[f"conv_norms.{i}.weight"] = (C,)
+        sh[f"conv_norms.{i}.bias"] = (C,)
+
+    def bn(prefix, n):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            sh[f"{prefix}.{k}"] = (n,)
+
+    for name in ("_class_embedding_projection", "_mask_embedding_projection"):
+        sh[name + ".conv.weight"] = (C, C, 1)
+        bn(name + ".norm", C)
+    sh["_predictor._transformer_mask_head.conv.weight"] = (Cm, C, 1)
+    bn("_predictor._transformer_mask_head.norm", Cm)
+    sh["_predictor._transformer_class_head.conv.weight"] = (K1, C, 1)
+    sh["_predictor._transformer_class_head.conv.bias"] = (K1,)
+    sh["_predictor._transformer_class_activation_head.conv.weight"] = (1, C, 1)
+    sh["_predictor._transformer_class_activation_head.conv.bias"] = (1,)
+    bn("_predictor._pixel_space_mask_batch_norm", 1)
+    return sh
+
+
+def cc_module_train(clip_query: Tensor, panoptic_features: Tensor, w: Weights, num_layers: int, num_clip_frames: int,
+                    atrous_rates=(1, 2, 3), p_attn_drop: float = 0.0, p_aspp_drop: float = 0.0, seed: int = 0, heads: int = 8):
+    """CrossClipTrackingModule.forward in train() mode (CC:275-322 with the predictor's training branch :53-57), dropout factors
+    from `dropout_keep` (site 10 + 2 l: attention maps of layer l, CC:106; 11 + 2 l: the ASPP's _proj_drop, CC:199).
+    -> (class logits per layer [1,Q,K1], mask logits per layer [B,Q,Tc*V,H,W], {bn site: [(batch mean, unbiased var) per layer]})."""
+    B, Q, Tc, C = clip_query.shape
+    Bp, Cp, TV, H, W = panoptic_features.shape
+    V = num_clip_frames
+    dt = clip_query.dtype
+    pf = panoptic_features.reshape(Bp, Cp, Tc, V, H, W).permute(0, 2, 1, 3, 4, 5).reshape(Bp * Tc, Cp, V * H, W)          # :278
+    cls_all, mask_all = [], []
+    stats: Dict[str, list] = {}
+
+    def bn(x, name):
+        y, m, v = _batch_norm_train(x, w, name)
+        stats.setdefault(name, []).append((m, v))
+        return y
+
+    for i in range(num_layers):
+        x = clip_query.permute(0, 2, 1, 3).reshape(B, Tc * Q, C)                                                           # :284
+        wl = _sub(w, f"transformer_trajectory_self_attention_layers.{i}")
+        N = Tc * Q
+        keep = dropout_keep(seed, 10 + 2 * i, B * heads * N * Tc * Q, p_attn_drop, dt).reshape(B, heads, N, Tc, Q) if p_attn_drop > 0 else None
+        x = _layer_norm(x + cc_trajectory_attention(x, _sub(wl, "self_attn"), Q, Tc, heads, keep), wl, "norm")               # :156-161
+        x = x.reshape(B, Tc, Q, C).permute(0, 2, 3, 1).reshape(B * Q, C, Tc)                                               # :290
+        a = aspp(x, _sub(w, f"conv_short_aggregate_layers.{i}"), (3, 3, 3), atrous_rates, "ln")
+        a = a * dropout_keep(seed, 11 + 2 * i, a.numel(), p_aspp_drop, dt).reshape(a.shape)                                 # :199
+        clip_query = _layer_norm((a + x).transpose(1, 2), w, f"conv_norms.{i}").reshape(B, Q, Tc, C)                       # :293-297
+        vq = clip_query.permute(0, 2, 3, 1).reshape(B * Tc, C, Q)                                                          # :298
+        ce = _gelu(bn(_conv1d_k1(vq, w, "_class_embedding_projection.conv"), "_class_embedding_projection.norm"))
+        me = _gelu(bn(_conv1d_k1(vq, w, "_mask_embedding_projection.conv"), "_mask_embedding_projection.norm"))
+        wp = _sub(w, "_predictor")
+        act = torch.softmax(_conv1d_k1(ce, wp, "_transformer_class_activation_head.conv"), dim=0)                          # :48-49
+        pooled = (ce * act).sum(0, keepdim=True)                                                                           # :50
+        logits = _conv1d_k1(pooled, wp, "_transformer_class_head.conv").permute(0, 2, 1)                                   # :51
+        K1 = logits.shape[-1]
+        void = logits.new_zeros(K1)
+        void[-1] = math.log((K1 - 1) * 0.9 / (1 - 0.9))
+        logits = logits + void                                                                                            # :52
+        kern = bn(_conv1d_k1(me, wp, "_transformer_mask_head.conv"), "_predictor._transformer_mask_head.norm")            # :53
+        masks = torch.einsum("bchw,bcn->bnhw", pf, kern)                                                                   # :55
+        masks = bn(masks.unsqueeze(1), "_predictor._pixel_space_mask_batch_norm").squeeze(1)                               # :56
+        masks = masks.reshape(B, Tc, Q, V, H, W).permute(0, 2, 1, 3, 4, 5).reshape(B, Q, Tc * V, H, W)                     # :57
+        cls_all.append(logits)
+        mask_all.append(masks)
+    return cls_all, mask_all, stats
 
 
 # --------------------------------------------------------------------------------------

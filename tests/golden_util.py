@@ -197,5 +197,16 @@ def train_grad_errors(z, grads):
     return errs
 
 
+CC_TRAIN = ["g13_cc_train_B1_Q16_Tc3_V2_H8_L2", "g13_cc_train_B1_Q16_Tc4_V2_H8_L2", "g13_cc_train_B2_Q8_Tc2_V1_H4_L1",
+            "g13_cc_train_B1_Q24_Tc5_V1_H8_L3"]
+
+
+def cc_train_inputs(m):
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Q"], m["Tc"], 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(m["B"], 128, m["Tc"] * m["V"], m["H"], m["W"], generator=g), dim=1)
+    return cq, pf
+
+
 POS_MASK = ["g11_pos3d_mask_B2_T3_H6_W7_n16", "g11_pos3d_mask_B1_T4_H12_W9_n64", "g11_pos3d_mask_B2_T2_H5_W8_n32"]
 GELU = ["g12_axial_gelu_B1_T2_C64_H6_W5", "g12_axial_gelu_B1_T3_C256_H16_W16"]

@@ -1,0 +1,130 @@
+"""GPU: the training tier of the cross-clip tracking module -- forward + backward through the C-ABI -- against the
+reference-autograd fixtures (tests/golden/g13_*, oracle/gen_golden_cc_train.py) and, at BASELINE config 4's size, against autograd on
+the float64 oracle restatement."""
+import numpy as np
+import pytest
+import torch
+
+import __graft_entry__ as ge
+import axvs_oracle as orc
+from golden_util import CC_TRAIN, load, rel_err, rel_l2, t, train_grad_errors, weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # fp32 activations, split-bf16 GEMMs with fp32 accuracy in the forward: observed ~1e-6 .. 2e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    ge.build()
+    assert torch.cuda.is_available()
+
+
+def make_module(m, w, seed):
+    import axial_vs_amd as ax
+    mod = ax.CrossClipTrackingModule(num_layers=m["layers"], num_classes=m["num_classes"], attn_drop=m["p_attn_drop"], aspp_drop=m["p_aspp_drop"],
+                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=m["V"])
+    sd = mod.state_dict()
+    sd.update(w)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.cuda().train()
+    mod.dropout_seed = seed
+    return mod
+
+
+def inputs(m):
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Q"], m["Tc"], 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(m["B"], 128, m["Tc"] * m["V"], m["H"], m["W"], generator=g), dim=1)
+    return cq, pf
+
+
+def run(mod, cq, pf, d_logits, d_masks):
+    q = cq.float().cuda().requires_grad_(True)
+    out = mod(q, pf.float().cuda())
+    logits = [a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]
+    masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+    assert all(x.is_cuda and x.requires_grad for x in logits + masks)       # the training branch keeps its outputs on the GPU (CC:53-57)
+    loss = sum((a * b.cuda()).sum() for a, b in zip(logits, d_logits)) + sum((a * b.cuda()).sum() for a, b in zip(masks, d_masks))
+    loss.backward()
+    return (torch.stack([x.detach() for x in logits]).cpu(), torch.stack([x.detach() for x in masks]).cpu(), q.grad.cpu(),
+            {k: v.grad.cpu() for k, v in mod.named_parameters()})
+
+
+@pytest.mark.parametrize("name", CC_TRAIN)
+def test_cc_training_tier_against_reference_autograd(name):
+    z, m = load(name)
+    w = weights(z, m)
+    cq, pf = inputs(m)
+    mod = make_module(m, w, m["dropout_seed"])
+    logits, masks, d_cq, grads = run(mod, cq, pf, list(t(z["d_logits"])), list(t(z["d_masks"])))
+    e = dict(logits=rel_err(logits, t(z["logits"])), masks=rel_err(masks, t(z["masks"])), d_clip_query=rel_err(d_cq, t(z["d_clip_query"])),
+             logits_l2=rel_l2(logits, t(z["logits"])), masks_l2=rel_l2(masks, t(z["masks"])), d_clip_query_l2=rel_l2(d_cq, t(z["d_clip_query"])))
+    ge_ = train_grad_errors(z, grads)
+    worst = max(ge_, key=ge_.get)
+    print(f"{name}: {e} worst parameter gradient {worst} {ge_[worst]:.2e}")
+    assert max(e.values()) < TOL, e
+    assert max(ge_.values()) < TOL, ge_
+    for k, p in mod.named_parameters():
+        assert p.grad.shape == p.shape and p.grad.dtype == p.dtype
+    # the forward updated the running statistics of the four BatchNorm sites like the reference's (once per layer, momentum 0.01)
+    for k, b in mod.named_buffers():
+        ref = t(z["buf." + k])
+        if b.dtype.is_floating_point:
+            assert rel_err(b.cpu(), ref) < TOL, k
+        else:
+            assert int(b) == int(ref), k
+
+
+def test_cc_training_dropout_is_a_function_of_the_seed_and_eval_tier_agrees():
+    z, m = load(CC_TRAIN[1])           # the fixture with both dropouts on
+    w = weights(z, m)
+    cq, pf = inputs(m)
+    dl, dm = list(t(z["d_logits"])), list(t(z["d_masks"]))
+    a = run(make_module(m, w, 7), cq, pf, dl, dm)
+    b = run(make_module(m, w, 7), cq, pf, dl, dm)
+    c = run(make_module(m, w, 8), cq, pf, dl, dm)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and all(torch.equal(a[3][k], b[3][k]) for k in a[3])
+    assert not torch.equal(a[1], c[1])
+
+
+def test_cc_training_at_baseline_config_4_vs_float64_oracle():
+    """BASELINE config 4 (4 clips x 4 frames, 64 x 64 pixel features, 128 queries, 4 layers): outputs and gradients against
+    torch.autograd on the float64 oracle restatement of the module's training branch."""
+    B, Q, Tc, V, H, W, nl, K = 1, 128, 4, 4, 64, 64, 4, 124
+    shapes = orc.cc_module_param_shapes(nl, K)
+    w = orc.random_weights(shapes, 77)
+    g = torch.Generator().manual_seed(78)
+    cq = torch.randn(B, Q, Tc, 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(B, 128, Tc * V, H, W, generator=g), dim=1)
+    d_logits = [torch.randn(1, Q, K + 1, generator=g) for _ in range(nl)]
+    d_masks = [torch.randn(B, Q, Tc * V, H, W, generator=g) * 0.01 for _ in range(nl)]
+    m = dict(layers=nl, num_classes=K, p_attn_drop=0.1, p_aspp_drop=0.1, V=V)
+    seed = 31337
+    wd = {k: v.double().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w.items()}
+    qd = cq.double().requires_grad_(True)
+    ref_logits, ref_masks, ref_stats = orc.cc_module_train(qd, pf.double(), wd, nl, V, [1, 2, 3], m["p_attn_drop"], m["p_aspp_drop"], seed)
+    loss = sum((a * b.double()).sum() for a, b in zip(ref_logits, d_logits)) + sum((a * b.double()).sum() for a, b in zip(ref_masks, d_masks))
+    loss.backward()
+    mod = make_module(m, w, seed)
+    logits, masks, d_cq, grads = run(mod, cq, pf, d_logits, d_masks)
+    rl, rm = torch.stack([x.detach() for x in ref_logits]), torch.stack([x.detach() for x in ref_masks])
+    e = dict(logits=rel_err(logits, rl), masks=rel_err(masks, rm), d_clip_query=rel_err(d_cq, qd.grad), logits_l2=rel_l2(logits, rl),
+             masks_l2=rel_l2(masks, rm), d_clip_query_l2=rel_l2(d_cq, qd.grad))
+    names = [k for k, v in wd.items() if v.requires_grad]
+    scale = max(float(wd[k].grad.norm()) for k in names)
+    pe = {k: float((grads[k].double() - wd[k].grad).norm() / max(float(wd[k].grad.norm()), 1e-3 * scale)) for k in names}
+    worst = max(pe, key=pe.get)
+    print(f"cfg 4: {e} worst parameter gradient {worst} {pe[worst]:.2e}")
+    assert max(e.values()) < TOL, e
+    assert max(pe.values()) < TOL, pe
+
+
+def test_cc_training_rejects_what_it_does_not_build():
+    import axial_vs_amd as ax
+    mod = ax.CrossClipTrackingModule(num_layers=1, num_classes=3, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3],
+                                     norm_fn="ln", num_clip_frames=1).cuda().train()
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        mod(torch.randn(1, 12, 2, 256, device="cuda"), torch.randn(1, 128, 2, 4, 8, device="cuda"))
+    with pytest.raises(NotImplementedError, match="panoptic_features"):
+        mod(torch.randn(1, 16, 2, 256, device="cuda"), torch.randn(1, 128, 2, 4, 8, device="cuda", requires_grad=True))

@@ -252,6 +252,35 @@ def test_training_oracle_against_reference_autograd(name):
     assert max(errs.values()) < 1e-6, errs
 
 
+@pytest.mark.parametrize("name", __import__("golden_util").CC_TRAIN)
+def test_cc_training_oracle_against_reference_autograd(name):
+    """orc.cc_module_train under autograd == the reference CrossClipTrackingModule in train() mode (float64, BatchNorm
+    on batch statistics, its nn.Dropout modules replaced by the hash-generated factors): the outputs of every layer, d_clip_query,
+    every parameter gradient and the running-statistics update."""
+    from golden_util import cc_train_inputs, train_grad_errors
+    z, m = load(name)
+    w0 = weights(z, m)
+    w = {k: v.double().requires_grad_("running" not in k) for k, v in w0.items()}
+    cq, pf = cc_train_inputs(m)
+    cq = cq.double().requires_grad_(True)
+    logits, masks, stats = orc.cc_module_train(cq, pf.double(), w, m["layers"], m["V"], (1, 2, 3), m["p_attn_drop"], m["p_aspp_drop"],
+                                               m["dropout_seed"])
+    loss = sum((a * b.double()).sum() for a, b in zip(logits, t(z["d_logits"]))) + sum((a * b.double()).sum() for a, b in zip(masks, t(z["d_masks"])))
+    loss.backward()
+    assert rel_err(torch.stack(logits).detach(), t(z["logits"])) < 1e-6          # the fixture is stored in fp32
+    assert rel_err(torch.stack(masks).detach(), t(z["masks"])) < 1e-6
+    assert rel_err(cq.grad, t(z["d_clip_query"])) < 1e-6
+    errs = train_grad_errors(z, {k: v.grad for k, v in w.items() if v.requires_grad})
+    assert max(errs.values()) < 1e-6, errs
+    for name_, per_layer in stats.items():                                        # momentum 0.01, one step per layer (CC:300-309)
+        rm, rv = w0[name_ + ".running_mean"].double(), w0[name_ + ".running_var"].double()
+        for mean, var in per_layer:
+            rm, rv = 0.99 * rm + 0.01 * mean, 0.99 * rv + 0.01 * var
+        assert rel_err(rm, t(z["buf." + name_ + ".running_mean"])) < 1e-7
+        assert rel_err(rv, t(z["buf." + name_ + ".running_var"])) < 1e-7
+        assert int(z["buf." + name_ + ".num_batches_tracked"]) == m["layers"]
+
+
 def test_dropout_hash_statistics_and_determinism():
     for p in (0.1, 0.25, 0.5):
         k = orc.dropout_keep(77, 3, 400000, p)
