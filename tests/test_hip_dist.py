@@ -79,3 +79,95 @@ def test_two_ranks_share_the_gpu_real_layer():
     for rank, r in res:
         print(rank, r)
         assert all(r.values()), (rank, r)
+
+
+def _syncbn_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import axvs_oracle as orc
+    import axial_vs_amd as ax
+    from golden_util import rel_err
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, Q, Tc, V, H, W, nl, K = 1, 16, 3, 2, 8, 8, 2, 7
+        w = orc.random_weights(orc.cc_module_param_shapes(nl, K), 91)
+        cqs, pfs, dls, dms = [], [], [], []
+        for r in range(world):                        # every rank knows every rank's (seeded) data: the expectation is the joint graph
+            g = torch.Generator().manual_seed(900 + r)
+            cqs.append(torch.randn(B, Q, Tc, 256, generator=g) + 0.3 * r)
+            pfs.append(torch.nn.functional.normalize(torch.randn(B, 128, Tc * V, H, W, generator=g), dim=1))
+            dls.append([torch.randn(1, Q, K + 1, generator=g) for _ in range(nl)])
+            dms.append([torch.randn(B, Q, Tc * V, H, W, generator=g) * 0.05 for _ in range(nl)])
+        wd = {k: v.double().requires_grad_("running" not in k) for k, v in w.items()}
+        qd = [c.double().requires_grad_(True) for c in cqs]
+        lg, mk, stats = orc.cc_module_train(qd, [p.double() for p in pfs], wd, nl, V, (1, 2, 3), 0.1, 0.1, 4242)
+        loss = sum((a * b.double()).sum() for r in range(world) for a, b in zip(lg[r], dls[r])) + \
+            sum((a * b.double()).sum() for r in range(world) for a, b in zip(mk[r], dms[r]))
+        loss.backward()
+        mod = ax.CrossClipTrackingModule(num_layers=nl, num_classes=K, attn_drop=0.1, aspp_drop=0.1, kernel_sizes=[3, 3, 3],
+                                         atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V)
+        sd = mod.state_dict()
+        sd.update(w)
+        mod.load_state_dict(sd, strict=True)
+        mod = mod.cuda().train()
+        mod.dropout_seed = 4242
+        cq = cqs[rank].cuda().requires_grad_(True)
+        out = mod(cq, pfs[rank].cuda())
+        logits = [a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]
+        masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+        (sum((a * b.cuda()).sum() for a, b in zip(logits, dls[rank])) + sum((a * b.cuda()).sum() for a, b in zip(masks, dms[rank]))).backward()
+        res = {}
+        res["logits"] = rel_err(torch.stack(logits).detach().cpu(), torch.stack(lg[rank]).detach())
+        res["masks"] = rel_err(torch.stack(masks).detach().cpu(), torch.stack(mk[rank]).detach())
+        res["d_clip_query"] = rel_err(cq.grad.cpu(), qd[rank].grad)
+        # parameter gradients: each rank holds its own share (as under DDP before the averaging); their sum is the joint gradient
+        scale = max(float(v.grad.norm()) for v in wd.values() if v.requires_grad)
+        worst = 0.0
+        for k, p in mod.named_parameters():
+            gsum = p.grad.detach().clone()
+            dist.all_reduce(gsum)
+            ref = wd[k].grad
+            worst = max(worst, float((gsum.cpu().double() - ref).norm() / max(float(ref.norm()), 1e-3 * scale)))
+        res["param_grads"] = worst
+        # running statistics: the joint batch statistics, identical on both ranks
+        for name, per_layer in stats.items():
+            rm, rv = w[name + ".running_mean"].double(), w[name + ".running_var"].double()
+            for mean, var in per_layer:
+                rm, rv = 0.99 * rm + 0.01 * mean, 0.99 * rv + 0.01 * var
+            bufs = dict(mod.named_buffers())
+            res["rm." + name] = rel_err(bufs[name + ".running_mean"].cpu(), rm)
+            res["rv." + name] = rel_err(bufs[name + ".running_var"].cpu(), rv)
+        torch.cuda.synchronize()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cross_clip_training_sync_batch_norm_over_two_ranks():
+    """CrossClipTrackingModule.train() on two ranks with different clips: the library's BatchNorm partial sums travel through the
+    all-reduce hook (gloo here, RCCL on a multi-GPU node), so outputs, input gradients, running statistics and the sum of the ranks'
+    parameter gradients equal the float64 restatement whose BatchNorm runs over both ranks' rows (nn.SyncBatchNorm semantics)."""
+    import __graft_entry__ as ge
+    ge.build()
+    assert torch.cuda.is_available()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, r in res:
+        print(rank, {k: f"{v:.1e}" for k, v in r.items()})
+        assert max(r.values()) < 1e-4, (rank, r)
