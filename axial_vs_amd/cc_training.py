@@ -245,7 +245,8 @@ def cc_module_train(mod, clip_query: Tensor, panoptic_features: Tensor):
             logits, masks, stats = _CCModuleTrain.apply(*args)
     else:
         logits, masks, stats = _CCModuleTrain.apply(*args)
-    # running statistics: one momentum step per layer call, in layer order (nn.BatchNorm semantics, momentum 0.01)
+    # running statistics: one momentum step per layer call, in layer order (nn.BatchNorm semantics, momentum 0.01), folded into
+    # one update per buffer: r <- (1-m)^nl r + sum_l m (1-m)^(nl-1-l) stat_l
     with torch.no_grad():
         off = 0
         for bn in bns:
@@ -254,9 +255,17 @@ def cc_module_train(mod, clip_query: Tensor, panoptic_features: Tensor):
             off += nl * 2 * Cn
             if not bn.track_running_stats or bn.running_mean is None:
                 continue
-            for l in range(nl):
-                bn.num_batches_tracked += 1
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - m).add_(st[l, 0].to(bn.running_mean.dtype), alpha=m)
-                bn.running_var.mul_(1 - m).add_(st[l, 1].to(bn.running_var.dtype), alpha=m)
+            if bn.momentum is None:          # cumulative moving average: the factor depends on the counter, step by step
+                for l in range(nl):
+                    bn.num_batches_tracked += 1
+                    m = 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1 - m).add_(st[l, 0].to(bn.running_mean.dtype), alpha=m)
+                    bn.running_var.mul_(1 - m).add_(st[l, 1].to(bn.running_var.dtype), alpha=m)
+                continue
+            m = float(bn.momentum)
+            coef = torch.tensor([m * (1 - m) ** (nl - 1 - l) for l in range(nl)], dtype=torch.float32, device=st.device)
+            upd = torch.einsum("l,lsc->sc", coef, st)
+            bn.running_mean.mul_((1 - m) ** nl).add_(upd[0].to(bn.running_mean.dtype))
+            bn.running_var.mul_((1 - m) ** nl).add_(upd[1].to(bn.running_var.dtype))
+            bn.num_batches_tracked += nl
     return logits, masks

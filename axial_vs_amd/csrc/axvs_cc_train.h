@@ -68,15 +68,17 @@ __global__ __launch_bounds__(256) void cct_gelu_drop_res_kernel(const float* __r
   u[i] = y[i] + drop_keep(dr, e) * gelu_f(z[i]);
 }
 
-// dz = keep * gelu'(z) * du
+// dz = keep * gelu'(z) * du;  dy = du (the residual branch of u = y + ...)
 __global__ __launch_bounds__(256) void cct_gelu_drop_bwd_kernel(const float* __restrict__ du, const float* __restrict__ z, float* __restrict__ dz,
-                                                                 long long M, int Tc, int C, Drop dr) {
+                                                                 float* __restrict__ dy, long long M, int Tc, int C, Drop dr) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)M * C) return;
   const long long m = (long long)(i / C);
   const int c = (int)(i - (size_t)m * C);
   const unsigned long long e = ((unsigned long long)(m / Tc) * C + c) * Tc + (unsigned long long)(m % Tc);
-  dz[i] = du[i] * drop_keep(dr, e) * gelu_d(z[i]);
+  const float d = du[i];
+  dy[i] = d;
+  dz[i] = d * drop_keep(dr, e) * gelu_d(z[i]);
 }
 
 // ---- BatchNorm with batch statistics, G groups (= layers: one statistics set per call of the reference module) of R rows -------
@@ -101,20 +103,20 @@ __global__ __launch_bounds__(256) void cct_bn_stats_kernel(const float* __restri
   }
 }
 
-// out[g][i] = sum_blk part[(g nblk + blk) n + i], blk ascending (deterministic); grid (ceil(n / 256), G)
-__global__ __launch_bounds__(256) void cct_reduce_groups_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out) {
+// out[g][i] = sum_blk part[(g nblk + blk) n + i], blk ascending (deterministic); grid (ceil(n / 256), G).  out2 (nullable): a
+// second copy of the sums (the all-reduce buffer next to this rank's own sums); count_ptr (nullable): receives count_val (the row
+// count that travels with the sums through the all-reduce)
+__global__ __launch_bounds__(256) void cct_reduce_groups_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out,
+                                                                 float* __restrict__ out2, float* __restrict__ count_ptr, float count_val) {
   const int i = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+  if (count_ptr && i == 0 && g == 0) *count_ptr = count_val;
   if (i >= n) return;
   double a = 0.0;
   for (int b = 0; b < nblk; ++b) a += (double)part[((size_t)g * nblk + b) * n + i];
   out[(size_t)g * n + i] = (float)a;
+  if (out2) out2[(size_t)g * n + i] = (float)a;
 }
 
-__global__ void cct_set_kernel(float* p, float v) { *p = v; }
-__global__ __launch_bounds__(256) void cct_copy_kernel(const float* __restrict__ a, float* __restrict__ b, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) b[i] = a[i];
-}
 __global__ __launch_bounds__(256) void cct_add_inplace_kernel(float* __restrict__ y, const float* __restrict__ a, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) y[i] += a[i];
@@ -216,23 +218,24 @@ __global__ __launch_bounds__(256) void cct_scalar_stats_kernel(const float* __re
                                                                 size_t per_blk) {
   __shared__ float red[2][256];
   const int g = blockIdx.y, nblk = gridDim.x;
-  const size_t e0 = (size_t)blockIdx.x * per_blk, e1 = e0 + per_blk < E ? e0 + per_blk : E;
-  const float* xg = x + (size_t)g * E;
+  const size_t e0 = (size_t)blockIdx.x * per_blk, e1 = e0 + per_blk < E ? e0 + per_blk : E;     // per_blk, E: multiples of 4
+  const float4* xg = reinterpret_cast<const float4*>(x + (size_t)g * E);
   float a = 0.f, b = 0.f;
   if (!dy) {
     const float s = shift ? shift[0] : 0.f;
-    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-      const float d = xg[e] - s;
-      a += d;
-      b += d * d;
+    for (size_t e = e0 / 4 + threadIdx.x; e < e1 / 4; e += 256) {
+      const float4 v = xg[e];
+      const float d0 = v.x - s, d1 = v.y - s, d2 = v.z - s, d3 = v.w - s;
+      a += (d0 + d1) + (d2 + d3);
+      b += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
   } else {
     const float mu = mean[g], rs = rstd[g];
-    const float* dg = dy + (size_t)g * E;
-    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-      const float d = dg[e];
-      a += d;
-      b += d * (xg[e] - mu) * rs;
+    const float4* dg = reinterpret_cast<const float4*>(dy + (size_t)g * E);
+    for (size_t e = e0 / 4 + threadIdx.x; e < e1 / 4; e += 256) {
+      const float4 d = dg[e], v = xg[e];
+      a += (d.x + d.y) + (d.z + d.w);
+      b += (d.x * (v.x - mu) + d.y * (v.y - mu) + d.z * (v.z - mu) + d.w * (v.w - mu)) * rs;
     }
   }
   red[0][threadIdx.x] = a;
@@ -379,19 +382,32 @@ __global__ __launch_bounds__(256) void cct_small_linear_bwd_x_kernel(const float
     dx[(size_t)r * C + c] = s;
   }
 }
-// dw[k][c] = sum_r dy[r][k] x[r][c], db[k] = sum_r dy[r][k]
-__global__ __launch_bounds__(256) void cct_small_linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                                                      float* __restrict__ db, int R, int C, int K1) {
-  const int k = blockIdx.x;
+// partial[(split K1 + k)][C + 1]: sum over the split's rows r of dy[r][k] x[r][c] (columns 0 .. C-1) and of dy[r][k] (column C);
+// grid (K1, splits); the caller adds the splits in order (cct_small_linear_bwd_w_final_kernel)
+__global__ __launch_bounds__(256) void cct_small_linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                                      int R, int C, int K1) {
+  const int k = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
+  const int rper = (R + nsp - 1) / nsp, r0 = sp * rper, r1 = min(R, r0 + rper);
+  float* out = part + ((size_t)sp * K1 + k) * (C + 1);
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f, sb = 0.f;
-    for (int r = 0; r < R; ++r) {
+    for (int r = r0; r < r1; ++r) {
       const float d = dy[(size_t)r * K1 + k];
       s += d * x[(size_t)r * C + c];
       sb += d;
     }
-    dw[(size_t)k * C + c] = s;
-    if (c == 0) db[k] = sb;
+    out[c] = s;
+    if (c == 0) out[C] = sb;
+  }
+}
+__global__ __launch_bounds__(256) void cct_small_linear_bwd_w_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                                            int nsp, int C, int K1) {
+  const int k = blockIdx.x;
+  for (int c = threadIdx.x; c <= C; c += 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < nsp; ++sp) s += part[((size_t)sp * K1 + k) * (C + 1) + c];
+    if (c < C) dw[(size_t)k * C + c] = s;
+    else db[k] = s;
   }
 }
 

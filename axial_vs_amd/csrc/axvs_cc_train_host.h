@@ -87,7 +87,7 @@ constexpr int kCcStatBlocks = 256;
 struct CCScratch {
   float *xcol, *dxcol, *mk, *kt, *part, *sync, *sums_local;
   // backward
-  float *dpre, *dkpart, *dk, *dmk, *dmk_pre, *dme, *dce, *dce_pre, *dme_pre, *dx2h, *dpooled, *part_wa, *part_ba, *dnext[2], *du, *dy, *dz, *dp,
+  float *dpre, *dkpart, *dk, *dmk, *dmk_pre, *dme, *dce, *dce_pre, *dme_pre, *dx2h, *dpooled, *part_wa, *part_ba, *part_cls, *dnext[2], *du, *dy, *dz, *dp,
       *dycat, *dx1;
   int dk_ksteps, dk_z;
 };
@@ -127,6 +127,7 @@ CCScratch carve_cc_scratch(Bump& b, const CCShape& s, bool backward) {
   c.dpooled = b.f(G * s.Q * kCcC);
   c.part_wa = b.f(G * s.Q * kCcC);
   c.part_ba = b.f(G * s.Q);
+  c.part_cls = b.f((size_t)16 * s.K1 * (kCcC + 1));
   c.dnext[0] = b.f(MC); c.dnext[1] = b.f(MC);
   c.du = b.f(MC); c.dy = b.f(MC); c.dz = b.f(MC); c.dp = b.f(MC);
   c.dycat = b.f(3 * MC);
@@ -153,32 +154,38 @@ int cc_sync(const CCCtx& k, float* buf, size_t n) {
 }
 
 // column statistics of x [G][R][C] (shifted by `shift`) -> sums [G][2][C]
-void cc_bn_stats(const CCCtx& k, const float* x, const float* shift, float* sums, long long R, int C) {
+// (count_ptr: where the row count goes, written by the same launch)
+void cc_bn_stats(const CCCtx& k, const float* x, const float* shift, float* sums, long long R, int C, float* count_ptr = nullptr) {
   int nblk = (int)((R + 31) / 32);
   nblk = nblk > kCcStatBlocks ? kCcStatBlocks : nblk;
   const int rpb = (int)((R + nblk - 1) / nblk);
   nblk = (int)((R + rpb - 1) / rpb);
   hipLaunchKernelGGL(cct_bn_stats_kernel, dim3(nblk, k.s.nl), dim3(256), 0, k.st, x, shift, k.x.part, R, C, rpb);
-  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 255) / 256, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums);
+  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 255) / 256, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums,
+                     (float*)nullptr, count_ptr, (float)R);
 }
+// sums: this rank's own sums (parameter gradients); sync_copy: the copy that goes through the all-reduce
 void cc_bn_bwd_stats(const CCCtx& k, const float* dy, const float* x, const float* mean, const float* rstd, const AxvsBN& bn, float* sums,
-                     long long R, int C, int gelu) {
+                     float* sync_copy, float* count_ptr, long long R, int C, int gelu) {
   int nblk = (int)((R + 31) / 32);
   nblk = nblk > kCcStatBlocks ? kCcStatBlocks : nblk;
   const int rpb = (int)((R + nblk - 1) / nblk);
   nblk = (int)((R + rpb - 1) / rpb);
   hipLaunchKernelGGL(cct_bn_bwd_stats_kernel, dim3(nblk, k.s.nl), dim3(256), 0, k.st, dy, x, mean, rstd, bn.w, bn.b, k.x.part, R, C, rpb, gelu);
-  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 255) / 256, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums);
+  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 255) / 256, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums,
+                     sync_copy, count_ptr, (float)R);
 }
 // statistics over the E elements of each layer's mask logits: sums [G][2]
-void cc_scalar_stats(const CCCtx& k, const float* x, const float* dy, const float* shift, const float* mean, const float* rstd, float* sums) {
-  const size_t per = 65536;
+void cc_scalar_stats(const CCCtx& k, const float* x, const float* dy, const float* shift, const float* mean, const float* rstd, float* sums,
+                     float* sync_copy, float* count_ptr) {
+  const size_t per = 16384;
   int nblk = (int)((k.s.E + per - 1) / per);
-  nblk = nblk > 2 * kCcStatBlocks ? 2 * kCcStatBlocks : nblk;
+  nblk = nblk > 4 * kCcStatBlocks ? 4 * kCcStatBlocks : nblk;
   const size_t pb = ((k.s.E + nblk - 1) / nblk + 3) / 4 * 4;
   nblk = (int)((k.s.E + pb - 1) / pb);
   hipLaunchKernelGGL(cct_scalar_stats_kernel, dim3(nblk, k.s.nl), dim3(256), 0, k.st, x, dy, shift, mean, rstd, k.x.part, k.s.E, pb);
-  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3(1, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2, sums);
+  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3(1, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2, sums, sync_copy, count_ptr,
+                     (float)k.s.E);
 }
 
 const float kVoidBias = logf(0.9f / 0.1f);   // add_bias_towards_void: log((K1 - 1) * 0.9 / 0.1) = log(K1 - 1) + this
@@ -219,8 +226,7 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
   if ((rc = c.g.fwd(sv.x2, hp.class_proj_w, sv.ce_pre, GM, C, C, 0.f, nullptr, ex)) != AXVS_OK) return rc;
   if ((rc = c.g.fwd(sv.x2, hp.mask_proj_w, sv.me_pre, GM, C, C, 0.f, nullptr, ex)) != AXVS_OK) return rc;
   cc_bn_stats(k, sv.ce_pre, hp.class_proj_bn.mean, sync, M, C);
-  cc_bn_stats(k, sv.me_pre, hp.mask_proj_bn.mean, sync + (size_t)G * 2 * C, M, C);
-  hipLaunchKernelGGL(cct_set_kernel, dim3(1), dim3(1), 0, k.st, sync + (size_t)G * 4 * C, (float)M);
+  cc_bn_stats(k, sv.me_pre, hp.mask_proj_bn.mean, sync + (size_t)G * 2 * C, M, C, sync + (size_t)G * 4 * C);
   if ((rc = cc_sync(k, sync, (size_t)G * 4 * C + 1)) != AXVS_OK) return rc;
   float* so = bn_stats_out;                         // [class_proj [G][2][C] | mask_proj [G][2][C] | mask_head [G][2][Cm] | pixel [G][2]]
   hipLaunchKernelGGL(cct_bn_finalize_kernel, dim3(1, G), dim3(256), 0, k.st, (const float*)sync, (const float*)(sync + (size_t)G * 4 * C),
@@ -238,8 +244,7 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
                      hp.class_head_b, logits_out, G * s.Q, C, s.K1, logf((float)(s.K1 - 1)) + kVoidBias);
   // mask branch (CC:53-57)
   if ((rc = c.g.fwd(sv.me, hp.mask_head_w, sv.mk_pre, GM, kCcCm, C, 0.f, nullptr, ex)) != AXVS_OK) return rc;
-  cc_bn_stats(k, sv.mk_pre, hp.mask_head_bn.mean, sync, M, kCcCm);
-  hipLaunchKernelGGL(cct_set_kernel, dim3(1), dim3(1), 0, k.st, sync + (size_t)G * 2 * kCcCm, (float)M);
+  cc_bn_stats(k, sv.mk_pre, hp.mask_head_bn.mean, sync, M, kCcCm, sync + (size_t)G * 2 * kCcCm);
   if ((rc = cc_sync(k, sync, (size_t)G * 2 * kCcCm + 1)) != AXVS_OK) return rc;
   so += (size_t)G * 4 * C;
   hipLaunchKernelGGL(cct_bn_finalize_kernel, dim3(1, G), dim3(256), 0, k.st, (const float*)sync, (const float*)(sync + (size_t)G * 2 * kCcCm),
@@ -263,8 +268,7 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
             return rc;
   }
   // one-channel BatchNorm over each layer's mask logits (CC:56)
-  cc_scalar_stats(k, sv.logits_pre, nullptr, hp.pixel_bn.mean, nullptr, nullptr, sync);
-  hipLaunchKernelGGL(cct_set_kernel, dim3(1), dim3(1), 0, k.st, sync + (size_t)G * 2, (float)s.E);
+  cc_scalar_stats(k, sv.logits_pre, nullptr, hp.pixel_bn.mean, nullptr, nullptr, sync, nullptr, sync + (size_t)G * 2);
   if ((rc = cc_sync(k, sync, (size_t)G * 2 + 1)) != AXVS_OK) return rc;
   so += (size_t)G * 2 * kCcCm;
   hipLaunchKernelGGL(cct_bn_finalize_kernel, dim3(1, G), dim3(256), 0, k.st, (const float*)sync, (const float*)(sync + (size_t)G * 2), hp.pixel_bn.mean,
@@ -289,10 +293,8 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
   float* const loc = x.sums_local;
   int rc;
   // ---- pixel-space BatchNorm ----
-  cc_scalar_stats(k, sv.logits_pre, d_masks, nullptr, sv.mean[3], sv.rstd[3], loc);
+  cc_scalar_stats(k, sv.logits_pre, d_masks, nullptr, sv.mean[3], sv.rstd[3], loc, sync, sync + (size_t)G * 2);
   hipLaunchKernelGGL(cct_bn_param_grads_kernel, dim3(1), dim3(256), 0, k.st, (const float*)loc, hg.pixel_bn.w, hg.pixel_bn.b, 1, G);
-  hipLaunchKernelGGL(cct_copy_kernel, dim3(1), dim3(256), 0, k.st, (const float*)loc, sync, (size_t)G * 2);
-  hipLaunchKernelGGL(cct_set_kernel, dim3(1), dim3(1), 0, k.st, sync + (size_t)G * 2, (float)s.E);
   if ((rc = cc_sync(k, sync, (size_t)G * 2 + 1)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(cct_scalar_bn_bwd_apply_kernel, dim3(eblocks(s.E / 4), G), dim3(256), 0, k.st, d_masks, (const float*)sv.logits_pre,
                      (const float*)sv.mean[3], (const float*)sv.rstd[3], hp.pixel_bn.w, (const float*)sync, (const float*)(sync + (size_t)G * 2), x.dpre,
@@ -320,10 +322,8 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
   }
   hipLaunchKernelGGL(cct_kern_unpack_kernel, dim3(eblocks((size_t)GM * Cm)), dim3(256), 0, k.st, (const float*)x.dk, x.dmk, G, s.B, s.Q, s.Tc, Cm);
   // ---- mask head: conv 1x1 + BatchNorm (no activation) ----
-  cc_bn_bwd_stats(k, x.dmk, sv.mk_pre, sv.mean[2], sv.rstd[2], hp.mask_head_bn, loc, M, Cm, 0);
+  cc_bn_bwd_stats(k, x.dmk, sv.mk_pre, sv.mean[2], sv.rstd[2], hp.mask_head_bn, loc, sync, sync + (size_t)G * 2 * Cm, M, Cm, 0);
   hipLaunchKernelGGL(cct_bn_param_grads_kernel, dim3(1), dim3(256), 0, k.st, (const float*)loc, hg.mask_head_bn.w, hg.mask_head_bn.b, Cm, G);
-  hipLaunchKernelGGL(cct_copy_kernel, dim3(eblocks((size_t)G * 2 * Cm)), dim3(256), 0, k.st, (const float*)loc, sync, (size_t)G * 2 * Cm);
-  hipLaunchKernelGGL(cct_set_kernel, dim3(1), dim3(1), 0, k.st, sync + (size_t)G * 2 * Cm, (float)M);
   if ((rc = cc_sync(k, sync, (size_t)G * 2 * Cm + 1)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(cct_bn_bwd_apply_kernel, dim3(eblocks((size_t)GM * Cm)), dim3(256), 0, k.st, (const float*)x.dmk, (const float*)sv.mk_pre,
                      (const float*)sv.mean[2], (const float*)sv.rstd[2], hp.mask_head_bn.w, hp.mask_head_bn.b, (const float*)sync,
@@ -331,20 +331,22 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
   if ((rc = c.wgrad(x.dmk_pre, sv.me, hg.mask_head_w, GM, Cm, C)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(x.dmk_pre, hp.mask_head_w, x.dme, GM, Cm, C, 0.f)) != AXVS_OK) return rc;
   // ---- class head, activation pooling ----
-  hipLaunchKernelGGL(cct_small_linear_bwd_w_kernel, dim3(s.K1), dim3(256), 0, k.st, d_logits, (const float*)sv.pooled, hg.class_head_w, hg.class_head_b,
-                     GQ, C, s.K1);
+  constexpr int kWSplits = 16;
+  hipLaunchKernelGGL(cct_small_linear_bwd_w_kernel, dim3(s.K1, kWSplits), dim3(256), 0, k.st, d_logits, (const float*)sv.pooled, x.part_cls, GQ, C, s.K1);
+  hipLaunchKernelGGL(cct_small_linear_bwd_w_final_kernel, dim3(s.K1), dim3(256), 0, k.st, (const float*)x.part_cls, hg.class_head_w, hg.class_head_b,
+                     kWSplits, C, s.K1);
   hipLaunchKernelGGL(cct_small_linear_bwd_x_kernel, dim3(GQ), dim3(256), 0, k.st, d_logits, hp.class_head_w, x.dpooled, GQ, C, s.K1);
   hipLaunchKernelGGL(cct_act_pool_bwd_kernel, dim3(s.Q, G), dim3(256), 0, k.st, (const float*)sv.ce, hp.act_head_w, (const float*)sv.pact,
                      (const float*)x.dpooled, x.dce, x.part_wa, x.part_ba, s.B, s.Q, s.Tc, C);
   hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(C, 256)), dim3(256), 0, k.st, (const float*)x.part_wa, GQ, (size_t)C, hg.act_head_w);
-  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3(1, 1), dim3(256), 0, k.st, (const float*)x.part_ba, GQ, 1, hg.act_head_b);
+  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3(1, 1), dim3(256), 0, k.st, (const float*)x.part_ba, GQ, 1, hg.act_head_b, (float*)nullptr,
+                     (float*)nullptr, 0.f);
   // ---- the two embedding projections: conv 1x1 + BatchNorm + GELU ----
-  cc_bn_bwd_stats(k, x.dce, sv.ce_pre, sv.mean[0], sv.rstd[0], hp.class_proj_bn, loc, M, C, 1);
-  cc_bn_bwd_stats(k, x.dme, sv.me_pre, sv.mean[1], sv.rstd[1], hp.mask_proj_bn, loc + (size_t)G * 2 * C, M, C, 1);
+  cc_bn_bwd_stats(k, x.dce, sv.ce_pre, sv.mean[0], sv.rstd[0], hp.class_proj_bn, loc, sync, nullptr, M, C, 1);
+  cc_bn_bwd_stats(k, x.dme, sv.me_pre, sv.mean[1], sv.rstd[1], hp.mask_proj_bn, loc + (size_t)G * 2 * C, sync + (size_t)G * 2 * C,
+                  sync + (size_t)G * 4 * C, M, C, 1);
   hipLaunchKernelGGL(cct_bn_param_grads_kernel, dim3(1), dim3(256), 0, k.st, (const float*)loc, hg.class_proj_bn.w, hg.class_proj_bn.b, C, G);
   hipLaunchKernelGGL(cct_bn_param_grads_kernel, dim3(1), dim3(256), 0, k.st, (const float*)(loc + (size_t)G * 2 * C), hg.mask_proj_bn.w, hg.mask_proj_bn.b, C, G);
-  hipLaunchKernelGGL(cct_copy_kernel, dim3(eblocks((size_t)G * 4 * C)), dim3(256), 0, k.st, (const float*)loc, sync, (size_t)G * 4 * C);
-  hipLaunchKernelGGL(cct_set_kernel, dim3(1), dim3(1), 0, k.st, sync + (size_t)G * 4 * C, (float)M);
   if ((rc = cc_sync(k, sync, (size_t)G * 4 * C + 1)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(cct_bn_bwd_apply_kernel, dim3(eblocks((size_t)GM * C)), dim3(256), 0, k.st, (const float*)x.dce, (const float*)sv.ce_pre,
                      (const float*)sv.mean[0], (const float*)sv.rstd[0], hp.class_proj_bn.w, hp.class_proj_bn.b, (const float*)sync,
@@ -370,8 +372,7 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
     c.colsum(dx2, M, C, g.conv_norm_b, L.u, L.meanu, L.rstdu, g.conv_norm_w);
     hipLaunchKernelGGL(tr_ln_bwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, k.st, (const float*)dx2, (const float*)L.u, p.conv_norm_w, (const float*)L.meanu,
                        (const float*)L.rstdu, x.du, M, C);
-    hipLaunchKernelGGL(cct_copy_kernel, dim3(eblocks(MC)), dim3(256), 0, k.st, (const float*)x.du, x.dy, MC);
-    hipLaunchKernelGGL(cct_gelu_drop_bwd_kernel, dim3(eblocks(MC)), dim3(256), 0, k.st, (const float*)x.du, (const float*)L.z, x.dz, M, s.Tc, C,
+    hipLaunchKernelGGL(cct_gelu_drop_bwd_kernel, dim3(eblocks(MC)), dim3(256), 0, k.st, (const float*)x.du, (const float*)L.z, x.dz, x.dy, M, s.Tc, C,
                        make_drop(k.cfg->p_aspp_drop, k.cfg->seed, 11 + 2 * l));
     // channels-first LayerNorm of the ASPP projection, the projection, the three convolutions
     c.colsum(x.dz, M, C, g.aspp_norm_b, L.p, L.meanz, L.rstdz, g.aspp_norm_w);

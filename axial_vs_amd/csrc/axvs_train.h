@@ -165,12 +165,15 @@ __global__ __launch_bounds__(256) void tr_spatial_fwd_mfma_kernel(const float* _
   const int Lp = (L + 15) & ~15, nkt = Lp >> 4, nqt = (N + 15) >> 4;
   float* ks = smem;
   float* vs = smem + Lp * kTrLd;
-  for (int f = 0; f < T; ++f) {
+  // few sequences (the cross-clip module: B x heads workgroups): gridDim.y splits the query tiles, gridDim.z the frames -- every
+  // (query tile, frame) is computed by exactly one wave whatever the split, with the same instructions
+  const int fper = (T + (int)gridDim.z - 1) / (int)gridDim.z, f0 = (int)blockIdx.z * fper, f1 = min(T, f0 + fper);
+  for (int f = f0; f < f1; ++f) {
     __syncthreads();
     stage_frame36(ks, k, rm, s, f, h, C, tid);
     stage_frame36(vs, v, rm, s, f, h, C, tid);
     __syncthreads();
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = (int)blockIdx.y * 4 + wave; qt < nqt; qt += 4 * (int)gridDim.y) {
       const int qn = qt * 16 + j;
       const long long mq = nat_row(rm, s * N + min(qn, N - 1));
       float qr[8];
@@ -246,12 +249,12 @@ __global__ __launch_bounds__(256) void tr_spatial_bwd_q_mfma_kernel(const float*
   const int Lp = (L + 15) & ~15, nkt = Lp >> 4, nqt = (N + 15) >> 4;
   float* ks = smem;
   float* vs = smem + Lp * kTrLd;
-  for (int f = 0; f < T; ++f) {
+  for (int f = 0; f < T; ++f) {            // (dq accumulates over the frames: they stay in one workgroup; gridDim.y splits the query tiles)
     __syncthreads();
     stage_frame36(ks, k, rm, s, f, h, C, tid);
     stage_frame36(vs, v, rm, s, f, h, C, tid);
     __syncthreads();
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = (int)blockIdx.y * 4 + wave; qt < nqt; qt += 4 * (int)gridDim.y) {
       const int qn = qt * 16 + j, qc = min(qn, N - 1);
       const long long mq = nat_row(rm, s * N + qc);
       float qr[8], dxr[8];
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(256) void tr_spatial_bwd_kv_mfma_kernel(const float
     }
     *reinterpret_cast<float4*>(qs + n * kTrLd + c4 * 4) = t;
   }
-  for (int f = 0; f < T; ++f) {
+  const int fper = (T + (int)gridDim.z - 1) / (int)gridDim.z, f0 = (int)blockIdx.z * fper, f1 = min(T, f0 + fper);   // as in the forward kernel
+  for (int f = f0; f < f1; ++f) {
     __syncthreads();
     for (int i = tid; i < Np * 8; i += 256) {
       const int n = i >> 3, c4 = i & 7;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256) void tr_spatial_bwd_kv_mfma_kernel(const float
       *reinterpret_cast<float4*>(ss + n * 4) = float4{st[0], n < N ? st[1] : 0.f, st[2], 0.f};
     }
     __syncthreads();
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = (int)blockIdx.y * 4 + wave; kt < nkt; kt += 4 * (int)gridDim.y) {
       const int kn = kt * 16 + j, kc = min(kn, L - 1);                  // key index within the frame
       const long long mk = nat_row(rm, s * N + f * L + kc);
       float kr[8], vr[8];
@@ -745,6 +749,33 @@ __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, size_t C, float* __restrict__ out) {
   __shared__ float4 red[256];
   const size_t c4 = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), n4 = C / 4;
+  const int g = threadIdx.x >> 6;
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < n4) {
+#pragma unroll 4
+    for (int i = g; i < nblk; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)i * C + c4 * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (g == 0 && c4 < n4) {
+    const float4 b = red[threadIdx.x + 64], c = red[threadIdx.x + 128], d = red[threadIdx.x + 192];
+    *reinterpret_cast<float4*>(out + c4 * 4) = float4{a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w};
+  }
+}
+
+// the same for TWO partial sets in one launch (a weight gradient and its bias gradient): blocks [0, blocks_a) reduce set a, the rest set b
+__global__ __launch_bounds__(256) void tr_colsum_final_pair_kernel(const float* __restrict__ part_a, size_t Ca, float* __restrict__ out_a,
+                                                                    const float* __restrict__ part_b, size_t Cb, float* __restrict__ out_b,
+                                                                    int nblk, int blocks_a) {
+  __shared__ float4 red[256];
+  const bool second = (int)blockIdx.x >= blocks_a;
+  const float* part = second ? part_b : part_a;
+  const size_t C = second ? Cb : Ca;
+  float* out = second ? out_b : out_a;
+  const size_t c4 = (size_t)(second ? blockIdx.x - blocks_a : blockIdx.x) * 64 + (threadIdx.x & 63), n4 = C / 4;
   const int g = threadIdx.x >> 6;
   float4 a = {0.f, 0.f, 0.f, 0.f};
   if (c4 < n4) {

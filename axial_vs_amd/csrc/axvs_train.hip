@@ -218,8 +218,13 @@ struct Ctx {
     int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np, db ? sc.part_a : nullptr, ldy, ldx);
     if (rc != AXVS_OK) return rc;
     const size_t n = (size_t)N * K;
-    hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
-    if (db) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_a, np, (size_t)N, db);
+    if (db) {      // one launch adds the partials of the weight and of the bias gradient (same order of additions as the single kernel)
+      const unsigned ba = blocks(n, 256), bb = blocks(N, 256);
+      hipLaunchKernelGGL(tr_colsum_final_pair_kernel, dim3(ba + bb), dim3(256), 0, st, (const float*)sc.wpart, n, dW, (const float*)sc.part_a, (size_t)N, db,
+                         np, (int)ba);
+    } else {
+      hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
+    }
     return AXVS_OK;
   }
   // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
@@ -238,6 +243,18 @@ bool mfma_spatial(const Dims& d, const RowMap& rm) {
   const size_t lds_q = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
   const size_t lds_kv = (size_t)((rm.N + 15) / 16 * 16) * (2 * kTrLd + 4) * sizeof(float);
   return d.D == 32 && !g_train_valu && lds_q <= 160 * 1024 && lds_kv <= 160 * 1024;
+}
+
+// Launch grid of the fp32 MFMA spatial-attention kernels: x = (sequence, head); with fewer than 256 of those (the cross-clip module has
+// B sequences) the 16-row tiles each wave walks (y) and the frames (z) are spread over more workgroups.  The within-clip layer
+// (B x W x heads >= 256 workgroups) keeps y = z = 1.
+dim3 spatial_grid(int sh, int tiles, int frames) {
+  if (sh >= 256) return dim3(sh, 1, 1);
+  const int z = frames;
+  int y = (512 + sh * z - 1) / (sh * z);
+  const int ymax = (tiles + 3) / 4;
+  y = y > ymax ? ymax : (y < 1 ? 1 : y);
+  return dim3(sh, y, z);
 }
 
 // one axial pass, forward: xout = xin + dropout1(TrajectoryAttention(q = k = xin + pos, v = xin))   WC/temporal_attention.py:35-76
@@ -260,7 +277,7 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   const size_t lds_mfma = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
   if (mfma_spatial(d, rm)) {                                            // head_dim 32 (every shipped config): fp32 MFMA kernels
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_fwd_mfma_kernel), lds_mfma)) != AXVS_OK) return rc;
-    hipLaunchKernelGGL(tr_spatial_fwd_mfma_kernel, dim3(S * d.heads), dim3(256), lds_mfma, c.st, (const float*)s.q, (const float*)s.k,
+    hipLaunchKernelGGL(tr_spatial_fwd_mfma_kernel, spatial_grid(S * d.heads, (rm.N + 15) / 16, d.T), dim3(256), lds_mfma, c.st, (const float*)s.q, (const float*)s.k,
                        (const float*)s.v, s.x, s.st, rm, d.T, C, d.heads, c.scale, attn_drop);
   } else
   AXVS_D_SWITCH(d.D, {
@@ -316,9 +333,9 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   if (mfma_spatial(d, rm)) {       // the forward was the MFMA kernel too: (max, 1 / sum) are in s.st
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_q_mfma_kernel), lds_q)) != AXVS_OK) return rc;
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_kv_mfma_kernel), lds_kv)) != AXVS_OK) return rc;
-    hipLaunchKernelGGL(tr_spatial_bwd_q_mfma_kernel, dim3(S * d.heads), dim3(256), lds_q, c.st, (const float*)s.q, (const float*)s.k,
+    hipLaunchKernelGGL(tr_spatial_bwd_q_mfma_kernel, spatial_grid(S * d.heads, (rm.N + 15) / 16, 1), dim3(256), lds_q, c.st, (const float*)s.q, (const float*)s.k,
                        (const float*)s.v, (const float*)s.x, (const float*)sc.dx, sc.dq, s.st, rm, T, C, d.heads, c.scale, attn_drop);
-    hipLaunchKernelGGL(tr_spatial_bwd_kv_mfma_kernel, dim3(S * d.heads), dim3(256), lds_kv, c.st, (const float*)s.q, (const float*)s.k,
+    hipLaunchKernelGGL(tr_spatial_bwd_kv_mfma_kernel, spatial_grid(S * d.heads, (rm.L + 15) / 16, T), dim3(256), lds_kv, c.st, (const float*)s.q, (const float*)s.k,
                        (const float*)s.v, (const float*)sc.dx, (const float*)s.st, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop);
   } else
   AXVS_D_SWITCH(d.D, {
