@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   cc_cfg4     BASELINE config 4: CrossClipTrackingModule forward, us per forward and output GB/s (N = 1)
                   wc_cfg3     BASELINE config 3: the whole within-clip tracking module at ConvNeXt-T size, ms per forward (N = 1)
                   train_step  forward + backward of the layer through the training tier, ms per step (N = 1)
+                  cc_train_cfg4  forward + backward of the cross-clip module in train() mode at config 4, ms per step (N = 1)
 """
 from __future__ import annotations
 
@@ -542,6 +543,43 @@ def main():
                 del tl, s_t, g_t
             except RuntimeError as e:
                 extras["train_step"] = {"error": str(e)[:200]}
+
+        # ---- one training step (forward + backward) of the cross-clip tracking module at BASELINE config 4 ----
+        if not args.no_extras and world == 1:
+            try:
+                Q, Tc, V, Hc, Wc, layers_cc, ncls = 128, 4, 4, 64, 64, 4, 124
+                cct = ax.CrossClipTrackingModule(num_layers=layers_cc, num_classes=ncls, attn_drop=0.1, aspp_drop=0.1, kernel_sizes=[3, 3, 3],
+                                                 atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V)
+                sdc = cct.state_dict()
+                sdc.update(random_weights({k: tuple(v.shape) for k, v in sdc.items() if v.dtype.is_floating_point}, 4))
+                cct.load_state_dict(sdc, strict=True)
+                cct = cct.to(dev).train()
+                gc_ = torch.Generator(device=dev).manual_seed(4)
+                cq_t = torch.randn(1, Q, Tc, 256, device=dev, generator=gc_).requires_grad_(True)
+                pf_t = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, Hc, Wc, device=dev, generator=gc_), dim=1)
+                from axial_vs_amd.cc_training import cc_module_train
+                dl_t = torch.randn(layers_cc, 1, Q, ncls + 1, device=dev, generator=gc_)
+                dm_t = torch.randn(layers_cc, 1, Q, Tc * V, Hc, Wc, device=dev, generator=gc_) * 0.01
+
+                def cc_step():
+                    lg_, mk_ = cc_module_train(cct, cq_t, pf_t)
+                    torch.autograd.backward([lg_, mk_], [dl_t, dm_t])
+                for _ in range(5):
+                    cc_step()
+                torch.cuda.synchronize(dev)
+                t_cc = time.perf_counter()
+                for _ in range(10):
+                    cc_step()
+                torch.cuda.synchronize(dev)
+                el = (time.perf_counter() - t_cc) / 10
+                extras["cc_train_cfg4"] = {"ms_per_step": round(el * 1e3, 3), "value": round(Tc * V / el, 1), "unit": "frames/s",
+                                           "what": "forward + backward of CrossClipTrackingModule.train() at BASELINE config 4 (4 clips x 4 frames, 64x64, "
+                                                   "128 queries, 4 layers, attn_drop = aspp_drop = 0.1, gradients on every layer's outputs) through "
+                                                   "axvs_cc_module_train_fwd/_bwd; BatchNorm on batch statistics (single rank: no all-reduce)",
+                                           "dtype": "f32 (GEMM operands split into bf16 pieces, fp32 accumulate)"}
+                del cct, cq_t, pf_t, dl_t, dm_t
+            except RuntimeError as e:
+                extras["cc_train_cfg4"] = {"error": str(e)[:200]}
 
         # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would just wait)
