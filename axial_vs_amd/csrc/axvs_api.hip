@@ -16,6 +16,7 @@
 #include "axvs_ffn_split.h"
 #include "axvs_gemm.h"
 #include "axvs_misc.h"
+#include "axvs_gemm_nt.h"
 
 using namespace axvs;
 
@@ -41,6 +42,11 @@ thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN a
 // kernel that emits the next pass's q/k/v ends in a 42 MB write burst with nothing to overlap it; 101.7 vs 101.3 us at B = 1, 870 vs
 // 838 us at B = 8) -- kept selectable, off by default:
 thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kernels read V in K's row layout (staged through the x tile, ds_read_b64_tr_b16) instead of V^T
+// option "msda_gemm": the deformable attention's three projections on the 128 x 128 split-precision GEMM of axvs_gemm_nt.h when the
+// level set has >= 2048 rows.  4 (default): two bf16 pieces for value_proj (its output is rounded to 16 bits anyway) and for the
+// offset | weight projection, three pieces (fp32 accuracy) for output_proj, whose result enters the residual stream without a norm;
+// 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels of axvs_gemm.h.
+thread_local int g_msda_gemm = 4;
 thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
@@ -871,6 +877,8 @@ int tl_heads_fwd_t(const float* x, const float* mf, float* logits, float* masks,
 struct MsdaPacked {
   u16 *wv, *wq, *wo;            // value_proj [Cp,C] (head blocks), sampling_offsets|attention_weights [3MLP,C], output_proj [C,Cp]
   float *bv, *bq, *bo;
+  float* wq32;                  // sampling_offsets | attention_weights as fp32 rows [3MLP][C]: operand of the 128 x 128 split-precision GEMM
+  float *wv32, *wo32;           // value_proj / output_proj as fp32 rows [C][C] (head_dim 32: the head-block order is the natural one)
 };
 MsdaPacked carve_msda(Carver& c, int C, int heads, int L, int P) {
   const size_t Cp = (size_t)heads * 32, nq = (size_t)3 * heads * L * P;
@@ -881,6 +889,9 @@ MsdaPacked carve_msda(Carver& c, int C, int heads, int L, int P) {
   m.bv = c.take<float>(Cp);
   m.bq = c.take<float>(nq);
   m.bo = c.take<float>(C);
+  m.wq32 = c.take<float>(nq * C);
+  m.wv32 = c.take<float>((size_t)C * C);
+  m.wo32 = c.take<float>((size_t)C * C);
   return m;
 }
 
@@ -899,6 +910,23 @@ int msda_levels(const int* shapes, int L, int S, MsdaLevels* lv) {
   return AXVS_OK;
 }
 
+// Y[M][N] = epilogue(X[M][K] (+ X2) . W[N][K]^T) on the 128 x 128 split-precision kernel (axvs_gemm_nt.h), option msda_gemm = pieces
+int launch_nt128(const float* X, const float* X2, const float* W, float* Y, long long M, int N, int K, const tr::GemmEpi& e, hipStream_t st,
+                 bool feeds_residual = false) {
+  tr::GemmLd ld{K, K, N, 0, X2};
+  const dim3 grid((unsigned)((M + tr::kGT - 1) / tr::kGT), (unsigned)((N + tr::kGT - 1) / tr::kGT));
+  if (g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual)) {
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>((tr::tr_gemm_nt_kernel<3, 1>)))) return rc;
+    hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<3, 1>), grid, dim3(512), tr::gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+  } else {
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>((tr::tr_gemm_nt_kernel<2, 1>)))) return rc;
+    hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<2, 1>), grid, dim3(512), tr::gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
+  }
+  return AXVS_OK;
+}
+// rows from which the 128 x 128 kernel beats the 64 x 64 one (fewer rows: too few workgroups)
+inline bool use_nt128(long long rows, int C, int heads) { return g_msda_gemm && rows >= 2048 && C % 4 == 0 && C / heads == 32; }
+
 // what: 0 = whole module (value_proj, offsets | logits, gather, output_proj), 1 = up to the gather with fp32 rows out
 // (`out` = sampled [N*Lq][C], no output_proj)
 template <bool BF>
@@ -914,22 +942,47 @@ int msda_fwd_t(const float* query, const float* refp, int ref_dim, const float* 
   g_prof_next = 0;
   mark(st, "begin");
   // value_proj and output_proj feed the module output directly (no residual / norm inside the module): split precision
-  EpiBlocked16<BF> ev{value16, Rv, p.bv, 1.f, 0, 0};
-  ev.zero_rows = mask;
-  launch_gemm<BF>(ALoadRowsF32Split3<BF>{input, (int)Rv, C}, p.wv, ev, (int)Rv, Cp, 3 * C, st);
+  const tr::Drop nodrop{0u, 0u, 0u, 1.f};
+  if (use_nt128(Rv, C, heads)) {          // fp32 rows in, one 16-bit piece out in the blocked layout the gather reads
+    tr::GemmEpi e{p.bv, 1.f, 0, nodrop, 0.f};
+    e.out16 = value16;
+    e.kind16 = BF ? 2 : 1;
+    e.zero_rows = mask;
+    if (int rc = launch_nt128(input, nullptr, p.wv32, nullptr, Rv, Cp, C, e, st)) return rc;
+  } else {
+    EpiBlocked16<BF> ev{value16, Rv, p.bv, 1.f, 0, 0};
+    ev.zero_rows = mask;
+    launch_gemm<BF>(ALoadRowsF32Split3<BF>{input, (int)Rv, C}, p.wv, ev, (int)Rv, Cp, 3 * C, st);
+  }
   mark(st, "msda.value_proj");
-  launch_gemm<BF>(ALoadRowsF32Split3<BF>{query, (int)Rq, C, qadd}, p.wq, EpiRowsF32{qproj, nullptr, p.bq, identity_map(Rq), nq, 1.f}, (int)Rq,
-                  nq, 3 * C, st);
+  // sampling offsets | attention logits: fp32 rows in, fp32 rows out, [N Lq] x [3 heads L P] x C -- at a few thousand rows and more
+  // the 128 x 128 split-precision kernel of the training tier (axvs_gemm_nt.h: fp32 operands split into bf16 pieces in its
+  // loader) beats the 64 x 64 one (config 3, 21504 rows: the three projections of a deformable layer 27 + 59 + 30 us -> ~65 us)
+  if (g_msda_gemm && Rq >= 2048 && C % 4 == 0 && nq % 4 == 0) {
+    const tr::GemmEpi e{p.bq, 1.f, 0, nodrop, 0.f};
+    if (int rc = launch_nt128(query, qadd, p.wq32, qproj, Rq, nq, C, e, st)) return rc;
+  } else {
+    launch_gemm<BF>(ALoadRowsF32Split3<BF>{query, (int)Rq, C, qadd}, p.wq, EpiRowsF32{qproj, nullptr, p.bq, identity_map(Rq), nq, 1.f}, (int)Rq,
+                    nq, 3 * C, st);
+  }
   mark(st, "msda.offsets+weights");
   const long long groups = Rq * heads;
   const dim3 ggrid((unsigned)((groups + 63) / 64));
-  float* of32 = what == 1 ? out : nullptr;
+  // the output projection on the 128 x 128 kernel reads the sampled rows as fp32 [N Lq][C] (same bytes as the two 16-bit pieces)
+  const bool out128 = what != 1 && use_nt128(Rq, C, heads);
+  float* of32 = what == 1 ? out : (out128 ? reinterpret_cast<float*>(o16) : nullptr);
   if (P == 4) hipLaunchKernelGGL((msda_gather_kernel<BF, 4>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P, of32, C / heads);
   else hipLaunchKernelGGL((msda_gather_kernel<BF, 0>), ggrid, dim3(256), 0, st, value16, qproj, refp, ref_dim, lv, o16, N, S, Lq, heads, P, of32, C / heads);
   mark(st, "msda.gather");
   if (what == 1) return last_launch_status();
-  launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, residual, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
-                  C, 3 * Cp, st);
+  if (out128) {
+    tr::GemmEpi e{p.bo, 1.f, 0, nodrop, 0.f};
+    e.res = residual;
+    if (int rc = launch_nt128(of32, nullptr, p.wo32, out, Rq, C, C, e, st, true)) return rc;
+  } else {
+    launch_gemm<BF>(ALoadBlockedSplit3<BF>{o16, Rq, (int)Rq, Cp}, p.wo, EpiRowsF32{out, residual, p.bo, identity_map(Rq), C, 1.f}, (int)Rq,
+                    C, 3 * Cp, st);
+  }
   mark(st, "msda.output_proj");
   return last_launch_status();
 }
@@ -1007,6 +1060,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
+  if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }
@@ -1519,6 +1573,10 @@ int axvs_msda_pack(const AxvsMsdaParams* p, void* packed, int C, int heads, int 
   copy_f32(p->sampling_offsets_b, m.bq, 2 * mlp, st);
   copy_f32(p->attention_weights_b, m.bq + 2 * mlp, mlp, st);
   copy_f32(p->output_proj_b, m.bo, C, st);
+  copy_f32(p->sampling_offsets_w, m.wq32, (size_t)2 * mlp * C, st);
+  copy_f32(p->attention_weights_w, m.wq32 + (size_t)2 * mlp * C, (size_t)mlp * C, st);
+  copy_f32(p->value_proj_w, m.wv32, (size_t)C * C, st);
+  copy_f32(p->output_proj_w, m.wo32, (size_t)C * C, st);
   return last_launch_status();
 }
 
@@ -1586,6 +1644,12 @@ int axvs_msda_output_proj_fwd(const float* x, const float* identity, float* out,
   const MsdaPacked mp = carve_msda(pc, C, heads, L, P);
   const EpiRowsF32 e{out, identity, mp.bo, identity_map(rows), C, 1.f};
   // split-precision operands as in the module path (the projection output has no norm behind it)
+  if (use_nt128(rows, C, heads)) {
+    tr::GemmEpi e128{mp.bo, 1.f, 0, tr::Drop{0u, 0u, 0u, 1.f}, 0.f};
+    e128.res = identity;
+    if (int rc = launch_nt128(x, nullptr, mp.wo32, out, rows, C, C, e128, st, true)) return rc;
+    return last_launch_status();
+  }
   if (dtype == AXVS_BF16) launch_gemm<true>(ALoadRowsF32Split3<true>{x, (int)rows, C}, mp.wo, e, (int)rows, C, 3 * C, st);
   else launch_gemm<false>(ALoadRowsF32Split3<false>{x, (int)rows, C}, mp.wo, e, (int)rows, C, 3 * C, st);
   return last_launch_status();

@@ -103,18 +103,23 @@ __global__ __launch_bounds__(256) void cct_bn_stats_kernel(const float* __restri
   }
 }
 
-// out[g][i] = sum_blk part[(g nblk + blk) n + i], blk ascending (deterministic); grid (ceil(n / 256), G).  out2 (nullable): a
+// out[g][i] = sum_blk part[(g nblk + blk) n + i] (deterministic); grid (ceil(n / 4), G).  out2 (nullable): a
 // second copy of the sums (the all-reduce buffer next to this rank's own sums); count_ptr (nullable): receives count_val (the row
 // count that travels with the sums through the all-reduce)
 __global__ __launch_bounds__(256) void cct_reduce_groups_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out,
                                                                  float* __restrict__ out2, float* __restrict__ count_ptr, float count_val) {
-  const int i = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-  if (count_ptr && i == 0 && g == 0) *count_ptr = count_val;
+  // one wave per output element: lanes stride over the partials (double accumulation), xor-shuffle tree -- a fixed order
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, g = blockIdx.y;
+  if (count_ptr && blockIdx.x == 0 && threadIdx.x == 0 && g == 0) *count_ptr = count_val;
   if (i >= n) return;
   double a = 0.0;
-  for (int b = 0; b < nblk; ++b) a += (double)part[((size_t)g * nblk + b) * n + i];
-  out[(size_t)g * n + i] = (float)a;
-  if (out2) out2[(size_t)g * n + i] = (float)a;
+  for (int b = lane; b < nblk; b += 64) a += (double)part[((size_t)g * nblk + b) * n + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) {
+    out[(size_t)g * n + i] = (float)a;
+    if (out2) out2[(size_t)g * n + i] = (float)a;
+  }
 }
 
 __global__ __launch_bounds__(256) void cct_add_inplace_kernel(float* __restrict__ y, const float* __restrict__ a, size_t n) {
@@ -378,6 +383,7 @@ __global__ __launch_bounds__(256) void cct_small_linear_bwd_x_kernel(const float
   const int r = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < K1; ++k) s += dy[(size_t)r * K1 + k] * w[(size_t)k * C + c];
     dx[(size_t)r * C + c] = s;
   }

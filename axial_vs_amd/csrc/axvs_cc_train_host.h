@@ -161,7 +161,7 @@ void cc_bn_stats(const CCCtx& k, const float* x, const float* shift, float* sums
   const int rpb = (int)((R + nblk - 1) / nblk);
   nblk = (int)((R + rpb - 1) / rpb);
   hipLaunchKernelGGL(cct_bn_stats_kernel, dim3(nblk, k.s.nl), dim3(256), 0, k.st, x, shift, k.x.part, R, C, rpb);
-  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 255) / 256, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums,
+  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 3) / 4, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums,
                      (float*)nullptr, count_ptr, (float)R);
 }
 // sums: this rank's own sums (parameter gradients); sync_copy: the copy that goes through the all-reduce
@@ -172,7 +172,7 @@ void cc_bn_bwd_stats(const CCCtx& k, const float* dy, const float* x, const floa
   const int rpb = (int)((R + nblk - 1) / nblk);
   nblk = (int)((R + rpb - 1) / rpb);
   hipLaunchKernelGGL(cct_bn_bwd_stats_kernel, dim3(nblk, k.s.nl), dim3(256), 0, k.st, dy, x, mean, rstd, bn.w, bn.b, k.x.part, R, C, rpb, gelu);
-  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 255) / 256, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums,
+  hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3((2 * C + 3) / 4, k.s.nl), dim3(256), 0, k.st, (const float*)k.x.part, nblk, 2 * C, sums,
                      sync_copy, count_ptr, (float)R);
 }
 // statistics over the E elements of each layer's mask logits: sums [G][2]

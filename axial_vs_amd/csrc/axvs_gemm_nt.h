@@ -1,0 +1,257 @@
+// C[M,N] = epilogue(A[M,K] B[N,K]^T) on fp32 operands in split precision ("bf16x3" / three-piece): the GEMM of the training tier's
+// Linear layers (axvs_train_gemm.h has the story) in a header of its own, because the inference path uses it too for projections
+// whose fp32 inputs and outputs make a 128 x 128 tile pay (the deformable attention's offset / weight projection, axvs_api.hip).
+// Everything here is a template or inline: the header may be included by several translation units -- but each of them must
+// instantiate the kernel under its OWN tag (template parameter TU): two code objects of one library that both carry a kernel of the
+// same mangled name share one host stub, and the HIP runtime aborts at the first launch through it.
+#pragma once
+#include <type_traits>
+
+#include "axvs_common.h"
+
+namespace axvs {
+namespace tr {
+
+__host__ __device__ __forceinline__ unsigned fmix32(unsigned h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+
+// keep element `idx` of dropout site `site` iff (hash >> 8) >= thr, thr = floor(p * 2^24)
+struct Drop {
+  unsigned seed, site, thr;
+  float scale;   // 1 / (1 - p)
+};
+
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned site, unsigned long long idx) {
+  unsigned h = seed ^ (site * 0x9E3779B9u);
+  h = fmix32(h ^ (unsigned)idx);
+  h = fmix32(h ^ (unsigned)(idx >> 32));
+  return h;
+}
+
+__device__ __forceinline__ float drop_keep(const Drop& d, unsigned long long idx) {   // 0 or 1/(1-p)
+  if (d.thr == 0) return 1.f;
+  return (drop_hash(d.seed, d.site, idx) >> 8) >= d.thr ? d.scale : 0.f;
+}
+
+constexpr int kGT = 128;                 // block tile (both output dimensions)
+constexpr int kGK = 32;                  // contraction step
+constexpr int kGTileElems = kGT * kGK;   // one 16-bit operand tile
+constexpr int kGLd = kGT + 4;            // fp32 row stride of the epilogue staging tile
+constexpr size_t kGemmLds = (size_t)kGT * kGLd * sizeof(float);   // 67.6 KB >= 2 stages x 4 tiles x 8 KB
+
+struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps > 0: split-K, that many 32-wide k-steps per blockIdx.z
+  long long a, b, c;
+  int ksteps;
+  const float* a2 = nullptr;   // optional second A operand with A's shape and stride, added element-wise on load (x + pos)
+};
+
+struct GemmEpi {
+  const float* bias;   // nullable [N]: added first
+  float mul;           // then multiplied
+  int relu;            // then max(., 0)
+  Drop dr;             // then dropout, element index row * N + col (thr = 0: none)
+  float beta;          // 0: overwrite C, 1: add to it
+  const float* res = nullptr;   // optional residual [M][ldc], added last (out = ... + res)
+  // out16 != nullptr: the result goes out as ONE 16-bit piece in the blocked activation layout [N/32][M][32] (kind16: 1 f16, 2 bf16)
+  // instead of fp32 rows; rows flagged in zero_rows (nullable, one byte per row) are written as zeros
+  u16* out16 = nullptr;
+  int kind16 = 0;
+  const unsigned char* zero_rows = nullptr;
+};
+
+// ---- C[M,N] = epilogue(A[M,K] . B[N,K]^T): both operands row-major with the contraction index contiguous -----------------------------
+// NS = 2: the bf16x3 product above.  NS = 3: operands split into THREE bf16 pieces (24 mantissa bits = all of fp32) and six MFMAs per
+// product (hh, hm, mh, mm, hl, lh; the dropped terms are 2^-24 of the product): as accurate as an fp32 GEMM at twice the matrix
+// time of NS = 2.  The FORWARD GEMMs run this way (option `train_exact`, default 1).  Why: the layer has one discontinuity, the ReLU.
+// With 1.5e-5 relative error on the pre-activations about one hidden unit in 1e5 lands on the other side of zero than in an fp32
+// forward, and every such flip moves the input gradient of its token by ~1e-2 of the gradient's scale (measured at [1,4,256,32,32],
+// d_ffn 1024, two-piece forward: d_src 7e-3 .. 2e-2 in max-norm, relative L2 3e-4, output 5e-6).  The three-piece forward costs
+// 0.06 ms of a 3.3 ms step (these GEMMs are bound by their fp32 operand traffic, not by the matrix pipe), so it is the default;
+// the backward GEMMs are smooth in their operands and stay two-piece.
+template <int NS>
+__device__ __forceinline__ void split_n(const float4& a, const float4& b, u16x8 (&p)[NS]) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float r = x[i];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const __bf16 h = (__bf16)r;
+      p[s][i] = __builtin_bit_cast(u16, h);
+      r -= (float)h;                       // exact in fp32
+    }
+  }
+}
+
+template <int NS>
+constexpr size_t gemm_nt_lds() {
+  return (size_t)2 * 2 * NS * kGTileElems * sizeof(u16) > kGemmLds ? (size_t)2 * 2 * NS * kGTileElems * sizeof(u16) : kGemmLds;
+}
+
+template <int NS, int TU = 0>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                         float* __restrict__ C, long long M, int N, int K, GemmLd ld, GemmEpi ep) {
+  extern __shared__ __attribute__((aligned(16))) char gsmem[];
+  u16* const sbuf = reinterpret_cast<u16*>(gsmem);            // [2 stages][A pieces | B pieces][128 rows][32] (rows chunk-swizzled)
+  constexpr int kStage = 2 * NS * kGTileElems;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const long long m0 = (long long)blockIdx.x * kGT;
+  const int n0 = blockIdx.y * kGT;
+  // staging: thread -> (tile row, 8-float chunk): 4 threads cover a 128-byte row segment
+  const int sr = tid >> 2, sq = tid & 3;
+  const bool a_ok = m0 + sr < M, b_ok = n0 + sr < N;
+  // split-K (ld.ksteps > 0): workgroup z contracts k-steps [z ksteps, (z + 1) ksteps) into the partial C + z M ldc
+  const int nk_all = (K + kGK - 1) / kGK;
+  const int ks0 = ld.ksteps > 0 ? (int)blockIdx.z * ld.ksteps : 0;
+  const int nk = ld.ksteps > 0 ? (nk_all - ks0 < ld.ksteps ? (nk_all - ks0 > 0 ? nk_all - ks0 : 0) : ld.ksteps) : nk_all;
+  const int kbase = ks0 * kGK;
+  const float* ap = A + (m0 + (a_ok ? sr : 0)) * ld.a + kbase + sq * 8;
+  const float* bp = B + (long long)(n0 + (b_ok ? sr : 0)) * ld.b + kbase + sq * 8;
+  C += (size_t)blockIdx.z * M * ld.c;
+  const int soff = sr * 32 + swz_chunk(sr, sq) * 8;
+  // global loads run TWO k-steps ahead of the MFMAs (two register slots, used alternately): with one step of lookahead a load had a
+  // single step's MFMAs (~0.3 us) to cover an L2 / HBM round trip and every step stalled at its LDS store
+  float4 ra[2][2], rb[2][2];
+  auto gload = [&](int ks, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = kbase + ks * kGK + sq * 8 + 4 * h;       // K % 4 == 0: a float4 is inside or outside
+      const bool kin = kk < K;
+      ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      if (ld.a2 && a_ok && kin) {
+        const float4 t = *reinterpret_cast<const float4*>(ld.a2 + (ap - A) + ks * kGK + 4 * h);
+        ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
+      }
+      rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lstore = [&](int stage, auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    u16* const base = sbuf + stage * kStage;
+    u16x8 p[NS];
+    split_n<NS>(ra[SL][0], ra[SL][1], p);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x8*>(base + s * kGTileElems + soff) = p[s];
+    split_n<NS>(rb[SL][0], rb[SL][1], p);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x8*>(base + (NS + s) * kGTileElems + soff) = p[s];
+  };
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int row = wm * 64 + mt * 16 + fi;
+    aoff[mt] = row * 32 + swz_chunk(row, fg) * 8;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int row = wn * 32 + nt * 16 + fi;
+    boff[nt] = row * 32 + swz_chunk(row, fg) * 8;
+  }
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // one k-step: stage `PAR` of LDS holds step ks; register slot PAR ^ 1 holds step ks + 1 (requested a step ago), slot PAR is free
+  auto kstep = [&](int ks, auto par_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    if (ks + 2 < nk) gload(ks + 2, std::integral_constant<int, PAR>{});
+    const u16* const base = sbuf + PAR * kStage;
+    u16x8 bf[2][NS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bf[nt][s] = *reinterpret_cast<const u16x8*>(base + (NS + s) * kGTileElems + boff[nt]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      u16x8 af[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const u16x8*>(base + s * kGTileElems + aoff[mt]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {                        // D[n = 4 fg + r][m = fi]
+        f32x4 c = acc[mt][nt];
+        c = H16<true>::mfma(bf[nt][0], af[0], c);
+        c = H16<true>::mfma(bf[nt][0], af[1], c);
+        c = H16<true>::mfma(bf[nt][1], af[0], c);
+        if constexpr (NS == 3) {
+          c = H16<true>::mfma(bf[nt][1], af[1], c);
+          c = H16<true>::mfma(bf[nt][0], af[2], c);
+          c = H16<true>::mfma(bf[nt][2], af[0], c);
+        }
+        acc[mt][nt] = c;
+      }
+    }
+    if (ks + 1 < nk) lstore(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});   // the other stage: every wave left its reads behind the previous barrier
+    __syncthreads();
+  };
+  if (nk > 0) gload(0, S0{});
+  if (nk > 1) gload(1, S1{});
+  if (nk > 0) lstore(0, S0{});
+  __syncthreads();
+  for (int ks = 0; ks < nk; ks += 2) {
+    kstep(ks, S0{});
+    if (ks + 1 < nk) kstep(ks + 1, S1{});
+  }
+  // ---- epilogue: accumulators -> fp32 staging tile [m][n] -> whole rows, 512 bytes per row segment ----
+  float* const stg = reinterpret_cast<float*>(gsmem);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      *reinterpret_cast<float4*>(stg + (wm * 64 + mt * 16 + fi) * kGLd + wn * 32 + nt * 16 + 4 * fg) =
+          float4{acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 512 * i, row = idx >> 5, c4 = idx & 31;
+    const long long gm = m0 + row;
+    const int gn = n0 + 4 * c4;
+    if (gm < M && gn < N) {
+      const float4 v = *reinterpret_cast<const float4*>(stg + row * kGLd + 4 * c4);
+      float t[4] = {v.x, v.y, v.z, v.w};
+      if (ep.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(ep.bias + gn);
+        t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
+      }
+      float* const cp = C + gm * ld.c + gn;
+      const unsigned long long e0 = (unsigned long long)gm * N + gn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t[e] *= ep.mul;
+        if (ep.relu) t[e] = fmaxf(t[e], 0.f);
+        t[e] *= drop_keep(ep.dr, e0 + e);
+      }
+      if (ep.out16) {
+        if (ep.zero_rows && ep.zero_rows[gm]) t[0] = t[1] = t[2] = t[3] = 0.f;
+        typedef unsigned short u16x4v __attribute__((ext_vector_type(4)));
+        u16x4v o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ep.kind16 == 2 ? H16<true>::from_f32(t[e]) : H16<false>::from_f32(t[e]);
+        *reinterpret_cast<u16x4v*>(ep.out16 + blk_off(M, gm, gn)) = o;
+        continue;
+      }
+      if (ep.beta != 0.f) {
+        const float4 o = *reinterpret_cast<const float4*>(cp);
+        t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
+      }
+      if (ep.res) {
+        const float4 o = *reinterpret_cast<const float4*>(ep.res + gm * ld.c + gn);
+        t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
+      }
+      *reinterpret_cast<float4*>(cp) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  }
+}
+
+}  // namespace tr
+}  // namespace axvs

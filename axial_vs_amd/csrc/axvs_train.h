@@ -8,36 +8,10 @@
 // recomputed forward, and the CPU oracle in the tests) regenerate them instead of storing them.
 #pragma once
 #include "axvs_common.h"
+#include "axvs_gemm_nt.h"
 
 namespace axvs {
 namespace tr {
-
-__host__ __device__ __forceinline__ unsigned fmix32(unsigned h) {
-  h ^= h >> 16;
-  h *= 0x85ebca6bu;
-  h ^= h >> 13;
-  h *= 0xc2b2ae35u;
-  h ^= h >> 16;
-  return h;
-}
-
-// keep element `idx` of dropout site `site` iff (hash >> 8) >= thr, thr = floor(p * 2^24)
-struct Drop {
-  unsigned seed, site, thr;
-  float scale;   // 1 / (1 - p)
-};
-
-__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned site, unsigned long long idx) {
-  unsigned h = seed ^ (site * 0x9E3779B9u);
-  h = fmix32(h ^ (unsigned)idx);
-  h = fmix32(h ^ (unsigned)(idx >> 32));
-  return h;
-}
-
-__device__ __forceinline__ float drop_keep(const Drop& d, unsigned long long idx) {   // 0 or 1/(1-p)
-  if (d.thr == 0) return 1.f;
-  return (drop_hash(d.seed, d.site, idx) >> 8) >= d.thr ? d.scale : 0.f;
-}
 
 template <int D>
 __device__ __forceinline__ void load_row(float (&r)[D], const float* p) {

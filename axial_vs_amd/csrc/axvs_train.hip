@@ -41,6 +41,8 @@ struct Gemm {
     if (N % 4 || K % 4 || ld.a % 4 || ld.b % 4 || ld.c % 4) return fail(AXVS_ERR_ARG, "training GEMM: N=%d, K=%d and the row strides must be multiples of 4", N, K);
     if (M <= 0) return AXVS_OK;
     const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT), (unsigned)zsplits);
+    // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
+    //  fixed cost -- ~11 us whatever K -- not by the load round trips of the k-loop)
     if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else hipLaunchKernelGGL(tr_gemm_nt_kernel<2>, grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
     return AXVS_OK;
