@@ -1,6 +1,7 @@
 // C-ABI entry points of libaxvs.so (see include/axvs.h) and the launch sequences behind them.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -777,7 +778,9 @@ int cc_masks_t(const float* pf, const u16* kern16, float* masks, const void* pac
   const long long TP = (long long)Tc * P;
   const EinsumMap mp{128 * TP, P, TP, (long long)Q * TP, P, TP, Tc, 1};
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128>))) return rc;
-  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride);
+  // every stride of the map is a multiple of P: the pixel rows are as aligned as P (and the two base pointers) allow
+  const int al = std::min(row_align(pf, P, P), row_align(masks, P, P));
+  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride, al);
   mark(st, "cc.mask_einsum");
   return AXVS_OK;
 }
@@ -848,12 +851,13 @@ int tl_masks_t(const float* mf, const u16* kern16, float* masks, int B, int Q, i
   const int T = Tc * fpc;
   dim3 grid((unsigned)((P + kEinsumPx - 1) / kEinsumPx), B * T);
   const EinsumMap mp{(long long)T * Cm * P, (long long)Cm * P, P, (long long)T * Q * P, (long long)Q * P, P, T, fpc};
+  const int al = std::min(row_align(mf, P, P), row_align(masks, P, P));
   if (Cm == 128) {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128>))) return rc;
-    hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride, al);
   } else {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 256>))) return rc;
-    hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), einsum_lds_bytes<256>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride);
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), einsum_lds_bytes<256>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride, al);
   }
   mark(st, "tl.mask_einsum");
   return AXVS_OK;
@@ -1395,7 +1399,6 @@ int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, f
                       size_t workspace_bytes, void* stream) {
   if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
   if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
-  if (((long long)V * H * W) % 4) return fail(AXVS_ERR_ARG, "V*H*W must be a multiple of 4");
   if (B * Tc > 1024) return fail(AXVS_ERR_ARG, "B*Tc > 1024 is not supported by the class head");
   if (workspace_bytes < axvs_cc_heads_workspace_bytes(B, Q, Tc)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1421,7 +1424,6 @@ int axvs_cc_module_fwd(const float* clip_query, const float* panoptic_features, 
   if (!clip_query || !panoptic_features || !pred_logits || !pred_masks || !last_query || !packed_layers || !packed_heads || !rates || !workspace)
     return fail(AXVS_ERR_ARG, "null pointer");
   if (B <= 0 || Q <= 0 || Tc <= 0 || V <= 0 || H <= 0 || W <= 0 || K1 <= 0 || num_layers <= 0) return fail(AXVS_ERR_ARG, "empty shape");
-  if (((long long)V * H * W) % 4) return fail(AXVS_ERR_ARG, "V*H*W must be a multiple of 4");
   if (B * Tc > 1024) return fail(AXVS_ERR_ARG, "B*Tc > 1024 is not supported by the class head");
   if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
   if (workspace_bytes < axvs_cc_module_workspace_bytes(B, Q, Tc, num_layers)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
@@ -1457,7 +1459,6 @@ int axvs_tl_cc_module_fwd(const float* clip_query, const float* mask_feature, fl
     return fail(AXVS_ERR_ARG, "null pointer");
   if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w_ <= 0 || K1 <= 0 || num_layers <= 0) return fail(AXVS_ERR_ARG, "empty shape");
   if (Cm != 128 && Cm != 256) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
-  if (((long long)h * w_) % 4) return fail(AXVS_ERR_ARG, "h*w must be a multiple of 4");
   if (Tc > 1024) return fail(AXVS_ERR_ARG, "more than 1024 clips are not supported by the class head");
   if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
   if (workspace_bytes < axvs_tl_cc_module_workspace_bytes(B, Q, Tc, Cm, num_layers)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
@@ -1533,7 +1534,6 @@ int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float*
   if (!clip_query || !mask_feature || !cls_logits || !mask_logits || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
   if (B <= 0 || Q <= 0 || Tc <= 0 || frames_per_clip <= 0 || h <= 0 || w <= 0 || K1 <= 0) return fail(AXVS_ERR_ARG, "empty shape");
   if (Cm != 128 && Cm != 256) return fail(AXVS_ERR_ARG, "mask feature channels must be 128 or 256 (got %d)", Cm);
-  if (((long long)h * w) % 4) return fail(AXVS_ERR_ARG, "h*w must be a multiple of 4");
   if (Tc > 1024) return fail(AXVS_ERR_ARG, "more than 1024 clips are not supported by the class head");
   if (workspace_bytes < axvs_tl_heads_workspace_bytes(B, Q, Tc, Cm)) return fail(AXVS_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = static_cast<hipStream_t>(stream);

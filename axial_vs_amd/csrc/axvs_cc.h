@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
                                                           EinsumMap mp, const float* __restrict__ pix_bn /* {mul, add} or null */,
                                                           int nl = 1 /* layers sharing the staged feature tile */,
                                                           long long kstride = 0 /* elements between the layers' kernels */,
-                                                          long long ostride = 0 /* ... and between their outputs */) {
+                                                          long long ostride = 0 /* ... and between their outputs */,
+                                                          int al = 4 /* alignment (floats) of the pixel rows of pf and out: P % 4 != 0 -> 2 or 1 */) {
   // Workgroup = 256 pixels of one unit (4 waves x 64 pixels = 4 MFMA row tiles per wave): every kernel fragment fetched from L2
   // feeds 4 MFMAs, and a wave's stores cover 256 contiguous bytes of a query's row (round 2; 64 pixels per workgroup before: the
   // kernel fragments were 3x the traffic of the features).
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long p = p0 + seg * 32 + i * 4;
-      v[i] = p + 3 < P ? *reinterpret_cast<const float4*>(src + i * 4) : float4{0.f, 0.f, 0.f, 0.f};
+      v[i] = ldg4(src + i * 4, (int)(P - p < 4 ? (P - p < 0 ? 0 : P - p) : 4), al);
     }
     const int kb = c >> 5, k = c & 31;
 #pragma unroll
@@ -175,9 +176,9 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc = H16<BF>::mfma(af[t][kb], bf[kb], acc);          // D[pixel][query]
         const long long p = p0 + wave * (16 * PXW) + t * 16 + fg * 4;
-        if (qt * 16 + fi < Q && p + 3 < P)
-          *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) =
-              float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
+        if (qt * 16 + fi < Q && p < P)
+          stg4(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p,
+               float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add}, (int)(P - p < 4 ? P - p : 4), al);
       }
     }
   }

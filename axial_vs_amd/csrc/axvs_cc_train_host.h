@@ -25,10 +25,9 @@ int make_cc_shape(CCShape& s, const AxvsCCTrainCfg* cfg) {
   if (cfg->B <= 0 || cfg->Q <= 0 || cfg->Tc <= 0 || cfg->V <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->K1 <= 0 || cfg->num_layers <= 0)
     return fail(AXVS_ERR_ARG, "non-positive dimension");
   if (cfg->num_layers > kCcMaxLayers) return fail(AXVS_ERR_ARG, "cross-clip training: num_layers=%d > %d", cfg->num_layers, kCcMaxLayers);
-  if (cfg->Tc > 8) return fail(AXVS_ERR_ARG, "cross-clip training: Tc=%d > 8 clips not built", cfg->Tc);
+  if (cfg->Tc > 16) return fail(AXVS_ERR_ARG, "cross-clip training: Tc=%d > 16 clips not built", cfg->Tc);
   if (cfg->Q % 8) return fail(AXVS_ERR_ARG, "cross-clip training: Q=%d must be a multiple of 8", cfg->Q);
-  const long long P = (long long)cfg->V * cfg->H * cfg->W;
-  if (P % 8) return fail(AXVS_ERR_ARG, "cross-clip training: V*H*W=%lld must be a multiple of 8", P);
+  const long long P = (long long)cfg->V * cfg->H * cfg->W;       // any pixel count: the einsum GEMMs take unaligned rows and tails
   if ((long long)cfg->B * cfg->Tc > 1024) return fail(AXVS_ERR_ARG, "cross-clip training: B*Tc > 1024");
   for (int k = 0; k < 3; ++k)
     if (cfg->rates[k] <= 0) return fail(AXVS_ERR_ARG, "cross-clip training: atrous rate %d", cfg->rates[k]);
@@ -255,16 +254,19 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
   // 'bchw,bcn->bnhw' per clip, all layers' kernels at once when the output rows (layer, query) are evenly strided (B == 1)
   const long long TP = (long long)s.Tc * s.P;
   const int GQ = G * s.Q;
+  const int al_pf = row_align(pf, s.P, s.P), al_lg = row_align(sv.logits_pre, s.P, s.P);   // rows start at multiples of P floats
   if (s.B == 1) {
     for (int t = 0; t < s.Tc; ++t)
-      if ((rc = c.g.tn_direct(k.x.kt + (size_t)t * kCcCm * GQ, pf + (size_t)t * s.P, sv.logits_pre + (size_t)t * s.P, kCcCm, GQ, (int)s.P, GQ, TP, TP)) != AXVS_OK)
+      if ((rc = c.g.tn_direct(k.x.kt + (size_t)t * kCcCm * GQ, pf + (size_t)t * s.P, sv.logits_pre + (size_t)t * s.P, kCcCm, GQ, (int)s.P, GQ, TP, TP,
+                              al_pf, al_lg)) != AXVS_OK)
         return rc;
   } else {
     for (int g = 0; g < G; ++g)
       for (int b = 0; b < s.B; ++b)
         for (int t = 0; t < s.Tc; ++t)
           if ((rc = c.g.tn_direct(k.x.kt + ((size_t)b * s.Tc + t) * kCcCm * GQ + (size_t)g * s.Q, pf + (size_t)b * kCcCm * TP + (size_t)t * s.P,
-                                  sv.logits_pre + (((size_t)g * s.B + b) * s.Q) * TP + (size_t)t * s.P, kCcCm, s.Q, (int)s.P, GQ, TP, TP)) != AXVS_OK)
+                                  sv.logits_pre + (((size_t)g * s.B + b) * s.Q) * TP + (size_t)t * s.P, kCcCm, s.Q, (int)s.P, GQ, TP, TP, al_pf,
+                                  al_lg)) != AXVS_OK)
             return rc;
   }
   // one-channel BatchNorm over each layer's mask logits (CC:56)
@@ -301,7 +303,9 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
                      s.E / 4);
   // ---- mask kernels: dk[(b t)][(g q)][c] = sum_p dpre[g][b][q][t P + p] pf[b][c][t P + p] (split-K partials, summed in a fixed order) ----
   const GemmEpi plain{nullptr, 1.f, 0, make_drop(0.f, 0, 0), 0.f};
-  const GemmLd ldk{TP, TP, Cm, x.dk_ksteps};
+  GemmLd ldk{TP, TP, Cm, x.dk_ksteps};
+  ldk.al_a = row_align(x.dpre, s.P, s.P);
+  ldk.al_b = row_align(pf, s.P, s.P);
   if (s.B == 1) {
     for (int t = 0; t < s.Tc; ++t) {
       if ((rc = c.g.nt(x.dpre + (size_t)t * s.P, pf + (size_t)t * s.P, x.dkpart, GQ, Cm, (int)s.P, ldk, plain, false, x.dk_z)) != AXVS_OK) return rc;

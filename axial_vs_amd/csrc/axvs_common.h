@@ -121,6 +121,48 @@ __device__ __forceinline__ long long nat_row(const RowMap& rm, int mp) {
   return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
 }
 
+// ---- rows of pixels: their count is whatever the image size gives (193 x 337 maps), so a row may start at any 4-byte boundary
+//      and end inside a group of four.  Alignment-aware 4-float accesses for the kernels that walk such rows.
+// row alignment (floats) of an operand whose rows start at base + i * ld + j * step for integers i, j
+inline int row_align(const void* base, long long ld, long long step) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  if (a % 16 == 0 && ld % 4 == 0 && step % 4 == 0) return 4;
+  if (a % 8 == 0 && ld % 2 == 0 && step % 2 == 0) return 2;
+  return 1;
+}
+
+// four consecutive floats at p of which the first `valid` exist (<= 0: none); al: alignment of p in floats
+__device__ __forceinline__ float4 ldg4(const float* p, int valid, int al) {
+  if (valid >= 4) {
+    if (al >= 4) return *reinterpret_cast<const float4*>(p);
+    if (al >= 2) {
+      const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
+      return float4{a.x, a.y, b.x, b.y};
+    }
+    return float4{p[0], p[1], p[2], p[3]};
+  }
+  float4 r = {0.f, 0.f, 0.f, 0.f};
+  if (valid > 0) r.x = p[0];
+  if (valid > 1) r.y = p[1];
+  if (valid > 2) r.z = p[2];
+  return r;
+}
+__device__ __forceinline__ void stg4(float* p, float4 v, int valid, int al) {
+  if (valid >= 4) {
+    if (al >= 4) { *reinterpret_cast<float4*>(p) = v; return; }
+    if (al >= 2) {
+      *reinterpret_cast<float2*>(p) = float2{v.x, v.y};
+      *reinterpret_cast<float2*>(p + 2) = float2{v.z, v.w};
+      return;
+    }
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    return;
+  }
+  if (valid > 0) p[0] = v.x;
+  if (valid > 1) p[1] = v.y;
+  if (valid > 2) p[2] = v.z;
+}
+
 // Same decomposition, also returning the (t, h, w) grid coordinates packed as t | h << 8 | w << 20 (T <= 255, H, W <= 4095):
 // what an in-kernel positional embedding needs.  l_is_h: the on-axis coordinate l is the image row (height pass).
 __device__ __forceinline__ long long nat_row_coords(const RowMap& rm, int mp, int l_is_h, int* packed) {

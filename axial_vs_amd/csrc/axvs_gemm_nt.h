@@ -49,6 +49,10 @@ struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps >
   long long a, b, c;
   int ksteps;
   const float* a2 = nullptr;   // optional second A operand with A's shape and stride, added element-wise on load (x + pos)
+  // alignment (in floats: 4, 2 or 1) every row start of A, B, C is known to have.  4: 16-byte vector accesses (the rule: row
+  // strides and extents multiples of 4); smaller: rows of pixels whose count is whatever the image size gives (the mask einsum
+  // over 193 x 337 maps) -- narrower accesses, and an extent that is not a multiple of 4 ends inside a group of four
+  int al_a = 4, al_b = 4, al_c = 4;
 };
 
 struct GemmEpi {
@@ -123,14 +127,14 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
     constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int kk = kbase + ks * kGK + sq * 8 + 4 * h;       // K % 4 == 0: a float4 is inside or outside
-      const bool kin = kk < K;
-      ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
-      if (ld.a2 && a_ok && kin) {
-        const float4 t = *reinterpret_cast<const float4*>(ld.a2 + (ap - A) + ks * kGK + 4 * h);
+      const int kk = kbase + ks * kGK + sq * 8 + 4 * h;
+      const int kv = K - kk;                                  // how many of the four columns exist
+      ra[SL][h] = ldg4(ap + ks * kGK + 4 * h, a_ok ? kv : 0, ld.al_a);
+      if (ld.a2 && a_ok && kv > 0) {
+        const float4 t = ldg4(ld.a2 + (ap - A) + ks * kGK + 4 * h, kv, ld.al_a);
         ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
       }
-      rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      rb[SL][h] = ldg4(bp + ks * kGK + 4 * h, b_ok ? kv : 0, ld.al_b);
     }
   };
   auto lstore = [&](int stage, auto slot_tag) {

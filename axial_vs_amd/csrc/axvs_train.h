@@ -514,19 +514,19 @@ __global__ __launch_bounds__(256) void tr_spatial_bwd_kv_kernel(const float* __r
 }
 
 // ---- temporal half (WC/temporal_attention.py:69-73), one thread per (token, head):
-//      logits_f = q2 . k2_f, a = softmax_f, o = sum_f a_f v2_f.   q2 [M,C] (already scaled), kv2 [M*T, 2C] = (k2 | v2), T <= 8.
-template <int D>
+//      logits_f = q2 . k2_f, a = softmax_f, o = sum_f a_f v2_f.   q2 [M,C] (already scaled), kv2 [M*T, 2C] = (k2 | v2), T <= TMAX (8: the clips of the within-clip layer; 16: the cross-clip module walks up to 16 clips).
+template <int D, int TMAX>
 __global__ __launch_bounds__(256) void tr_temporal_fwd_kernel(const float* __restrict__ q2, const float* __restrict__ kv2,
                                                                float* __restrict__ o, long long M, int T, int C, int heads) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= M * heads) return;
   const long long m = i / heads;
   const int h = (int)(i - m * heads);
-  float qr[D], acc[D], lg[8];
+  float qr[D], acc[D], lg[TMAX];
   load_row<D>(qr, q2 + m * C + h * D);
   float mx = -INFINITY;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       float kr[D];
       load_row<D>(kr, kv2 + (m * T + f) * 2 * C + h * D);
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void tr_temporal_fwd_kernel(const float* __res
     }
   float sum = 0.f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       lg[f] = __expf(lg[f] - mx);
       sum += lg[f];
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void tr_temporal_fwd_kernel(const float* __res
 #pragma unroll
   for (int c = 0; c < D; ++c) acc[c] = 0.f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       float vr[D];
       load_row<D>(vr, kv2 + (m * T + f) * 2 * C + C + h * D);
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void tr_temporal_fwd_kernel(const float* __res
 }
 
 // backward: d_o -> dq2 [M,C], dkv2 [M*T, 2C]
-template <int D>
+template <int D, int TMAX>
 __global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __restrict__ q2, const float* __restrict__ kv2,
                                                                const float* __restrict__ d_o, float* __restrict__ dq2,
                                                                float* __restrict__ dkv2, long long M, int T, int C, int heads) {
@@ -567,12 +567,12 @@ __global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __res
   if (i >= M * heads) return;
   const long long m = i / heads;
   const int h = (int)(i - m * heads);
-  float qr[D], gr[D], lg[8], da[8];
+  float qr[D], gr[D], lg[TMAX], da[TMAX];
   load_row<D>(qr, q2 + m * C + h * D);
   load_row<D>(gr, d_o + m * C + h * D);
   float mx = -INFINITY;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       float kr[D], vr[D];
       load_row<D>(kr, kv2 + (m * T + f) * 2 * C + h * D);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __res
     }
   float sum = 0.f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       lg[f] = __expf(lg[f] - mx);
       sum += lg[f];
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __res
   const float inv = 1.f / sum;
   float dot = 0.f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       lg[f] *= inv;
       dot += lg[f] * da[f];
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void tr_temporal_bwd_kernel(const float* __res
 #pragma unroll
   for (int c = 0; c < D; ++c) dqr[c] = 0.f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < TMAX; ++f)
     if (f < T) {
       const float dl = lg[f] * (da[f] - dot);
       float kr[D], t0[D], t1[D];

@@ -38,7 +38,8 @@ struct Gemm {
   // exact: three bf16 pieces per operand (fp32 accuracy) -- for the GEMM in front of the ReLU (see tr_gemm_nt_kernel)
   // ld (optional): row strides of X, W, Y (sub-matrices of wider buffers); ld.ksteps > 0 with zsplits: split-K partials [z][M][ld.c]
   int nt(const float* X, const float* W, float* Y, long long M, int N, int K, GemmLd ld, const GemmEpi& e, bool exact, int zsplits = 1) const {
-    if (N % 4 || K % 4 || ld.a % 4 || ld.b % 4 || ld.c % 4) return fail(AXVS_ERR_ARG, "training GEMM: N=%d, K=%d and the row strides must be multiples of 4", N, K);
+    if (N % 4 || ld.c % 4 || (ld.al_a == 4 && ld.a % 4) || (ld.al_b == 4 && ld.b % 4))
+      return fail(AXVS_ERR_ARG, "training GEMM: N=%d and the row strides must be multiples of 4 (K=%d)", N, K);
     if (M <= 0) return AXVS_OK;
     const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT), (unsigned)zsplits);
     // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
@@ -70,11 +71,15 @@ struct Gemm {
   }
   // P[N][K] (row stride ldo) = A[Mc][N]^T X[Mc][K]: the contraction over a FEW rows Mc (the 128 channels of the mask einsum,
   // CC:55) in one split, straight into the caller's tensor
-  int tn_direct(const float* A, const float* X, float* P, int Mc, int N, int K, long long lda, long long ldx, long long ldo) const {
-    if (N % 8 || K % 8 || lda % 4 || ldx % 4 || ldo % 4) return fail(AXVS_ERR_ARG, "einsum GEMM: N=%d and K=%d must be multiples of 8", N, K);
+  // al_x / al_o: alignment (floats) of the rows of X and P -- K is a pixel count and need not be a multiple of anything
+  int tn_direct(const float* A, const float* X, float* P, int Mc, int N, int K, long long lda, long long ldx, long long ldo, int al_x, int al_o) const {
+    if (N % 4 || lda % 4) return fail(AXVS_ERR_ARG, "einsum GEMM: N=%d must be a multiple of 4", N);
     const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), 1u);
     const long long chunk = (Mc + kGK - 1) / kGK * kGK;
-    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, GemmLd{lda, ldx, ldo, 0});
+    GemmLd ld{lda, ldx, ldo, 0};
+    ld.al_b = al_x;
+    ld.al_c = al_o;
+    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
     return AXVS_OK;
   }
 };
@@ -91,7 +96,7 @@ int make_dims(Dims& d, int B, int T, int H, int W, int C, int heads, int F) {
   const int D = C / heads;
   if (D != 8 && D != 16 && D != 32) return fail(AXVS_ERR_ARG, "training tier: head_dim=%d not built (8, 16, 32)", D);
   if (F % 8) return fail(AXVS_ERR_ARG, "training tier: d_ffn=%d must be a multiple of 8", F);
-  if (T > 8) return fail(AXVS_ERR_ARG, "training tier: T=%d > 8 frames per clip not built", T);
+  if (T > 16) return fail(AXVS_ERR_ARG, "training tier: T=%d > 16 frames per clip not built", T);
   const long long M = (long long)B * T * H * W;
   if (M * (long long)(T > 1 ? T : 1) > INT32_MAX) return fail(AXVS_ERR_ARG, "training tier: B*T*H*W*T exceeds 2^31 rows");
   if ((size_t)2 * (H > W ? H : W) * D * sizeof(float) > 160 * 1024) return fail(AXVS_ERR_ARG, "training tier: axis length too long for LDS");
@@ -292,8 +297,10 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   if ((rc = c.g.fwd(s.xd, w.proj_q_w, s.q2, M, C, C, 0.f, &epq, ex)) != AXVS_OK) return rc;
   if ((rc = c.g.fwd(s.x, w.proj_kv_w, s.kv2, M * d.T, 2 * C, C, 0.f, &epkv, ex)) != AXVS_OK) return rc;
   AXVS_D_SWITCH(d.D, {
-    hipLaunchKernelGGL(tr_temporal_fwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
-                       (const float*)s.kv2, s.o, M, d.T, C, d.heads);
+    if (d.T <= 8) hipLaunchKernelGGL((tr_temporal_fwd_kernel<kD, 8>), dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
+                                     (const float*)s.kv2, s.o, M, d.T, C, d.heads);
+    else hipLaunchKernelGGL((tr_temporal_fwd_kernel<kD, 16>), dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
+                            (const float*)s.kv2, s.o, M, d.T, C, d.heads);
   })
   if ((rc = c.g.fwd(s.o, w.proj_w, c.sc.t0, M, C, C, 0.f, nullptr, ex)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_bias_drop_res_kernel, dim3(blocks((size_t)M * C / 4)), dim3(256), 0, c.st, (const float*)c.sc.t0, w.proj_b, xin, xout, rm,
@@ -317,8 +324,10 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   if ((rc = c.dgrad(sc.t0, w.proj_w, sc.d_o, M, C, C, 0.f)) != AXVS_OK) return rc;
   // temporal half
   AXVS_D_SWITCH(d.D, {
-    hipLaunchKernelGGL(tr_temporal_bwd_kernel<kD>, dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
-                       (const float*)s.kv2, (const float*)sc.d_o, sc.dq2, sc.dkv2, M, T, C, d.heads);
+    if (T <= 8) hipLaunchKernelGGL((tr_temporal_bwd_kernel<kD, 8>), dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
+                                   (const float*)s.kv2, (const float*)sc.d_o, sc.dq2, sc.dkv2, M, T, C, d.heads);
+    else hipLaunchKernelGGL((tr_temporal_bwd_kernel<kD, 16>), dim3(blocks((size_t)M * d.heads)), dim3(256), 0, c.st, (const float*)s.q2,
+                            (const float*)s.kv2, (const float*)sc.d_o, sc.dq2, sc.dkv2, M, T, C, d.heads);
   })
   if ((rc = c.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C, gw.proj_kv_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dkv2, w.proj_kv_w, sc.dx, M * T, 2 * C, C, 0.f)) != AXVS_OK) return rc;

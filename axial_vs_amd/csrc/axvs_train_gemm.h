@@ -79,7 +79,6 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
   const long long me = ms + rows_per_split < M ? ms + rows_per_split : M;
   // staging: thread -> (row m of the step, 8-float chunk): 16 threads cover a 512-byte row segment
   const int sr = tid >> 4, sc = tid & 15;
-  const bool n_ok = n0 + sc * 8 < N, k_ok = k0 + sc * 8 < K;         // N, K % 8 == 0 (host check)
   const int soff = sr * kGT + tn_chunk(sr, sc) * 8;
   const int nsteps = (int)((me - ms + kGK - 1) / kGK);
   const bool do_bias = part_b != nullptr && k0 == 0;                 // workgroup-uniform
@@ -90,8 +89,8 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
     const bool m_ok = m < me;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      ra[h] = m_ok && n_ok ? *reinterpret_cast<const float4*>(dY + m * ld.a + n0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
-      rb[h] = m_ok && k_ok ? *reinterpret_cast<const float4*>(X + m * ld.b + k0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      ra[h] = ldg4(dY + m * ld.a + n0 + sc * 8 + 4 * h, m_ok ? N - (n0 + sc * 8 + 4 * h) : 0, ld.al_a);
+      rb[h] = ldg4(X + m * ld.b + k0 + sc * 8 + 4 * h, m_ok ? K - (k0 + sc * 8 + 4 * h) : 0, ld.al_b);
     }
   };
   auto lstore = [&](int stage) {
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const int n = n0 + wn * 64 + nt * 16 + fi, k = k0 + wk * 32 + kt * 16 + 4 * fg;
-      if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * ld.c + k) = float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
+      if (n < N) stg4(out + (size_t)n * ld.c + k, float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]}, K - k, ld.al_c);
     }
   if (do_bias) {                 // (the loop's last barrier is behind every wave: the operand stages are free)
     float* const red = reinterpret_cast<float*>(gsmem);        // [32 staging rows][128 columns]

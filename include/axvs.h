@@ -199,7 +199,7 @@ int axvs_cc_heads_pack(const AxvsCCHeadParams* p, void* packed, int K1, int dtyp
 size_t axvs_cc_heads_workspace_bytes(int B, int Q, int Tc);
 /* clip_query fp32 [B,Q,Tc,256]; panoptic_features fp32 [B,128,Tc*V,H,W];
  * pred_logits fp32 [1,Q,K1] (softmax pooling runs over all B*Tc entries, like the reference's dim-0 softmax);
- * pred_masks fp32 [B,Q,Tc*V,H,W].  V*H*W must be a multiple of 4. */
+ * pred_masks fp32 [B,Q,Tc*V,H,W] (any V*H*W: rows of pixels may start at any 4-byte boundary). */
 int axvs_cc_heads_fwd(const float* clip_query, const float* panoptic_features, float* pred_logits, float* pred_masks,
                       const void* packed, int B, int Q, int Tc, int V, int H, int W, int K1, int dtype, void* workspace,
                       size_t workspace_bytes, void* stream);
@@ -219,7 +219,7 @@ size_t axvs_tl_heads_packed_bytes(int K1, int Cm);
 int axvs_tl_heads_pack(const AxvsTLHeadParams* p, void* packed, int K1, int Cm, int dtype, void* stream);
 size_t axvs_tl_heads_workspace_bytes(int B, int Q, int Tc, int Cm);
 /* clip_query fp32 [B,Q,Tc,256] (a cross-clip layer's output, axvs_cc_layer_fwd layout); mask_feature fp32 [B,Tc*fpc,Cm,h,w];
- * cls_logits fp32 [B,Q,K1]; mask_logits fp32 [B,Tc*fpc,Q,h,w].  Cm in {128,256}; h*w must be a multiple of 4. */
+ * cls_logits fp32 [B,Q,K1]; mask_logits fp32 [B,Tc*fpc,Q,h,w].  Cm in {128,256}; any h*w. */
 int axvs_tl_heads_fwd(const float* clip_query, const float* mask_feature, float* cls_logits, float* mask_logits,
                       const void* packed, int B, int Q, int Tc, int frames_per_clip, int h, int w, int K1, int Cm, int dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
@@ -354,7 +354,7 @@ int axvs_scaled_residual(const float* a, const float* b, const float* gamma, flo
  * dropout(p_dropout) on the spatial attention maps (:32, :55 -- the layer passes `dropout` as the attention's attn_drop, :164-165),
  * dropout1(p_attn_drop) on both pass outputs (:166, :204, :213), dropout2 / dropout3(p_dropout) in the FFN (:172-174, :182-183).
  * fp32 activations in natural [B,T,H,W,C] order; the Linear layers run on split-precision bf16 MFMA GEMMs (axvs_train_gemm.h,
- * no vendor BLAS); head_dim in {8,16,32}; T <= 8.
+ * no vendor BLAS); head_dim in {8,16,32}; T <= 16.
  * Dropout masks are a pure function of (seed, site, element offset in the reference's tensor at that site):
  *   h = seed ^ (site * 0x9E3779B9);  h = fmix32(h ^ lo32(idx));  h = fmix32(h ^ hi32(idx));  keep iff (h >> 8) >= floor(p * 2^24)
  *   (fmix32 = MurmurHash3's finaliser); sites: 1 height attention map [(B W) heads, T H, T, H], 2 height pass output [(B W), T H, C],
@@ -390,7 +390,8 @@ int axvs_axial_layer_train_bwd(const float* d_out, const float* src, const float
  * p_attn_drop, site 10 + 2 l, index as in the layer above), ASPP (:176-201; _proj_drop p_aspp_drop, site 11 + 2 l, element
  * index of the reference's [(B Q), 256, Tc] tensor) + residual + LayerNorm (:293-295); then for EVERY layer the embedding
  * projections and the predictor's training branch (:300-309, :45-57) with (Sync)BatchNorm on BATCH statistics (eps 1e-3).
- * Sizes: C = 256, 8 heads, mask channels 128, norm_fn 'ln', kernel sizes 3; Q % 8 == 0, V*H*W % 8 == 0, Tc <= 8.
+ * Sizes: C = 256, 8 heads, mask channels 128, norm_fn 'ln', kernel sizes 3; Q % 8 == 0, Tc <= 16, any V*H*W (the shipped
+ * training setting: 12 clips of 2 frames, 193 x 337 pixel features).
  *
  * SyncBatchNorm: `allreduce` (NULL in a single process) is called with a device buffer of partial sums (and the row count)
  * that it must SUM over the ranks in place, ordered on `stream` -- three times per forward and three times per backward call.

@@ -27,13 +27,18 @@ CONFIGS = [  # B, Q, Tc, V, H, W, layers, classes, p_attn, p_aspp
     (1, 16, 4, 2, 8, 8, 2, 19, 0.1, 0.2),
     (2, 8, 2, 1, 4, 8, 1, 5, 0.0, 0.0),
     (1, 24, 5, 1, 8, 8, 3, 7, 0.0, 0.1),
+    (1, 8, 12, 1, 5, 7, 1, 5, 0.0, 0.1),      # 12 clips (NUM_VIDEO_FRAMES 24 / NUM_CLIP_FRAMES 2: the shipped training config), 35 pixels per clip (odd)
+    (1, 16, 2, 2, 3, 5, 2, 7, 0.1, 0.0),      # 30 pixels per clip: rows 8-byte aligned only
 ]
+ONLY = None   # set to a list of indices to regenerate a subset
 
 
 def main():
     torch.manual_seed(0)
     _, _, cc = gg.load_reference()
-    for (B, Q, Tc, V, H, W, nl, K, p_attn, p_aspp) in CONFIGS:
+    for ci, (B, Q, Tc, V, H, W, nl, K, p_attn, p_aspp) in enumerate(CONFIGS):
+        if ONLY is not None and ci not in ONLY:
+            continue
         m = cc.CrossClipTrackingModule(num_layers=nl, num_classes=K, attn_drop=p_attn, aspp_drop=p_aspp, kernel_sizes=[3, 3, 3],
                                        atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=V)
         seed = 13000 + Tc * 100 + Q + nl
@@ -67,4 +72,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        ONLY = [int(a) for a in sys.argv[1:]]
     main()

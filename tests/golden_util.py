@@ -198,7 +198,7 @@ def train_grad_errors(z, grads):
 
 
 CC_TRAIN = ["g13_cc_train_B1_Q16_Tc3_V2_H8_L2", "g13_cc_train_B1_Q16_Tc4_V2_H8_L2", "g13_cc_train_B2_Q8_Tc2_V1_H4_L1",
-            "g13_cc_train_B1_Q24_Tc5_V1_H8_L3"]
+            "g13_cc_train_B1_Q24_Tc5_V1_H8_L3", "g13_cc_train_B1_Q8_Tc12_V1_H5_L1", "g13_cc_train_B1_Q16_Tc2_V2_H3_L2"]
 
 
 def cc_train_inputs(m):

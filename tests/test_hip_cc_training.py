@@ -124,7 +124,9 @@ def test_cc_training_rejects_what_it_does_not_build():
     import axial_vs_amd as ax
     mod = ax.CrossClipTrackingModule(num_layers=1, num_classes=3, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3],
                                      norm_fn="ln", num_clip_frames=1).cuda().train()
-    with pytest.raises(RuntimeError, match="multiple of 8"):
+    with pytest.raises(RuntimeError, match="multiple of 8"):                      # the number of queries
         mod(torch.randn(1, 12, 2, 256, device="cuda"), torch.randn(1, 128, 2, 4, 8, device="cuda"))
+    with pytest.raises(RuntimeError, match="16 clips"):
+        mod(torch.randn(1, 8, 17, 256, device="cuda"), torch.randn(1, 128, 17, 4, 8, device="cuda"))
     with pytest.raises(NotImplementedError, match="panoptic_features"):
         mod(torch.randn(1, 16, 2, 256, device="cuda"), torch.randn(1, 128, 2, 4, 8, device="cuda", requires_grad=True))

@@ -405,6 +405,31 @@ def test_cross_clip_module_golden(name):
         assert e_m < TOL_F16 and e_m2 < TOL_F16
 
 
+@pytest.mark.parametrize("V,H,W", [(1, 5, 7), (2, 3, 5), (2, 7, 9), (1, 4, 9)])
+def test_cross_clip_module_any_pixel_count(V, H, W):
+    """Pixel features of the shipped VIPSeg setting are 193 x 337 per frame: V*H*W = 130082 is not a multiple of 4 and the clips' rows
+    start 8 bytes apart from a 16-byte boundary.  Odd (35), 8-byte (30, 126) and 16-byte (36) pixel counts against the float64 oracle."""
+    import axial_vs_amd as ax
+    B, Q, Tc, nl, K = 1, 16, 3, 2, 11
+    w = orc.random_weights(orc.cc_module_param_shapes(nl, K), 61)
+    g = torch.Generator().manual_seed(62)
+    cq = torch.randn(B, Q, Tc, 256, generator=g)
+    pf = torch.nn.functional.normalize(torch.randn(B, 128, Tc * V, H, W, generator=g), dim=1)
+    ref = orc.cross_clip_module(cq.double(), pf.double(), {k: v.double() for k, v in w.items()}, nl, V)
+    mod = ax.CrossClipTrackingModule(num_layers=nl, num_classes=K, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3],
+                                     norm_fn="ln", num_clip_frames=V).eval()
+    sd = mod.state_dict()
+    sd.update(w)
+    mod.load_state_dict(sd, strict=True)
+    mod = mod.cuda()
+    out = mod(dev(cq), dev(pf))
+    e_m, e_m2 = rel_err(out["pred_masks"], ref["pred_masks"]), rel_l2(out["pred_masks"], ref["pred_masks"])
+    e_a = rel_err(out["aux_outputs"][0]["pred_masks"], ref["aux_outputs"][0]["pred_masks"])
+    print(f"P = {V * H * W}: masks max/max {e_m:.2e} relL2 {e_m2:.2e}, aux {e_a:.2e}")
+    assert e_m < TOL_F16 and e_m2 < TOL_F16 and e_a < TOL_F16
+    assert rel_err(out["pred_logits"], ref["pred_logits"]) < TOL_F16
+
+
 @pytest.mark.parametrize("name", ["g6_tl_cc_head_Tc3_Q16_f2_L2", "g6_tl_cc_head_Tc2_Q20_f1_L1", "g6_tl_cc_head_Tc4_Q100_f2_L4"])
 def test_tube_link_cross_clip_head_golden(name):
     """Tube-Link flavour of the cross-clip module: layer loop + forward_head_clips + pred_class against the
