@@ -919,13 +919,14 @@ int launch_nt128(const float* X, const float* X2, const float* W, float* Y, long
                  bool feeds_residual = false) {
   tr::GemmLd ld{K, K, N, 0, X2};
   const dim3 grid((unsigned)((M + tr::kGT - 1) / tr::kGT), (unsigned)((N + tr::kGT - 1) / tr::kGT));
-  if (g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual)) {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>((tr::tr_gemm_nt_kernel<3, 1>)))) return rc;
-    hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<3, 1>), grid, dim3(512), tr::gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
-  } else {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>((tr::tr_gemm_nt_kernel<2, 1>)))) return rc;
-    hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<2, 1>), grid, dim3(512), tr::gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
-  }
+  const bool exact = g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual), gen = tr::gemm_nt_general(ld, K);
+  const void* fn = exact ? (gen ? reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<3, 1, true>) : reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<3, 1>))
+                         : (gen ? reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<2, 1, true>) : reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<2, 1>));
+  if (int rc = ensure_max_lds(fn)) return rc;
+  if (exact && gen) hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<3, 1, true>), grid, dim3(512), tr::gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+  else if (exact) hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<3, 1>), grid, dim3(512), tr::gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+  else if (gen) hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<2, 1, true>), grid, dim3(512), tr::gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
+  else hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<2, 1>), grid, dim3(512), tr::gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
   return AXVS_OK;
 }
 // rows from which the 128 x 128 kernel beats the 64 x 64 one (fewer rows: too few workgroups)

@@ -55,6 +55,8 @@ struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps >
   int al_a = 4, al_b = 4, al_c = 4;
 };
 
+inline bool gemm_nt_general(const GemmLd& ld, int K) { return !(ld.al_a == 4 && ld.al_b == 4 && (K & 3) == 0 && ld.a2 == nullptr); }
+
 struct GemmEpi {
   const float* bias;   // nullable [N]: added first
   float mul;           // then multiplied
@@ -98,7 +100,10 @@ constexpr size_t gemm_nt_lds() {
   return (size_t)2 * 2 * NS * kGTileElems * sizeof(u16) > kGemmLds ? (size_t)2 * 2 * NS * kGTileElems * sizeof(u16) : kGemmLds;
 }
 
-template <int NS, int TU = 0>
+// GEN: the general loader (rows at any 4-byte boundary, K not a multiple of 4, the x + pos addend) -- its own instantiation, so the
+// kernel of the common case carries none of that code (these kernels are sensitive to their size: +3 us per launch with both
+// loaders in one body)
+template <int NS, int TU = 0, bool GEN = false>
 __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                          float* __restrict__ C, long long M, int N, int K, GemmLd ld, GemmEpi ep) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
@@ -125,16 +130,24 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   float4 ra[2][2], rb[2][2];
   auto gload = [&](int ks, auto slot_tag) {
     constexpr int SL = decltype(slot_tag)::value;
+    if constexpr (!GEN) {                                     // 16-byte rows, K % 4 == 0, no addend: a float4 is inside or outside
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int kk = kbase + ks * kGK + sq * 8 + 4 * h;
-      const int kv = K - kk;                                  // how many of the four columns exist
-      ra[SL][h] = ldg4(ap + ks * kGK + 4 * h, a_ok ? kv : 0, ld.al_a);
-      if (ld.a2 && a_ok && kv > 0) {
-        const float4 t = ldg4(ld.a2 + (ap - A) + ks * kGK + 4 * h, kv, ld.al_a);
-        ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
+      for (int h = 0; h < 2; ++h) {
+        const bool kin = kbase + ks * kGK + sq * 8 + 4 * h < K;
+        ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+        rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
       }
-      rb[SL][h] = ldg4(bp + ks * kGK + 4 * h, b_ok ? kv : 0, ld.al_b);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int kv = K - (kbase + ks * kGK + sq * 8 + 4 * h);   // how many of the four columns exist
+        ra[SL][h] = ldg4(ap + ks * kGK + 4 * h, a_ok ? kv : 0, ld.al_a);
+        rb[SL][h] = ldg4(bp + ks * kGK + 4 * h, b_ok ? kv : 0, ld.al_b);
+        if (ld.a2 && a_ok && kv > 0) {
+          const float4 t = ldg4(ld.a2 + (ap - A) + ks * kGK + 4 * h, kv, ld.al_a);
+          ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
+        }
+      }
     }
   };
   auto lstore = [&](int stage, auto slot_tag) {

@@ -302,41 +302,53 @@ __global__ __launch_bounds__(256) void tr_spatial_bwd_kv_mfma_kernel(const float
                                                                       const float* __restrict__ v, const float* __restrict__ dx,
                                                                       const float* __restrict__ stats, float* __restrict__ dk,
                                                                       float* __restrict__ dv, RowMap rm, int T, int C, int heads, float scale,
-                                                                      Drop dr) {
+                                                                      Drop dr, int Nc /* queries staged at a time: a multiple of 16 */) {
   extern __shared__ float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
   const int s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
-  const int Np = (N + 15) & ~15, nqt = Np >> 4, nkt = (L + 15) >> 4;
-  float* qs = smem;                      // [Np][kTrLd] scale * q
-  float* gs = qs + Np * kTrLd;           // [Np][kTrLd] dx of the frame
-  float* ss = gs + Np * kTrLd;           // [Np][4]     max, 1/sum, D of (query, frame)
-  for (int i = tid; i < Np * 8; i += 256) {            // scaled q once
-    const int n = i >> 3, c4 = i & 7;
-    float4 t = {0.f, 0.f, 0.f, 0.f};
-    if (n < N) {
-      t = *reinterpret_cast<const float4*>(q + nat_row(rm, s * N + n) * C + h * 32 + c4 * 4);
-      t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
-    }
-    *reinterpret_cast<float4*>(qs + n * kTrLd + c4 * 4) = t;
-  }
-  const int fper = (T + (int)gridDim.z - 1) / (int)gridDim.z, f0 = (int)blockIdx.z * fper, f1 = min(T, f0 + fper);   // as in the forward kernel
-  for (int f = f0; f < f1; ++f) {
-    __syncthreads();
-    for (int i = tid; i < Np * 8; i += 256) {
+  const int Np = (N + 15) & ~15, nkt = (L + 15) >> 4;
+  const int nchunks = (Np + Nc - 1) / Nc;          // 1: the whole sequence's queries fit (the within-clip layer); more: 12+ clips of 128 queries
+  float* qs = smem;                      // [Nc][kTrLd] scale * q
+  float* gs = qs + Nc * kTrLd;           // [Nc][kTrLd] dx of the frame
+  float* ss = gs + Nc * kTrLd;           // [Nc][4]     max, 1/sum, D of (query, frame)
+  auto stage_q = [&](int c0) {           // scaled q rows c0 .. c0 + Nc
+    for (int i = tid; i < Nc * 8; i += 256) {
       const int n = i >> 3, c4 = i & 7;
       float4 t = {0.f, 0.f, 0.f, 0.f};
-      if (n < N) t = *reinterpret_cast<const float4*>(dx + (nat_row(rm, s * N + n) * T + f) * C + h * 32 + c4 * 4);
+      if (c0 + n < N) {
+        t = *reinterpret_cast<const float4*>(q + nat_row(rm, s * N + c0 + n) * C + h * 32 + c4 * 4);
+        t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+      }
+      *reinterpret_cast<float4*>(qs + n * kTrLd + c4 * 4) = t;
+    }
+  };
+  auto stage_frame = [&](int c0, int f) { // dx and the statistics of frame f for the same rows
+    for (int i = tid; i < Nc * 8; i += 256) {
+      const int n = i >> 3, c4 = i & 7;
+      float4 t = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + n < N) t = *reinterpret_cast<const float4*>(dx + (nat_row(rm, s * N + c0 + n) * T + f) * C + h * 32 + c4 * 4);
       *reinterpret_cast<float4*>(gs + n * kTrLd + c4 * 4) = t;
     }
-    for (int n = tid; n < Np; n += 256) {
-      const float* st = stats + ((((size_t)s * heads + h) * N + min(n, N - 1)) * T + f) * 3;
+    for (int n = tid; n < Nc; n += 256) {
+      const float* st = stats + ((((size_t)s * heads + h) * N + min(c0 + n, N - 1)) * T + f) * 3;
       // padding queries: 1/sum = 0 makes their probabilities vanish
-      *reinterpret_cast<float4*>(ss + n * 4) = float4{st[0], n < N ? st[1] : 0.f, st[2], 0.f};
+      *reinterpret_cast<float4*>(ss + n * 4) = float4{st[0], c0 + n < N ? st[1] : 0.f, st[2], 0.f};
     }
-    __syncthreads();
-    for (int kt = (int)blockIdx.y * 4 + wave; kt < nkt; kt += 4 * (int)gridDim.y) {
+  };
+  if (nchunks == 1) stage_q(0);
+  const int fper = (T + (int)gridDim.z - 1) / (int)gridDim.z, f0 = (int)blockIdx.z * fper, f1 = min(T, f0 + fper);   // as in the forward kernel
+  const int iters = (nkt + 4 * (int)gridDim.y - 1) / (4 * (int)gridDim.y);   // key tiles per wave (uniform: every wave meets every barrier)
+  for (int f = f0; f < f1; ++f) {
+    if (nchunks == 1) {
+      __syncthreads();
+      stage_frame(0, f);
+      __syncthreads();
+    }
+    for (int it = 0; it < iters; ++it) {
+      const int kt = (it * (int)gridDim.y + (int)blockIdx.y) * 4 + wave;
+      const bool have = kt < nkt;
       const int kn = kt * 16 + j, kc = min(kn, L - 1);                  // key index within the frame
-      const long long mk = nat_row(rm, s * N + f * L + kc);
+      const long long mk = nat_row(rm, s * N + f * L + (have ? kc : 0));
       float kr[8], vr[8];
       {
         const float* kp = k + mk * C + h * 32 + 8 * g;
@@ -347,41 +359,52 @@ __global__ __launch_bounds__(256) void tr_spatial_bwd_kv_mfma_kernel(const float
         vr[0] = c.x; vr[1] = c.y; vr[2] = c.z; vr[3] = c.w; vr[4] = d.x; vr[5] = d.y; vr[6] = d.z; vr[7] = d.w;
       }
       f32x4 dka[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, dva[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      for (int qt = 0; qt < nqt; ++qt) {
-        const float* qp = qs + (qt * 16 + j) * kTrLd + 8 * g;
-        const float* gp = gs + (qt * 16 + j) * kTrLd + 8 * g;
-        const float4 qa = *reinterpret_cast<const float4*>(qp), qb = *reinterpret_cast<const float4*>(qp + 4);
-        const float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
-        const float qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        const float gr[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {                 // D[i = query 4 g' + r][j = key]: A = query rows, B = key rows
-          sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[t], kr[t], sc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[t], vr[t], dp, 0, 0, 0);
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = ch * Nc;
+        if (nchunks > 1) {                 // (the chunk order is the order of additions into dk / dv: fixed)
+          __syncthreads();
+          stage_q(c0);
+          stage_frame(c0, f);
+          __syncthreads();
         }
-        const int q0 = qt * 16 + 4 * g;               // my 4 queries: q0 .. q0 + 3
-        float pk[4], ds[4];
+        const int nq_here = min(Nc, Np - c0) >> 4;
+        if (have)
+          for (int qt = 0; qt < nq_here; ++qt) {
+            const float* qp = qs + (qt * 16 + j) * kTrLd + 8 * g;
+            const float* gp = gs + (qt * 16 + j) * kTrLd + 8 * g;
+            const float4 qa = *reinterpret_cast<const float4*>(qp), qb = *reinterpret_cast<const float4*>(qp + 4);
+            const float4 ga = *reinterpret_cast<const float4*>(gp), gb = *reinterpret_cast<const float4*>(gp + 4);
+            const float qr[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            const float gr[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float4 st = *reinterpret_cast<const float4*>(ss + (q0 + r) * 4);
-          const float P = __expf(sc[r] - st.x) * st.y;
-          const float kp_ = (q0 + r < N && kn < L)
-                                ? drop_keep(dr, ((((unsigned long long)s * heads + h) * N + q0 + r) * T + f) * L + kn) : 0.f;
-          pk[r] = P * kp_;
-          ds[r] = P * (kp_ * dp[r] - st.z);
-        }
+            for (int t = 0; t < 8; ++t) {                 // D[i = query 4 g' + r][j = key]: A = query rows, B = key rows
+              sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[t], kr[t], sc, 0, 0, 0);
+              dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gr[t], vr[t], dp, 0, 0, 0);
+            }
+            const int ql = qt * 16 + 4 * g;               // my 4 queries within the chunk: ql .. ql + 3 (global: c0 + ql ..)
+            float pk[4], ds[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* gq = gs + (q0 + r) * kTrLd + j;      // A: dx^T (resp. q^T) of query q0 + r, channels j and 16 + j
-          const float* qq = qs + (q0 + r) * kTrLd + j;
-          dva[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[0], pk[r], dva[0], 0, 0, 0);
-          dva[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[16], pk[r], dva[1], 0, 0, 0);
-          dka[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[0], ds[r], dka[0], 0, 0, 0);
-          dka[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[16], ds[r], dka[1], 0, 0, 0);
-        }
+            for (int r = 0; r < 4; ++r) {
+              const float4 st = *reinterpret_cast<const float4*>(ss + (ql + r) * 4);
+              const float P = __expf(sc[r] - st.x) * st.y;
+              const float kp_ = (c0 + ql + r < N && kn < L)
+                                    ? drop_keep(dr, ((((unsigned long long)s * heads + h) * N + c0 + ql + r) * T + f) * L + kn) : 0.f;
+              pk[r] = P * kp_;
+              ds[r] = P * (kp_ * dp[r] - st.z);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float* gq = gs + (ql + r) * kTrLd + j;      // A: dx^T (resp. q^T) of query ql + r, channels j and 16 + j
+              const float* qq = qs + (ql + r) * kTrLd + j;
+              dva[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[0], pk[r], dva[0], 0, 0, 0);
+              dva[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(gq[16], pk[r], dva[1], 0, 0, 0);
+              dka[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[0], ds[r], dka[0], 0, 0, 0);
+              dka[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qq[16], ds[r], dka[1], 0, 0, 0);
+            }
+          }
       }
-      if (kn < L) {                                    // lane (key j, group g): channels dt * 16 + 4 g + r
+      if (have && kn < L) {                            // lane (key j, group g): channels dt * 16 + 4 g + r
         float* ok = dk + mk * C + h * 32 + 4 * g;
         float* ov = dv + mk * C + h * 32 + 4 * g;
         *reinterpret_cast<float4*>(ok) = float4{dka[0][0], dka[0][1], dka[0][2], dka[0][3]};

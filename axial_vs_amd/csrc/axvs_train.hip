@@ -32,7 +32,10 @@ struct Gemm {
     st = s;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3>))) return rc;
-    return ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel));
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<true>))) return rc;
+    return ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false>));
   }
   // row-major:  Y[M,N] = beta Y + epilogue(X[M,K] W[N,K]^T); epilogue (optional): + bias, * mul, ReLU, dropout by element index
   // exact: three bf16 pieces per operand (fp32 accuracy) -- for the GEMM in front of the ReLU (see tr_gemm_nt_kernel)
@@ -44,7 +47,10 @@ struct Gemm {
     const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT), (unsigned)zsplits);
     // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
     //  fixed cost -- ~11 us whatever K -- not by the load round trips of the k-loop)
-    if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+    const bool gen = gemm_nt_general(ld, K);
+    if (exact && gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<3, 0, true>), grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+    else if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+    else if (gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<2, 0, true>), grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
     else hipLaunchKernelGGL(tr_gemm_nt_kernel<2>, grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
     return AXVS_OK;
   }
@@ -64,7 +70,7 @@ struct Gemm {
     chunk = (chunk + kGK - 1) / kGK * kGK;                 // whole k-steps per split
     const int np = (int)((M + chunk - 1) / chunk);
     const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), (unsigned)np);
-    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b,
+    hipLaunchKernelGGL(tr_gemm_tn_kernel<false>, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b,
                        GemmLd{ldy ? ldy : N, ldx ? ldx : K, K, 0});
     *nparts = np;
     return AXVS_OK;
@@ -79,7 +85,8 @@ struct Gemm {
     GemmLd ld{lda, ldx, ldo, 0};
     ld.al_b = al_x;
     ld.al_c = al_o;
-    hipLaunchKernelGGL(tr_gemm_tn_kernel, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
+    if (al_x == 4 && al_o == 4 && K % 4 == 0) hipLaunchKernelGGL(tr_gemm_tn_kernel<false>, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
+    else hipLaunchKernelGGL(tr_gemm_tn_kernel<true>, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
     return AXVS_OK;
   }
 };
@@ -246,10 +253,15 @@ struct Ctx {
 
 // The spatial half runs on the fp32 MFMA kernels (forward and both backward parts, or none of them: the backward reads the
 // statistics the forward leaves) when head_dim is 32 and a sequence's scaled q + dx rows fit in LDS.
+// queries the key-side backward kernel stages at a time: all of a sequence when they fit in LDS (the within-clip layer: <= 512),
+// else chunks of 512 (the cross-clip module over 12 clips of 128 queries)
+int spatial_kv_chunk(const RowMap& rm) {
+  const int Np = (rm.N + 15) / 16 * 16;
+  return Np <= 512 ? Np : 512;
+}
 bool mfma_spatial(const Dims& d, const RowMap& rm) {
   const size_t lds_q = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
-  const size_t lds_kv = (size_t)((rm.N + 15) / 16 * 16) * (2 * kTrLd + 4) * sizeof(float);
-  return d.D == 32 && !g_train_valu && lds_q <= 160 * 1024 && lds_kv <= 160 * 1024;
+  return d.D == 32 && !g_train_valu && lds_q <= 160 * 1024;
 }
 
 // Launch grid of the fp32 MFMA spatial-attention kernels: x = (sequence, head); with fewer than 256 of those (the cross-clip module has
@@ -340,14 +352,15 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   constexpr int QC = 32;
   const size_t lds2 = (size_t)(QC * d.D + QC * T * d.D + QC * T * 3) * sizeof(float);
   const size_t lds_q = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
-  const size_t lds_kv = (size_t)((rm.N + 15) / 16 * 16) * (2 * kTrLd + 4) * sizeof(float);
+  const int kv_chunk = spatial_kv_chunk(rm);
+  const size_t lds_kv = (size_t)kv_chunk * (2 * kTrLd + 4) * sizeof(float);
   if (mfma_spatial(d, rm)) {       // the forward was the MFMA kernel too: (max, 1 / sum) are in s.st
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_q_mfma_kernel), lds_q)) != AXVS_OK) return rc;
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_kv_mfma_kernel), lds_kv)) != AXVS_OK) return rc;
     hipLaunchKernelGGL(tr_spatial_bwd_q_mfma_kernel, spatial_grid(S * d.heads, (rm.N + 15) / 16, 1), dim3(256), lds_q, c.st, (const float*)s.q, (const float*)s.k,
                        (const float*)s.v, (const float*)s.x, (const float*)sc.dx, sc.dq, s.st, rm, T, C, d.heads, c.scale, attn_drop);
     hipLaunchKernelGGL(tr_spatial_bwd_kv_mfma_kernel, spatial_grid(S * d.heads, (rm.L + 15) / 16, T), dim3(256), lds_kv, c.st, (const float*)s.q, (const float*)s.k,
-                       (const float*)s.v, (const float*)sc.dx, (const float*)s.st, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop);
+                       (const float*)s.v, (const float*)sc.dx, (const float*)s.st, sc.dk, sc.dv, rm, T, C, d.heads, c.scale, attn_drop, kv_chunk);
   } else
   AXVS_D_SWITCH(d.D, {
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_bwd_q_kernel<kD>), lds)) != AXVS_OK) return rc;

@@ -66,6 +66,7 @@ __device__ __forceinline__ u16x8 tn_frag(const u16* tile, int col0, int fi, int 
 // part_b (nullable): [split][N] partial COLUMN SUMS of dY (the bias gradient of the same Linear layer), added in fp32 from the
 // staging registers by the workgroups of the first k-tile (a bias gradient can be a sum that cancels to zero -- the k bias of a
 // softmax -- so it does not go through the bf16 split) and reduced over the 32 staging rows through LDS in a fixed order.
+template <bool GEN>      // GEN: rows at any 4-byte boundary / extents that are not multiples of 4 (see tr_gemm_nt_kernel)
 __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
                                                             long long M, int N, int K, long long rows_per_split,
                                                             float* __restrict__ part_b, GemmLd ld) {
@@ -89,8 +90,13 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
     const bool m_ok = m < me;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      ra[h] = ldg4(dY + m * ld.a + n0 + sc * 8 + 4 * h, m_ok ? N - (n0 + sc * 8 + 4 * h) : 0, ld.al_a);
-      rb[h] = ldg4(X + m * ld.b + k0 + sc * 8 + 4 * h, m_ok ? K - (k0 + sc * 8 + 4 * h) : 0, ld.al_b);
+      if constexpr (!GEN) {              // 16-byte rows, extents in whole groups of four
+        ra[h] = m_ok && n0 + sc * 8 + 4 * h < N ? *reinterpret_cast<const float4*>(dY + m * ld.a + n0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+        rb[h] = m_ok && k0 + sc * 8 + 4 * h < K ? *reinterpret_cast<const float4*>(X + m * ld.b + k0 + sc * 8 + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        ra[h] = ldg4(dY + m * ld.a + n0 + sc * 8 + 4 * h, m_ok ? N - (n0 + sc * 8 + 4 * h) : 0, ld.al_a);
+        rb[h] = ldg4(X + m * ld.b + k0 + sc * 8 + 4 * h, m_ok ? K - (k0 + sc * 8 + 4 * h) : 0, ld.al_b);
+      }
     }
   };
   auto lstore = [&](int stage) {
@@ -144,7 +150,12 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const int n = n0 + wn * 64 + nt * 16 + fi, k = k0 + wk * 32 + kt * 16 + 4 * fg;
-      if (n < N) stg4(out + (size_t)n * ld.c + k, float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]}, K - k, ld.al_c);
+      const float4 o4 = float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
+      if constexpr (!GEN) {
+        if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * ld.c + k) = o4;
+      } else if (n < N) {
+        stg4(out + (size_t)n * ld.c + k, o4, K - k, ld.al_c);
+      }
     }
   if (do_bias) {                 // (the loop's last barrier is behind every wave: the operand stages are free)
     float* const red = reinterpret_cast<float*>(gsmem);        // [32 staging rows][128 columns]

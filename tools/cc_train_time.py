@@ -1,6 +1,6 @@
 """Training step (forward + backward) of CrossClipTrackingModule at BASELINE config 4 through the training tier; --torch: the
 same math as torch-eager autograd on this GPU (the oracle restatement in fp32 on the device).
-    python tools/cc_train_time.py [steps] [--torch] [--p 0.1]"""
+    python tools/cc_train_time.py [steps] [--torch] [--p 0.1] [--shape Q,Tc,V,H,W,layers]"""
 import os
 import sys
 import time
@@ -15,6 +15,8 @@ import axial_vs_amd as ax  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 10
 p = float(sys.argv[sys.argv.index("--p") + 1]) if "--p" in sys.argv else 0.1
 B, Q, Tc, V, H, W, nl, K = 1, 128, 4, 4, 64, 64, 4, 124
+if "--shape" in sys.argv:          # --shape Q,Tc,V,H,W,layers   e.g. the shipped VIPSeg training setting: 128,12,2,193,337,6
+    Q, Tc, V, H, W, nl = (int(v) for v in sys.argv[sys.argv.index("--shape") + 1].split(","))
 dev = torch.device("cuda:0")
 w = orc.random_weights(orc.cc_module_param_shapes(nl, K), 4)
 g = torch.Generator().manual_seed(4)
