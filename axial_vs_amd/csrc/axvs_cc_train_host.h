@@ -96,8 +96,8 @@ void dk_plan(const CCShape& s, int* ksteps, int* z) {
   const int nk = (int)((s.P + kGK - 1) / kGK);
   const long long rows = s.B == 1 ? (long long)s.nl * s.Q : s.Q;
   const int mt = (int)((rows + kGT - 1) / kGT);
-  int want = 1024 / (mt > 0 ? mt : 1);
-  want = want < 1 ? 1 : (want > 64 ? 64 : want);
+  int want = 1024 / (mt > 0 ? mt : 1);         // ~1024 workgroups: several per CU, the k-loop is bound by its load round trips
+  want = want < 1 ? 1 : (want > 256 ? 256 : want);
   int ks = (nk + want - 1) / want;
   ks = ks < 4 ? 4 : ks;
   *ksteps = ks;

@@ -143,21 +143,31 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
     if (s + 1 < nsteps) lstore(cur ^ 1);
     __syncthreads();
   }
-  // partial tile: lane (n = fi, 4 consecutive k) -> 16-byte stores into part[split][n][k]
+  // partial tile -> fp32 staging tile [n][k] in LDS (the loop's last barrier is behind every wave: the operand stages are free) ->
+  // whole rows: 32 lanes x 16 bytes = 512 contiguous bytes per row of part[split][n][..] (straight from the accumulators a store
+  // instruction covered 64-byte pieces of 16 rows: the einsum form, whose output is the large operand, ran at 1.5 - 2 TB/s)
   float* const out = part + (size_t)blockIdx.y * N * ld.c;     // (ld.c != K only with a single split: the einsum form below)
+  float* const stg = reinterpret_cast<float*>(gsmem);
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const int n = n0 + wn * 64 + nt * 16 + fi, k = k0 + wk * 32 + kt * 16 + 4 * fg;
-      const float4 o4 = float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
-      if constexpr (!GEN) {
-        if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * ld.c + k) = o4;
-      } else if (n < N) {
-        stg4(out + (size_t)n * ld.c + k, o4, K - k, ld.al_c);
-      }
+    for (int kt = 0; kt < 2; ++kt)
+      *reinterpret_cast<float4*>(stg + (wn * 64 + nt * 16 + fi) * kGLd + wk * 32 + kt * 16 + 4 * fg) =
+          float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 512 * i, row = idx >> 5, c4 = idx & 31;
+    const int n = n0 + row, k = k0 + 4 * c4;
+    const float4 o4 = *reinterpret_cast<const float4*>(stg + row * kGLd + 4 * c4);
+    if constexpr (!GEN) {
+      if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * ld.c + k) = o4;
+    } else if (n < N) {
+      stg4(out + (size_t)n * ld.c + k, o4, K - k, ld.al_c);
     }
-  if (do_bias) {                 // (the loop's last barrier is behind every wave: the operand stages are free)
+  }
+  if (do_bias) __syncthreads();  // the bias reduction below reuses the staging tile
+  if (do_bias) {
     float* const red = reinterpret_cast<float*>(gsmem);        // [32 staging rows][128 columns]
     *reinterpret_cast<float4*>(red + sr * kGT + sc * 8) = float4{bsum[0], bsum[1], bsum[2], bsum[3]};
     *reinterpret_cast<float4*>(red + sr * kGT + sc * 8 + 4) = float4{bsum[4], bsum[5], bsum[6], bsum[7]};

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/cctraintrace
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/cc_train_time.py 5 > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/cc_train_time.py 3 "$@" > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/*/*kernel_trace.csv")[0]
