@@ -780,7 +780,12 @@ int cc_masks_t(const float* pf, const u16* kern16, float* masks, const void* pac
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128>))) return rc;
   // every stride of the map is a multiple of P: the pixel rows are as aligned as P (and the two base pointers) allow
   const int al = std::min(row_align(pf, P, P), row_align(masks, P, P));
-  hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride, al);
+  if (al == 4 && P % 4 == 0) {
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride, al);
+  } else {
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128, true>))) return rc;
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, 128, true>), grid, dim3(256), einsum_lds_bytes<128>(), st, pf, kern16, masks, Q, Tc, P, R, mp, p.pix, nl, kstride, ostride, al);
+  }
   mark(st, "cc.mask_einsum");
   return AXVS_OK;
 }
@@ -852,13 +857,19 @@ int tl_masks_t(const float* mf, const u16* kern16, float* masks, int B, int Q, i
   dim3 grid((unsigned)((P + kEinsumPx - 1) / kEinsumPx), B * T);
   const EinsumMap mp{(long long)T * Cm * P, (long long)Cm * P, P, (long long)T * Q * P, (long long)Q * P, P, T, fpc};
   const int al = std::min(row_align(mf, P, P), row_align(masks, P, P));
-  if (Cm == 128) {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 128>))) return rc;
-    hipLaunchKernelGGL((mask_einsum_kernel<BF, 128>), grid, dim3(256), einsum_lds_bytes<128>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride, al);
-  } else {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, 256>))) return rc;
-    hipLaunchKernelGGL((mask_einsum_kernel<BF, 256>), grid, dim3(256), einsum_lds_bytes<256>(), st, mf, kern16, masks, Q, Tc, P, R, mp, (const float*)nullptr, nl, kstride, ostride, al);
+  const bool gen = !(al == 4 && P % 4 == 0);
+#define AXVS_EINSUM(CK_, GEN_)                                                                                                            \
+  {                                                                                                                                        \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&mask_einsum_kernel<BF, CK_, GEN_>))) return rc;                           \
+    hipLaunchKernelGGL((mask_einsum_kernel<BF, CK_, GEN_>), grid, dim3(256), einsum_lds_bytes<CK_>(), st, mf, kern16, masks, Q, Tc, P, R, mp, \
+                       (const float*)nullptr, nl, kstride, ostride, al);                                                                   \
   }
+  if (Cm == 128) {
+    if (gen) AXVS_EINSUM(128, true) else AXVS_EINSUM(128, false)
+  } else {
+    if (gen) AXVS_EINSUM(256, true) else AXVS_EINSUM(256, false)
+  }
+#undef AXVS_EINSUM
   mark(st, "tl.mask_einsum");
   return AXVS_OK;
 }
@@ -919,14 +930,20 @@ int launch_nt128(const float* X, const float* X2, const float* W, float* Y, long
                  bool feeds_residual = false) {
   tr::GemmLd ld{K, K, N, 0, X2};
   const dim3 grid((unsigned)((M + tr::kGT - 1) / tr::kGT), (unsigned)((N + tr::kGT - 1) / tr::kGT));
-  const bool exact = g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual), gen = tr::gemm_nt_general(ld, K);
-  const void* fn = exact ? (gen ? reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<3, 1, true>) : reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<3, 1>))
-                         : (gen ? reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<2, 1, true>) : reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<2, 1>));
-  if (int rc = ensure_max_lds(fn)) return rc;
-  if (exact && gen) hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<3, 1, true>), grid, dim3(512), tr::gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
-  else if (exact) hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<3, 1>), grid, dim3(512), tr::gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
-  else if (gen) hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<2, 1, true>), grid, dim3(512), tr::gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
-  else hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<2, 1>), grid, dim3(512), tr::gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
+  const bool exact = g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual), gen = tr::gemm_nt_general(ld, K), add = X2 != nullptr;
+#define AXVS_NT128(NS_, GEN_, ADD_)                                                                                                  \
+  {                                                                                                                                   \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr::tr_gemm_nt_kernel<NS_, 1, GEN_, ADD_>))) return rc;                \
+    hipLaunchKernelGGL((tr::tr_gemm_nt_kernel<NS_, 1, GEN_, ADD_>), grid, dim3(512), tr::gemm_nt_lds<NS_>(), st, X, W, Y, M, N, K, ld, e); \
+  }
+  if (gen) {
+    if (exact) AXVS_NT128(3, true, false) else AXVS_NT128(2, true, false)
+  } else if (add) {
+    if (exact) AXVS_NT128(3, false, true) else AXVS_NT128(2, false, true)
+  } else {
+    if (exact) AXVS_NT128(3, false, false) else AXVS_NT128(2, false, false)
+  }
+#undef AXVS_NT128
   return AXVS_OK;
 }
 // rows from which the 128 x 128 kernel beats the 64 x 64 one (fewer rows: too few workgroups)

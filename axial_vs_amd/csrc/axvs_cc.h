@@ -111,7 +111,9 @@ struct EinsumMap {
   int units, upc;              // units per batch entry; units per clip
 };
 
-template <bool BF, int CK>
+// GEN: pixel rows that start at any 4-byte boundary / P % 4 != 0 (193 x 337 maps) -- its own instantiation: the run-time
+// alignment branches in the loads cost the common case 18 % (241 -> 285 us at config 4)
+template <bool BF, int CK, bool GEN = false>
 __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restrict__ pf, const u16* __restrict__ kern16,
                                                           float* __restrict__ out, int Q, int Tc, long long P, long long Rk,
                                                           EinsumMap mp, const float* __restrict__ pix_bn /* {mul, add} or null */,
@@ -136,7 +138,8 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long p = p0 + seg * 32 + i * 4;
-      v[i] = ldg4(src + i * 4, (int)(P - p < 4 ? (P - p < 0 ? 0 : P - p) : 4), al);
+      if constexpr (GEN) v[i] = ldg4(src + i * 4, (int)(P - p < 4 ? (P - p < 0 ? 0 : P - p) : 4), al);
+      else v[i] = p + 3 < P ? *reinterpret_cast<const float4*>(src + i * 4) : float4{0.f, 0.f, 0.f, 0.f};
     }
     const int kb = c >> 5, k = c & 31;
 #pragma unroll
@@ -176,9 +179,12 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) acc = H16<BF>::mfma(af[t][kb], bf[kb], acc);          // D[pixel][query]
         const long long p = p0 + wave * (16 * PXW) + t * 16 + fg * 4;
-        if (qt * 16 + fi < Q && p < P)
-          stg4(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p,
-               float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add}, (int)(P - p < 4 ? P - p : 4), al);
+        const float4 o4 = float4{acc[0] * bn_mul + bn_add, acc[1] * bn_mul + bn_add, acc[2] * bn_mul + bn_add, acc[3] * bn_mul + bn_add};
+        if constexpr (GEN) {
+          if (qt * 16 + fi < Q && p < P) stg4(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p, o4, (int)(P - p < 4 ? P - p : 4), al);
+        } else {
+          if (qt * 16 + fi < Q && p + 3 < P) *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) = o4;
+        }
       }
     }
   }

@@ -55,7 +55,7 @@ struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps >
   int al_a = 4, al_b = 4, al_c = 4;
 };
 
-inline bool gemm_nt_general(const GemmLd& ld, int K) { return !(ld.al_a == 4 && ld.al_b == 4 && (K & 3) == 0 && ld.a2 == nullptr); }
+inline bool gemm_nt_general(const GemmLd& ld, int K) { return !(ld.al_a == 4 && ld.al_b == 4 && (K & 3) == 0); }
 
 struct GemmEpi {
   const float* bias;   // nullable [N]: added first
@@ -103,7 +103,8 @@ constexpr size_t gemm_nt_lds() {
 // GEN: the general loader (rows at any 4-byte boundary, K not a multiple of 4, the x + pos addend) -- its own instantiation, so the
 // kernel of the common case carries none of that code (these kernels are sensitive to their size: +3 us per launch with both
 // loaders in one body)
-template <int NS, int TU = 0, bool GEN = false>
+// ADD (with !GEN): the x + pos addend ld.a2 on the 16-byte path (the general loader takes it at run time).
+template <int NS, int TU = 0, bool GEN = false, bool ADD = false>
 __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                          float* __restrict__ C, long long M, int N, int K, GemmLd ld, GemmEpi ep) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   // global loads run TWO k-steps ahead of the MFMAs (two register slots, used alternately): with one step of lookahead a load had a
   // single step's MFMAs (~0.3 us) to cover an L2 / HBM round trip and every step stalled at its LDS store
   float4 ra[2][2], rb[2][2];
+  const float* const a2p = ld.a2 ? ld.a2 + (ap - A) : nullptr;
   auto gload = [&](int ks, auto slot_tag) {
     constexpr int SL = decltype(slot_tag)::value;
     if constexpr (!GEN) {                                     // 16-byte rows, K % 4 == 0, no addend: a float4 is inside or outside
@@ -136,6 +138,10 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
         const bool kin = kbase + ks * kGK + sq * 8 + 4 * h < K;
         ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
         rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (ADD) {
+          const float4 t = a_ok && kin ? *reinterpret_cast<const float4*>(a2p + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
+          ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
+        }
       }
     } else {
 #pragma unroll

@@ -47,7 +47,7 @@ struct Gemm {
     const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT), (unsigned)zsplits);
     // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
     //  fixed cost -- ~11 us whatever K -- not by the load round trips of the k-loop)
-    const bool gen = gemm_nt_general(ld, K);
+    const bool gen = gemm_nt_general(ld, K) || ld.a2 != nullptr;      // (the general loader takes the addend at run time)
     if (exact && gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<3, 0, true>), grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else if (gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<2, 0, true>), grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
