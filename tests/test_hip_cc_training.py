@@ -130,3 +130,36 @@ def test_cc_training_rejects_what_it_does_not_build():
         mod(torch.randn(1, 8, 17, 256, device="cuda"), torch.randn(1, 128, 17, 4, 8, device="cuda"))
     with pytest.raises(NotImplementedError, match="panoptic_features"):
         mod(torch.randn(1, 16, 2, 256, device="cuda"), torch.randn(1, 128, 2, 4, 8, device="cuda", requires_grad=True))
+
+
+def test_cc_training_amp_autocast_and_grad_scaling():
+    """The shipped config trains with AMP (SOLVER.AMP.ENABLED, maxtron_cc_r50.yaml:98-99): under torch.autocast with half-precision
+    inputs the module computes in fp32 at its boundary (outputs fp32), hands gradients back in each input's dtype, and is linear in
+    the loss scale -- so GradScaler works unchanged."""
+    z, m = load(CC_TRAIN[1])
+    w = weights(z, m)
+    cq, pf = inputs(m)
+    dl = [x.cuda() for x in t(z["d_logits"])]
+    dm = [x.cuda() for x in t(z["d_masks"])]
+
+    def loss_of(out, scale):
+        logits = [a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]
+        masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+        return (sum((a * b).sum() for a, b in zip(logits, dl)) + sum((a * b).sum() for a, b in zip(masks, dm))) * scale, logits, masks
+
+    mod = make_module(m, w, 5)
+    q32 = cq.cuda().half().float().requires_grad_(True)          # the same fp16-representable inputs, in fp32 without autocast
+    p32 = pf.cuda().half().float()
+    loss_of(mod(q32, p32), 1.0)[0].backward()
+    g32 = {k: v.grad.clone() for k, v in mod.named_parameters()}
+    mod2 = make_module(m, w, 5)
+    q16 = cq.cuda().half().requires_grad_(True)
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        loss, logits, masks = loss_of(mod2(q16, pf.cuda().half()), 1024.0)
+    assert all(x.dtype == torch.float32 for x in logits + masks)
+    loss.backward()
+    assert q16.grad.dtype == torch.float16
+    for k, v in mod2.named_parameters():
+        assert v.grad.dtype == torch.float32
+        assert rel_l2(v.grad.cpu() / 1024.0, g32[k].cpu()) < 1e-5 or float(g32[k].norm()) < 1e-4 * max(float(x.norm()) for x in g32.values()), k
+    assert rel_l2(q16.grad.float().cpu() / 1024.0, q32.grad.cpu()) < 1e-3      # d_clip_query is returned in fp16
