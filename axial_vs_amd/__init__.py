@@ -13,9 +13,9 @@ from .pixel_decoder import (MSDeformAttnPixelDecoder, MSDeformAttnTransformerEnc
                             PositionEmbeddingSine, WithinClipTrackingModule)
 from .matching import linear_sum_assignment, match_clips, match_from_embds
 from .tube_link import MultiScaleDeformableAxialTrajectoryAttention
-from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer, ms_deform_attn_forward
+from .msda import MSDeformAttn, MSDeformAttnFunction, MSDeformAttnTransformerEncoderLayer, ms_deform_attn_backward, ms_deform_attn_forward
 
 __all__ = ["MultiScaleDeformableAxialTrajectoryAttention", "linear_sum_assignment", "match_from_embds", "match_clips", "WithinClipTrackingModule", "MSDeformAttnPixelDecoder", "MSDeformAttnTransformerEncoder", "MSDeformAttnTransformerEncoderOnly",
-           "PositionEmbeddingSine", "CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
+           "PositionEmbeddingSine", "CrossClipTrackingModule", "TubeLinkCrossClipHead", "MSDeformAttn", "MSDeformAttnTransformerEncoderLayer", "ms_deform_attn_forward", "ms_deform_attn_backward", "MSDeformAttnFunction", "TrajectoryAttention", "TemporalAxialTrajectoryAttentionLayer", "TemporalTrajectoryAttentionLayer",
            "TemporalEncoder", "TubeLinkTemporalEncoder", "PositionEmbeddingSine3D", "AxialTrajectoryAttention5D",
            "set_default_dtype", "GraphedForward", "invalidate_pack", "enable_range_check", "range_check_report", "disable_range_check"]

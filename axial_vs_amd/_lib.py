@@ -164,6 +164,7 @@ SIGNATURES = {
     "axvs_msda_layer_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_msda_layer_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, _fp, C.POINTER(C.c_int), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp]),
     "axvs_msda_core_fwd": (C.c_int, [_fp, C.POINTER(C.c_int), _fp, _fp, _fp] + [C.c_int] * 7 + [_fp]),
+    "axvs_msda_core_bwd": (C.c_int, [_fp, C.POINTER(C.c_int), _fp, _fp, _fp, _fp, _fp, _fp] + [C.c_int] * 7 + [_fp]),
     "axvs_cc_module_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "axvs_cc_module_fwd": (C.c_int, [_fp] * 5 + [C.POINTER(_fp), _fp] + [C.c_int] * 8 + [C.POINTER(C.c_int), C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_tl_cc_module_workspace_bytes": (C.c_size_t, [C.c_int] * 5),

@@ -1751,6 +1751,32 @@ int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const floa
   return last_launch_status();
 }
 
+int axvs_msda_core_bwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight, const float* grad_output,
+                       float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M, int D, int Lq, int L, int P,
+                       void* stream) {
+  if (!value || !spatial_shapes || !sampling_loc || !attn_weight || !grad_output || !grad_value || !grad_sampling_loc || !grad_attn_weight)
+    return fail(AXVS_ERR_ARG, "null pointer");
+  if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || Lq <= 0 || P <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  MsdaLevels lv;
+  if (int rc = msda_levels(spatial_shapes, L, S, &lv)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long total = (long long)N * Lq * M * D, samples = (long long)N * Lq * M * L * P;
+  if (hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * sizeof(float), st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemsetAsync failed");
+  const bool shfl = D <= 64 && (D & (D - 1)) == 0;        // a (n, q, m) group = D aligned lanes of one wave
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (shfl) {
+    hipLaunchKernelGGL(msda_core_bwd_kernel<true>, grid, dim3(256), 0, st, value, lv, sampling_loc, attn_weight, grad_output, grad_value,
+                       grad_sampling_loc, grad_attn_weight, N, S, M, D, Lq, P);
+  } else {
+    if (hipMemsetAsync(grad_sampling_loc, 0, (size_t)samples * 2 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(grad_attn_weight, 0, (size_t)samples * sizeof(float), st) != hipSuccess)
+      return fail(AXVS_ERR_LAUNCH, "hipMemsetAsync failed");
+    hipLaunchKernelGGL(msda_core_bwd_kernel<false>, grid, dim3(256), 0, st, value, lv, sampling_loc, attn_weight, grad_output, grad_value,
+                       grad_sampling_loc, grad_attn_weight, N, S, M, D, Lq, P);
+  }
+  return last_launch_status();
+}
+
 // ---- pixel-decoder glue ----
 size_t axvs_conv1x1_gn_packed_bytes(int Cin, int Cout) {
   Carver c(nullptr);

@@ -54,6 +54,91 @@ __global__ __launch_bounds__(256) void msda_core_kernel(const float* __restrict_
   out[idx] = acc;
 }
 
+// ---- backward of the compatibility core op (the reference extension's ms_deform_attn_backward: OPS/src/cuda/ms_deform_attn_cuda.cu:
+//      89-157, kernels ms_deformable_col2im_* in OPS/src/cuda/ms_deform_im2col_cuda.cuh).  Same thread mapping as the forward: one
+//      thread per (n, q, m, d), d fastest.  Per sample (l, p): the four corner values v1..v4 (zero outside the map), bilinear
+//      weights w1 = hh hw, w2 = hh lw, w3 = lh hw, w4 = lh lw (lh = y - floor y, lw = x - floor x, hh = 1 - lh, hw = 1 - lw);
+//        grad_value[corner][d]      += w_corner * attn * g[d]                  (atomic adds, like the reference)
+//        grad_attn[l,p]              = sum_d g[d] (w1 v1 + w2 v2 + w3 v3 + w4 v4)
+//        grad_loc[l,p] (x, y)        = sum_d attn g[d] (W (-hh v1 + hh v2 - lh v3 + lh v4),  H (-hw v1 - lw v2 + hw v3 + lw v4))
+//      SHFL: D is a power of two <= 64: the sums over d are xor-shuffles inside the D lanes of a (n, q, m) group (fixed order);
+//      otherwise atomic adds into zero-initialised grad_loc / grad_attn. ----
+template <bool SHFL>
+__global__ __launch_bounds__(256) void msda_core_bwd_kernel(const float* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
+                                                            const float* __restrict__ aw, const float* __restrict__ gout,
+                                                            float* __restrict__ gvalue, float* __restrict__ gloc, float* __restrict__ gaw, int N,
+                                                            int S, int M, int D, int Lq, int P) {
+  const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)N * Lq * M * D;
+  const bool live = idx0 < total;
+  const long long idx = live ? idx0 : total - 1;              // (dead lanes keep the shuffles of their group well defined)
+  const int d = (int)(idx % D);
+  long long r = idx / D;
+  const int m = (int)(r % M);
+  r /= M;                                                     // r = n*Lq + q
+  const int n = (int)(r / Lq);
+  const float* lp = loc + (r * M + m) * lv.L * P * 2;
+  const float* ap = aw + (r * M + m) * lv.L * P;
+  const long long vb = ((long long)n * S * M + m) * D + d;
+  const float g = live ? gout[idx] : 0.f;
+  for (int l = 0; l < lv.L; ++l) {
+    const int H = lv.H[l], W = lv.W[l];
+    const long long vl = vb + (long long)lv.start[l] * M * D;
+    for (int p = 0; p < P; ++p) {
+      const float x = lp[(l * P + p) * 2] * W - 0.5f, y = lp[(l * P + p) * 2 + 1] * H - 0.5f;
+      const float a = ap[l * P + p];
+      float ga = 0.f, gx = 0.f, gy = 0.f;
+      if (y > -1.f && x > -1.f && y < H && x < W) {
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float lw = x - xf, lh = y - yf, hw = 1.f - lw, hh = 1.f - lh;
+        const float tg = g * a;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (y0 >= 0 && x0 >= 0) {
+          const long long o = vl + ((long long)y0 * W + x0) * M * D;
+          v1 = value[o];
+          if (live) atomicAdd(gvalue + o, hh * hw * tg);
+        }
+        if (y0 >= 0 && x0 + 1 < W) {
+          const long long o = vl + ((long long)y0 * W + x0 + 1) * M * D;
+          v2 = value[o];
+          if (live) atomicAdd(gvalue + o, hh * lw * tg);
+        }
+        if (y0 + 1 < H && x0 >= 0) {
+          const long long o = vl + ((long long)(y0 + 1) * W + x0) * M * D;
+          v3 = value[o];
+          if (live) atomicAdd(gvalue + o, lh * hw * tg);
+        }
+        if (y0 + 1 < H && x0 + 1 < W) {
+          const long long o = vl + ((long long)(y0 + 1) * W + x0 + 1) * M * D;
+          v4 = value[o];
+          if (live) atomicAdd(gvalue + o, lh * lw * tg);
+        }
+        ga = g * (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
+        gx = W * tg * (-hh * v1 + hh * v2 - lh * v3 + lh * v4);
+        gy = H * tg * (-hw * v1 - lw * v2 + hw * v3 + lw * v4);
+      }
+      const long long s = (r * M + m) * lv.L * P + l * P + p;
+      if (SHFL) {
+        for (int o = D >> 1; o > 0; o >>= 1) {
+          ga += __shfl_xor(ga, o, 64);
+          gx += __shfl_xor(gx, o, 64);
+          gy += __shfl_xor(gy, o, 64);
+        }
+        if (live && d == 0) {
+          gaw[s] = ga;
+          gloc[2 * s] = gx;
+          gloc[2 * s + 1] = gy;
+        }
+      } else if (live) {
+        atomicAdd(gaw + s, ga);
+        atomicAdd(gloc + 2 * s, gx);
+        atomicAdd(gloc + 2 * s + 1, gy);
+      }
+    }
+  }
+}
+
 // ---- module path: softmax over the L*P logits, sampling locations from the reference points, bilinear gather, weighted
 //      sum.  value16: blocked 16-bit [M][N*S][32] (head blocks, written by the value_proj GEMM epilogue);
 //      qproj: fp32 [N*Lq][3*M*L*P] = sampling offsets (M,L,P,2) | attention logits (M,L,P) (one GEMM on the query);

@@ -1,6 +1,6 @@
 // Training tier of the axial-trajectory attention layer: fp32 activations in natural [B,T,H,W] row order, the
-// attention / softmax / dropout / LayerNorm kernels here, the Linear layers' plain GEMMs (forward, dgrad, wgrad) through rocBLAS
-// (axvs_train.hip).  Nothing here is on the inference path; that stays on the fused 16-bit MFMA kernels (axvs_fused.h).
+// attention / softmax / dropout / LayerNorm kernels here, the Linear layers' GEMMs (forward, dgrad, wgrad) in axvs_gemm_nt.h /
+// axvs_train_gemm.h (split-precision bf16 MFMA; host side: axvs_train.hip).  Nothing here is on the inference path; that stays on the fused 16-bit MFMA kernels (axvs_fused.h).
 //
 // Reference semantics (WC/temporal_attention.py): TrajectoryAttention.forward :35-76 (dropout on the spatial attention map :55),
 // TemporalAxialTrajectoryAttentionLayer.forward :187-220 (dropout1 on each pass output :204, :213; dropout2 / dropout3 in the

@@ -4,7 +4,9 @@ Reference: OPS = MaXTron_Video-kMaX/maxtron_deeplab/modeling/within_clip_trackin
   `MSDeformAttn` (OPS/modules/ms_deform_attn.py:35-125; Tube-Link uses mmcv's MultiScaleDeformableAttention with the same
   math), `MSDeformAttnFunction` / `ms_deform_attn_core_pytorch` (OPS/functions/ms_deform_attn_func.py:33-77).
 Same constructor, parameter names (state-dict keys), initialisation and forward signature; forward runs in libaxvs.so.
-Forward only (the reference's backward kernel is SURVEY 8f-4), GPU only.
+eval(): the fused module kernels (`axvs_msda_fwd`, `axvs_msda_layer_fwd`).  train(): the reference module's own arithmetic under
+torch autograd around `MSDeformAttnFunction`, whose forward AND backward are the HIP kernels of the native op
+(`axvs_msda_core_fwd` / `axvs_msda_core_bwd` = the extension's ms_deform_attn_forward / _backward).  GPU only.
 """
 from __future__ import annotations
 
@@ -15,6 +17,7 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch import Tensor
 
 from . import _lib
@@ -46,6 +49,48 @@ def ms_deform_attn_forward(value: Tensor, value_spatial_shapes, value_level_star
     _lib.check(_lib.lib().axvs_msda_core_fwd(v.data_ptr(), arr, loc.data_ptr(), aw.data_ptr(), out.data_ptr(), N, S, M, D, Lq, L, P,
                                              _stream(v.device)), "axvs_msda_core_fwd")
     return out
+
+
+@_guarded
+def ms_deform_attn_backward(value: Tensor, value_spatial_shapes, value_level_start_index, sampling_locations: Tensor,
+                            attention_weights: Tensor, grad_output: Tensor, im2col_step: int = 64):
+    """Drop-in for `MSDA.ms_deform_attn_backward` (OPS/src/ms_deform_attn.h:49-67): -> (grad_value [N,S,M,D],
+    grad_sampling_loc [N,Lq,M,L,P,2], grad_attn_weight [N,Lq,M,L,P]), fp32."""
+    v = _dev_f32(value, "value")
+    loc = _dev_f32(sampling_locations, "sampling_locations")
+    aw = _dev_f32(attention_weights, "attention_weights")
+    go = _dev_f32(grad_output, "grad_output")
+    N, S, M, D = v.shape
+    _, Lq, _, L, P, _ = loc.shape
+    shp = _shapes_host(value_spatial_shapes)
+    arr = (C.c_int * (2 * L))(*[x for hw in shp for x in hw])
+    gv, gl, ga = torch.empty_like(v), torch.empty_like(loc), torch.empty_like(aw)
+    _lib.check(_lib.lib().axvs_msda_core_bwd(v.data_ptr(), arr, loc.data_ptr(), aw.data_ptr(), go.data_ptr(), gv.data_ptr(), gl.data_ptr(),
+                                             ga.data_ptr(), N, S, M, D, Lq, L, P, _stream(v.device)), "axvs_msda_core_bwd")
+    return gv, gl, ga
+
+
+class MSDeformAttnFunction(torch.autograd.Function):
+    """The reference's autograd wrapper of its CUDA op (OPS/functions/ms_deform_attn_func.py:32-52) over the HIP kernels: same
+    signature, same saved tensors; gradients for value, sampling_locations and attention_weights."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.shapes = _shapes_host(value_spatial_shapes)
+        ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
+        v, loc, aw = (t.detach().float().contiguous() for t in (value, sampling_locations, attention_weights))
+        output = ms_deform_attn_forward(v, ctx.shapes, value_level_start_index, loc, aw, im2col_step)
+        ctx.save_for_backward(v, loc, aw)
+        return output
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        v, loc, aw = ctx.saved_tensors
+        gv, gl, ga = ms_deform_attn_backward(v, ctx.shapes, None, loc, aw, grad_output.float().contiguous(), ctx.im2col_step)
+        dv, dl, da = ctx.in_dtypes
+        return gv.to(dv), None, None, gl.to(dl), ga.to(da), None
 
 
 class MSDeformAttn(nn.Module):
@@ -120,7 +165,9 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         """query (N, Len_q, C); reference_points (N, Len_q, n_levels, 2 | 4) in [0,1]; input_flatten (N, sum H_l W_l, C);
         input_spatial_shapes (n_levels, 2) = (H_l, W_l); input_padding_mask (N, sum H_l W_l) True = padding -> (N, Len_q, C)"""
-        _require_eval(self)
+        if self.training or (torch.is_grad_enabled() and any(t.requires_grad for t in (query, input_flatten))):
+            return self._forward_autograd(query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                                          input_padding_mask)
         q = _dev_f32(query, "query")
         x = _dev_f32(input_flatten, "input_flatten")
         ref = _dev_f32(reference_points, "reference_points")
@@ -148,6 +195,34 @@ class MSDeformAttn(nn.Module):
                                    arr, out.data_ptr(), packed.data_ptr(), N, Lq, S, self.d_model, self.n_heads, self.n_levels,
                                    self.n_points, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(), _stream(dev)), "axvs_msda_fwd")
         return out
+
+
+    def _forward_autograd(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index, input_padding_mask):
+        """train() mode (or gradients wanted): the reference module's forward as it stands (OPS/modules/ms_deform_attn.py:93-125) --
+        its nn.Linear / softmax / location arithmetic under torch autograd around `MSDeformAttnFunction`, whose forward and
+        backward are the HIP kernels of the native op (axvs_msda_core_fwd / _bwd)."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        shp = _shapes_host(input_spatial_shapes)
+        if sum(h * w for h, w in shp) != Len_in:
+            raise AssertionError("input_spatial_shapes do not cover input_flatten")
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.tensor([[w, h] for h, w in shp], dtype=sampling_offsets.dtype, device=sampling_offsets.device)
+            sampling_locations = reference_points[:, :, None, :, None, :] + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(reference_points.shape[-1]))
+        output = MSDeformAttnFunction.apply(value, shp, input_level_start_index, sampling_locations, attention_weights, self.im2col_step)
+        return self.output_proj(output)
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
@@ -216,7 +291,13 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     @_guarded
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index=None, padding_mask=None):
-        _require_eval(self)
+        if self.training or (torch.is_grad_enabled() and src.requires_grad):
+            # train() mode: the reference layer's forward (WC/msdeformattn.py:203-216) under torch autograd; the deformable attention
+            # op inside runs (forward and backward) on the HIP kernels through MSDeformAttnFunction
+            src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes, level_start_index, padding_mask)
+            src = self.norm1(src + self.dropout1(src2))
+            src2 = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+            return self.norm2(src + self.dropout3(src2))
         x = _dev_f32(src, "src")
         p = _dev_f32(pos, "pos") if pos is not None else None
         ref = _dev_f32(reference_points, "reference_points")

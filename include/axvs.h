@@ -296,6 +296,13 @@ int axvs_msda_layer_fwd(const float* src, const float* pos, const float* referen
 /* value fp32 [N,S,M,D]; sampling_loc fp32 [N,Lq,M,L,P,2]; attn_weight fp32 [N,Lq,M,L,P]; out fp32 [N,Lq,M*D] */
 int axvs_msda_core_fwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight,
                        float* out, int N, int S, int M, int D, int Lq, int L, int P, void* stream);
+/* backward of the native op: replaces ms_deform_attn_backward (OPS/src/ms_deform_attn.h:49-67, OPS/src/cuda/ms_deform_attn_cuda.cu:
+ * 89-157, the ms_deformable_col2im kernels of OPS/src/cuda/ms_deform_im2col_cuda.cuh).  grad_output fp32 [N,Lq,M*D] ->
+ * grad_value fp32 [N,S,M,D] (zeroed here, accumulated with atomic adds like the reference: the summation order is not fixed),
+ * grad_sampling_loc fp32 [N,Lq,M,L,P,2], grad_attn_weight fp32 [N,Lq,M,L,P] (written; for D not a power of two <= 64 accumulated). */
+int axvs_msda_core_bwd(const float* value, const int* spatial_shapes, const float* sampling_loc, const float* attn_weight,
+                       const float* grad_output, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int N, int S, int M,
+                       int D, int Lq, int L, int P, void* stream);
 
 /* ---- Pixel-decoder glue: nn.Sequential(Conv2d(k=1), GroupNorm) between backbone NCHW maps and token rows
  *      (WC/msdeformattn.py:349-375 input_proj / output_proj; used at :412 and :434), PositionEmbeddingSine

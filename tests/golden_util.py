@@ -72,11 +72,15 @@ def msda_core_inputs(m):
     g = torch.Generator().manual_seed(m["seed"])
     shapes, N, M, D, Lq, P, spread = m["shapes"], m["N"], m["M"], m["D"], m["Lq"], m["P"], m["spread"]
     L, S = len(shapes), sum(h * w for h, w in shapes)
-    value = torch.rand(N, S, M, D, generator=g) * 0.01
+    value = torch.rand(N, S, M, D, generator=g) * m.get("scale", 0.01)
     loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * (1 + 2 * spread) - spread
     aw = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
     aw = aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
     return value, loc, aw
+
+
+MSDA_BWD = ["g14_msda_bwd_N1_M2_D2_Lq2_L2_P2", "g14_msda_bwd_N2_M8_D32_Lq50_L3_P4", "g14_msda_bwd_N1_M4_D30_Lq33_L2_P3",
+            "g14_msda_bwd_N1_M8_D16_Lq40_L1_P5"]
 
 
 def msda_module_case(z, m):

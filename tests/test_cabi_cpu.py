@@ -223,3 +223,21 @@ def test_training_buffer_sizes_and_argument_checks():
     assert L.axvs_axial_layer_train_scratch_bytes(1, 4, 64, 64, 256, 8, 1024, 1) > L.axvs_axial_layer_train_scratch_bytes(1, 4, 64, 64, 256, 8, 1024, 0)
     assert L.axvs_axial_layer_train_saved_bytes(1, 4, 8, 8, 512, 8, 1024) == 0 and b"head_dim" in L.axvs_last_error()
     assert L.axvs_axial_layer_train_saved_bytes(1, 17, 8, 8, 256, 8, 1024) == 0 and b"T=17" in L.axvs_last_error()
+
+
+def test_reference_extension_stand_in_exposes_the_two_entry_points():
+    """`import MultiScaleDeformableAttention as MSDA` (OPS/functions/ms_deform_attn_func.py:22) resolves to the stand-in module and
+    finds ms_deform_attn_forward / ms_deform_attn_backward with the extension's argument lists (OPS/src/ms_deform_attn.h:24-67)."""
+    import importlib
+    import inspect
+    import sys
+    import axial_vs_amd
+    sys.path.insert(0, os.path.join(os.path.dirname(axial_vs_amd.__file__), "compat"))
+    try:
+        MSDA = importlib.import_module("MultiScaleDeformableAttention")
+    finally:
+        sys.path.pop(0)
+    f = list(inspect.signature(MSDA.ms_deform_attn_forward).parameters)
+    b = list(inspect.signature(MSDA.ms_deform_attn_backward).parameters)
+    assert f == ["value", "value_spatial_shapes", "value_level_start_index", "sampling_locations", "attention_weights", "im2col_step"]
+    assert b == ["value", "value_spatial_shapes", "value_level_start_index", "sampling_locations", "attention_weights", "grad_output", "im2col_step"]

@@ -152,6 +152,24 @@ def test_msda_module(name):
     assert rel_err(got, ref_out) < 5e-5
 
 
+from golden_util import MSDA_BWD  # noqa: E402
+
+
+@pytest.mark.parametrize("name", MSDA_BWD)
+def test_msda_core_oracle_gradients(name):
+    """autograd on orc.msda_core == autograd on the reference's ms_deform_attn_core_pytorch (float64): the gradient oracle of the
+    native op's backward (OPS/src/cuda/ms_deform_im2col_cuda.cuh col2im kernels)."""
+    z, m = load(name)
+    value, loc, aw = msda_core_inputs(m)
+    v, l, a = (x.double().requires_grad_(True) for x in (value, loc, aw))
+    out = orc.msda_core(v, m["shapes"], l, a)
+    out.backward(t(z["grad_output"]).double())
+    assert rel_err(out.detach(), t(z["out"])) < 1e-6
+    assert rel_err(v.grad, t(z["grad_value"])) < 1e-6
+    assert rel_err(l.grad, t(z["grad_sampling_loc"])) < 1e-6
+    assert rel_err(a.grad, t(z["grad_attn_weight"])) < 1e-6
+
+
 from golden_util import MSDA_ENCLAYER, msda_enclayer_case  # noqa: E402
 
 
