@@ -111,6 +111,8 @@ class MSDeformAttnTransformerEncoder(nn.Module):
     @_guarded
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos, padding_mask, pos_3d=None):
         """src / pos [BT, S, C]; spatial_shapes: list of (H, W); valid_ratios: BT (all maps valid); pos_3d: list of [B,T,H,W,C]."""
+        if self.training or (torch.is_grad_enabled() and src.requires_grad):
+            return self._forward_train(src, spatial_shapes, level_start_index, pos, padding_mask, pos_3d)
         output = src
         key = (tuple(spatial_shapes), src.shape[0], src.device)
         if getattr(self, "_ref_key", None) != key:
@@ -133,6 +135,25 @@ class MSDeformAttnTransformerEncoder(nn.Module):
         return output, h_attn, w_attn
 
 
+    def _forward_train(self, src, spatial_shapes, level_start_index, pos, padding_mask, pos_3d):
+        """train() mode: the reference's stage loop as it stands (WC/msdeformattn.py:244-273: split, temporal layers, cat -- out of
+        place, one stream) around layers that run their own training tiers."""
+        output = src
+        key = (tuple(spatial_shapes), src.shape[0], src.device)
+        if getattr(self, "_ref_key", None) != key:
+            self._ref, self._ref_key = self.get_reference_points(spatial_shapes, src.shape[0], src.device), key
+        sizes = [h * w for h, w in spatial_shapes]
+        h_attn = w_attn = None
+        for i, spatial_layer in enumerate(self.spatial_layers):
+            output = spatial_layer(output, pos, self._ref, spatial_shapes, level_start_index, padding_mask)
+            if self.transformer_num_temporal_feature_levels > 0:
+                parts = list(torch.split(output, sizes, dim=1))
+                for j in range(self.transformer_num_temporal_feature_levels):
+                    parts[j], h_attn, w_attn = self.temporal_layers[i](src=parts[j].contiguous(), pos=pos_3d[j])
+                output = torch.cat(parts, dim=1)
+        return output, h_attn, w_attn
+
+
 class TemporalTransformerEncoder(nn.Module):
     """Temporal-only stage loop (WC/msdeformattn.py:276-290): per stage, the temporal encoder on the coarsest levels; the other
     levels pass through.  Works on the concatenated [BT, S, C] token buffer like the spatial + temporal encoder."""
@@ -146,6 +167,13 @@ class TemporalTransformerEncoder(nn.Module):
     def forward(self, src, spatial_shapes, pos_3d):
         sizes = [h * w for h, w in spatial_shapes]
         nt = self.transformer_num_temporal_feature_levels
+        if self.training or (torch.is_grad_enabled() and src.requires_grad):      # the reference's loop (WC/msdeformattn.py:282-290), out of place
+            parts = list(torch.split(src, sizes, dim=1))
+            h_attn = w_attn = None
+            for temporal_layer in self.temporal_layers:
+                for j in range(nt):
+                    parts[j], h_attn, w_attn = temporal_layer(src=parts[j].contiguous(), pos=pos_3d[j])
+            return torch.cat(parts, dim=1), h_attn, w_attn
         parts = [p.contiguous() for p in torch.split(src, sizes, dim=1)[:nt]]
         h_attn = w_attn = None
         for temporal_layer in self.temporal_layers:
@@ -273,8 +301,43 @@ class MSDeformAttnPixelDecoder(nn.Module):
         with _on(next(iter(features.values())).device):
             return self._forward_features(features)
 
+    def _forward_features_train(self, features):
+        """train() mode (WC/msdeformattn.py:404-437, :91-174 under autograd): the 1x1 convolutions + GroupNorm and the level embeddings
+        are the reference's torch modules; the sine embeddings come from the library's kernels (constants); the encoder's layers run
+        their training tiers (deformable attention: HIP forward / backward of the op; axial-trajectory layers: axvs_axial_layer_train_*)."""
+        order = self.transformer_spatial_in_features[::-1]
+        xs = [features[f] for f in order]
+        BT = xs[0].shape[0]
+        B = BT // self.num_clip_frames        # (self.training: WC/msdeformattn.py:406)
+        T = BT // B
+        dev = xs[0].device
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in xs]
+        spatial = self.transformer.num_spatial_layers > 0
+        srcs, poss, pos_3d = [], [], []
+        for idx, (f, x) in enumerate(zip(order, xs)):
+            H, W = shapes[idx]
+            srcs.append(self.input_proj[idx](x.float()).flatten(2).transpose(1, 2))
+            if spatial:
+                sine = torch.empty(BT, H * W, self.conv_dims, dtype=torch.float32, device=dev)
+                self.pe_layer.tokens_into(sine, None, BT, H, W, 0)
+                poss.append(sine + self.transformer.level_embed_2d[idx].view(1, 1, -1))
+            if self.transformer_temporal_layers > 0 and f in self.transformer_temporal_in_features:
+                sine3 = self.pe_layer_3d.channels_last(B, T, H, W, dev)
+                pos_3d.append(torch.as_tensor(sine3) + self.transformer.level_embed_3d[len(pos_3d)].view(1, 1, 1, 1, -1))
+        src = torch.cat(srcs, 1)
+        if spatial:
+            y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, torch.cat(poss, 1), None, pos_3d)
+        else:
+            y, h_attn, w_attn = self.transformer.encoder(src, shapes, pos_3d)
+        out = {}
+        for i, (f, z) in enumerate(zip(order, torch.split(y, [h * w for h, w in shapes], dim=1))):
+            H, W = shapes[i]
+            out[f] = self.output_proj[i](z.transpose(1, 2).contiguous().view(BT, -1, H, W))
+        return out, h_attn, w_attn
+
     def _forward_features(self, features):
-        _require_eval(self)
+        if self.training:
+            return self._forward_features_train(features)
         order = self.transformer_spatial_in_features[::-1]          # low -> high resolution (WC/msdeformattn.py:411)
         xs = [_dev_f32(features[f], f) for f in order]
         BT = xs[0].shape[0]
