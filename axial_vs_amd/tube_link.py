@@ -117,7 +117,9 @@ class MultiScaleDeformableAxialTrajectoryAttention(nn.Module):
         (bs, num_query, C) with ``batch_first``; bs = B*T frames; query_pos3d[i]: [B, T, H_i, W_i, C] for the i-th (coarsest
         first) temporal level; reference_points (bs, num_query, num_levels, 2 | 4); spatial_shapes (num_levels, 2) = (h, w).
         Returns the tensor in the layout of `query`."""
-        _require_eval(self)
+        if self.training or (torch.is_grad_enabled() and query.requires_grad):
+            return self._forward_autograd(query, value, identity, query_pos, query_pos3d, key_padding_mask, reference_points, spatial_shapes,
+                                          level_start_index)
         v_is_q, id_is_q = value is None or value is query, identity is None or identity is query     # TL:567-570 defaults
         if value is None:
             value = query
@@ -174,3 +176,47 @@ class MultiScaleDeformableAxialTrajectoryAttention(nn.Module):
         _lib.check(L.axvs_msda_output_proj_fwd(sampled.data_ptr(), ident.data_ptr(), out.data_ptr(), packed.data_ptr(), bs * nq, Cq,
                                                self.num_heads, self.num_levels, self.num_points, dt, st), "axvs_msda_output_proj_fwd")
         return out if self.batch_first else out.permute(1, 0, 2)
+
+    def _forward_autograd(self, query, value, identity, query_pos, query_pos3d, key_padding_mask, reference_points, spatial_shapes,
+                          level_start_index):
+        """train() mode: the reference's forward as it stands (TL:561-638) under torch autograd -- its Linear / softmax / location
+        arithmetic around `MSDeformAttnFunction` (HIP forward / backward of the deformable op) and the temporal encoder, whose
+        axial-trajectory layers run the library's training tier."""
+        from .msda import MSDeformAttnFunction, _shapes_host
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        num_value = value.shape[1]
+        shp = _shapes_host(spatial_shapes)
+        assert sum(h * w for h, w in shp) == num_value
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        sampling_offsets = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        attention_weights = self.attention_weights(query).view(bs, num_query, self.num_heads, self.num_levels * self.num_points).softmax(-1)
+        attention_weights = attention_weights.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.tensor([[w, h] for h, w in shp], dtype=sampling_offsets.dtype, device=sampling_offsets.device)
+            sampling_locations = reference_points[:, :, None, :, None, :] + sampling_offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError(f'Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.')
+        output = MSDeformAttnFunction.apply(value, shp, level_start_index, sampling_locations, attention_weights, self.im2col_step)
+        outs = list(torch.split(output, [h * w for h, w in shp], dim=1))
+        for i in range(self.num_temporal_levels):
+            f = outs[i].contiguous()
+            enc = self.temporal_layer(src=f, pos=query_pos3d[i])
+            outs[i] = f + self.gamma * enc if self.skip_connect else enc
+        output = self.output_proj(torch.cat(outs, dim=1))
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
