@@ -71,7 +71,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 class AxvsCCTrainCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "Q", "Tc", "V", "H", "W", "K1", "num_layers")] + \
                [("rates", C.c_int * 3), ("p_attn_drop", C.c_float), ("p_aspp_drop", C.c_float), ("seed", C.c_uint),
-                ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p)]
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p), ("chain_only", C.c_int)]
 
 
 class AxvsTLHeadParams(C.Structure):
@@ -127,6 +127,9 @@ SIGNATURES = {
                                            _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
     "axvs_cc_module_train_bwd": (C.c_int, [_fp] * 4 + [C.POINTER(AxvsCCLayerParams), C.POINTER(AxvsCCHeadParams), C.POINTER(AxvsCCLayerParams),
                                            C.POINTER(AxvsCCHeadGrads), _fp, C.POINTER(AxvsCCTrainCfg), _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
+    "axvs_cc_layers_train_fwd": (C.c_int, [_fp, _fp, C.POINTER(AxvsCCLayerParams), C.POINTER(AxvsCCTrainCfg), _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
+    "axvs_cc_layers_train_bwd": (C.c_int, [_fp, _fp, C.POINTER(AxvsCCLayerParams), C.POINTER(AxvsCCLayerParams), _fp, C.POINTER(AxvsCCTrainCfg),
+                                           _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
     "axvs_axial_pass_fwd": (C.c_int, [_fp, _fp, _fp, _fp] + [C.c_int] * 9 + [_fp, C.c_size_t, _fp]),
     "axvs_axial_layer_workspace_bytes_ex": (C.c_size_t, [C.c_int] * 9),
     "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),

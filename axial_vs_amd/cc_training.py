@@ -119,6 +119,7 @@ def _cfg(dims, rates, p_attn, p_aspp, seed, hook) -> _lib.AxvsCCTrainCfg:
     c.p_attn_drop, c.p_aspp_drop, c.seed = float(p_attn), float(p_aspp), int(seed)
     c.allreduce = hook.fn if hook is not None else _lib.ALLREDUCE_FN()
     c.allreduce_user = None
+    c.chain_only = 0
     return c
 
 
@@ -269,3 +270,99 @@ def cc_module_train(mod, clip_query: Tensor, panoptic_features: Tensor):
             bn.running_var.mul_((1 - m) ** nl).add_(upd[1].to(bn.running_var.dtype))
             bn.num_batches_tracked += nl
     return logits, masks
+
+
+# ---- the layer chain alone: the Tube-Link head's train() mode (its prediction heads are torch modules around it) ----------------------
+def chain_parameters(mod, num_layers: int) -> List[Tensor]:
+    ps: List[Tensor] = []
+    for i in range(num_layers):
+        lay, asp, cn = mod.transformer_trajectory_self_attention_layers[i], mod.conv_short_aggregate_layers[i], mod.conv_norms[i]
+        at = lay.self_attn
+        ps += [at.qkv.weight, at.qkv.bias, at.proj_q.weight, at.proj_q.bias, at.proj_kv.weight, at.proj_kv.bias, at.proj.weight, at.proj.bias,
+               lay.norm.weight, lay.norm.bias]
+        for k in range(3):
+            conv = getattr(asp, f"_aspp_conv{k}")
+            ps += [conv.weight, conv.bias]
+        ps += [asp._proj_conv_bn_act.conv.weight, asp._proj_conv_bn_act.norm.weight, asp._proj_conv_bn_act.norm.bias, cn.weight, cn.bias]
+    return ps
+
+
+class _CCLayersTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip_query, cfg, *params):
+        from .modules import _stream
+        dims, rates, p_attn, p_aspp, seed = cfg
+        if not clip_query.is_cuda:
+            raise RuntimeError("axial_vs_amd: the training tier needs GPU tensors; there is no CPU fallback")
+        B, Q, Tc, nl = dims
+        cq = _f32c(clip_query)
+        ws = [_f32c(w) for w in params]
+        L = _lib.lib()
+        dev = cq.device
+        full = (B, Q, Tc, 1, 1, 1, 1, nl)
+        with torch.cuda.device(dev):
+            c = _cfg(full, rates, p_attn, p_aspp, seed, None)
+            c.chain_only = 1
+            nsaved = L.axvs_cc_module_train_saved_bytes(C.byref(c))
+            nscr = L.axvs_cc_module_train_scratch_bytes(C.byref(c), 0)
+            if nsaved == 0 or nscr == 0:
+                raise RuntimeError("axvs_cc_module_train_saved_bytes: " + L.axvs_last_error().decode())
+            saved = torch.empty(nsaved, dtype=torch.uint8, device=dev)
+            scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
+            out = torch.empty(nl, B, Q, Tc, 256, dtype=torch.float32, device=dev)
+            ptrs = [w.data_ptr() for w in ws]
+            layers = (_lib.AxvsCCLayerParams * nl)(*[_layer_struct(ptrs[i * _PER_LAYER:(i + 1) * _PER_LAYER]) for i in range(nl)])
+            _lib.check(L.axvs_cc_layers_train_fwd(cq.data_ptr(), out.data_ptr(), layers, C.byref(c), saved.data_ptr(), nsaved, scratch.data_ptr(), nscr,
+                                                  _stream(dev)), "axvs_cc_layers_train_fwd")
+        ctx.save_for_backward(cq, *ws)
+        ctx.cfg = (full, rates, p_attn, p_aspp, seed)
+        ctx.saved_buf = saved
+        ctx.in_dtypes = (clip_query.dtype, [w.dtype for w in params])
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        from .modules import _stream
+        cq, *ws = ctx.saved_tensors
+        full, rates, p_attn, p_aspp, seed = ctx.cfg
+        nl = full[-1]
+        L = _lib.lib()
+        dev = cq.device
+        with torch.cuda.device(dev):
+            g = _f32c(d_out)
+            c = _cfg(full, rates, p_attn, p_aspp, seed, None)
+            c.chain_only = 1
+            nsaved = L.axvs_cc_module_train_saved_bytes(C.byref(c))
+            nscr = L.axvs_cc_module_train_scratch_bytes(C.byref(c), 1)
+            scratch = torch.empty(nscr, dtype=torch.uint8, device=dev)
+            sizes = [w.numel() for w in ws]
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            grads, off = [], 0
+            for w, n in zip(ws, sizes):
+                grads.append(flat[off:off + n].view(w.shape))
+                off += n
+            d_cq = torch.empty_like(cq)
+            ptrs, gptrs = [w.data_ptr() for w in ws], [t.data_ptr() for t in grads]
+            layers = (_lib.AxvsCCLayerParams * nl)(*[_layer_struct(ptrs[i * _PER_LAYER:(i + 1) * _PER_LAYER]) for i in range(nl)])
+            lgrads = (_lib.AxvsCCLayerParams * nl)(*[_layer_struct(gptrs[i * _PER_LAYER:(i + 1) * _PER_LAYER]) for i in range(nl)])
+            _lib.check(L.axvs_cc_layers_train_bwd(g.data_ptr(), cq.data_ptr(), layers, lgrads, d_cq.data_ptr(), C.byref(c), ctx.saved_buf.data_ptr(),
+                                                  nsaved, scratch.data_ptr(), nscr, _stream(dev)), "axvs_cc_layers_train_bwd")
+        qd, wd = ctx.in_dtypes
+        return (d_cq.to(qd), None, *[t.to(dt) for t, dt in zip(grads, wd)])
+
+
+def cc_layers_train(mod, clip_query: Tensor, num_layers: int, rates, p_attn: float, p_aspp: float) -> Tensor:
+    """Differentiable layer chain of a cross-clip module (clip_query [B,Q,Tc,256]) -> the clip queries after every layer [nl,B,Q,Tc,256]."""
+    B, Q, Tc, Cq = clip_query.shape
+    if Cq != 256:
+        raise RuntimeError("clip_query must be [B,Q,Tc,256]")
+    seed = getattr(mod, "dropout_seed", None)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p_attn > 0 or p_aspp > 0) else 0
+    cfg = ((int(B), int(Q), int(Tc), int(num_layers)), tuple(int(r) for r in rates), float(p_attn), float(p_aspp), int(seed))
+    args = (clip_query, cfg, *chain_parameters(mod, num_layers))
+    if torch.is_autocast_enabled():
+        with torch.autocast(device_type="cuda", enabled=False):
+            return _CCLayersTrain.apply(*args)
+    return _CCLayersTrain.apply(*args)

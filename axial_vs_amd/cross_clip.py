@@ -318,9 +318,31 @@ class TubeLinkCrossClipHead(nn.Module):
         self._packed, self._packed_key = (layers, hbuf, K1, Cm), key
         return self._packed
 
+    def _forward_train(self, clip_query: Tensor, mask_features: Tensor):
+        """train() mode (TLCC:925-947 with forward_head_clips :761-781 and pred_class :783-797 under autograd): the layer chain on the
+        library's training tier (axvs_cc_layers_train_fwd / _bwd), the prediction heads -- post_norm, class pooling, the mask MLP,
+        the per-clip einsum -- as the reference's torch modules."""
+        from .cc_training import cc_layers_train
+        B, Tc, Q, _ = clip_query.shape
+        T = mask_features.shape[1]
+        fpc = T // Tc
+        trj = self.transformer_trajectory_self_attention_layers[0].self_attn.attn_drop.p
+        asp = self.conv_short_aggregate_layers[0]._proj_drop.p
+        queries = cc_layers_train(self, clip_query.permute(0, 2, 1, 3).contiguous(), self.num_cc_layers, self.atrous_rates, trj, asp)
+        cls_all, mask_all = [], []
+        for i in range(self.num_cc_layers):
+            xn = self.transformer_decoder.post_norm(queries[i]).permute(0, 2, 1, 3)              # [B,Tc,Q,C]   TLCC:768-769
+            act = torch.softmax(self.activation_proj(xn), dim=1)                                  # softmax over the clips, :789-791
+            cls_all.append(self.cls_embed((xn * act).sum(dim=1)))
+            me = self.mask_embed(xn)                                                               # [B,Tc,Q,Cm]
+            mask_all.append(torch.cat([torch.einsum("bqc,btchw->btqhw", me[:, c], mask_features[:, fpc * c:fpc * (c + 1)])
+                                       for c in range(Tc)], dim=1))                                # :774-778
+        return tuple(cls_all), tuple(mask_all)
+
     @_guarded
     def forward(self, clip_query: Tensor, mask_features: Tensor):
-        _require_eval(self)
+        if self.training:
+            return self._forward_train(clip_query, mask_features)
         cq = _dev_f32(clip_query, "clip_query")
         mf = _dev_f32(mask_features, "mask_features")
         B, Tc, Q, Cq = cq.shape

@@ -22,18 +22,20 @@ struct CCShape {
 
 int make_cc_shape(CCShape& s, const AxvsCCTrainCfg* cfg) {
   if (!cfg) return fail(AXVS_ERR_ARG, "null configuration");
-  if (cfg->B <= 0 || cfg->Q <= 0 || cfg->Tc <= 0 || cfg->V <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->K1 <= 0 || cfg->num_layers <= 0)
+  const bool chain = cfg->chain_only != 0;
+  if (cfg->B <= 0 || cfg->Q <= 0 || cfg->Tc <= 0 || cfg->num_layers <= 0 || (!chain && (cfg->V <= 0 || cfg->H <= 0 || cfg->W <= 0 || cfg->K1 <= 0)))
     return fail(AXVS_ERR_ARG, "non-positive dimension");
   if (cfg->num_layers > kCcMaxLayers) return fail(AXVS_ERR_ARG, "cross-clip training: num_layers=%d > %d", cfg->num_layers, kCcMaxLayers);
   if (cfg->Tc > 16) return fail(AXVS_ERR_ARG, "cross-clip training: Tc=%d > 16 clips not built", cfg->Tc);
-  if (cfg->Q % 8) return fail(AXVS_ERR_ARG, "cross-clip training: Q=%d must be a multiple of 8", cfg->Q);
-  const long long P = (long long)cfg->V * cfg->H * cfg->W;       // any pixel count: the einsum GEMMs take unaligned rows and tails
+  if (!chain && cfg->Q % 8) return fail(AXVS_ERR_ARG, "cross-clip training: Q=%d must be a multiple of 8", cfg->Q);
+  const long long P = chain ? 4 : (long long)cfg->V * cfg->H * cfg->W;       // any pixel count: the einsum GEMMs take unaligned rows and tails
   if ((long long)cfg->B * cfg->Tc > 1024) return fail(AXVS_ERR_ARG, "cross-clip training: B*Tc > 1024");
   for (int k = 0; k < 3; ++k)
     if (cfg->rates[k] <= 0) return fail(AXVS_ERR_ARG, "cross-clip training: atrous rate %d", cfg->rates[k]);
   if (!(cfg->p_attn_drop >= 0.f && cfg->p_attn_drop < 1.f) || !(cfg->p_aspp_drop >= 0.f && cfg->p_aspp_drop < 1.f))
     return fail(AXVS_ERR_ARG, "dropout probability outside [0, 1)");
-  s.B = cfg->B; s.Q = cfg->Q; s.Tc = cfg->Tc; s.V = cfg->V; s.H = cfg->H; s.W = cfg->W; s.K1 = cfg->K1; s.nl = cfg->num_layers;
+  s.B = cfg->B; s.Q = cfg->Q; s.Tc = cfg->Tc; s.V = chain ? 1 : cfg->V; s.H = chain ? 1 : cfg->H; s.W = chain ? 4 : cfg->W;
+  s.K1 = chain ? 4 : cfg->K1; s.nl = cfg->num_layers;
   for (int k = 0; k < 3; ++k) s.rates[k] = cfg->rates[k];
   s.M = (long long)s.B * s.Q * s.Tc;
   s.P = P;
@@ -189,8 +191,8 @@ void cc_scalar_stats(const CCCtx& k, const float* x, const float* dy, const floa
 
 const float kVoidBias = logf(0.9f / 0.1f);   // add_bias_towards_void: log((K1 - 1) * 0.9 / 0.1) = log(K1 - 1) + this
 
-int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_out, float* masks_out, float* bn_stats_out,
-               const AxvsCCLayerParams* layers, const AxvsCCHeadParams& hp, const CCSaved& sv) {
+// the layer chain (trajectory attention layer -> ASPP -> norms) of all layers: sv.x2[l] = the clip queries after layer l
+int cc_chain_forward(const CCCtx& k, const float* cq, const AxvsCCLayerParams* layers, const CCSaved& sv) {
   const CCShape& s = k.s;
   const Ctx& c = k.c;
   const long long M = s.M;
@@ -219,6 +221,18 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
     hipLaunchKernelGGL(tr_ln_fwd_kernel, dim3(blocks(M, 4)), dim3(256), 0, k.st, (const float*)L.u, p.conv_norm_w, p.conv_norm_b, sv.x2 + (size_t)l * MC,
                        L.meanu, L.rstdu, M, C, 1e-5f);
   }
+  return status();
+}
+
+int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_out, float* masks_out, float* bn_stats_out,
+               const AxvsCCLayerParams* layers, const AxvsCCHeadParams& hp, const CCSaved& sv) {
+  const CCShape& s = k.s;
+  const Ctx& c = k.c;
+  const long long M = s.M;
+  const int C = kCcC, G = s.nl;
+  const bool ex = g_train_exact != 0;
+  int rc;
+  if ((rc = cc_chain_forward(k, cq, layers, sv)) != AXVS_OK) return rc;
   // ---- heads of all layers ----
   const long long GM = (long long)G * M;
   float* const sync = k.x.sync;
@@ -279,6 +293,8 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
                      (const float*)sv.rstd[3], hp.pixel_bn.w, hp.pixel_bn.b, masks_out, s.E / 4);
   return status();
 }
+
+int cc_chain_backward(const CCCtx& k, const float* cq, const AxvsCCLayerParams* layers, const AxvsCCLayerGrads* lg, float* d_cq, const CCSaved& sv);
 
 int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, const float* cq, const float* pf, const AxvsCCLayerParams* layers,
                 const AxvsCCHeadParams& hp, const AxvsCCLayerGrads* lg, const AxvsCCHeadGrads& hg, float* d_cq, const CCSaved& sv) {
@@ -364,7 +380,19 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
   //  conv_norms bias gradient is a sum that cancels exactly, and two-piece rounding would be all that is left of it)
   if ((rc = c.dgrad(x.dce_pre, hp.class_proj_w, x.dx2h, GM, C, C, 0.f, 0, true)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(x.dme_pre, hp.mask_proj_w, x.dx2h, GM, C, C, 1.f, 0, true)) != AXVS_OK) return rc;
-  // ---- the layer chain, last layer first ----
+  return cc_chain_backward(k, cq, layers, lg, d_cq, sv);
+}
+
+// the layer chain, last layer first; x.dx2h [nl][M][C] holds the gradient that reaches each layer's output from OUTSIDE the chain
+// (the heads), the next layer's input gradient is added on the way
+int cc_chain_backward(const CCCtx& k, const float* cq, const AxvsCCLayerParams* layers, const AxvsCCLayerGrads* lg, float* d_cq, const CCSaved& sv) {
+  const CCShape& s = k.s;
+  const Ctx& c = k.c;
+  const CCScratch& x = k.x;
+  const long long M = s.M;
+  const int C = kCcC, G = s.nl;
+  const size_t MC = (size_t)M * C;
+  int rc;
   const Drop none = make_drop(0.f, 0, 0);
   for (int l = G - 1; l >= 0; --l) {
     const CCLayerSaved& L = sv.l[l];

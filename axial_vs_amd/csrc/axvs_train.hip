@@ -589,4 +589,37 @@ int axvs_cc_module_train_bwd(const float* d_logits, const float* d_masks, const 
   return cc_backward(k, d_logits, d_masks, clip_query, panoptic_features, layers, *heads, layer_grads, *head_grads, d_clip_query, sv);
 }
 
+// ---- the layer chain of the cross-clip modules alone (the Tube-Link head trains its own prediction heads around it) -----------------
+int axvs_cc_layers_train_fwd(const float* clip_query, float* out_queries, const AxvsCCLayerParams* layers, const AxvsCCTrainCfg* cfg, void* saved,
+                             size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!clip_query || !out_queries || !layers || !cfg || !saved || !scratch) return fail(AXVS_ERR_ARG, "null pointer");
+  CCCtx k{};
+  CCSaved sv;
+  int rc;
+  if ((rc = cc_setup(k, cfg, scratch, scratch_bytes, saved, saved_bytes, sv, false, stream)) != AXVS_OK) return rc;
+  for (int l = 0; l < k.s.nl; ++l)
+    if ((rc = cc_check_ptrs(&layers[l], sizeof(AxvsCCLayerParams), "AxvsCCLayerParams")) != AXVS_OK) return rc;
+  if ((rc = cc_chain_forward(k, clip_query, layers, sv)) != AXVS_OK) return rc;
+  const size_t n = (size_t)k.s.nl * k.s.M * kCcC;
+  if (hipMemcpyAsync(out_queries, sv.x2, n * sizeof(float), hipMemcpyDeviceToDevice, k.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
+  return status();
+}
+
+int axvs_cc_layers_train_bwd(const float* d_queries, const float* clip_query, const AxvsCCLayerParams* layers, const AxvsCCLayerGrads* layer_grads,
+                             float* d_clip_query, const AxvsCCTrainCfg* cfg, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                             void* stream) {
+  if (!d_queries || !clip_query || !layers || !layer_grads || !d_clip_query || !cfg || !saved || !scratch) return fail(AXVS_ERR_ARG, "null pointer");
+  CCCtx k{};
+  CCSaved sv;
+  int rc;
+  if ((rc = cc_setup(k, cfg, scratch, scratch_bytes, saved, saved_bytes, sv, true, stream)) != AXVS_OK) return rc;
+  for (int l = 0; l < k.s.nl; ++l) {
+    if ((rc = cc_check_ptrs(&layers[l], sizeof(AxvsCCLayerParams), "AxvsCCLayerParams")) != AXVS_OK) return rc;
+    if ((rc = cc_check_ptrs(&layer_grads[l], sizeof(AxvsCCLayerGrads), "AxvsCCLayerGrads")) != AXVS_OK) return rc;
+  }
+  const size_t n = (size_t)k.s.nl * k.s.M * kCcC;            // the chain adds the next layer's input gradient into this buffer
+  if (hipMemcpyAsync(k.x.dx2h, d_queries, n * sizeof(float), hipMemcpyDeviceToDevice, k.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
+  return cc_chain_backward(k, clip_query, layers, layer_grads, d_clip_query, sv);
+}
+
 }  // extern "C"

@@ -433,6 +433,7 @@ typedef struct AxvsCCTrainCfg {
   unsigned seed;
   axvs_allreduce_fn allreduce;
   void* allreduce_user;
+  int chain_only;            /* != 0: buffers and checks for axvs_cc_layers_train_* only (any Q; V, H, W, K1 ignored) */
 } AxvsCCTrainCfg;
 size_t axvs_cc_module_train_saved_bytes(const AxvsCCTrainCfg* cfg);
 size_t axvs_cc_module_train_scratch_bytes(const AxvsCCTrainCfg* cfg, int backward);
@@ -449,6 +450,17 @@ int axvs_cc_module_train_bwd(const float* d_logits, const float* d_masks, const 
                              const AxvsCCLayerParams* layers, const AxvsCCHeadParams* heads, const AxvsCCLayerGrads* layer_grads,
                              const AxvsCCHeadGrads* head_grads, float* d_clip_query, const AxvsCCTrainCfg* cfg, void* saved, size_t saved_bytes,
                              void* scratch, size_t scratch_bytes, void* stream);
+
+/* The layer chain alone (TrajectoryAttentionLayer + ASPP + norms of every layer, no prediction heads): Tube-Link's
+ * Mask2FormerVideoCCHeadTube trains its own heads around the same layers (TL/models/video/tube_link_vis/mask2former_video_cc_head.py:
+ * 925-947).  cfg: B, Q, Tc, num_layers, rates, dropouts, seed, chain_only = 1 (no all-reduce: the chain has no BatchNorm); buffers
+ * sized by axvs_cc_module_train_saved_bytes / _scratch_bytes of that cfg.  out_queries / d_queries: fp32 [nl,B,Q,Tc,256] -- the clip
+ * queries after every layer / the gradient that reaches each of them from outside the chain. */
+int axvs_cc_layers_train_fwd(const float* clip_query, float* out_queries, const AxvsCCLayerParams* layers, const AxvsCCTrainCfg* cfg, void* saved,
+                             size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+int axvs_cc_layers_train_bwd(const float* d_queries, const float* clip_query, const AxvsCCLayerParams* layers, const AxvsCCLayerGrads* layer_grads,
+                             float* d_clip_query, const AxvsCCTrainCfg* cfg, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes,
+                             void* stream);
 
 #ifdef __cplusplus
 }

@@ -163,3 +163,37 @@ def test_cc_training_amp_autocast_and_grad_scaling():
         assert v.grad.dtype == torch.float32
         assert rel_l2(v.grad.cpu() / 1024.0, g32[k].cpu()) < 1e-5 or float(g32[k].norm()) < 1e-4 * max(float(x.norm()) for x in g32.values()), k
     assert rel_l2(q16.grad.float().cpu() / 1024.0, q32.grad.cpu()) < 1e-3      # d_clip_query is returned in fp16
+
+
+@pytest.mark.parametrize("name", ["g6_tl_cc_head_Tc3_Q16_f2_L2", "g6_tl_cc_head_Tc2_Q20_f1_L1", "g6_tl_cc_head_Tc4_Q100_f2_L4"])
+def test_tube_link_cross_clip_head_trains(name):
+    """Tube-Link's cross-clip head in train() mode, dropouts 0: the layer chain on the library's training tier
+    (axvs_cc_layers_train_*), its prediction heads as torch modules.  Outputs of every layer against the reference class's fixtures at
+    fp32 accuracy; gradients of the clip queries and of every parameter against autograd on the float64 oracle."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w = weights(z, m)
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    cq = torch.randn(m["B"], m["Tc"], m["Q"], 256, generator=g)
+    mf = torch.nn.functional.normalize(torch.randn(m["B"], m["Tc"] * m["fpc"], m["Cm"], m["h"], m["w"], generator=g), dim=2)
+    mod = ax.TubeLinkCrossClipHead(num_classes=m["num_classes"], out_channels=m["Cm"], num_cc_layers=m["layers"], trajectory_drop_out=0.0,
+                                   drop_path_prob=0.0)
+    mod.load_state_dict(w, strict=True)
+    mod = mod.cuda().train()
+    q = cq.cuda().requires_grad_(True)
+    cls, masks = mod(q, mf.cuda())
+    assert rel_err(cls[-1].detach().cpu(), t(z["cls_last"])) < TOL and rel_err(cls[0].detach().cpu(), t(z["cls_first"])) < TOL
+    d_cls = [torch.randn(c.shape, generator=g) for c in cls]
+    d_masks = [torch.randn(x.shape, generator=g) * 0.05 for x in masks]
+    (sum((a * b.cuda()).sum() for a, b in zip(cls, d_cls)) + sum((a * b.cuda()).sum() for a, b in zip(masks, d_masks))).backward()
+    wd = {k: v.double().requires_grad_(True) for k, v in w.items()}
+    qd = cq.double().requires_grad_(True)
+    rc, rm = orc.tl_cross_clip_head(qd, mf.double(), wd, m["layers"])
+    (sum((a * b.double()).sum() for a, b in zip(rc, d_cls)) + sum((a * b.double()).sum() for a, b in zip(rm, d_masks))).backward()
+    e = dict(masks=rel_err(masks[-1].detach().cpu(), rm[-1].detach()), d_clip_query=rel_err(q.grad.cpu(), qd.grad))
+    scale = max(float(v.grad.norm()) for v in wd.values() if v.grad is not None)
+    pe = {k: float((p.grad.cpu().double() - wd[k].grad).norm() / max(float(wd[k].grad.norm()), 1e-3 * scale)) for k, p in mod.named_parameters()
+          if wd[k].grad is not None}
+    worst = max(pe, key=pe.get)
+    print(f"{name}: {e} worst parameter gradient {worst} {pe[worst]:.2e} ({len(pe)} parameters)")
+    assert max(e.values()) < TOL and max(pe.values()) < TOL
