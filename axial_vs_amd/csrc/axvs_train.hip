@@ -32,6 +32,8 @@ struct Gemm {
     st = s;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, false, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<true>))) return rc;
@@ -47,18 +49,21 @@ struct Gemm {
     const dim3 grid((unsigned)((M + kGT - 1) / kGT), (unsigned)((N + kGT - 1) / kGT), (unsigned)zsplits);
     // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
     //  fixed cost -- ~11 us whatever K -- not by the load round trips of the k-loop)
-    const bool gen = gemm_nt_general(ld, K) || ld.a2 != nullptr;      // (the general loader takes the addend at run time)
+    const bool gen = gemm_nt_general(ld, K), add = ld.a2 != nullptr;   // (the general loader takes the addend at run time)
     if (exact && gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<3, 0, true>), grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
+    else if (exact && add) hipLaunchKernelGGL((tr_gemm_nt_kernel<3, 0, false, true>), grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else if (gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<2, 0, true>), grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
+    else if (add) hipLaunchKernelGGL((tr_gemm_nt_kernel<2, 0, false, true>), grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
     else hipLaunchKernelGGL(tr_gemm_nt_kernel<2>, grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
     return AXVS_OK;
   }
+  // X2 (nullable): added to X element-wise in the loader (q = k = Linear(x + pos) without an x + pos buffer)
   int fwd(const float* X, const float* W, float* Y, long long M, int N, int K, float beta = 0.f, const GemmEpi* ep = nullptr,
-          bool exact = false) const {
+          bool exact = false, const float* X2 = nullptr) const {
     GemmEpi e = ep ? *ep : GemmEpi{nullptr, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, 0.f};
     e.beta = beta;
-    return nt(X, W, Y, M, N, K, GemmLd{K, K, N, 0}, e, exact);
+    return nt(X, W, Y, M, N, K, GemmLd{K, K, N, 0, X2}, e, exact);
   }
   // dW[N,K] = dY[M,N]^T X[M,K]: the reduction runs over the M rows and the output is small, so the rows are split kSplit ways
   // into `part` ([kSplit + 1][N*K]); the caller sums the partials (deterministic).  ldy / ldx: row strides of dY / X (0: N / K).
@@ -284,13 +289,12 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   const int C = d.C;
   const Drop none = make_drop(0.f, 0, 0);
   int rc;
-  const float* const xa = pos ? c.sc.a : xin;           // q = k = x (+ pos): the cross-clip layer has no positional term (CC:96)
-  if (pos) c.add(xin, pos, c.sc.a, (size_t)M * C);
+  // q = k = Linear(x + pos): the sum is formed in the GEMM's A loader (the cross-clip layer has no positional term, CC:96)
   // (the biases ride in the GEMM epilogues; `ex`: option train_exact -- forward products with fp32 accuracy)
   const bool ex = g_train_exact != 0;
   const GemmEpi eq{w.q_b, 1.f, 0, none, 0.f}, ek{w.k_b, 1.f, 0, none, 0.f}, ev{w.v_b, 1.f, 0, none, 0.f};
-  if ((rc = c.g.fwd(xa, w.q_w, s.q, M, C, C, 0.f, &eq, ex)) != AXVS_OK) return rc;
-  if ((rc = c.g.fwd(xa, w.k_w, s.k, M, C, C, 0.f, &ek, ex)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(xin, w.q_w, s.q, M, C, C, 0.f, &eq, ex, pos)) != AXVS_OK) return rc;
+  if ((rc = c.g.fwd(xin, w.k_w, s.k, M, C, C, 0.f, &ek, ex, pos)) != AXVS_OK) return rc;
   if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C, 0.f, &ev, ex)) != AXVS_OK) return rc;
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
   const size_t lds_mfma = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);

@@ -353,7 +353,10 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         self.mfma_dtype = mfma_dtype
         self.return_attn = False
         self.use_generated_pos = True   # a `pos` made by PositionEmbeddingSine3D is evaluated in-kernel instead of read (SineTag)
-        self.recompute = True           # train() mode: backward rebuilds the activations instead of keeping them (training.py)
+        # train() mode: False (default) keeps the activations between forward and backward like the reference under autograd does
+        # (44 C floats per token and layer: 0.74 GB at the metric shape -- sized for 288 GB of HBM); True: backward rebuilds them
+        # from (src, pos, seed) first (+1 forward, nothing kept)
+        self.recompute = False
         self.dropout_seed: Optional[int] = None   # train() mode: fixed dropout seed (tests); None = drawn from torch's CPU generator
         self._packed: Optional[Tensor] = None
         self._packed_key = None

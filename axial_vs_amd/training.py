@@ -6,8 +6,9 @@ backward pass both run in the library (``axvs_axial_layer_train_fwd`` / ``_bwd``
 softmax / dropout / LayerNorm kernels, split-precision bf16 MFMA GEMMs for the Linear layers); this file is the ``torch.autograd.Function`` that
 binds them, nothing is computed here.
 
-* recompute (default): the forward pass keeps only (src, pos, seed); backward rebuilds the activations first.  ``recompute=False``
-  keeps them (~44 M C floats per layer) and saves the second forward.
+* ``layer.recompute = False`` (default): the activations stay in HBM between forward and backward (~44 C floats per token and layer),
+  like the reference under autograd.  ``layer.recompute = True``: the forward pass keeps only (src, pos, seed); backward rebuilds the
+  activations first (one more forward, no memory held).
 * dropout masks are a counter-based hash of (seed, site, element offset) -- see include/axvs.h -- so they are regenerated, never
   stored; ``seed`` comes from torch's CPU generator (``torch.manual_seed`` makes runs repeatable) or ``layer.dropout_seed``.
 * AMP: under ``torch.autocast`` the inputs are cast to fp32 at the boundary and the layer returns fp32 (LayerNorm output is fp32

@@ -532,15 +532,16 @@ def main():
                         train_step()
                     torch.cuda.synchronize(dev)
                     return (time.perf_counter() - t_tr) / n_t
-                el = time_train()
-                tl.recompute = False
-                el_kept = time_train()
+                el = time_train()                       # default: activations kept between forward and backward
+                tl.recompute = True
+                el_rec = time_train()
                 extras["train_step"] = {"ms_per_step": round(el * 1e3, 3), "value": round(B * T / el, 1), "unit": "frames/s",
-                                        "ms_per_step_activations_kept": round(el_kept * 1e3, 3),
+                                        "ms_per_step_recompute": round(el_rec * 1e3, 3),
                                         "what": "forward + backward of one layer through the training tier (axvs_axial_layer_train_fwd/_bwd), "
-                                                "dropout 0.1 / attn_drop 0.1; ms_per_step: activations recomputed in backward (default), "
-                                                "ms_per_step_activations_kept: layer.recompute = False.  Linear layers on the library's own "
-                                                "split-precision bf16 MFMA GEMMs (fp32-accurate forward), attention on fp32 MFMA",
+                                                "dropout 0.1 / attn_drop 0.1; ms_per_step: activations kept in HBM between forward and backward "
+                                                "(the default, as the reference under autograd), ms_per_step_recompute: layer.recompute = True "
+                                                "(backward rebuilds them).  Linear layers on the library's own split-precision bf16 MFMA GEMMs "
+                                                "(fp32-accurate forward), attention on fp32 MFMA",
                                         "dtype": "f32 (GEMM operands split into bf16 pieces, fp32 accumulate)"}
                 del tl, s_t, g_t
             except RuntimeError as e:
