@@ -22,6 +22,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                   wc_cfg3     BASELINE config 3: the whole within-clip tracking module at ConvNeXt-T size, ms per forward (N = 1)
                   train_step  forward + backward of the layer through the training tier, ms per step (N = 1)
                   cc_train_cfg4  forward + backward of the cross-clip module in train() mode at config 4, ms per step (N = 1)
+                  wc_train_cfg3  forward + backward of the whole within-clip module in train() mode at config 3, ms per step (N = 1)
 """
 from __future__ import annotations
 
@@ -583,6 +584,46 @@ def main():
                 del cct, cq_t, pf_t, dl_t, dm_t
             except RuntimeError as e:
                 extras["cc_train_cfg4"] = {"error": str(e)[:200]}
+
+        # ---- one training step of the whole within-clip module at BASELINE config 3 (deformable op fwd / bwd + axial training tiers) ----
+        if not args.no_extras and world == 1:
+            try:
+                class _Shape2:
+                    def __init__(self, c, s_):
+                        self.channels, self.stride = c, s_
+                chans, sizes3 = {"res3": 192, "res4": 384, "res5": 768}, {"res3": (64, 64), "res4": (32, 32), "res5": (16, 16)}
+                wct = ax.WithinClipTrackingModule(
+                    {k: _Shape2(c, st_) for (k, c), st_ in zip(chans.items(), (8, 16, 32))}, transformer_dropout=0.1, transformer_attn_drop=0.1,
+                    transformer_nheads=8, transformer_dim_feedforward=1024, transformer_num_stages=2, transformer_spatial_layers=2,
+                    transformer_temporal_layers=4, transformer_temporal_attn_type="axial-trajectory", transformer_conv_dims=256,
+                    transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
+                    num_clip_frames=4, cross_clip_training=True)
+                sdw = wct.within_clip_tracking_module.state_dict()
+                sdw.update(random_weights({k: tuple(v.shape) for k, v in sdw.items() if v.dtype.is_floating_point}, 3))
+                wct.within_clip_tracking_module.load_state_dict(sdw, strict=True)
+                wct = wct.to(dev).train()
+                gw = torch.Generator(device=dev).manual_seed(3)
+                featsw = {k: torch.randn(4, chans[k], *sizes3[k], device=dev, generator=gw) for k in chans}
+                dw = {k: torch.randn(4, chans[k], *sizes3[k], device=dev, generator=gw) for k in chans}
+
+                def wc_step():
+                    o_, _, _ = wct.forward_features(dict(featsw))
+                    sum((o_[k] * dw[k]).sum() for k in chans).backward()
+                for _ in range(3):
+                    wc_step()
+                torch.cuda.synchronize(dev)
+                t_w = time.perf_counter()
+                for _ in range(5):
+                    wc_step()
+                torch.cuda.synchronize(dev)
+                el = (time.perf_counter() - t_w) / 5
+                extras["wc_train_cfg3"] = {"ms_per_step": round(el * 1e3, 3), "value": round(4 / el, 1), "unit": "frames/s",
+                                           "what": "forward + backward of WithinClipTrackingModule.train() at BASELINE config 3 (4 frames, 2 stages x (1 "
+                                                   "deformable layer + 2 axial-trajectory layers on res5 / res4), dropout 0.1): the deformable op's forward "
+                                                   "/ backward and the axial layers' training tier in HIP, 1x1 convolution + GroupNorm glue on torch"}
+                del wct, featsw, dw
+            except RuntimeError as e:
+                extras["wc_train_cfg3"] = {"error": str(e)[:200]}
 
         # ---- CPU baseline: the oracle (a torch CPU port of the reference) on this host, same workload ----
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks would just wait)
