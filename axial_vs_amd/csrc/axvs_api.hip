@@ -1077,6 +1077,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_reassoc")) { g_no_reassoc = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_valu")) { g_train_valu = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_exact")) { g_train_exact = value; return AXVS_OK; }
+  if (key && !strcmp(key, "train_spatial_wgs")) { g_spatial_wgs = value > 0 ? value : 512; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }

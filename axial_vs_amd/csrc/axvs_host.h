@@ -21,6 +21,8 @@ inline int g_train_valu = 0;
 // forward decides the ReLU masks); axvs_set_option("train_exact", 0) makes them two-piece (1.5e-5 per product, 3 MFMAs) like the
 // backward ones, 2: three pieces for the input-gradient GEMMs as well -- see axvs_train_gemm.h.  Process-wide like train_valu.
 inline int g_train_exact = 1;
+// axvs_set_option("train_spatial_wgs", n): workgroups the spatial-attention kernels of the training tier are spread over
+inline int g_spatial_wgs = 512;
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

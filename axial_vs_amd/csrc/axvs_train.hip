@@ -269,13 +269,14 @@ bool mfma_spatial(const Dims& d, const RowMap& rm) {
   return d.D == 32 && !g_train_valu && lds_q <= 160 * 1024;
 }
 
-// Launch grid of the fp32 MFMA spatial-attention kernels: x = (sequence, head); with fewer than 256 of those (the cross-clip module has
-// B sequences) the 16-row tiles each wave walks (y) and the frames (z) are spread over more workgroups.  The within-clip layer
-// (B x W x heads >= 256 workgroups) keeps y = z = 1.
+// Launch grid of the fp32 MFMA spatial-attention kernels: x = (sequence, head); the 16-row tiles each wave walks (y) and the frames (z)
+// are spread over more workgroups until there are about g_spatial_wgs of them -- every (tile, frame) is computed by exactly one
+// wave with the same instructions whatever the split.
 dim3 spatial_grid(int sh, int tiles, int frames) {
-  if (sh >= 256) return dim3(sh, 1, 1);
+  const int target = g_spatial_wgs;                  // workgroups wanted (option "train_spatial_wgs")
+  if (sh >= target) return dim3(sh, 1, 1);
   const int z = frames;
-  int y = (512 + sh * z - 1) / (sh * z);
+  int y = (target + sh * z - 1) / (sh * z);
   const int ymax = (tiles + 3) / 4;
   y = y > ymax ? ymax : (y < 1 ? 1 : y);
   return dim3(sh, y, z);

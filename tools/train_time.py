@@ -9,7 +9,12 @@ import axial_vs_amd as ax
 B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 from axial_vs_amd import _lib
-for exact, recompute in ((0, True), (0, False), (1, True), (1, False)):
+for a in sys.argv[2:]:          # library options: key=value
+    if "=" in a:
+        k, v = a.split("=")
+        _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), "axvs_set_option")
+        print("option", k, v)
+for exact, recompute in ((1, True), (1, False)):
     _lib.lib().axvs_set_option(b"train_exact", exact)
     layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, dropout=0.1, attn_drop=0.1, n_heads=8)
     layer.load_state_dict(orc.random_weights(orc.axial_layer_param_shapes(C, F), 1), strict=True)
