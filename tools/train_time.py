@@ -16,7 +16,8 @@ for a in sys.argv[2:]:          # library options: key=value
         print("option", k, v)
 for exact, recompute in ((1, True), (1, False)):
     _lib.lib().axvs_set_option(b"train_exact", exact)
-    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, dropout=0.1, attn_drop=0.1, n_heads=8)
+    pd = float(os.environ.get("AXVS_P_DROP", "0.1"))
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, dropout=pd, attn_drop=pd, n_heads=8)
     layer.load_state_dict(orc.random_weights(orc.axial_layer_param_shapes(C, F), 1), strict=True)
     layer = layer.cuda().train()
     layer.recompute = recompute
