@@ -38,7 +38,8 @@ thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
 thread_local int g_no_reassoc = 0;       // option "no_reassoc": generic tier computes k2, v2 = proj_kv(x) for every frame slot (the reference's form)
 thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN activation is exact GELU (F.gelu) instead of ReLU -- set by the
-                                         // host module around its calls for activation="gelu" (WC/temporal_attention.py:9-17); unfused FFN path
+                                         // host module around its calls for activation="gelu" (WC/temporal_attention.py:9-17): the FFN then runs on the
+                                         // stand-alone fused kernels' GELU instantiation instead of riding in the width-pass kernel
 // Two round-3 variants that are bit-identical to the default path and measured NOT faster on MI355X (the
 // kernel that emits the next pass's q/k/v ends in a 42 MB write burst with nothing to overlap it; 101.7 vs 101.3 us at B = 1, 870 vs
 // 838 us at B = 8) -- kept selectable, off by default:
@@ -225,7 +226,8 @@ bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn, long long row
 bool can_fuse_ffn_into_pass(int T, int F, long long M) {
   return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096 && (M >= 128 * 64 || g_no_small_tiles);
 }
-bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && !g_ffn_gelu && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
+// (activation = gelu: the stand-alone fused FFN kernels have a GELU instantiation; only the width-pass kernel does not carry it)
+bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
 // few rows: one workgroup per (64-row tile, 256-unit chunk of the hidden layer) + a row-wise finishing kernel (axvs_ffn_split.h);
 // bit-identical to the one-workgroup-per-tile kernels, so the row count may decide
 bool ffn_split_applies(int C, int heads, int F, long long M) {
@@ -468,9 +470,14 @@ template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
             hipStream_t st, float* part = nullptr /* [F/256][M][256] fp32: enables the chunk-per-workgroup form for few rows */) {
   if (part != nullptr && ffn_split_applies(C, heads, F, M)) {
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF>))) return rc;
-    hipLaunchKernelGGL((ffn_split_kernel<BF>), dim3((unsigned)((M + kRows - 1) / kRows), F / 256), dim3(512), kFfnSplitLds, st, (const float*)X, p.w1,
-                       p.b1, p.w2, p.g1, p.be1, part, M, F);
+    const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 256);
+    if (g_ffn_gelu) {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true>))) return rc;
+      hipLaunchKernelGGL((ffn_split_kernel<BF, true>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F);
+    } else {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF>))) return rc;
+      hipLaunchKernelGGL((ffn_split_kernel<BF>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F);
+    }
     hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
                        p.g2, p.be2, out, M, F / 256);
     mark(st, "norm1+ffn+norm2");
@@ -479,9 +486,14 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
   if (ffn_kernel_is_fused(C, heads, F)) {
     const size_t lds = ffn_lds_bytes(F);
     if (lds > 160 * 1024) return fail(AXVS_ERR_ARG, "d_ffn=%d too large for the fused FFN kernel", F);
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>))) return rc;
-    hipLaunchKernelGGL((ffn_fused_kernel<BF>), dim3((unsigned)((M + kRows - 1) / kRows)), dim3(512), lds, st, X, p.w1, p.b1,
-                       p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+    const dim3 fgrid((unsigned)((M + kRows - 1) / kRows));
+    if (g_ffn_gelu) {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF, true>))) return rc;
+      hipLaunchKernelGGL((ffn_fused_kernel<BF, true>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+    } else {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>))) return rc;
+      hipLaunchKernelGGL((ffn_fused_kernel<BF>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+    }
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }

@@ -121,6 +121,9 @@ __device__ __forceinline__ long long nat_row(const RowMap& rm, int mp) {
   return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
 }
 
+// exact (erf) GELU: F.gelu / nn.GELU() defaults
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
 // ---- rows of pixels: their count is whatever the image size gives (193 x 337 maps), so a row may start at any 4-byte boundary
 //      and end inside a group of four.  Alignment-aware 4-float accesses for the kernels that walk such rows.
 // row alignment (floats) of an operand whose rows start at base + i * ld + j * step for integers i, j

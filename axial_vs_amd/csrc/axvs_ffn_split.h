@@ -16,7 +16,7 @@ namespace axvs {
 
 constexpr size_t kFfnSplitLds = 2 * 8 * kTileElems * sizeof(u16) + (size_t)kRows * kEpiLd * sizeof(float);   // y | h | fp32 rows
 
-template <bool BF>
+template <bool BF, bool GELU = false>
 __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict__ X, const u16* __restrict__ W1, const float* __restrict__ b1,
                                                         const u16* __restrict__ W2, const float* __restrict__ g1,
                                                         const float* __restrict__ be1, float* __restrict__ part /* [F/256][M][256] */,
@@ -67,8 +67,13 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       f32x4 v = acc1[nt][mt];
-      v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
-      v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+      if constexpr (GELU) {
+        v[0] = gelu_exact(v[0] + bias.x); v[1] = gelu_exact(v[1] + bias.y);
+        v[2] = gelu_exact(v[2] + bias.z); v[3] = gelu_exact(v[3] + bias.w);
+      } else {
+        v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
+        v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+      }
       act_store4<BF>(htile, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);
     }
   }

@@ -168,7 +168,9 @@ __device__ __forceinline__ void ffn_stage_params(const FfnLds& l, const float* _
 // Precondition: xtile rows 8*wave .. 8*wave+7 were written by THIS wave (or a barrier has passed), parameters staged and a
 // barrier passed since; w1f holds the linear1 fragments of chunk `crot` (rotation `rot`).
 // `row_off(r)`: element offset of tile row r in `out`, or < 0 for a row that does not exist (ragged last tile).
-template <bool BF, class RowOff>
+// GELU: the hidden activation is the exact (erf) GELU of F.gelu instead of ReLU (WC/temporal_attention.py:9-17) -- a template flag so
+// that the ReLU kernels (every shipped config, and the width-pass kernel that carries this body) keep their code as it is.
+template <bool BF, class RowOff, bool GELU = false>
 __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], const u16* __restrict__ W1, const u16* __restrict__ W2,
                                          float* __restrict__ out, RowOff row_off, int F, int rot, int crot, int tid, int wt = 0) {
   constexpr int C = 256, KB = 8;
@@ -226,8 +228,13 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         f32x4 v = acc1[nt][mt];
-        v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
-        v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+        if constexpr (GELU) {
+          v[0] = gelu_exact(v[0] + bias.x); v[1] = gelu_exact(v[1] + bias.y);
+          v[2] = gelu_exact(v[2] + bias.z); v[3] = gelu_exact(v[3] + bias.w);
+        } else {
+          v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
+          v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+        }
         act_store4<BF>(l.htile, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
       }
     }
@@ -298,7 +305,7 @@ constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kT
 inline size_t ffn_lds_bytes(int F) { return kFfnTiles + (size_t)(F + 5 * 256) * sizeof(float); }
 
 // stand-alone kernel: X fp32 [M][256] rows in, out rows out
-template <bool BF>
+template <bool BF, bool GELU = false>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict__ X, const u16* __restrict__ W1,
                                                         const float* __restrict__ b1, const u16* __restrict__ W2,
                                                         const float* __restrict__ b2, const float* __restrict__ g1,
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
     }
   }
   __syncthreads();                       // parameters staged
-  ffn_body<BF>(l, w1f, W1, W2, out, [=](int r) { return m0 + r < M ? (m0 + r) * C : -1ll; }, F, rot, crot, tid);
+  auto row_off = [=](int r) { return m0 + r < M ? (m0 + r) * C : -1ll; };
+  ffn_body<BF, decltype(row_off), GELU>(l, w1f, W1, W2, out, row_off, F, rot, crot, tid);
 }
 
 

@@ -158,7 +158,6 @@ struct ALoadBlockedSplit3 {
 };
 
 // ---------------- epilogues: 4 consecutive output channels n..n+3 of token m ----------------
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <bool BF>
 struct EpiBlocked16 {

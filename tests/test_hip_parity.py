@@ -943,8 +943,10 @@ def test_pos3d_with_padding_mask_golden(name):
 
 @pytest.mark.parametrize("name", __import__("golden_util").GELU)
 def test_axial_layer_gelu_golden(name):
-    """activation="gelu" (round 1 refused it): the FFN leaves the fused kernels for LayerNorm / GEMM+GELU / GEMM / LayerNorm; the
-    attention passes stay fused.  The option is scoped to the call: a ReLU layer afterwards is unaffected."""
+    """activation="gelu" (round 1 refused it; round 2 ran the FFN on LayerNorm / GEMM+GELU / GEMM / LayerNorm): C = 256 layers run the
+    FFN on the GELU instantiation of the stand-alone fused FFN kernels (norm1 -> linear1 -> exact GELU -> linear2 -> residual ->
+    norm2 in one or two launches); the attention passes stay fused.  The option is scoped to the call: a ReLU layer afterwards is
+    unaffected."""
     import axial_vs_amd as ax
     z, m = load(name)
     w = weights(z, m)
