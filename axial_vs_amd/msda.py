@@ -198,31 +198,44 @@ class MSDeformAttn(nn.Module):
 
 
     def _forward_autograd(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index, input_padding_mask):
-        """train() mode (or gradients wanted): the reference module's forward as it stands (OPS/modules/ms_deform_attn.py:93-125) --
-        its nn.Linear / softmax / location arithmetic under torch autograd around `MSDeformAttnFunction`, whose forward and
-        backward are the HIP kernels of the native op (axvs_msda_core_fwd / _bwd)."""
-        N, Len_q, _ = query.shape
-        N, Len_in, _ = input_flatten.shape
+        """train() mode (or gradients wanted): the arithmetic of the reference module (OPS/modules/ms_deform_attn.py:93-125) under
+        torch autograd -- the four nn.Linear layers, the softmax over the L*P logits, the sampling locations -- around
+        `MSDeformAttnFunction`, whose forward and backward are the HIP kernels of the native op (axvs_msda_core_fwd / _bwd)."""
         shp = _shapes_host(input_spatial_shapes)
-        if sum(h * w for h, w in shp) != Len_in:
+        if sum(h * w for h, w in shp) != input_flatten.shape[1]:
             raise AssertionError("input_spatial_shapes do not cover input_flatten")
-        value = self.value_proj(input_flatten)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
-        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
-        if reference_points.shape[-1] == 2:
-            offset_normalizer = torch.tensor([[w, h] for h, w in shp], dtype=sampling_offsets.dtype, device=sampling_offsets.device)
-            sampling_locations = reference_points[:, :, None, :, None, :] + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
-        else:
-            raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(reference_points.shape[-1]))
-        output = MSDeformAttnFunction.apply(value, shp, input_level_start_index, sampling_locations, attention_weights, self.im2col_step)
-        return self.output_proj(output)
+        sampled = deformable_sample(self.value_proj, self.sampling_offsets, self.attention_weights, query, input_flatten, reference_points, shp,
+                                    input_level_start_index, input_padding_mask, self.n_heads, self.n_points, self.im2col_step)
+        return self.output_proj(sampled)
+
+
+def sampling_locations(reference_points: Tensor, offsets: Tensor, shp, n_points: int) -> Tensor:
+    """OPS/modules/ms_deform_attn.py:107-117: reference points [N,Lq,L,2] + offsets in pixels of each level, or reference boxes
+    [N,Lq,L,4] + offsets in units of half a box per point.  offsets [N,Lq,M,L,P,2] -> locations of the same shape, in [0,1]."""
+    ref = reference_points[:, :, None, :, None, :]
+    if reference_points.shape[-1] == 2:
+        wh = torch.tensor([[w, h] for h, w in shp], dtype=offsets.dtype, device=offsets.device)
+        return ref + offsets / wh[None, None, None, :, None, :]
+    if reference_points.shape[-1] == 4:
+        return ref[..., :2] + offsets / n_points * ref[..., 2:] * 0.5
+    raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'.format(reference_points.shape[-1]))
+
+
+def deformable_sample(value_proj, offsets_proj, weights_proj, query, value_in, reference_points, shp, level_start_index, padding_mask,
+                      n_heads: int, n_points: int, im2col_step: int) -> Tensor:
+    """The part of MSDeformAttn.forward in front of output_proj, differentiable: value_proj (+ padding mask) -> [N,S,M,D]; offsets and
+    softmaxed weights from the query; `MSDeformAttnFunction` on the sampling locations.  Shared by the Video-kMaX module and the
+    Tube-Link plugin (same math: TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:589-611)."""
+    N, Lq, _ = query.shape
+    S, L = value_in.shape[1], len(shp)
+    value = value_proj(value_in)
+    if padding_mask is not None:
+        value = value.masked_fill(padding_mask[..., None], 0.0)
+    value = value.view(N, S, n_heads, -1)
+    offsets = offsets_proj(query).view(N, Lq, n_heads, L, n_points, 2)
+    weights = F.softmax(weights_proj(query).view(N, Lq, n_heads, L * n_points), -1).view(N, Lq, n_heads, L, n_points)
+    return MSDeformAttnFunction.apply(value, shp, level_start_index, sampling_locations(reference_points, offsets, shp, n_points), weights,
+                                      im2col_step)
 
 
 class MSDeformAttnTransformerEncoderLayer(nn.Module):

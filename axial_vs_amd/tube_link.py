@@ -179,44 +179,25 @@ class MultiScaleDeformableAxialTrajectoryAttention(nn.Module):
 
     def _forward_autograd(self, query, value, identity, query_pos, query_pos3d, key_padding_mask, reference_points, spatial_shapes,
                           level_start_index):
-        """train() mode: the reference's forward as it stands (TL:561-638) under torch autograd -- its Linear / softmax / location
-        arithmetic around `MSDeformAttnFunction` (HIP forward / backward of the deformable op) and the temporal encoder, whose
-        axial-trajectory layers run the library's training tier."""
-        from .msda import MSDeformAttnFunction, _shapes_host
-        if value is None:
-            value = query
-        if identity is None:
-            identity = query
-        if query_pos is not None:
-            query = query + query_pos
+        """train() mode: the reference's forward (TL:561-638) under torch autograd -- deformable sampling (msda.deformable_sample: the
+        op's HIP forward / backward inside), then per temporal level `f + gamma * encoder(f)` with the axial-trajectory layers on the
+        library's training tier, output_proj, dropout, identity shortcut."""
+        from .msda import _shapes_host, deformable_sample
+        value = query if value is None else value
+        shortcut = query if identity is None else identity
+        q = query if query_pos is None else query + query_pos
         if not self.batch_first:
-            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
-        bs, num_query, _ = query.shape
-        num_value = value.shape[1]
+            q, value = q.permute(1, 0, 2), value.permute(1, 0, 2)
         shp = _shapes_host(spatial_shapes)
-        assert sum(h * w for h, w in shp) == num_value
-        value = self.value_proj(value)
-        if key_padding_mask is not None:
-            value = value.masked_fill(key_padding_mask[..., None], 0.0)
-        value = value.view(bs, num_value, self.num_heads, -1)
-        sampling_offsets = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
-        attention_weights = self.attention_weights(query).view(bs, num_query, self.num_heads, self.num_levels * self.num_points).softmax(-1)
-        attention_weights = attention_weights.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
-        if reference_points.shape[-1] == 2:
-            normalizer = torch.tensor([[w, h] for h, w in shp], dtype=sampling_offsets.dtype, device=sampling_offsets.device)
-            sampling_locations = reference_points[:, :, None, :, None, :] + sampling_offsets / normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / self.num_points * reference_points[:, :, None, :, None, 2:] * 0.5
-        else:
-            raise ValueError(f'Last dim of reference_points must be 2 or 4, but get {reference_points.shape[-1]} instead.')
-        output = MSDeformAttnFunction.apply(value, shp, level_start_index, sampling_locations, attention_weights, self.im2col_step)
-        outs = list(torch.split(output, [h * w for h, w in shp], dim=1))
-        for i in range(self.num_temporal_levels):
-            f = outs[i].contiguous()
+        assert sum(h * w for h, w in shp) == value.shape[1]
+        sampled = deformable_sample(self.value_proj, self.sampling_offsets, self.attention_weights, q, value, reference_points, shp,
+                                    level_start_index, key_padding_mask, self.num_heads, self.num_points, self.im2col_step)
+        levels = list(torch.split(sampled, [h * w for h, w in shp], dim=1))
+        for i in range(self.num_temporal_levels):                       # coarsest levels first (TL:613-630); the others pass through
+            f = levels[i].contiguous()
             enc = self.temporal_layer(src=f, pos=query_pos3d[i])
-            outs[i] = f + self.gamma * enc if self.skip_connect else enc
-        output = self.output_proj(torch.cat(outs, dim=1))
+            levels[i] = f + self.gamma * enc if self.skip_connect else enc
+        out = self.output_proj(torch.cat(levels, dim=1))
         if not self.batch_first:
-            output = output.permute(1, 0, 2)
-        return self.dropout(output) + identity
+            out = out.permute(1, 0, 2)
+        return self.dropout(out) + shortcut
