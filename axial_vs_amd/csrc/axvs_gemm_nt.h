@@ -64,6 +64,7 @@ struct GemmEpi {
   Drop dr;             // then dropout, element index row * N + col (thr = 0: none)
   float beta;          // 0: overwrite C, 1: add to it
   const float* res = nullptr;   // optional residual [M][ldc], added last (out = ... + res)
+  const float* res2 = nullptr;  // a second one (d_in = dv Wv + d_out + da in one epilogue)
   // out16 != nullptr: the result goes out as ONE 16-bit piece in the blocked activation layout [N/32][M][32] (kind16: 1 f16, 2 bf16)
   // instead of fp32 rows; rows flagged in zero_rows (nullable, one byte per row) are written as zeros
   u16* out16 = nullptr;
@@ -269,6 +270,10 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
       }
       if (ep.res) {
         const float4 o = *reinterpret_cast<const float4*>(ep.res + gm * ld.c + gn);
+        t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
+      }
+      if (ep.res2) {
+        const float4 o = *reinterpret_cast<const float4*>(ep.res2 + gm * ld.c + gn);
         t[0] += o.x; t[1] += o.y; t[2] += o.z; t[3] += o.w;
       }
       *reinterpret_cast<float4*>(cp) = make_float4(t[0], t[1], t[2], t[3]);

@@ -743,7 +743,8 @@ __global__ __launch_bounds__(256) void tr_colsum_kernel(const float* __restrict_
 
 // stage 2 (also the reduction of split-K weight-gradient partials): out[c] = sum_i part[i][c].  A block = 64 float4 columns x 4
 // partial groups (1 KiB contiguous per wave and partial row), joined through LDS in a fixed order; C % 4 == 0.
-__global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, size_t C, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __restrict__ part, int nblk, size_t C, float* __restrict__ out,
+                                                               float mul = 1.f) {
   __shared__ float4 red[256];
   const size_t c4 = (size_t)blockIdx.x * 64 + (threadIdx.x & 63), n4 = C / 4;
   const int g = threadIdx.x >> 6;
@@ -759,14 +760,15 @@ __global__ __launch_bounds__(256) void tr_colsum_final_kernel(const float* __res
   __syncthreads();
   if (g == 0 && c4 < n4) {
     const float4 b = red[threadIdx.x + 64], c = red[threadIdx.x + 128], d = red[threadIdx.x + 192];
-    *reinterpret_cast<float4*>(out + c4 * 4) = float4{a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w};
+    *reinterpret_cast<float4*>(out + c4 * 4) =
+        float4{(a.x + b.x + c.x + d.x) * mul, (a.y + b.y + c.y + d.y) * mul, (a.z + b.z + c.z + d.z) * mul, (a.w + b.w + c.w + d.w) * mul};
   }
 }
 
 // the same for TWO partial sets in one launch (a weight gradient and its bias gradient): blocks [0, blocks_a) reduce set a, the rest set b
 __global__ __launch_bounds__(256) void tr_colsum_final_pair_kernel(const float* __restrict__ part_a, size_t Ca, float* __restrict__ out_a,
                                                                     const float* __restrict__ part_b, size_t Cb, float* __restrict__ out_b,
-                                                                    int nblk, int blocks_a) {
+                                                                    int nblk, int blocks_a, float mul = 1.f) {
   __shared__ float4 red[256];
   const bool second = (int)blockIdx.x >= blocks_a;
   const float* part = second ? part_b : part_a;
@@ -786,7 +788,8 @@ __global__ __launch_bounds__(256) void tr_colsum_final_pair_kernel(const float* 
   __syncthreads();
   if (g == 0 && c4 < n4) {
     const float4 b = red[threadIdx.x + 64], c = red[threadIdx.x + 128], d = red[threadIdx.x + 192];
-    *reinterpret_cast<float4*>(out + c4 * 4) = float4{a.x + b.x + c.x + d.x, a.y + b.y + c.y + d.y, a.z + b.z + c.z + d.z, a.w + b.w + c.w + d.w};
+    *reinterpret_cast<float4*>(out + c4 * 4) =
+        float4{(a.x + b.x + c.x + d.x) * mul, (a.y + b.y + c.y + d.y) * mul, (a.z + b.z + c.z + d.z) * mul, (a.w + b.w + c.w + d.w) * mul};
   }
 }
 

@@ -231,8 +231,9 @@ struct Ctx {
     if (x) hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(N, 256)), dim3(256), 0, st, (const float*)sc.part_b, nblk, (size_t)N, out_b);
   }
   // dW[N,K] = dY[M,N]^T X[M,K]; db (nullable) [N] = column sums of dY -- the bias gradient rides in the same GEMM launch
+  // mul: the gradients are those of mul * dY (a scale that sits between the Linear layer and the tensor dY belongs to)
   int wgrad(const float* dY, const float* X, float* dW, long long M, int N, int K, float* db = nullptr, long long ldy = 0,
-            long long ldx = 0) const {
+            long long ldx = 0, float mul = 1.f) const {
     int np = 0;
     int rc = g.wgrad_partials(dY, X, sc.wpart, M, N, K, &np, db ? sc.part_a : nullptr, ldy, ldx);
     if (rc != AXVS_OK) return rc;
@@ -240,17 +241,21 @@ struct Ctx {
     if (db) {      // one launch adds the partials of the weight and of the bias gradient (same order of additions as the single kernel)
       const unsigned ba = blocks(n, 256), bb = blocks(N, 256);
       hipLaunchKernelGGL(tr_colsum_final_pair_kernel, dim3(ba + bb), dim3(256), 0, st, (const float*)sc.wpart, n, dW, (const float*)sc.part_a, (size_t)N, db,
-                         np, (int)ba);
+                         np, (int)ba, mul);
     } else {
-      hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW);
+      hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, st, (const float*)sc.wpart, np, n, dW, mul);
     }
     return AXVS_OK;
   }
   // dX[M,K] = beta dX + dY[M,N] W[N,K]      (through W^T, in the forward GEMM's form)
   // exact: three-piece operands (see axvs_train_gemm.h) -- where the result feeds a sum that cancels analytically
-  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta, long long ldy = 0, bool exact = false) const {
+  // mul: dX = mul * dY W; res / res2 (nullable, [M][K]): added in the epilogue
+  int dgrad(const float* dY, const float* W, float* dX, long long M, int N, int K, float beta, long long ldy = 0, bool exact = false,
+            float mul = 1.f, const float* res = nullptr, const float* res2 = nullptr) const {
     hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, sc.wt, N, K);
-    GemmEpi e{nullptr, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, beta};
+    GemmEpi e{nullptr, mul, 0, Drop{0u, 0u, 0u, 1.f}, beta};
+    e.res = res;
+    e.res2 = res2;
     return g.nt(dY, sc.wt, dX, M, K, N, GemmLd{ldy ? ldy : N, N, K, 0}, e, exact || g_train_exact >= 2);
   }
   int spatial_lds(const void* fn, size_t bytes) const { return bytes > 64 * 1024 ? ensure_max_lds(fn) : AXVS_OK; }
@@ -348,9 +353,9 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   })
   if ((rc = c.wgrad(sc.dkv2, s.x, gw.proj_kv_w, M * T, 2 * C, C, gw.proj_kv_b)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dkv2, w.proj_kv_w, sc.dx, M * T, 2 * C, C, 0.f)) != AXVS_OK) return rc;
-  hipLaunchKernelGGL(tr_scale_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dq2, MC / 4, c.scale);   // q2 = scale (proj_q(xd))
-  if ((rc = c.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C, gw.proj_q_b)) != AXVS_OK) return rc;
-  if ((rc = c.dgrad(sc.dq2, w.proj_q_w, sc.dxd, M, C, C, 0.f)) != AXVS_OK) return rc;
+  // q2 = scale (proj_q(xd)): the scale rides in the two GEMMs' epilogues
+  if ((rc = c.wgrad(sc.dq2, s.xd, gw.proj_q_w, M, C, C, gw.proj_q_b, 0, 0, c.scale)) != AXVS_OK) return rc;
+  if ((rc = c.dgrad(sc.dq2, w.proj_q_w, sc.dxd, M, C, C, 0.f, 0, false, c.scale)) != AXVS_OK) return rc;
   hipLaunchKernelGGL(tr_diag_scatter_add_kernel, dim3(blocks(MC / 4)), dim3(256), 0, c.st, sc.dx, (const float*)sc.dxd, M, T, d.HW, C);
   // spatial half
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
@@ -383,9 +388,7 @@ int pass_bwd(const Ctx& c, const float* d_out, const float* xin, const float* po
   if ((rc = c.dgrad(sc.dq, w.q_w, sc.da, M, C, C, 0.f)) != AXVS_OK) return rc;
   if ((rc = c.dgrad(sc.dk, w.k_w, sc.da, M, C, C, 1.f)) != AXVS_OK) return rc;
   // d_in = d_out (residual) + dv Wv + da;   d_pos (+)= da
-  if (hipMemcpyAsync(d_in, d_out, MC * sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
-  if ((rc = c.dgrad(sc.dv, w.v_w, d_in, M, C, C, 1.f)) != AXVS_OK) return rc;
-  c.add(d_in, sc.da, d_in, MC);
+  if ((rc = c.dgrad(sc.dv, w.v_w, d_in, M, C, C, 0.f, 0, false, 1.f, d_out, sc.da)) != AXVS_OK) return rc;
   if (d_pos) {
     if (pos_first) {
       if (hipMemcpyAsync(d_pos, sc.da, MC * sizeof(float), hipMemcpyDeviceToDevice, c.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
