@@ -106,7 +106,7 @@ int make_dims(Dims& d, int B, int T, int H, int W, int C, int heads, int F) {
   if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || F <= 0) return fail(AXVS_ERR_ARG, "non-positive dimension");
   if (C % heads) return fail(AXVS_ERR_ARG, "C=%d must be a multiple of heads=%d", C, heads);
   const int D = C / heads;
-  if (D != 8 && D != 16 && D != 32) return fail(AXVS_ERR_ARG, "training tier: head_dim=%d not built (8, 16, 32)", D);
+  if (D != 8 && D != 16 && D != 32 && D != 64) return fail(AXVS_ERR_ARG, "training tier: head_dim=%d not built (8, 16, 32, 64)", D);
   if (F % 8) return fail(AXVS_ERR_ARG, "training tier: d_ffn=%d must be a multiple of 8", F);
   if (T > 16) return fail(AXVS_ERR_ARG, "training tier: T=%d > 16 frames per clip not built", T);
   const long long M = (long long)B * T * H * W;
@@ -204,6 +204,7 @@ inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + pe
   switch (D_) {                                      \
     case 8: { constexpr int kD = 8; __VA_ARGS__; } break;   \
     case 16: { constexpr int kD = 16; __VA_ARGS__; } break; \
+    case 64: { constexpr int kD = 64; __VA_ARGS__; } break; \
     default: { constexpr int kD = 32; __VA_ARGS__; } break; \
   }
 

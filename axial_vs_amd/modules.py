@@ -362,6 +362,8 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         self._packed_key = None
 
     def _dtype(self) -> str:
+        if self.linear1.in_features // self.n_heads > 32:
+            return "f32"          # head_dim 64 (dim 256 / 4 heads, 512 / 8): built on the fp32 tier only; the 16-bit tiers stop at 32
         return self.mfma_dtype or _DEFAULT_DTYPE
 
     def _pack(self) -> Tensor:
@@ -407,7 +409,8 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         if self._dtype() == "f32":
             # fp32 tier: the training tier's forward with dropout off -- fp32 MFMA (v_mfma_f32_16x16x4_f32) attention, fp32 GEMMs, fp32
             # everywhere (1e-6 against the float64 oracle).  ~12x the time of the 16-bit tier: for operands beyond the fp16 range
-            # (enable_range_check reports them) or callers that need more than the 1e-3 bar.  head_dim in {8, 16, 32}, T <= 8.
+            # (enable_range_check reports them) or callers that need more than the 1e-3 bar.  head_dim in {8, 16, 32, 64}, T <= 16
+            # (head_dim 64 always runs here).
             if self.return_attn:
                 raise NotImplementedError("axial_vs_amd: attention maps are an output of the 16-bit tier (mfma_dtype 'f16' / 'bf16')")
             from .training import axial_layer_train

@@ -364,7 +364,7 @@ int axvs_scaled_residual(const float* a, const float* b, const float* gamma, flo
  * dropout(p_dropout) on the spatial attention maps (:32, :55 -- the layer passes `dropout` as the attention's attn_drop, :164-165),
  * dropout1(p_attn_drop) on both pass outputs (:166, :204, :213), dropout2 / dropout3(p_dropout) in the FFN (:172-174, :182-183).
  * fp32 activations in natural [B,T,H,W,C] order; the Linear layers run on split-precision bf16 MFMA GEMMs (axvs_train_gemm.h,
- * no vendor BLAS); head_dim in {8,16,32}; T <= 16.
+ * no vendor BLAS); head_dim in {8,16,32,64}; T <= 16.
  * Dropout masks are a pure function of (seed, site, element offset in the reference's tensor at that site):
  *   h = seed ^ (site * 0x9E3779B9);  h = fmix32(h ^ lo32(idx));  h = fmix32(h ^ hi32(idx));  keep iff (h >> 8) >= floor(p * 2^24)
  *   (fmix32 = MurmurHash3's finaliser); sites: 1 height attention map [(B W) heads, T H, T, H], 2 height pass output [(B W), T H, C],

@@ -221,7 +221,7 @@ def test_training_buffer_sizes_and_argument_checks():
     M, C, T, F = 4 * 64 * 64, 256, 4, 1024
     assert saved >= 4 * (2 * (6 + 3 * T) * M * C + 4 * M * C + M * F)          # per pass q,k,v,xd,q2,o + x + kv2; pass outputs, z, u; r
     assert L.axvs_axial_layer_train_scratch_bytes(1, 4, 64, 64, 256, 8, 1024, 1) > L.axvs_axial_layer_train_scratch_bytes(1, 4, 64, 64, 256, 8, 1024, 0)
-    assert L.axvs_axial_layer_train_saved_bytes(1, 4, 8, 8, 512, 8, 1024) == 0 and b"head_dim" in L.axvs_last_error()
+    assert L.axvs_axial_layer_train_saved_bytes(1, 4, 8, 8, 512, 4, 1024) == 0 and b"head_dim" in L.axvs_last_error()
     assert L.axvs_axial_layer_train_saved_bytes(1, 17, 8, 8, 256, 8, 1024) == 0 and b"T=17" in L.axvs_last_error()
 
 

@@ -176,10 +176,39 @@ def test_encoder_stack_trains():
 
 def test_unsupported_training_shapes_fail_loudly():
     import axial_vs_amd as ax
-    layer = ax.TemporalAxialTrajectoryAttentionLayer(512, 256, n_heads=8).cuda().train()      # head_dim 64
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(512, 256, n_heads=4).cuda().train()      # head_dim 128
     src, pos = orc.synthetic_clip(1, 2, 512, 4, 4, 1)
     with pytest.raises(RuntimeError, match="head_dim"):
         layer(src.cuda(), pos.cuda())
+
+
+@pytest.mark.parametrize("C,heads", [(256, 4), (512, 8), (128, 2)])
+def test_head_dim_64_trains_and_infers_on_the_fp32_tier(C, heads):
+    """The reference accepts any dim % num_heads == 0 (WC/temporal_attention.py:21-27); head_dim 64 (256 / 4, 512 / 8) is built on the
+    fp32 tier: train() against autograd on the float64 oracle, eval() routed to the same tier (the 16-bit kernels stop at 32)."""
+    B, T, H, W, F = 1, 3, 7, 10, 128
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 640 + heads)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 640 + heads)
+    d_out = torch.randn(B * T, H * W, C, generator=torch.Generator().manual_seed(3))
+    wd = {k: v.double().requires_grad_(True) for k, v in w.items()}
+    sd, pd = src.double().requires_grad_(True), pos.double().requires_grad_(True)
+    ref = orc.axial_layer_train(sd, pd, wd, heads, 0.1, 0.1, 77)
+    ref.backward(d_out.double())
+    layer = make_layer(C, F, w, 0.1, 0.1, 77, heads)
+    out, d_src, d_pos, grads = run(layer, src, pos, d_out)
+    scale = max(float(v.grad.norm()) for v in wd.values())
+    errs = [rel_err(out, ref.detach()), rel_err(d_src, sd.grad), rel_err(d_pos, pd.grad)] + \
+           [float((grads[k].double() - wd[k].grad).norm() / max(float(wd[k].grad.norm()), 1e-3 * scale)) for k in wd]
+    print(f"head_dim {C // heads} ({C} / {heads}): train worst error {max(errs):.2e}")
+    assert max(errs) < TOL, errs
+    layer.eval()
+    assert layer._dtype() == "f32"
+    with torch.no_grad():
+        y = layer(src.cuda(), pos.cuda())[0].cpu()
+        ref_eval = orc.axial_layer_train(src.double(), pos.double(), {k: v.double() for k, v in w.items()}, heads, 0.0, 0.0, 0)
+    e = rel_err(y, ref_eval)
+    print(f"head_dim {C // heads}: eval {e:.2e}")
+    assert e < 1e-5
 
 
 def test_training_random_shapes_sweep():
