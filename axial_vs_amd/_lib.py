@@ -205,3 +205,45 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().axvs_last_error().decode(errors="replace")
         raise RuntimeError(f"axial_vs_amd: {what} failed (code {rc}): {msg}")
+
+
+# ---- torch.autocast -> 16-bit products in the training tier -------------------------------------------------------------------------
+# Under autocast the reference's nn.Linear layers multiply 16-bit operands with fp32 accumulation.  The training tier does the same
+# when it is called under autocast: library option "train_amp" (1: bf16 pieces, 2: fp16 pieces, one per operand) for the duration
+# of the forward call, and again for the backward call of the same graph.  `AMP_COMPUTE = False` (or `module.amp_compute = False`)
+# keeps the split-precision (fp32-accurate) products under autocast.
+AMP_COMPUTE = True
+_AMP_MODE = 0
+
+
+def autocast_mode(owner=None) -> int:
+    import torch
+    if not torch.is_autocast_enabled() or not AMP_COMPUTE or (owner is not None and not getattr(owner, "amp_compute", True)):
+        return 0
+    return 2 if torch.get_autocast_dtype("cuda") == torch.float16 else 1
+
+
+def current_amp() -> int:
+    return _AMP_MODE
+
+
+class train_amp:
+    """Context manager: the library's X W^T GEMMs of the training tier run with `mode` (0 off, 1 bf16, 2 fp16) inside."""
+
+    def __init__(self, mode: int):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        global _AMP_MODE
+        self.prev = _AMP_MODE
+        _AMP_MODE = self.mode
+        if self.mode != self.prev:
+            check(lib().axvs_set_option(b"train_amp", self.mode), "axvs_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        global _AMP_MODE
+        _AMP_MODE = self.prev
+        if self.mode != self.prev:
+            lib().axvs_set_option(b"train_amp", self.prev)
+        return False

@@ -166,6 +166,7 @@ class _CCModuleTrain(torch.autograd.Function):
                 raise hook.error
             _lib.check(rc, "axvs_cc_module_train_fwd")
         ctx.save_for_backward(cq, pf, *ws)
+        ctx.amp = _lib.current_amp()
         ctx.running = rn
         ctx.cfg = cfg
         ctx.saved_buf = saved
@@ -205,9 +206,10 @@ class _CCModuleTrain(torch.autograd.Function):
             lgrads = (_lib.AxvsCCLayerParams * nl)(*[_layer_struct(gptrs[i * _PER_LAYER:(i + 1) * _PER_LAYER]) for i in range(nl)])
             heads = _head_struct(ptrs[nl * _PER_LAYER:], [(m.data_ptr(), v.data_ptr()) for m, v in ctx.running])
             hgrads = _head_grads(gptrs[nl * _PER_LAYER:])
-            rc = L.axvs_cc_module_train_bwd(gl.data_ptr(), gm.data_ptr(), cq.data_ptr(), pf.data_ptr(), layers, C.byref(heads), lgrads,
-                                            C.byref(hgrads), d_cq.data_ptr(), C.byref(c), ctx.saved_buf.data_ptr(), nsaved, scratch.data_ptr(), nscr,
-                                            _stream(dev))
+            with _lib.train_amp(ctx.amp):
+                rc = L.axvs_cc_module_train_bwd(gl.data_ptr(), gm.data_ptr(), cq.data_ptr(), pf.data_ptr(), layers, C.byref(heads), lgrads,
+                                                C.byref(hgrads), d_cq.data_ptr(), C.byref(c), ctx.saved_buf.data_ptr(), nsaved, scratch.data_ptr(), nscr,
+                                                _stream(dev))
             if hook is not None and hook.error is not None:
                 raise hook.error
             _lib.check(rc, "axvs_cc_module_train_bwd")
@@ -242,7 +244,8 @@ def cc_module_train(mod, clip_query: Tensor, panoptic_features: Tensor):
     running = [(bn.running_mean, bn.running_var) for bn in bns]
     args = (clip_query, panoptic_features, cfg, running, *module_parameters(mod))
     if torch.is_autocast_enabled():
-        with torch.autocast(device_type="cuda", enabled=False):
+        amp = _lib.autocast_mode(mod)       # (read before autocast is switched off for the call)
+        with torch.autocast(device_type="cuda", enabled=False), _lib.train_amp(amp):
             logits, masks, stats = _CCModuleTrain.apply(*args)
     else:
         logits, masks, stats = _CCModuleTrain.apply(*args)
@@ -315,6 +318,7 @@ class _CCLayersTrain(torch.autograd.Function):
             _lib.check(L.axvs_cc_layers_train_fwd(cq.data_ptr(), out.data_ptr(), layers, C.byref(c), saved.data_ptr(), nsaved, scratch.data_ptr(), nscr,
                                                   _stream(dev)), "axvs_cc_layers_train_fwd")
         ctx.save_for_backward(cq, *ws)
+        ctx.amp = _lib.current_amp()
         ctx.cfg = (full, rates, p_attn, p_aspp, seed)
         ctx.saved_buf = saved
         ctx.in_dtypes = (clip_query.dtype, [w.dtype for w in params])
@@ -346,8 +350,9 @@ class _CCLayersTrain(torch.autograd.Function):
             ptrs, gptrs = [w.data_ptr() for w in ws], [t.data_ptr() for t in grads]
             layers = (_lib.AxvsCCLayerParams * nl)(*[_layer_struct(ptrs[i * _PER_LAYER:(i + 1) * _PER_LAYER]) for i in range(nl)])
             lgrads = (_lib.AxvsCCLayerParams * nl)(*[_layer_struct(gptrs[i * _PER_LAYER:(i + 1) * _PER_LAYER]) for i in range(nl)])
-            _lib.check(L.axvs_cc_layers_train_bwd(g.data_ptr(), cq.data_ptr(), layers, lgrads, d_cq.data_ptr(), C.byref(c), ctx.saved_buf.data_ptr(),
-                                                  nsaved, scratch.data_ptr(), nscr, _stream(dev)), "axvs_cc_layers_train_bwd")
+            with _lib.train_amp(ctx.amp):
+                _lib.check(L.axvs_cc_layers_train_bwd(g.data_ptr(), cq.data_ptr(), layers, lgrads, d_cq.data_ptr(), C.byref(c), ctx.saved_buf.data_ptr(),
+                                                      nsaved, scratch.data_ptr(), nscr, _stream(dev)), "axvs_cc_layers_train_bwd")
         qd, wd = ctx.in_dtypes
         return (d_cq.to(qd), None, *[t.to(dt) for t, dt in zip(grads, wd)])
 
@@ -363,6 +368,7 @@ def cc_layers_train(mod, clip_query: Tensor, num_layers: int, rates, p_attn: flo
     cfg = ((int(B), int(Q), int(Tc), int(num_layers)), tuple(int(r) for r in rates), float(p_attn), float(p_aspp), int(seed))
     args = (clip_query, cfg, *chain_parameters(mod, num_layers))
     if torch.is_autocast_enabled():
-        with torch.autocast(device_type="cuda", enabled=False):
+        amp = _lib.autocast_mode(mod)       # (read before autocast is switched off for the call)
+        with torch.autocast(device_type="cuda", enabled=False), _lib.train_amp(amp):
             return _CCLayersTrain.apply(*args)
     return _CCLayersTrain.apply(*args)

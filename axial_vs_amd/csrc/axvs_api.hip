@@ -1089,6 +1089,11 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_reassoc")) { g_no_reassoc = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_valu")) { g_train_valu = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_exact")) { g_train_exact = value; return AXVS_OK; }
+  if (key && !strcmp(key, "train_amp")) {
+    if (value < 0 || value > 2) return fail(AXVS_ERR_ARG, "train_amp: 0 (off), 1 (bf16 products) or 2 (fp16 products)");
+    g_train_amp = value;
+    return AXVS_OK;
+  }
   if (key && !strcmp(key, "train_spatial_wgs")) { g_spatial_wgs = value > 0 ? value : 512; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }

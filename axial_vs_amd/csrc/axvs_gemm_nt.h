@@ -81,7 +81,10 @@ struct GemmEpi {
 // d_ffn 1024, two-piece forward: d_src 7e-3 .. 2e-2 in max-norm, relative L2 3e-4, output 5e-6).  The three-piece forward costs
 // 0.06 ms of a 3.3 ms step (these GEMMs are bound by their fp32 operand traffic, not by the matrix pipe), so it is the default;
 // the backward GEMMs are smooth in their operands and stay two-piece.
-template <int NS>
+// NS = 1 (option `train_amp`, set by the Python layer under torch.autocast): ONE 16-bit piece per operand -- the products torch's
+// autocast gives the reference's nn.Linear layers (16-bit operands, fp32 accumulation); F16 selects fp16 pieces (autocast's default
+// dtype on GPUs; the caller scales the loss as with the reference) instead of bf16.
+template <int NS, bool F16 = false>
 __device__ __forceinline__ void split_n(const float4& a, const float4& b, u16x8 (&p)[NS]) {
   const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -89,9 +92,13 @@ __device__ __forceinline__ void split_n(const float4& a, const float4& b, u16x8 
     float r = x[i];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const __bf16 h = (__bf16)r;
-      p[s][i] = __builtin_bit_cast(u16, h);
-      r -= (float)h;                       // exact in fp32
+      if constexpr (F16) {
+        p[s][i] = __builtin_bit_cast(u16, (_Float16)r);
+      } else {
+        const __bf16 h = (__bf16)r;
+        p[s][i] = __builtin_bit_cast(u16, h);
+        r -= (float)h;                       // exact in fp32
+      }
     }
   }
 }
@@ -105,8 +112,8 @@ constexpr size_t gemm_nt_lds() {
 // kernel of the common case carries none of that code (these kernels are sensitive to their size: +3 us per launch with both
 // loaders in one body)
 // ADD (with !GEN): the x + pos addend ld.a2 on the 16-byte path (the general loader takes it at run time).
-template <int NS, int TU = 0, bool GEN = false, bool ADD = false>
-__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+template <int NS, int TU = 0, bool GEN = false, bool ADD = false, bool F16 = false>
+__global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                          float* __restrict__ C, long long M, int N, int K, GemmLd ld, GemmEpi ep) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
   u16* const sbuf = reinterpret_cast<u16*>(gsmem);            // [2 stages][A pieces | B pieces][128 rows][32] (rows chunk-swizzled)
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
     constexpr int SL = decltype(slot_tag)::value;
     u16* const base = sbuf + stage * kStage;
     u16x8 p[NS];
-    split_n<NS>(ra[SL][0], ra[SL][1], p);
+    split_n<NS, F16>(ra[SL][0], ra[SL][1], p);
 #pragma unroll
     for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x8*>(base + s * kGTileElems + soff) = p[s];
-    split_n<NS>(rb[SL][0], rb[SL][1], p);
+    split_n<NS, F16>(rb[SL][0], rb[SL][1], p);
 #pragma unroll
     for (int s = 0; s < NS; ++s) *reinterpret_cast<u16x8*>(base + (NS + s) * kGTileElems + soff) = p[s];
   };
@@ -204,9 +211,11 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {                        // D[n = 4 fg + r][m = fi]
         f32x4 c = acc[mt][nt];
-        c = H16<true>::mfma(bf[nt][0], af[0], c);
-        c = H16<true>::mfma(bf[nt][0], af[1], c);
-        c = H16<true>::mfma(bf[nt][1], af[0], c);
+        c = H16<!F16>::mfma(bf[nt][0], af[0], c);
+        if constexpr (NS >= 2) {
+          c = H16<true>::mfma(bf[nt][0], af[1], c);
+          c = H16<true>::mfma(bf[nt][1], af[0], c);
+        }
         if constexpr (NS == 3) {
           c = H16<true>::mfma(bf[nt][1], af[1], c);
           c = H16<true>::mfma(bf[nt][0], af[2], c);

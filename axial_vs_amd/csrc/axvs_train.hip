@@ -36,6 +36,12 @@ struct Gemm {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, false, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, true, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, true, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<true>))) return rc;
     return ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false>));
   }
@@ -50,6 +56,18 @@ struct Gemm {
     // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
     //  fixed cost -- ~11 us whatever K -- not by the load round trips of the k-loop)
     const bool gen = gemm_nt_general(ld, K), add = ld.a2 != nullptr;   // (the general loader takes the addend at run time)
+    if (g_train_amp) {                // torch.autocast: one 16-bit piece per operand (1: bf16, 2: fp16), whatever the caller's `exact`
+#define AXVS_NT1(F16_)                                                                                                                              \
+  do {                                                                                                                                              \
+    if (gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<1, 0, true, false, F16_>), grid, dim3(512), gemm_nt_lds<1>(), st, X, W, Y, M, N, K, ld, e);      \
+    else if (add) hipLaunchKernelGGL((tr_gemm_nt_kernel<1, 0, false, true, F16_>), grid, dim3(512), gemm_nt_lds<1>(), st, X, W, Y, M, N, K, ld, e); \
+    else hipLaunchKernelGGL((tr_gemm_nt_kernel<1, 0, false, false, F16_>), grid, dim3(512), gemm_nt_lds<1>(), st, X, W, Y, M, N, K, ld, e);         \
+  } while (0)
+      if (g_train_amp == 2) AXVS_NT1(true);
+      else AXVS_NT1(false);
+#undef AXVS_NT1
+      return AXVS_OK;
+    }
     if (exact && gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<3, 0, true>), grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else if (exact && add) hipLaunchKernelGGL((tr_gemm_nt_kernel<3, 0, false, true>), grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);
     else if (exact) hipLaunchKernelGGL(tr_gemm_nt_kernel<3>, grid, dim3(512), gemm_nt_lds<3>(), st, X, W, Y, M, N, K, ld, e);

@@ -12,7 +12,11 @@ binds them, nothing is computed here.
 * dropout masks are a counter-based hash of (seed, site, element offset) -- see include/axvs.h -- so they are regenerated, never
   stored; ``seed`` comes from torch's CPU generator (``torch.manual_seed`` makes runs repeatable) or ``layer.dropout_seed``.
 * AMP: under ``torch.autocast`` the inputs are cast to fp32 at the boundary and the layer returns fp32 (LayerNorm output is fp32
-  under autocast in the reference as well); gradients come back in each input's own dtype, so ``GradScaler`` works unchanged.
+  under autocast in the reference as well); gradients come back in each input's own dtype, so ``GradScaler`` works unchanged.  The
+  Linear layers then multiply ONE 16-bit piece per operand in the autocast dtype (bf16 / fp16, fp32 accumulation) -- what autocast
+  gives the reference's ``nn.Linear`` -- in the forward and in the input-gradient GEMMs (library option ``train_amp``);
+  ``layer.amp_compute = False`` keeps the split-precision (fp32-accurate) products.  Attention, softmax, LayerNorm and the weight
+  gradients stay fp32 / split precision.
 """
 from __future__ import annotations
 
@@ -87,6 +91,7 @@ class _AxialLayerTrain(torch.autograd.Function):
                                                     float(p_dropout), float(p_attn_drop), int(seed), saved_ptr, nsaved, scratch_ptr, nscr,
                                                     _stream(dev)), "axvs_axial_layer_train_fwd")
         ctx.save_for_backward(s, p, *ws)
+        ctx.amp = _lib.current_amp()
         ctx.cfg = (dims, float(p_dropout), float(p_attn_drop), int(seed), bool(recompute))
         ctx.saved_buf = saved
         ctx.in_dtypes = (src.dtype, pos.dtype, [w.dtype for w in params])
@@ -123,10 +128,11 @@ class _AxialLayerTrain(torch.autograd.Function):
                 scratch_ptr, saved_ptr = buf.data_ptr(), ctx.saved_buf.data_ptr()
             st = _struct([w.data_ptr() for w in ws])
             gs = _struct([t.data_ptr() for t in grads])
-            _lib.check(L.axvs_axial_layer_train_bwd(g.data_ptr(), s.data_ptr(), p.data_ptr(), C.byref(st), C.byref(gs), d_src.data_ptr(),
-                                                    d_pos.data_ptr() if want_pos else None, B, T, H, W, C_, heads, F, p_dropout, p_attn_drop,
-                                                    seed, int(recompute), saved_ptr, nsaved, scratch_ptr, nscr, _stream(dev)),
-                       "axvs_axial_layer_train_bwd")
+            with _lib.train_amp(ctx.amp):
+                _lib.check(L.axvs_axial_layer_train_bwd(g.data_ptr(), s.data_ptr(), p.data_ptr(), C.byref(st), C.byref(gs), d_src.data_ptr(),
+                                                        d_pos.data_ptr() if want_pos else None, B, T, H, W, C_, heads, F, p_dropout, p_attn_drop,
+                                                        seed, int(recompute), saved_ptr, nsaved, scratch_ptr, nscr, _stream(dev)),
+                           "axvs_axial_layer_train_bwd")
         # (the saved activations stay with ctx until autograd releases it: a second backward through the same graph --
         #  retain_graph=True, shared subgraphs -- finds them again)
         sd, pd, wd = ctx.in_dtypes
@@ -154,6 +160,7 @@ def axial_layer_train(layer, src: Tensor, pos: Tensor, dropout: bool = True, rec
     dims = (int(B), int(T), int(H), int(W), int(C_), int(layer.n_heads), int(layer.linear1.out_features))
     args = (src, pos, dims, p_drop, p_attn, int(seed), bool(recompute), *layer_parameters(layer))
     if torch.is_autocast_enabled():
-        with torch.autocast(device_type="cuda", enabled=False):
+        amp = _lib.autocast_mode(layer)       # (read before autocast is switched off for the call)
+        with torch.autocast(device_type="cuda", enabled=False), _lib.train_amp(amp):
             return _AxialLayerTrain.apply(*args)
     return _AxialLayerTrain.apply(*args)

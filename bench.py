@@ -534,15 +534,26 @@ def main():
                     torch.cuda.synchronize(dev)
                     return (time.perf_counter() - t_tr) / n_t
                 el = time_train()                       # default: activations kept between forward and backward
+
+                def train_step_amp():
+                    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                        y_t = tl(s_t, pos)[0]
+                    y_t.backward(g_t)
+                plain_step, train_step = train_step, train_step_amp
+                el_amp = time_train()                   # under torch.autocast: one bf16 piece per operand in the X W^T GEMMs
+                train_step = plain_step
                 tl.recompute = True
                 el_rec = time_train()
                 extras["train_step"] = {"ms_per_step": round(el * 1e3, 3), "value": round(B * T / el, 1), "unit": "frames/s",
                                         "ms_per_step_recompute": round(el_rec * 1e3, 3),
+                                        "ms_per_step_autocast_bf16": round(el_amp * 1e3, 3),
                                         "what": "forward + backward of one layer through the training tier (axvs_axial_layer_train_fwd/_bwd), "
                                                 "dropout 0.1 / attn_drop 0.1; ms_per_step: activations kept in HBM between forward and backward "
                                                 "(the default, as the reference under autograd), ms_per_step_recompute: layer.recompute = True "
                                                 "(backward rebuilds them).  Linear layers on the library's own split-precision bf16 MFMA GEMMs "
-                                                "(fp32-accurate forward), attention on fp32 MFMA",
+                                                "(fp32-accurate forward), attention on fp32 MFMA; ms_per_step_autocast_bf16: the same step called "
+                                                "under torch.autocast(bfloat16) -- forward and input-gradient GEMMs with one bf16 piece per operand "
+                                                "(what autocast gives the reference's nn.Linear), everything else unchanged",
                                         "dtype": "f32 (GEMM operands split into bf16 pieces, fp32 accumulate)"}
                 del tl, s_t, g_t
             except RuntimeError as e:

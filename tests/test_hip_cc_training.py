@@ -153,6 +153,7 @@ def test_cc_training_amp_autocast_and_grad_scaling():
     loss_of(mod(q32, p32), 1.0)[0].backward()
     g32 = {k: v.grad.clone() for k, v in mod.named_parameters()}
     mod2 = make_module(m, w, 5)
+    mod2.amp_compute = False                                     # split-precision products under autocast too: the boundary alone is under test
     q16 = cq.cuda().half().requires_grad_(True)
     with torch.autocast(device_type="cuda", dtype=torch.float16):
         loss, logits, masks = loss_of(mod2(q16, pf.cuda().half()), 1024.0)
@@ -163,6 +164,39 @@ def test_cc_training_amp_autocast_and_grad_scaling():
         assert v.grad.dtype == torch.float32
         assert rel_l2(v.grad.cpu() / 1024.0, g32[k].cpu()) < 1e-5 or float(g32[k].norm()) < 1e-4 * max(float(x.norm()) for x in g32.values()), k
     assert rel_l2(q16.grad.float().cpu() / 1024.0, q32.grad.cpu()) < 1e-3      # d_clip_query is returned in fp16
+
+
+def test_cc_training_amp_runs_16_bit_products():
+    """The default under autocast (the shipped config's SOLVER.AMP): the X W^T GEMMs of the module -- q/k/v, projections, ASPP
+    branches, heads, the mask einsum -- multiply one fp16 piece per operand, as autocast makes the reference's Linear / Conv / einsum
+    do; BatchNorm statistics, softmax, LayerNorm and weight gradients stay fp32 / split precision.  Against the fp32 tier on the
+    same inputs: relative L2 at the fp16 level."""
+    z, m = load(CC_TRAIN[1])
+    w = weights(z, m)
+    cq, pf = inputs(m)
+    dl = [x.cuda() for x in t(z["d_logits"])]
+    dm = [x.cuda() for x in t(z["d_masks"])]
+
+    def run(amp):
+        mod = make_module(m, w, 5)
+        q = cq.cuda().requires_grad_(True)
+        if amp:
+            with torch.autocast(device_type="cuda", dtype=torch.float16):
+                out = mod(q, pf.cuda())
+        else:
+            out = mod(q, pf.cuda())
+        logits = [a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]
+        masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+        ((sum((a * b).sum() for a, b in zip(logits, dl)) + sum((a * b).sum() for a, b in zip(masks, dm))) * 64.0).backward()
+        return torch.stack(masks).detach().cpu(), q.grad.cpu() / 64.0, {k: v.grad.cpu() / 64.0 for k, v in mod.named_parameters()}
+
+    mk32, dq32, g32 = run(False)
+    mk16, dq16, g16 = run(True)
+    scale = max(float(v.norm()) for v in g32.values())
+    e_w = max(float((g16[k] - g32[k]).norm()) / max(float(g32[k].norm()), 1e-2 * scale) for k in g32)
+    e = dict(masks=rel_l2(mk16, mk32), d_clip_query=rel_l2(dq16, dq32), worst_param_grad=e_w)
+    print("cross-clip module under fp16 autocast vs the fp32 tier (relative L2):", {k: f"{v:.2e}" for k, v in e.items()})
+    assert 1e-6 < e["masks"] < 1e-2 and e["d_clip_query"] < 5e-2 and e_w < 5e-2, e
 
 
 @pytest.mark.parametrize("name", ["g6_tl_cc_head_Tc3_Q16_f2_L2", "g6_tl_cc_head_Tc2_Q20_f1_L1", "g6_tl_cc_head_Tc4_Q100_f2_L4"])

@@ -130,6 +130,7 @@ def test_amp_autocast_and_grad_scaling():
     w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 13)
     src, pos = orc.synthetic_clip(B, T, C, H, W, 13)
     layer = make_layer(C, F, w, 0.1, 0.1, 99)
+    layer.amp_compute = False                                   # split-precision products under autocast too: the boundary alone is under test
     s32 = src.cuda().half().float().requires_grad_(True)        # the same fp16-representable inputs, in fp32 without autocast
     out32 = layer(s32, pos.cuda().half().float())[0]
     out32.sum().backward()
@@ -146,6 +147,45 @@ def test_amp_autocast_and_grad_scaling():
         assert v.grad.dtype == torch.float32
         assert rel_l2(v.grad.cpu() / 1024.0, g32[k].cpu()) < 1e-5 or float(g32[k].norm()) < 1e-4, k
     assert rel_l2(s16.grad.float().cpu() / 1024.0, s32.grad.cpu()) < 1e-3      # d_src is returned in fp16
+
+
+@pytest.mark.parametrize("dtype,bound", [(torch.float16, 6e-3), (torch.bfloat16, 4e-2)])
+def test_amp_autocast_runs_16_bit_products(dtype, bound):
+    """Under torch.autocast the Linear layers multiply ONE 16-bit piece per operand in the autocast dtype with fp32 accumulation (what
+    autocast gives the reference's nn.Linear: WC/temporal_attention.py under SOLVER.AMP) -- library option train_amp for the forward
+    and the backward of that graph.  Against the fp32 tier on the same inputs: relative L2 at the 16-bit level (max-norm is not a
+    measure here: a ReLU unit that changes side moves one token's gradient by 1e-2), linear in the loss scale (bf16: to the bit;
+    fp16: the scaled run is the more accurate one), and off again after the call."""
+    from axial_vs_amd import _lib
+    B, T, C, H, W, F = 1, 3, 256, 12, 10, 512
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 17)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 17)
+    layer = make_layer(C, F, w, 0.1, 0.1, 99)
+    s32 = src.cuda().requires_grad_(True)
+    out32 = layer(s32, pos.cuda())[0]
+    out32.square().sum().backward()
+    g32 = {k: v.grad.clone() for k, v in layer.named_parameters()}
+    res = {}
+    for scale in (1.0, 256.0):
+        layer.zero_grad()
+        s16 = src.cuda().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=dtype):
+            out = layer(s16, pos.cuda())[0]
+            loss = out.square().sum() * scale
+        assert out.dtype == torch.float32 and _lib.current_amp() == 0
+        loss.backward()
+        res[scale] = (out.detach(), s16.grad.clone(), {k: v.grad.clone() for k, v in layer.named_parameters()})
+    out, d_src, g = res[1.0]
+    e_out, e_src = rel_l2(out.cpu(), out32.detach().cpu()), rel_l2(d_src.cpu(), s32.grad.cpu())
+    e_w = max(rel_l2(g[k].cpu(), g32[k].cpu()) for k in g if float(g32[k].norm()) > 1e-3 * max(float(x.norm()) for x in g32.values()))
+    print(f"autocast {dtype}: output {e_out:.2e}, d_src {e_src:.2e}, worst parameter gradient {e_w:.2e} (relative L2 against the fp32 tier)")
+    assert 1e-5 < e_out < bound and e_src < 4 * bound and e_w < 4 * bound      # 16-bit products did run, and stay at the 16-bit level
+    if dtype == torch.bfloat16:           # fp32's exponent range: a power-of-two loss scale changes no bit
+        assert torch.equal(res[256.0][1] / 256.0, d_src)
+        for k in g:
+            assert torch.equal(res[256.0][2][k] / 256.0, g[k]), k
+    else:                                 # fp16 pieces: small gradients are subnormal in fp16 without the scale -- why GradScaler exists
+        assert rel_l2(res[256.0][1].cpu() / 256.0, s32.grad.cpu()) <= e_src * 1.05
 
 
 def test_encoder_stack_trains():

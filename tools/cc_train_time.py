@@ -59,8 +59,14 @@ else:
     mod = mod.to(dev).train()
     from axial_vs_amd.cc_training import cc_module_train
 
+    amp_dt = torch.bfloat16 if "--amp" in sys.argv else torch.float16 if "--amp16" in sys.argv else None   # under torch.autocast: 16-bit products
+
     def step():
-        lg, mk = cc_module_train(mod, cq, pf)
+        if amp_dt is not None:
+            with torch.autocast(device_type="cuda", dtype=amp_dt):
+                lg, mk = cc_module_train(mod, cq, pf)
+        else:
+            lg, mk = cc_module_train(mod, cq, pf)
         torch.autograd.backward([lg, mk], [d_l, d_m])
 
     def fwd():

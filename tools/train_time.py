@@ -24,8 +24,14 @@ for exact, recompute in ((1, True), (1, False)):
     src, pos = orc.synthetic_clip(B, T, C, H, W, 1)
     s, p = src.cuda().requires_grad_(True), pos.cuda()
     g = torch.randn_like(s)
+    amp = {"--amp": torch.bfloat16, "--amp16": torch.float16}
+    amp_dt = next((v for k, v in amp.items() if k in sys.argv), None)      # under torch.autocast: 16-bit products in the Linear layers
     def step():
-        out = layer(s, p)[0]
+        if amp_dt is not None:
+            with torch.autocast(device_type="cuda", dtype=amp_dt):
+                out = layer(s, p)[0]
+        else:
+            out = layer(s, p)[0]
         out.backward(g)
     for _ in range(3):
         step()
