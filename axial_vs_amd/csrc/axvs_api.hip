@@ -216,7 +216,9 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 // per sequence, partial key tiles are masked.
 // Frame counts the fused trajectory kernels exist for: T <= 8 (64- / 32-row tiles), and 9 .. 12 on 16-row tiles (x tile T * 8 KiB)
 // for problems with few rows -- whole-video cross-clip inference with up to 12 clips (Q * Tc rows per video).
-bool fused_frames(int T, long long rows) { return T <= 8 || (T <= 12 && rows < 128 * 64 && !g_no_small_tiles); }
+// (The choice depends on T alone, not on the number of rows of the call: the fused and the generic tier differ at the 16-bit level,
+//  and a clip's result must not depend on how many other clips share its batch -- batch sharding is bit-exact.)
+bool fused_frames(int T, long long /*rows*/) { return T <= 8 || (T <= 12 && !g_no_small_tiles); }
 bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn, long long rows) {
   return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && fused_frames(T, rows) && !want_attn && L >= 16 && L <= 128;
 }

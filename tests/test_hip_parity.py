@@ -867,6 +867,26 @@ def test_sharded_forward_real_layer_single_process():
     assert torch.equal(torch.cat(parts, 0), whole)
 
 
+def test_batch_sharding_is_bit_exact_for_9_to_12_frames_too():
+    """The tier that runs 9 .. 12 frames (fused 16-row kernels) is chosen from T alone: a batch whose total row count crosses the
+    old 8192-row switch gives every clip the bits it gets alone (advisor finding, round 2: the fused and the generic tier are
+    only tolerance-equal, so the choice must not depend on the batch)."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = 2, 10, 256, 16, 32, 512               # 10240 rows together, 5120 per clip
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 10)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 10)
+    src, pos = dev(src), dev(pos)
+    whole = layer(src, pos)[0]
+    for b in range(B):
+        alone = layer(src[b * T:(b + 1) * T].contiguous(), pos[b:b + 1].contiguous())[0]
+        assert torch.equal(alone, whole[b * T:(b + 1) * T]), b
+    ref, _, _ = orc.axial_layer(src[:T].double().cpu(), pos[:1].double().cpu(), w, 8, want_attn=False)
+    assert rel_err(whole[:T].cpu(), ref) < TOL_F16
+
+
 def _ref_match_from_embds(tgt, cur):
     """maxtron_cc_model.py:360-369 as written there (torch CPU + SciPy, the reference's own dependency)."""
     from scipy.optimize import linear_sum_assignment
