@@ -171,3 +171,28 @@ def test_cross_clip_training_sync_batch_norm_over_two_ranks():
     for rank, r in res:
         print(rank, {k: f"{v:.1e}" for k, v in r.items()})
         assert max(r.values()) < 1e-4, (rank, r)
+
+
+def test_bench_launcher_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver runs it at N > 1 -- the self-launch into torch.distributed.run, one rank per process,
+    barrier + max-over-ranks timing, rank 0's single JSON line -- with both ranks on cuda:0 over gloo (AXVS_BENCH_SHARE_GPU=1: the
+    box has one GPU; on a node the same command runs one rank per GPU over RCCL)."""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as ge
+    ge.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AXVS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "10", "--warmup", "3",
+           "--no-cpu-baseline", "--no-extras", "--settle-ms", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 alone prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "weak" and j["value"] > 0
+    assert abs(j["value"] - 2 * 4 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3      # whole-job frames/s: both ranks' clips / max-over-ranks time
+    print("bench.py --gpus 2 (two ranks sharing cuda:0 over gloo):", j["value"], j["unit"], j["ms_per_step"], "ms per step")
