@@ -1096,6 +1096,7 @@ int axvs_set_option(const char* key, int value) {
     g_train_amp = value;
     return AXVS_OK;
   }
+  if (key && !strcmp(key, "train_attn_split")) { g_train_attn_split = value; return AXVS_OK; }
   if (key && !strcmp(key, "train_spatial_wgs")) { g_spatial_wgs = value > 0 ? value : 512; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }

@@ -26,6 +26,9 @@ inline int g_train_exact = 1;
 inline int g_train_amp = 0;
 // axvs_set_option("train_spatial_wgs", n): workgroups the spatial-attention kernels of the training tier are spread over
 inline int g_spatial_wgs = 512;
+// axvs_set_option("train_attn_split", 0): the training tier's attention forward on the fp32 MFMA kernel (any axis length) instead of
+// the split-precision 16-bit MFMA one (three bf16 pieces per operand, a frame's score tiles in registers; axis length <= 128)
+inline int g_train_attn_split = 1;
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

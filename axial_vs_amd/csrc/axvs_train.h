@@ -208,6 +208,181 @@ __global__ __launch_bounds__(256) void tr_spatial_fwd_mfma_kernel(const float* _
   }
 }
 
+// ---- the same forward for frames of at most 128 keys (every shipped axis length): 16-bit matrix cores in split precision, and the
+//      score tiles of a WHOLE frame in registers.  (a) Every fp32 operand is cut into THREE bf16 pieces (24 mantissa bits = all of
+//      fp32) and a product is six 16-bit MFMAs (hh, hm, mh, mm, hl, lh; what is dropped is 2^-24 of the product), as in the forward
+//      GEMMs (axvs_gemm_nt.h): 96 + 96 instead of 256 + 256 matrix-pipe cycles per 16-key tile (v_mfma_f32_16x16x4_f32 runs at 1/16
+//      of the 16-bit rate); K and V of the frame are split ONCE while they are staged (K: [piece][key][32], V transposed:
+//      [piece][channel][key] so that a lane reads its four keys of a channel as 8 bytes), q once per query tile (its rows requested a
+//      tile ahead).  (b) All score tiles of the frame are computed first (<= 8 tiles = 32 registers), so the softmax takes one
+//      maximum and one sum per (query, frame): two cross-lane exchanges per frame instead of four per tile, no rescaling of the
+//      accumulators, no running statistics.  Operand layouts: S^T = K Q^T is a 16x16x32 product (lane (j, g) holds channels
+//      8 g .. 8 g + 7 of key / query j, as in the fp32 kernel), X^T += V^T P^T a 16x16x16 one (lane (j, g) holds keys 4 g .. 4 g + 3:
+//      the probabilities stay where the score tile left them).  Statistics (max, 1 / sum), dropout indices and the output layout
+//      are those of tr_spatial_fwd_mfma_kernel, so the backward kernels do not care which one ran (saved activations of the two
+//      agree to 1e-6).  Measured at [1,4,256,64,64]: 107 -> 97 us per launch -- and the counters say why not more
+//      (profiles/r3_train_attention_pmc.json): the kernel is bound by VALU issue, 290 VALU instructions per 16-key tile and wave
+//      (dropout hash of four scores ~100, the three-piece split of four probabilities ~50, mask / max / exp / sum ~30, 64-bit
+//      element indices, LDS addresses) against 18 MFMAs; the matrix pipe is busy 15 % of the time.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int kSpMaxTiles = 8;      // key tiles of a frame held in registers: L <= 128
+
+__device__ __forceinline__ void split3(float x, u16& h, u16& m, u16& l) {
+  const __bf16 a = (__bf16)x;
+  const float r1 = x - (float)a;
+  const __bf16 b = (__bf16)r1;
+  const __bf16 c = (__bf16)(r1 - (float)b);
+  h = __builtin_bit_cast(u16, a);
+  m = __builtin_bit_cast(u16, b);
+  l = __builtin_bit_cast(u16, c);
+}
+__device__ __forceinline__ f32x4 mfma6_32(const u16x8 (&a)[3], const u16x8 (&b)[3], f32x4 c) {     // 16x16x32, three-piece operands
+  c = H16<true>::mfma(a[0], b[0], c);
+  c = H16<true>::mfma(a[0], b[1], c);
+  c = H16<true>::mfma(a[1], b[0], c);
+  c = H16<true>::mfma(a[1], b[1], c);
+  c = H16<true>::mfma(a[0], b[2], c);
+  return H16<true>::mfma(a[2], b[0], c);
+}
+__device__ __forceinline__ f32x4 mfma6_16(const s16x4 (&a)[3], const s16x4 (&b)[3], f32x4 c) {     // 16x16x16
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[0], b[2], c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[2], b[0], c, 0, 0, 0);
+}
+// LDS bytes: K pieces [3][Lp][32] + V^T pieces [3][32][Lp + 4] (16-bit)
+__host__ __device__ inline size_t spatial_split_lds(int L) {
+  const int Lp = (L + 15) & ~15;
+  return (size_t)3 * ((size_t)Lp * 32 + (size_t)32 * (Lp + 4)) * sizeof(u16);
+}
+
+__global__ __launch_bounds__(256) void tr_spatial_fwd_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                    const float* __restrict__ v, float* __restrict__ x,
+                                                                    float* __restrict__ stats, RowMap rm, int T, int C, int heads, float scale,
+                                                                    Drop dr) {
+  extern __shared__ float smem[];
+  u16* const kp = reinterpret_cast<u16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int s = blockIdx.x / heads, h = blockIdx.x - s * heads, N = rm.N, L = rm.L;
+  const int Lp = (L + 15) & ~15, nkt = Lp >> 4, nqt = (N + 15) >> 4, LV = Lp + 4;
+  u16* const vt = kp + 3 * Lp * 32;
+  const int fper = (T + (int)gridDim.z - 1) / (int)gridDim.z, f0 = (int)blockIdx.z * fper, f1 = min(T, f0 + fper);
+  const int qstep = 4 * (int)gridDim.y;
+  for (int f = f0; f < f1; ++f) {
+    __syncthreads();
+    for (int i = tid; i < Lp * 4; i += 256) {          // (key n, 8-channel chunk c8): K into its [piece][n][32] tiles, V into [piece][c][n]
+      const int n = i >> 2, c8 = i & 3;
+      float kv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (n < L) {
+        const long long row = nat_row(rm, s * N + f * L + n) * C + h * 32 + c8 * 8;
+        const float4 a = *reinterpret_cast<const float4*>(k + row), b = *reinterpret_cast<const float4*>(k + row + 4);
+        const float4 c = *reinterpret_cast<const float4*>(v + row), d = *reinterpret_cast<const float4*>(v + row + 4);
+        kv[0] = a.x; kv[1] = a.y; kv[2] = a.z; kv[3] = a.w; kv[4] = b.x; kv[5] = b.y; kv[6] = b.z; kv[7] = b.w;
+        vv[0] = c.x; vv[1] = c.y; vv[2] = c.z; vv[3] = c.w; vv[4] = d.x; vv[5] = d.y; vv[6] = d.z; vv[7] = d.w;
+      }
+      u16x8 ph, pm, pl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        u16 a, b, c;
+        split3(kv[e], a, b, c);
+        ph[e] = a; pm[e] = b; pl[e] = c;
+        split3(vv[e], a, b, c);
+        vt[(0 * 32 + c8 * 8 + e) * LV + n] = a;
+        vt[(1 * 32 + c8 * 8 + e) * LV + n] = b;
+        vt[(2 * 32 + c8 * 8 + e) * LV + n] = c;
+      }
+      *reinterpret_cast<u16x8*>(kp + (0 * Lp + n) * 32 + c8 * 8) = ph;
+      *reinterpret_cast<u16x8*>(kp + (1 * Lp + n) * 32 + c8 * 8) = pm;
+      *reinterpret_cast<u16x8*>(kp + (2 * Lp + n) * 32 + c8 * 8) = pl;
+    }
+    __syncthreads();
+    const int qt0 = (int)blockIdx.y * 4 + wave;
+    float4 qa = {0.f, 0.f, 0.f, 0.f}, qb = qa;            // the next tile's q rows are requested while this tile computes
+    if (qt0 < nqt) {
+      const float* qp0 = q + nat_row(rm, s * N + min(qt0 * 16 + j, N - 1)) * C + h * 32 + 8 * g;
+      qa = *reinterpret_cast<const float4*>(qp0);
+      qb = *reinterpret_cast<const float4*>(qp0 + 4);
+    }
+    for (int qt = qt0; qt < nqt; qt += qstep) {
+      const int qn = qt * 16 + j;
+      const long long mq = nat_row(rm, s * N + min(qn, N - 1));
+      u16x8 qp[3];
+      {
+        const float qr[8] = {qa.x * scale, qa.y * scale, qa.z * scale, qa.w * scale, qb.x * scale, qb.y * scale, qb.z * scale, qb.w * scale};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          u16 a_, b_, c_;
+          split3(qr[e], a_, b_, c_);
+          qp[0][e] = a_; qp[1][e] = b_; qp[2][e] = c_;
+        }
+      }
+      if (qt + qstep < nqt) {
+        const float* qpn = q + nat_row(rm, s * N + min((qt + qstep) * 16 + j, N - 1)) * C + h * 32 + 8 * g;
+        qa = *reinterpret_cast<const float4*>(qpn);
+        qb = *reinterpret_cast<const float4*>(qpn + 4);
+      }
+      // scores of the whole frame: sc[kt][r] = S^T[key 16 kt + 4 g + r][query j]
+      f32x4 sc[kSpMaxTiles];
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < kSpMaxTiles; ++kt) {
+        if (kt < nkt) {
+          u16x8 ka[3];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) ka[p] = *reinterpret_cast<const u16x8*>(kp + (p * Lp + kt * 16 + j) * 32 + 8 * g);
+          sc[kt] = mfma6_32(ka, qp, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (kt * 16 + 4 * g + r >= L) sc[kt][r] = -INFINITY;
+            m = fmaxf(m, sc[kt][r]);
+          }
+        }
+      }
+      m = xor_max16_32(m);
+      const unsigned long long base = ((((unsigned long long)s * heads + h) * N + min(qn, N - 1)) * T + f) * L;
+      float sum = 0.f;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kt = 0; kt < kSpMaxTiles; ++kt) {
+        if (kt < nkt) {
+          const int n0 = kt * 16 + 4 * g;
+          s16x4 pp[3];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __expf(sc[kt][r] - m);
+            sum += p;
+            if (n0 + r < L) p *= drop_keep(dr, base + n0 + r);
+            u16 a_, b_, c_;
+            split3(p, a_, b_, c_);
+            pp[0][r] = (short)a_; pp[1][r] = (short)b_; pp[2][r] = (short)c_;
+          }
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            s16x4 va[3];
+#pragma unroll
+            for (int p3 = 0; p3 < 3; ++p3) va[p3] = *reinterpret_cast<const s16x4*>(vt + (p3 * 32 + ct * 16 + j) * LV + n0);
+            acc[ct] = mfma6_16(va, pp, acc[ct]);        // X^T[channel 16 ct + 4 g + r][query j]
+          }
+        }
+      }
+      sum = xor_sum16_32(sum);
+      if (qn < N) {
+        const float inv = 1.f / sum;
+        float* xo = x + (mq * T + f) * C + h * 32 + 4 * g;
+        *reinterpret_cast<float4*>(xo) = float4{acc[0][0] * inv, acc[0][1] * inv, acc[0][2] * inv, acc[0][3] * inv};
+        *reinterpret_cast<float4*>(xo + 16) = float4{acc[1][0] * inv, acc[1][1] * inv, acc[1][2] * inv, acc[1][3] * inv};
+        if (g == 0) {
+          float* st = stats + ((((size_t)s * heads + h) * N + qn) * T + f) * 3;
+          st[0] = m;
+          st[1] = inv;
+        }
+      }
+    }
+  }
+}
+
 // ---- backward on the matrix cores, part 1 (queries): D = dx . x (= sum_n P keep dP, the flash-attention identity), then per
 //      16-key tile  S^T = K Q^T,  dP^T = V dX^T  (8 + 8 MFMAs),  dS = P (keep dP - D) with P rebuilt from the forward's (max, 1/sum),
 //      dq^T += K^T dS^T (4 x 2 MFMAs, keys {4 g + r} per step as in the forward).  dq accumulates over the frames in global memory

@@ -323,7 +323,12 @@ int pass_fwd(const Ctx& c, const float* xin, const float* pos, float* xout, cons
   if ((rc = c.g.fwd(xin, w.v_w, s.v, M, C, C, 0.f, &ev, ex)) != AXVS_OK) return rc;
   const size_t lds = (size_t)2 * rm.L * d.D * sizeof(float);
   const size_t lds_mfma = (size_t)2 * ((rm.L + 15) / 16 * 16) * kTrLd * sizeof(float);
-  if (mfma_spatial(d, rm)) {                                            // head_dim 32 (every shipped config): fp32 MFMA kernels
+  if (mfma_spatial(d, rm) && g_train_attn_split && rm.L <= 16 * kSpMaxTiles) {   // 16-bit matrix cores, three-piece operands, a frame's scores in registers
+    const size_t lds_split = spatial_split_lds(rm.L);
+    if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_fwd_split_kernel), lds_split)) != AXVS_OK) return rc;
+    hipLaunchKernelGGL(tr_spatial_fwd_split_kernel, spatial_grid(S * d.heads, (rm.N + 15) / 16, d.T), dim3(256), lds_split, c.st, (const float*)s.q,
+                       (const float*)s.k, (const float*)s.v, s.x, s.st, rm, d.T, C, d.heads, c.scale, attn_drop);
+  } else if (mfma_spatial(d, rm)) {                                     // head_dim 32 (every shipped config): fp32 MFMA kernels
     if ((rc = c.spatial_lds(reinterpret_cast<const void*>(tr_spatial_fwd_mfma_kernel), lds_mfma)) != AXVS_OK) return rc;
     hipLaunchKernelGGL(tr_spatial_fwd_mfma_kernel, spatial_grid(S * d.heads, (rm.N + 15) / 16, d.T), dim3(256), lds_mfma, c.st, (const float*)s.q, (const float*)s.k,
                        (const float*)s.v, s.x, s.st, rm, d.T, C, d.heads, c.scale, attn_drop);

@@ -284,11 +284,13 @@ def test_lds_attribute_is_not_pinned_to_the_first_shape():
     shape in the same process (multi-scale training) -- or the height pass of a clip with H > W, which follows the smaller
     width pass inside one backward -- failed to launch.  Two shapes with 304 * ceil16(T * L) > 64 KiB, in increasing order."""
     worst = 0.0
-    for i, (B, T, C, H, W, F) in enumerate([(1, 4, 256, 8, 56, 256), (1, 4, 256, 96, 60, 256)]):
-        # (seed 300 at the first shape puts one linear1 pre-activation within fp32 rounding of zero: the fp32 tier and the float64
-        #  oracle then disagree about that unit's ReLU mask and d_src moves by 1e-2 at one token -- a tie, not an error)
-        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 310 + i)
-        src, pos = orc.synthetic_clip(B, T, C, H, W, 310 + i)
+    for i, (B, T, C, H, W, F, seed) in enumerate([(1, 4, 256, 8, 56, 256, 310), (1, 4, 256, 96, 60, 256, 312)]):
+        # (The seeds are chosen: with 5.9 M hidden units the second shape has a linear1 pre-activation within fp32 rounding of zero
+        #  for about four seeds in ten -- 14 scanned, the same rate with either attention-forward kernel; the fp32 tier and the
+        #  float64 oracle then disagree about that unit's ReLU mask and d_src moves by 1e-2 around one token: a tie, not an error.
+        #  312 .. 314, 317, 318, 400, 403, 405, 407 .. 409, 412 are free of ties with both kernels.)
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), seed)
+        src, pos = orc.synthetic_clip(B, T, C, H, W, seed)
         d_out = torch.randn(B * T, H * W, C, generator=torch.Generator().manual_seed(i))
         wd = {k: v.double().requires_grad_(True) for k, v in w.items()}
         sd, pd = src.double().requires_grad_(True), pos.double().requires_grad_(True)
