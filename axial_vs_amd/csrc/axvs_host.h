@@ -21,7 +21,7 @@ inline int g_train_valu = 0;
 // forward decides the ReLU masks); axvs_set_option("train_exact", 0) makes them two-piece (1.5e-5 per product, 3 MFMAs) like the
 // backward ones, 2: three pieces for the input-gradient GEMMs as well -- see axvs_train_gemm.h.  Process-wide like train_valu.
 inline int g_train_exact = 1;
-// axvs_set_option("train_amp", 1 | 2): the X W^T GEMMs of the training tier (forward and input gradients) take ONE 16-bit piece per
+// axvs_set_option("train_amp", 1 | 2): the GEMMs of the training tier (forward, input gradients, weight gradients) take ONE 16-bit piece per
 // operand (1: bf16, 2: fp16) -- the products torch.autocast gives the reference's nn.Linear layers; 0 (default): split precision
 inline int g_train_amp = 0;
 // axvs_set_option("train_spatial_wgs", n): workgroups the spatial-attention kernels of the training tier are spread over

@@ -42,6 +42,8 @@ struct Gemm {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, true, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, true, false, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false, 1>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false, 2>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<true>))) return rc;
     return ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false>));
   }
@@ -93,8 +95,10 @@ struct Gemm {
     chunk = (chunk + kGK - 1) / kGK * kGK;                 // whole k-steps per split
     const int np = (int)((M + chunk - 1) / chunk);
     const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), (unsigned)np);
-    hipLaunchKernelGGL(tr_gemm_tn_kernel<false>, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b,
-                       GemmLd{ldy ? ldy : N, ldx ? ldx : K, K, 0});
+    const GemmLd ld{ldy ? ldy : N, ldx ? ldx : K, K, 0};
+    if (g_train_amp == 1) hipLaunchKernelGGL((tr_gemm_tn_kernel<false, 1>), grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b, ld);
+    else if (g_train_amp == 2) hipLaunchKernelGGL((tr_gemm_tn_kernel<false, 2>), grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b, ld);
+    else hipLaunchKernelGGL(tr_gemm_tn_kernel<false>, grid, dim3(512), kGemmLds, st, dY, X, part, M, N, K, chunk, part_b, ld);
     *nparts = np;
     return AXVS_OK;
   }

@@ -66,7 +66,8 @@ __device__ __forceinline__ u16x8 tn_frag(const u16* tile, int col0, int fi, int 
 // part_b (nullable): [split][N] partial COLUMN SUMS of dY (the bias gradient of the same Linear layer), added in fp32 from the
 // staging registers by the workgroups of the first k-tile (a bias gradient can be a sum that cancels to zero -- the k bias of a
 // softmax -- so it does not go through the bf16 split) and reduced over the 32 staging rows through LDS in a fixed order.
-template <bool GEN>      // GEN: rows at any 4-byte boundary / extents that are not multiples of 4 (see tr_gemm_nt_kernel)
+// AMP = 1 / 2 (option train_amp, under torch.autocast): ONE bf16 / fp16 piece per operand, as in tr_gemm_nt_kernel<1>.
+template <bool GEN, int AMP = 0>      // GEN: rows at any 4-byte boundary / extents that are not multiples of 4 (see tr_gemm_nt_kernel)
 __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
                                                             long long M, int N, int K, long long rows_per_split,
                                                             float* __restrict__ part_b, GemmLd ld) {
@@ -106,12 +107,20 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
       bsum[0] += ra[0].x; bsum[1] += ra[0].y; bsum[2] += ra[0].z; bsum[3] += ra[0].w;
       bsum[4] += ra[1].x; bsum[5] += ra[1].y; bsum[6] += ra[1].z; bsum[7] += ra[1].w;
     }
-    split8(ra[0], ra[1], hi, lo);
-    *reinterpret_cast<u16x8*>(base + soff) = hi;
-    *reinterpret_cast<u16x8*>(base + kGTileElems + soff) = lo;
-    split8(rb[0], rb[1], hi, lo);
-    *reinterpret_cast<u16x8*>(base + 2 * kGTileElems + soff) = hi;
-    *reinterpret_cast<u16x8*>(base + 3 * kGTileElems + soff) = lo;
+    if constexpr (AMP != 0) {
+      u16x8 one[1];
+      split_n<1, AMP == 2>(ra[0], ra[1], one);
+      *reinterpret_cast<u16x8*>(base + soff) = one[0];
+      split_n<1, AMP == 2>(rb[0], rb[1], one);
+      *reinterpret_cast<u16x8*>(base + 2 * kGTileElems + soff) = one[0];
+    } else {
+      split8(ra[0], ra[1], hi, lo);
+      *reinterpret_cast<u16x8*>(base + soff) = hi;
+      *reinterpret_cast<u16x8*>(base + kGTileElems + soff) = lo;
+      split8(rb[0], rb[1], hi, lo);
+      *reinterpret_cast<u16x8*>(base + 2 * kGTileElems + soff) = hi;
+      *reinterpret_cast<u16x8*>(base + 3 * kGTileElems + soff) = lo;
+    }
   };
   f32x4 acc[4][2];
 #pragma unroll
@@ -131,14 +140,19 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       xh[kt] = tn_frag(base + 2 * kGTileElems, wk * 32 + kt * 16, fi, fg);
-      xl[kt] = tn_frag(base + 3 * kGTileElems, wk * 32 + kt * 16, fi, fg);
+      if constexpr (AMP == 0) xl[kt] = tn_frag(base + 3 * kGTileElems, wk * 32 + kt * 16, fi, fg);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const u16x8 yh = tn_frag(base, wn * 64 + nt * 16, fi, fg);
-      const u16x8 yl = tn_frag(base + kGTileElems, wn * 64 + nt * 16, fi, fg);
+      if constexpr (AMP == 0) {
+        const u16x8 yl = tn_frag(base + kGTileElems, wn * 64 + nt * 16, fi, fg);
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) acc[nt][kt] = mfma3(xh[kt], xl[kt], yh, yl, acc[nt][kt]);   // D[k = 4 fg + r][n = fi]
+        for (int kt = 0; kt < 2; ++kt) acc[nt][kt] = mfma3(xh[kt], xl[kt], yh, yl, acc[nt][kt]);   // D[k = 4 fg + r][n = fi]
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) acc[nt][kt] = H16<AMP != 2>::mfma(xh[kt], yh, acc[nt][kt]);
+      }
     }
     if (s + 1 < nsteps) lstore(cur ^ 1);
     __syncthreads();

@@ -14,9 +14,9 @@ binds them, nothing is computed here.
 * AMP: under ``torch.autocast`` the inputs are cast to fp32 at the boundary and the layer returns fp32 (LayerNorm output is fp32
   under autocast in the reference as well); gradients come back in each input's own dtype, so ``GradScaler`` works unchanged.  The
   Linear layers then multiply ONE 16-bit piece per operand in the autocast dtype (bf16 / fp16, fp32 accumulation) -- what autocast
-  gives the reference's ``nn.Linear`` -- in the forward and in the input-gradient GEMMs (library option ``train_amp``);
-  ``layer.amp_compute = False`` keeps the split-precision (fp32-accurate) products.  Attention, softmax, LayerNorm and the weight
-  gradients stay fp32 / split precision.
+  gives the reference's ``nn.Linear`` -- in the forward, input-gradient and weight-gradient GEMMs (library option ``train_amp``);
+  ``layer.amp_compute = False`` keeps the split-precision (fp32-accurate) products.  Attention, softmax, LayerNorm and bias
+  gradients stay fp32.
 """
 from __future__ import annotations
 

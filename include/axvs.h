@@ -83,7 +83,7 @@ const char* axvs_profile_stage_name(int i);
  *      measured not faster: DESIGN.md 4a);  process-wide: "train_valu" (VALU instead of fp32-MFMA attention kernels of the
  *      training tier), "train_exact" (default 1: forward GEMMs of the training tier with fp32 accuracy; 0: two-piece bf16
  *      products in the forward too; 2: three-piece input-gradient GEMMs as well), "train_amp" (default 0; 1 / 2: the X W^T GEMMs
- *      of the training tier -- forward and input gradients -- multiply ONE bf16 / fp16 piece per operand with fp32 accumulation:
+ *      of the training tier -- forward, input gradients, weight gradients -- multiply ONE bf16 / fp16 piece per operand with fp32 accumulation:
  *      the products torch.autocast gives the reference's nn.Linear; the Python layer sets it for calls made under autocast and
  *      for the backward of their graphs), "train_spatial_wgs" (default 512: workgroups the
  *      training tier's attention kernels are spread over -- measured flat from 512 to 8192 at the metric shape);
