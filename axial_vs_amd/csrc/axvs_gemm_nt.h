@@ -118,6 +118,10 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
   u16* const sbuf = reinterpret_cast<u16*>(gsmem);            // [2 stages][A pieces | B pieces][128 rows][32] (rows chunk-swizzled)
   constexpr int kStage = 2 * NS * kGTileElems;
+#ifdef AXVS_STAMPS_TR      // diagnostic build (tools/build_diag.py): phase stamps of the LAST launch, workgroups 0 .. 7
+  AXVS_STAMP_DECL;
+  AXVS_STAMP(0);
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
   const long long m0 = (long long)blockIdx.x * kGT;
@@ -231,10 +235,16 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   if (nk > 1) gload(1, S1{});
   if (nk > 0) lstore(0, S0{});
   __syncthreads();
+#ifdef AXVS_STAMPS_TR
+  AXVS_STAMP(1);
+#endif
   for (int ks = 0; ks < nk; ks += 2) {
     kstep(ks, S0{});
     if (ks + 1 < nk) kstep(ks + 1, S1{});
   }
+#ifdef AXVS_STAMPS_TR
+  AXVS_STAMP(2);
+#endif
   // ---- epilogue: accumulators -> fp32 staging tile [m][n] -> whole rows, 512 bytes per row segment ----
   float* const stg = reinterpret_cast<float*>(gsmem);
 #pragma unroll
@@ -244,6 +254,9 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
       *reinterpret_cast<float4*>(stg + (wm * 64 + mt * 16 + fi) * kGLd + wn * 32 + nt * 16 + 4 * fg) =
           float4{acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
   __syncthreads();
+#ifdef AXVS_STAMPS_TR
+  AXVS_STAMP(3);
+#endif
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = tid + 512 * i, row = idx >> 5, c4 = idx & 31;
@@ -288,6 +301,21 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
       *reinterpret_cast<float4*>(cp) = make_float4(t[0], t[1], t[2], t[3]);
     }
   }
+#ifdef AXVS_STAMPS_TR
+  AXVS_STAMP(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AXVS_STAMP(5);
+  if constexpr (TU == 0) {
+    AXVS_STAMP_FLUSH(6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {           // slot 6: the launch's shape
+      ::axvs::g_stamps[6 * 64 + 0] = (unsigned long long)M;
+      ::axvs::g_stamps[6 * 64 + 1] = (unsigned long long)N;
+      ::axvs::g_stamps[6 * 64 + 2] = (unsigned long long)K;
+      ::axvs::g_stamps[6 * 64 + 3] = (unsigned long long)NS;
+      ::axvs::g_stamps[6 * 64 + 4] = (unsigned long long)(ep.res != nullptr) + 2 * (ep.bias != nullptr) + 4 * (ep.dr.thr != 0);
+    }
+  }
+#endif
 }
 
 }  // namespace tr

@@ -475,6 +475,12 @@ int forward(const Ctx& c, const float* src, const float* pos, float* out, const 
 
 using namespace axvs;
 
+#ifdef AXVS_STAMPS_TR
+extern "C" int axvs_debug_read_stamps_tr(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(axvs::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 extern "C" {
 
 size_t axvs_axial_layer_train_saved_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {
