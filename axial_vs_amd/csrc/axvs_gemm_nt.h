@@ -257,6 +257,82 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
 #ifdef AXVS_STAMPS_TR
   AXVS_STAMP(3);
 #endif
+  // The common epilogues (nothing, + bias, * mul) without the per-round branches of the general form below: the eight LDS reads of
+  // a thread first, then eight stores (the stamps put the general form at 675 cycles per round: ten uniform branches and their
+  // waits between an LDS read and its store; this one at a third of that).
+  const bool plain_epi = !ep.relu && ep.dr.thr == 0 && !ep.out16 && ep.beta == 0.f && !ep.res && !ep.res2;
+  if (plain_epi) {
+    const int c4 = tid & 31, gn = n0 + 4 * c4;
+    float4 b = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias && gn < N) b = *reinterpret_cast<const float4*>(ep.bias + gn);
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(stg + ((tid >> 5) + 16 * i) * kGLd + 4 * c4);
+    const float mul = ep.mul;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long gm = m0 + (tid >> 5) + 16 * i;
+      if (gm < M && gn < N)
+        *reinterpret_cast<float4*>(C + gm * ld.c + gn) = make_float4((v[i].x + b.x) * mul, (v[i].y + b.y) * mul, (v[i].z + b.z) * mul, (v[i].w + b.w) * mul);
+    }
+  } else if (!ep.out16) {
+    // fp32 rows with ReLU / dropout / accumulate / residuals: the same arithmetic as the loop below, but per half (four rounds) every
+    // load -- LDS, C for beta, the residuals -- is issued before the first use and each uniform condition is tested once per half
+    const int c4 = tid & 31, gn = n0 + 4 * c4;
+    const bool cin = gn < N, drop = ep.dr.thr != 0, relu = ep.relu != 0;
+    float4 b = {0.f, 0.f, 0.f, 0.f};
+    if (ep.bias && cin) b = *reinterpret_cast<const float4*>(ep.bias + gn);
+    const float mul = ep.mul;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float4 v[4], o[4], r1[4], r2[4];
+      bool ok[4];
+      long long off[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 5) + 16 * (4 * hf + i);
+        ok[i] = cin && m0 + row < M;
+        off[i] = (m0 + row) * ld.c + gn;
+        v[i] = *reinterpret_cast<const float4*>(stg + row * kGLd + 4 * c4);
+        o[i] = r1[i] = r2[i] = float4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (ep.beta != 0.f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ok[i]) o[i] = *reinterpret_cast<const float4*>(C + off[i]);
+      }
+      if (ep.res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ok[i]) r1[i] = *reinterpret_cast<const float4*>(ep.res + off[i]);
+      }
+      if (ep.res2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ok[i]) r2[i] = *reinterpret_cast<const float4*>(ep.res2 + off[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t[4] = {(v[i].x + b.x) * mul, (v[i].y + b.y) * mul, (v[i].z + b.z) * mul, (v[i].w + b.w) * mul};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = relu ? fmaxf(t[e], 0.f) : t[e];
+        if (drop) {
+          const unsigned long long e0 = (unsigned long long)(m0 + (tid >> 5) + 16 * (4 * hf + i)) * N + gn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] *= drop_keep(ep.dr, e0 + e);
+        }
+        // (the sums in the order of the loop below: + C, + res, + res2)
+        const float ox[4] = {o[i].x, o[i].y, o[i].z, o[i].w}, ax[4] = {r1[i].x, r1[i].y, r1[i].z, r1[i].w}, bx[4] = {r2[i].x, r2[i].y, r2[i].z, r2[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ep.beta != 0.f) t[e] += ox[e];
+          if (ep.res) t[e] += ax[e];
+          if (ep.res2) t[e] += bx[e];
+        }
+        if (ok[i]) *reinterpret_cast<float4*>(C + off[i]) = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = tid + 512 * i, row = idx >> 5, c4 = idx & 31;
