@@ -207,28 +207,31 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int s = 0; s < NS; ++s) bf[nt][s] = *reinterpret_cast<const u16x8*>(base + (NS + s) * kGTileElems + boff[nt]);
+    // Piece products in the order hh, hm, mh, mm, hl, lh PER ACCUMULATOR (that order is what the result's bits depend on), but
+    // issued round-robin over the four accumulators of two m-tiles: an MFMA never waits for the one before it.
+    constexpr int kPieceA[6] = {0, 1, 0, 1, 2, 0}, kPieceB[6] = {0, 0, 1, 1, 0, 2};   // (af piece, bf piece) of product p
+    constexpr int kProducts = NS == 1 ? 1 : NS == 2 ? 3 : 6;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      u16x8 af[NS];
+    for (int mp = 0; mp < 2; ++mp) {
+      u16x8 af[2][NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) af[s] = *reinterpret_cast<const u16x8*>(base + s * kGTileElems + aoff[mt]);
+      for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {                        // D[n = 4 fg + r][m = fi]
-        f32x4 c = acc[mt][nt];
-        c = H16<!F16>::mfma(bf[nt][0], af[0], c);
-        if constexpr (NS >= 2) {
-          c = H16<true>::mfma(bf[nt][0], af[1], c);
-          c = H16<true>::mfma(bf[nt][1], af[0], c);
-        }
-        if constexpr (NS == 3) {
-          c = H16<true>::mfma(bf[nt][1], af[1], c);
-          c = H16<true>::mfma(bf[nt][0], af[2], c);
-          c = H16<true>::mfma(bf[nt][2], af[0], c);
-        }
-        acc[mt][nt] = c;
-      }
+        for (int s = 0; s < NS; ++s) af[m2][s] = *reinterpret_cast<const u16x8*>(base + s * kGTileElems + aoff[2 * mp + m2]);
+#pragma unroll
+      for (int p = 0; p < kProducts; ++p)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {                      // D[n = 4 fg + r][m = fi]
+            if (p == 0) acc[2 * mp + m2][nt] = H16<!F16>::mfma(bf[nt][0], af[m2][0], acc[2 * mp + m2][nt]);
+            else acc[2 * mp + m2][nt] = H16<true>::mfma(bf[nt][kPieceB[p]], af[m2][kPieceA[p]], acc[2 * mp + m2][nt]);
+          }
     }
-    if (ks + 1 < nk) lstore(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});   // the other stage: every wave left its reads behind the previous barrier
+    // the next step's operands into the other stage (every wave left its reads of it behind the previous barrier) -- unconditionally:
+    // after the last step the registers hold an old tile and the stage is not read again.  (Forcing the split's VALU instructions
+    // between the MFMAs with sched_group_barrier -- 1 MFMA : 2 VALU -- was measured: k-loop 24.0 k -> 27.6 k cycles, not kept.)
+    lstore(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});
     __syncthreads();
   };
   if (nk > 0) gload(0, S0{});
