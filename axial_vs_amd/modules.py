@@ -414,7 +414,7 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             if self.return_attn:
                 raise NotImplementedError("axial_vs_amd: attention maps are an output of the 16-bit tier (mfma_dtype 'f16' / 'bf16')")
             from .training import axial_layer_train
-            with torch.no_grad():
+            with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):      # (the fp32 tier stays fp32 under autocast)
                 return axial_layer_train(self, src, pos, dropout=False), None, None
         B, T, H, W = pos.shape[:4]
         s, p = _dev_f32(src, "src"), _dev_f32(pos, "pos")
