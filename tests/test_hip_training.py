@@ -249,6 +249,8 @@ def test_head_dim_64_trains_and_infers_on_the_fp32_tier(C, heads):
     e = rel_err(y, ref_eval)
     print(f"head_dim {C // heads}: eval {e:.2e}")
     assert e < 1e-5
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16):      # the fp32 tier stays fp32 under autocast
+        assert torch.equal(layer(src.cuda(), pos.cuda())[0].float().cpu(), y)
 
 
 def test_training_random_shapes_sweep():
