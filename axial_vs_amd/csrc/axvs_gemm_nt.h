@@ -200,6 +200,9 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   // one k-step: stage `PAR` of LDS holds step ks; register slot PAR ^ 1 holds step ks + 1 (requested a step ago), slot PAR is free
   auto kstep = [&](int ks, auto par_tag) {
     constexpr int PAR = decltype(par_tag)::value;
+#ifdef AXVS_STAMPS_TR
+    if (ks == 2) AXVS_STAMP(8);
+#endif
     if (ks + 2 < nk) gload(ks + 2, std::integral_constant<int, PAR>{});
     const u16* const base = sbuf + PAR * kStage;
     u16x8 bf[2][NS];
@@ -231,8 +234,20 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
     // the next step's operands into the other stage (every wave left its reads of it behind the previous barrier) -- unconditionally:
     // after the last step the registers hold an old tile and the stage is not read again.  (Forcing the split's VALU instructions
     // between the MFMAs with sched_group_barrier -- 1 MFMA : 2 VALU -- was measured: k-loop 24.0 k -> 27.6 k cycles, not kept.)
+#ifdef AXVS_STAMPS_TR
+    if (ks == 2) AXVS_STAMP(9);                  // fragments read, MFMAs issued
+#endif
     lstore(PAR ^ 1, std::integral_constant<int, PAR ^ 1>{});
+#ifdef AXVS_STAMPS_TR
+    if (ks == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AXVS_STAMP(10);                            // next tile split and stored (its global loads waited for)
+    }
+#endif
     __syncthreads();
+#ifdef AXVS_STAMPS_TR
+    if (ks == 2) AXVS_STAMP(11);                 // barrier passed
+#endif
   };
   if (nk > 0) gload(0, S0{});
   if (nk > 1) gload(1, S1{});
@@ -386,6 +401,8 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   AXVS_STAMP(5);
   if constexpr (TU == 0) {
     AXVS_STAMP_FLUSH(6);
+    if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)
+      for (int i_ = 8; i_ < 12; ++i_) ::axvs::g_stamps[(i_ + 2) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = st_[i_];
     if (blockIdx.x == 0 && threadIdx.x == 0) {           // slot 6: the launch's shape
       ::axvs::g_stamps[6 * 64 + 0] = (unsigned long long)M;
       ::axvs::g_stamps[6 * 64 + 1] = (unsigned long long)N;

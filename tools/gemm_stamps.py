@@ -33,3 +33,7 @@ print(f"last tr_gemm_nt_kernel<{NS}> launch: M={M} N={N} K={K} (flags res/bias/d
 for i, nm in enumerate(names):
     print(f"  {nm:52s} {int(np.median(d[i])):7d}   (min {int(d[i].min())}, max {int(d[i].max())})")
 print(f"  total {int(np.median(st[5] - st[0]))} cycles")
+ks = a[10:14, :nwg * 8]                         # one k-step (the third): entry, MFMAs issued, next tile stored, barrier passed
+dk = np.diff(ks, axis=0)
+for i, nm in enumerate(["k-step 2: loads requested, fragments read, MFMAs issued", "          next tile: global loads waited for, split, stored to LDS", "          barrier"]):
+    print(f"  {nm:70s} {int(np.median(dk[i])):6d}   (min {int(dk[i].min())}, max {int(dk[i].max())})")
