@@ -587,10 +587,48 @@ def main():
                     cc_step()
                 torch.cuda.synchronize(dev)
                 el = (time.perf_counter() - t_cc) / 10
+
+                def cc_step_amp():                       # the shipped config trains under AMP (SOLVER.AMP.ENABLED): fp16 products in the GEMMs
+                    with torch.autocast(device_type="cuda", dtype=torch.float16):
+                        lg_, mk_ = cc_module_train(cct, cq_t, pf_t)
+                    torch.autograd.backward([lg_, mk_], [dl_t, dm_t])
+                for _ in range(3):
+                    cc_step_amp()
+                torch.cuda.synchronize(dev)
+                t_cc = time.perf_counter()
+                for _ in range(10):
+                    cc_step_amp()
+                torch.cuda.synchronize(dev)
+                el_amp = (time.perf_counter() - t_cc) / 10
+                # the shipped VIPSeg training setting (maxtron_cc_r50.yaml): 24 frames = 12 clips x 2 frames, 769 x 1345 images -> 193 x 337 features
+                Tc2, V2, H2, W2 = 12, 2, 193, 337
+                cct.num_clip_frames = V2
+                cq2 = torch.randn(1, Q, Tc2, 256, device=dev, generator=gc_).requires_grad_(True)
+                pf2 = torch.nn.functional.normalize(torch.randn(1, 128, Tc2 * V2, H2, W2, device=dev, generator=gc_), dim=1)
+                dl2 = torch.randn(layers_cc, 1, Q, ncls + 1, device=dev, generator=gc_)
+                dm2 = torch.randn(layers_cc, 1, Q, Tc2 * V2, H2, W2, device=dev, generator=gc_) * 0.01
+
+                def cc_step_vipseg():
+                    lg_, mk_ = cc_module_train(cct, cq2, pf2)
+                    torch.autograd.backward([lg_, mk_], [dl2, dm2])
+                for _ in range(2):
+                    cc_step_vipseg()
+                torch.cuda.synchronize(dev)
+                t_cc = time.perf_counter()
+                for _ in range(4):
+                    cc_step_vipseg()
+                torch.cuda.synchronize(dev)
+                el_vip = (time.perf_counter() - t_cc) / 4
+                del cq2, pf2, dl2, dm2
                 extras["cc_train_cfg4"] = {"ms_per_step": round(el * 1e3, 3), "value": round(Tc * V / el, 1), "unit": "frames/s",
+                                           "ms_per_step_autocast_f16": round(el_amp * 1e3, 3),
+                                           "ms_per_step_vipseg_12x2_193x337": round(el_vip * 1e3, 3),
                                            "what": "forward + backward of CrossClipTrackingModule.train() at BASELINE config 4 (4 clips x 4 frames, 64x64, "
                                                    "128 queries, 4 layers, attn_drop = aspp_drop = 0.1, gradients on every layer's outputs) through "
-                                                   "axvs_cc_module_train_fwd/_bwd; BatchNorm on batch statistics (single rank: no all-reduce)",
+                                                   "axvs_cc_module_train_fwd/_bwd; BatchNorm on batch statistics (single rank: no all-reduce); "
+                                                   "ms_per_step_autocast_f16: the same step under torch.autocast(float16) (one fp16 piece per GEMM operand); "
+                                                   "ms_per_step_vipseg_12x2_193x337: the shipped VIPSeg training setting, 12 clips x 2 frames on 193 x 337 "
+                                                   "features (130082 pixels per frame), fp32",
                                            "dtype": "f32 (GEMM operands split into bf16 pieces, fp32 accumulate)"}
                 del cct, cq_t, pf_t, dl_t, dm_t
             except RuntimeError as e:
