@@ -134,15 +134,15 @@ inline int row_align(const void* base, long long ld, long long step) {
   return 1;
 }
 
-// four consecutive floats at p of which the first `valid` exist (<= 0: none); al: alignment of p in floats
-__device__ __forceinline__ float4 ldg4(const float* p, int valid, int al) {
+// four consecutive floats at p of which the first `valid` exist (<= 0: none); al: alignment of p in floats.
+// GLOBAL memory only: gfx950 code objects run with unaligned access enabled, so four floats at a 4-byte boundary are ONE
+// global_load_dwordx4 / global_store_dwordx4 (the type below tells the compiler the alignment; it emits the wide instruction) --
+// rows of 130082 pixels (the shipped VIPSeg training shape: 8-byte aligned) move 16 bytes per lane like aligned ones.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ldg4(const float* p, int valid, int /*al*/) {
   if (valid >= 4) {
-    if (al >= 4) return *reinterpret_cast<const float4*>(p);
-    if (al >= 2) {
-      const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 2);
-      return float4{a.x, a.y, b.x, b.y};
-    }
-    return float4{p[0], p[1], p[2], p[3]};
+    const f32x4_u v = *reinterpret_cast<const f32x4_u*>(p);
+    return float4{v.x, v.y, v.z, v.w};
   }
   float4 r = {0.f, 0.f, 0.f, 0.f};
   if (valid > 0) r.x = p[0];
@@ -150,15 +150,9 @@ __device__ __forceinline__ float4 ldg4(const float* p, int valid, int al) {
   if (valid > 2) r.z = p[2];
   return r;
 }
-__device__ __forceinline__ void stg4(float* p, float4 v, int valid, int al) {
+__device__ __forceinline__ void stg4(float* p, float4 v, int valid, int /*al*/) {
   if (valid >= 4) {
-    if (al >= 4) { *reinterpret_cast<float4*>(p) = v; return; }
-    if (al >= 2) {
-      *reinterpret_cast<float2*>(p) = float2{v.x, v.y};
-      *reinterpret_cast<float2*>(p + 2) = float2{v.z, v.w};
-      return;
-    }
-    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    *reinterpret_cast<f32x4_u*>(p) = f32x4_u{v.x, v.y, v.z, v.w};
     return;
   }
   if (valid > 0) p[0] = v.x;

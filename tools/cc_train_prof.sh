@@ -1,12 +1,13 @@
 #!/bin/bash
-# per-kernel durations of a training step of the cross-clip module at BASELINE config 4: tools/cc_train_prof.sh <tag>
+# per-kernel durations of a training step of the cross-clip module at BASELINE config 4: tools/cc_train_prof.sh <tag> [cc_train_time.py args, e.g. --shape 128,12,2,193,337,4]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/cctrainprof_$1
+shift
 mkdir -p $OUT
-python3 $R/tools/cc_train_time.py 10
-python3 $R/tools/cc_train_time.py 10 --torch
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/cc_train_time.py 10 > $OUT/log.txt 2>&1
+python3 $R/tools/cc_train_time.py 10 "$@"
+python3 $R/tools/cc_train_time.py 10 --torch "$@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/cc_train_time.py 10 "$@" > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, glob
 for f in glob.glob("$OUT/*/*kernel_stats.csv"):
