@@ -269,11 +269,20 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
   const long long TP = (long long)s.Tc * s.P;
   const int GQ = G * s.Q;
   const int al_pf = row_align(pf, s.P, s.P), al_lg = row_align(sv.logits_pre, s.P, s.P);   // rows start at multiples of P floats
+  // B == 1 and whole 128-row tiles per layer (the shipped 128 queries): the einsum's epilogue also leaves the tile sums the
+  // one-channel BatchNorm needs -- one pass over the 0.8 GB of a layer's mask logits saved
+  const int tiles_p = (int)((s.P + kGT - 1) / kGT), qtiles = s.Q / kGT;
+  const long long stat_nblk = (long long)s.Tc * tiles_p * qtiles;
+  const bool fused_stats = s.B == 1 && s.Q % kGT == 0 && stat_nblk <= (long long)kCcStatBlocks * kCcC;
   if (s.B == 1) {
-    for (int t = 0; t < s.Tc; ++t)
+    for (int t = 0; t < s.Tc; ++t) {
+      GemmLd stat{0, 0, 0, 0};
+      stat.stat_part = k.x.part; stat.stat_shift = hp.pixel_bn.mean; stat.stat_nblk = (int)stat_nblk; stat.stat_blk0 = t * tiles_p * qtiles;
+      stat.stat_rows = s.Q;
       if ((rc = c.g.tn_direct(k.x.kt + (size_t)t * kCcCm * GQ, pf + (size_t)t * s.P, sv.logits_pre + (size_t)t * s.P, kCcCm, GQ, (int)s.P, GQ, TP, TP,
-                              al_pf, al_lg)) != AXVS_OK)
+                              al_pf, al_lg, fused_stats ? &stat : nullptr)) != AXVS_OK)
         return rc;
+    }
   } else {
     for (int g = 0; g < G; ++g)
       for (int b = 0; b < s.B; ++b)
@@ -284,7 +293,10 @@ int cc_forward(const CCCtx& k, const float* cq, const float* pf, float* logits_o
             return rc;
   }
   // one-channel BatchNorm over each layer's mask logits (CC:56)
-  cc_scalar_stats(k, sv.logits_pre, nullptr, hp.pixel_bn.mean, nullptr, nullptr, sync, nullptr, sync + (size_t)G * 2);
+  if (fused_stats)
+    hipLaunchKernelGGL(cct_reduce_groups_kernel, dim3(1, G), dim3(256), 0, k.st, (const float*)k.x.part, (int)stat_nblk, 2, sync, (float*)nullptr,
+                       sync + (size_t)G * 2, (float)s.E);
+  else cc_scalar_stats(k, sv.logits_pre, nullptr, hp.pixel_bn.mean, nullptr, nullptr, sync, nullptr, sync + (size_t)G * 2);
   if ((rc = cc_sync(k, sync, (size_t)G * 2 + 1)) != AXVS_OK) return rc;
   so += (size_t)G * 2 * kCcCm;
   hipLaunchKernelGGL(cct_bn_finalize_kernel, dim3(1, G), dim3(256), 0, k.st, (const float*)sync, (const float*)(sync + (size_t)G * 2), hp.pixel_bn.mean,

@@ -53,6 +53,12 @@ struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps >
   // strides and extents multiples of 4); smaller: rows of pixels whose count is whatever the image size gives (the mask einsum
   // over 193 x 337 maps) -- narrower accesses, and an extent that is not a multiple of 4 ends inside a group of four
   int al_a = 4, al_b = 4, al_c = 4;
+  // tr_gemm_tn_kernel<.., STATS>: the output tile's sum (x - *stat_shift) and sum (x - *stat_shift)^2 go to
+  // stat_part[(g stat_nblk + stat_blk0 + tile)][2], g = first row of the tile / stat_rows (a tile lies inside one group of rows) --
+  // the one-channel BatchNorm statistics of the mask logits without a pass of their own over them
+  float* stat_part = nullptr;
+  const float* stat_shift = nullptr;
+  int stat_nblk = 0, stat_blk0 = 0, stat_rows = 0;
 };
 
 inline bool gemm_nt_general(const GemmLd& ld, int K) { return !(ld.al_a == 4 && ld.al_b == 4 && (K & 3) == 0); }

@@ -42,6 +42,8 @@ struct Gemm {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, true, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, true, false, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false, 0, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<true, 0, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false, 1>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<false, 2>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_tn_kernel<true>))) return rc;
@@ -105,13 +107,23 @@ struct Gemm {
   // P[N][K] (row stride ldo) = A[Mc][N]^T X[Mc][K]: the contraction over a FEW rows Mc (the 128 channels of the mask einsum,
   // CC:55) in one split, straight into the caller's tensor
   // al_x / al_o: alignment (floats) of the rows of X and P -- K is a pixel count and need not be a multiple of anything
-  int tn_direct(const float* A, const float* X, float* P, int Mc, int N, int K, long long lda, long long ldx, long long ldo, int al_x, int al_o) const {
+  // stat (nullable): GemmLd with the stat_* fields set -- the tile sums of P for the BatchNorm behind the einsum (STATS instantiation)
+  int tn_direct(const float* A, const float* X, float* P, int Mc, int N, int K, long long lda, long long ldx, long long ldo, int al_x, int al_o,
+                const GemmLd* stat = nullptr) const {
     if (N % 4 || lda % 4) return fail(AXVS_ERR_ARG, "einsum GEMM: N=%d must be a multiple of 4", N);
     const dim3 grid((unsigned)(((N + kGT - 1) / kGT) * ((K + kGT - 1) / kGT)), 1u);
     const long long chunk = (Mc + kGK - 1) / kGK * kGK;
     GemmLd ld{lda, ldx, ldo, 0};
     ld.al_b = al_x;
     ld.al_c = al_o;
+    if (stat) {
+      ld.stat_part = stat->stat_part; ld.stat_shift = stat->stat_shift; ld.stat_nblk = stat->stat_nblk; ld.stat_blk0 = stat->stat_blk0;
+      ld.stat_rows = stat->stat_rows;
+      if (al_x == 4 && al_o == 4 && K % 4 == 0)
+        hipLaunchKernelGGL((tr_gemm_tn_kernel<false, 0, true>), grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
+      else hipLaunchKernelGGL((tr_gemm_tn_kernel<true, 0, true>), grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
+      return AXVS_OK;
+    }
     if (al_x == 4 && al_o == 4 && K % 4 == 0) hipLaunchKernelGGL(tr_gemm_tn_kernel<false>, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
     else hipLaunchKernelGGL(tr_gemm_tn_kernel<true>, grid, dim3(512), kGemmLds, st, A, X, P, (long long)Mc, N, K, chunk, (float*)nullptr, ld);
     return AXVS_OK;

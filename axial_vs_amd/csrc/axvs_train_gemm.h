@@ -67,7 +67,8 @@ __device__ __forceinline__ u16x8 tn_frag(const u16* tile, int col0, int fi, int 
 // staging registers by the workgroups of the first k-tile (a bias gradient can be a sum that cancels to zero -- the k bias of a
 // softmax -- so it does not go through the bf16 split) and reduced over the 32 staging rows through LDS in a fixed order.
 // AMP = 1 / 2 (option train_amp, under torch.autocast): ONE bf16 / fp16 piece per operand, as in tr_gemm_nt_kernel<1>.
-template <bool GEN, int AMP = 0>      // GEN: rows at any 4-byte boundary / extents that are not multiples of 4 (see tr_gemm_nt_kernel)
+// STATS: GemmLd::stat_* -- sums of the output tile for the BatchNorm that follows the mask einsum
+template <bool GEN, int AMP = 0, bool STATS = false>      // GEN: rows at any 4-byte boundary / extents that are not multiples of 4 (see tr_gemm_nt_kernel)
 __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
                                                             long long M, int N, int K, long long rows_per_split,
                                                             float* __restrict__ part_b, GemmLd ld) {
@@ -169,6 +170,9 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
       *reinterpret_cast<float4*>(stg + (wn * 64 + nt * 16 + fi) * kGLd + wk * 32 + kt * 16 + 4 * fg) =
           float4{acc[nt][kt][0], acc[nt][kt][1], acc[nt][kt][2], acc[nt][kt][3]};
   __syncthreads();
+  float sa = 0.f, sb = 0.f;
+  float sshift = 0.f;
+  if constexpr (STATS) sshift = ld.stat_shift ? ld.stat_shift[0] : 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = tid + 512 * i, row = idx >> 5, c4 = idx & 31;
@@ -178,6 +182,42 @@ __global__ __launch_bounds__(512, 4) void tr_gemm_tn_kernel(const float* __restr
       if (n < N && k < K) *reinterpret_cast<float4*>(out + (size_t)n * ld.c + k) = o4;
     } else if (n < N) {
       stg4(out + (size_t)n * ld.c + k, o4, K - k, ld.al_c);
+    }
+    if constexpr (STATS) {
+      const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n < N && k + e < K) {
+          const float d = ov[e] - sshift;
+          sa += d;
+          sb += d * d;
+        }
+    }
+  }
+  if constexpr (STATS) {      // thread -> wave (xor tree) -> workgroup (eight values, in order): a fixed summation order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sa += __shfl_xor(sa, o, 64);
+      sb += __shfl_xor(sb, o, 64);
+    }
+    __syncthreads();           // every wave is done with the staging tile
+    float* const red = reinterpret_cast<float*>(gsmem);
+    if (lane == 0) {
+      red[wave * 2] = sa;
+      red[wave * 2 + 1] = sb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float ta = 0.f, tb = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        ta += red[w * 2];
+        tb += red[w * 2 + 1];
+      }
+      const int g = n0 / ld.stat_rows, tile = (int)(blockIdx.x % tiles_k) + tiles_k * ((n0 % ld.stat_rows) / kGT);
+      float* const sp = ld.stat_part + ((size_t)g * ld.stat_nblk + ld.stat_blk0 + tile) * 2;
+      sp[0] = ta;
+      sp[1] = tb;
     }
   }
   if (do_bias) __syncthreads();  // the bias reduction below reuses the staging tile
