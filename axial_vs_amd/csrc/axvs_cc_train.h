@@ -286,6 +286,18 @@ __global__ __launch_bounds__(256) void cct_scalar_bn_bwd_apply_kernel(const floa
       make_float4(k * (d.x - a - (v.x - mu) * s), k * (d.y - a - (v.y - mu) * s), k * (d.z - a - (v.z - mu) * s), k * (d.w - a - (v.w - mu) * s));
 }
 
+// the same input gradient as three coefficients per group, dx = c1 dy + c2 x + c3, for the GEMM that consumes it (GemmLd::aff)
+__global__ void cct_scalar_bn_bwd_coef_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ w,
+                                              const float* __restrict__ sums, const float* __restrict__ count, float* __restrict__ coef, int G) {
+  const int g = threadIdx.x;
+  if (g >= G) return;
+  const float mu = mean[g], rs = rstd[g], inv = 1.f / *count;
+  const float k = w[0] * rs, a = sums[g * 2] * inv, s = sums[g * 2 + 1] * inv * rs;
+  coef[g * 3] = k;
+  coef[g * 3 + 1] = -k * s;
+  coef[g * 3 + 2] = k * (mu * s - a);
+}
+
 // ---- class-activation pooling (CC:48-50): per layer g and query q, softmax over the B*Tc entries (b, t) of a = CE . wa + ba,
 //      pooled[g][q][c] = sum_e p_e CE[row_e][c].  Rows: m = (b Q + q) Tc + t.  One block per (q, g); C <= 1024, B*Tc <= 1024.
 __global__ __launch_bounds__(256) void cct_act_pool_fwd_kernel(const float* __restrict__ ce, const float* __restrict__ wa, const float* __restrict__ ba,

@@ -326,21 +326,31 @@ int cc_backward(const CCCtx& k, const float* d_logits, const float* d_masks, con
   cc_scalar_stats(k, sv.logits_pre, d_masks, nullptr, sv.mean[3], sv.rstd[3], loc, sync, sync + (size_t)G * 2);
   hipLaunchKernelGGL(cct_bn_param_grads_kernel, dim3(1), dim3(256), 0, k.st, (const float*)loc, hg.pixel_bn.w, hg.pixel_bn.b, 1, G);
   if ((rc = cc_sync(k, sync, (size_t)G * 2 + 1)) != AXVS_OK) return rc;
-  hipLaunchKernelGGL(cct_scalar_bn_bwd_apply_kernel, dim3(eblocks(s.E / 4), G), dim3(256), 0, k.st, d_masks, (const float*)sv.logits_pre,
-                     (const float*)sv.mean[3], (const float*)sv.rstd[3], hp.pixel_bn.w, (const float*)sync, (const float*)(sync + (size_t)G * 2), x.dpre,
-                     s.E / 4);
   // ---- mask kernels: dk[(b t)][(g q)][c] = sum_p dpre[g][b][q][t P + p] pf[b][c][t P + p] (split-K partials, summed in a fixed order) ----
   const GemmEpi plain{nullptr, 1.f, 0, make_drop(0.f, 0, 0), 0.f};
   GemmLd ldk{TP, TP, Cm, x.dk_ksteps};
-  ldk.al_a = row_align(x.dpre, s.P, s.P);
   ldk.al_b = row_align(pf, s.P, s.P);
   if (s.B == 1) {
+    // B == 1: the BatchNorm's input gradient dpre = c1 d_masks + c2 logits_pre + c3 (per layer) is formed in the loader of the GEMM
+    // that contracts it with the pixel features -- no pass that writes 0.8 GB per layer and reads it back
+    float* const coef = x.sums_local + (size_t)G * 2;          // (behind the local sums: 3 floats per layer)
+    hipLaunchKernelGGL(cct_scalar_bn_bwd_coef_kernel, dim3(1), dim3(64), 0, k.st, (const float*)sv.mean[3], (const float*)sv.rstd[3], hp.pixel_bn.w,
+                       (const float*)sync, (const float*)(sync + (size_t)G * 2), coef, G);
+    const int al_d = row_align(d_masks, s.P, s.P), al_l = row_align(sv.logits_pre, s.P, s.P);
+    ldk.al_a = al_d < al_l ? al_d : al_l;
+    ldk.aff = coef;
+    ldk.aff_rows = s.Q;
     for (int t = 0; t < s.Tc; ++t) {
-      if ((rc = c.g.nt(x.dpre + (size_t)t * s.P, pf + (size_t)t * s.P, x.dkpart, GQ, Cm, (int)s.P, ldk, plain, false, x.dk_z)) != AXVS_OK) return rc;
+      ldk.a2 = sv.logits_pre + (size_t)t * s.P;
+      if ((rc = c.g.nt(d_masks + (size_t)t * s.P, pf + (size_t)t * s.P, x.dkpart, GQ, Cm, (int)s.P, ldk, plain, false, x.dk_z)) != AXVS_OK) return rc;
       const size_t n = (size_t)GQ * Cm;
       hipLaunchKernelGGL(tr_colsum_final_kernel, dim3(blocks(n, 256)), dim3(256), 0, k.st, (const float*)x.dkpart, x.dk_z, n, x.dk + (size_t)t * n);
     }
   } else {
+    hipLaunchKernelGGL(cct_scalar_bn_bwd_apply_kernel, dim3(eblocks(s.E / 4), G), dim3(256), 0, k.st, d_masks, (const float*)sv.logits_pre,
+                       (const float*)sv.mean[3], (const float*)sv.rstd[3], hp.pixel_bn.w, (const float*)sync, (const float*)(sync + (size_t)G * 2),
+                       x.dpre, s.E / 4);
+    ldk.al_a = row_align(x.dpre, s.P, s.P);
     for (int g = 0; g < G; ++g)
       for (int b = 0; b < s.B; ++b)
         for (int t = 0; t < s.Tc; ++t) {

@@ -56,6 +56,11 @@ struct GemmLd {     // row strides (floats, multiples of 4) of A, B, C; ksteps >
   // tr_gemm_tn_kernel<.., STATS>: the output tile's sum (x - *stat_shift) and sum (x - *stat_shift)^2 go to
   // stat_part[(g stat_nblk + stat_blk0 + tile)][2], g = first row of the tile / stat_rows (a tile lies inside one group of rows) --
   // the one-channel BatchNorm statistics of the mask logits without a pass of their own over them
+  // tr_gemm_nt_kernel<.., AFF>: the A operand is an affine function of A and a2, per group of aff_rows rows:
+  // A_eff = aff[3 g] A + aff[3 g + 1] a2 + aff[3 g + 2], g = row / aff_rows (the input gradient of a one-channel BatchNorm formed in the
+  // loader of the GEMM that consumes it, instead of a pass that writes it out)
+  const float* aff = nullptr;
+  int aff_rows = 1;
   float* stat_part = nullptr;
   const float* stat_shift = nullptr;
   int stat_nblk = 0, stat_blk0 = 0, stat_rows = 0;
@@ -118,7 +123,7 @@ constexpr size_t gemm_nt_lds() {
 // kernel of the common case carries none of that code (these kernels are sensitive to their size: +3 us per launch with both
 // loaders in one body)
 // ADD (with !GEN): the x + pos addend ld.a2 on the 16-byte path (the general loader takes it at run time).
-template <int NS, int TU = 0, bool GEN = false, bool ADD = false, bool F16 = false>
+template <int NS, int TU = 0, bool GEN = false, bool ADD = false, bool F16 = false, bool AFF = false>
 __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                                          float* __restrict__ C, long long M, int N, int K, GemmLd ld, GemmEpi ep) {
   extern __shared__ __attribute__((aligned(16))) char gsmem[];
@@ -148,6 +153,11 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
   // single step's MFMAs (~0.3 us) to cover an L2 / HBM round trip and every step stalled at its LDS store
   float4 ra[2][2], rb[2][2];
   const float* const a2p = ld.a2 ? ld.a2 + (ap - A) : nullptr;
+  float af1 = 1.f, af2 = 0.f, af3 = 0.f;                      // AFF: this thread's row group
+  if constexpr (AFF) {
+    const float* cf = ld.aff + 3 * (int)((m0 + (a_ok ? sr : 0)) / ld.aff_rows);
+    af1 = cf[0]; af2 = cf[1]; af3 = cf[2];
+  }
   auto gload = [&](int ks, auto slot_tag) {
     constexpr int SL = decltype(slot_tag)::value;
     if constexpr (!GEN) {                                     // 16-byte rows, K % 4 == 0, no addend: a float4 is inside or outside
@@ -156,9 +166,15 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
         const bool kin = kbase + ks * kGK + sq * 8 + 4 * h < K;
         ra[SL][h] = a_ok && kin ? *reinterpret_cast<const float4*>(ap + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
         rb[SL][h] = b_ok && kin ? *reinterpret_cast<const float4*>(bp + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (ADD) {
+        if constexpr (ADD || AFF) {
           const float4 t = a_ok && kin ? *reinterpret_cast<const float4*>(a2p + ks * kGK + 4 * h) : float4{0.f, 0.f, 0.f, 0.f};
-          ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
+          if constexpr (AFF) {
+            const float c3 = a_ok && kin ? af3 : 0.f;
+            ra[SL][h].x = af1 * ra[SL][h].x + af2 * t.x + c3; ra[SL][h].y = af1 * ra[SL][h].y + af2 * t.y + c3;
+            ra[SL][h].z = af1 * ra[SL][h].z + af2 * t.z + c3; ra[SL][h].w = af1 * ra[SL][h].w + af2 * t.w + c3;
+          } else {
+            ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
+          }
         }
       }
     } else {
@@ -167,7 +183,12 @@ __global__ __launch_bounds__(512, NS <= 2 ? 4 : 2) void tr_gemm_nt_kernel(const 
         const int kv = K - (kbase + ks * kGK + sq * 8 + 4 * h);   // how many of the four columns exist
         ra[SL][h] = ldg4(ap + ks * kGK + 4 * h, a_ok ? kv : 0, ld.al_a);
         rb[SL][h] = ldg4(bp + ks * kGK + 4 * h, b_ok ? kv : 0, ld.al_b);
-        if (ld.a2 && a_ok && kv > 0) {
+        if constexpr (AFF) {
+          const int nv = a_ok ? kv : 0;
+          const float4 t = ldg4(a2p + ks * kGK + 4 * h, nv, ld.al_a);
+          ra[SL][h].x = nv > 0 ? af1 * ra[SL][h].x + af2 * t.x + af3 : 0.f; ra[SL][h].y = nv > 1 ? af1 * ra[SL][h].y + af2 * t.y + af3 : 0.f;
+          ra[SL][h].z = nv > 2 ? af1 * ra[SL][h].z + af2 * t.z + af3 : 0.f; ra[SL][h].w = nv > 3 ? af1 * ra[SL][h].w + af2 * t.w + af3 : 0.f;
+        } else if (ld.a2 && a_ok && kv > 0) {
           const float4 t = ldg4(ld.a2 + (ap - A) + ks * kGK + 4 * h, kv, ld.al_a);
           ra[SL][h].x += t.x; ra[SL][h].y += t.y; ra[SL][h].z += t.z; ra[SL][h].w += t.w;
         }

@@ -36,6 +36,8 @@ struct Gemm {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<3, 0, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, true, false, false, true>))) return rc;
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<2, 0, false, false, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, false, true>))) return rc;
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(tr_gemm_nt_kernel<1, 0, true>))) return rc;
@@ -60,6 +62,12 @@ struct Gemm {
     // (a deeper register prefetch for grids of a few workgroups was measured and does not pay: these launches are bound by their
     //  fixed cost -- ~11 us whatever K -- not by the load round trips of the k-loop)
     const bool gen = gemm_nt_general(ld, K), add = ld.a2 != nullptr;   // (the general loader takes the addend at run time)
+    if (ld.aff) {                     // affine A operand (two-piece products: an input-gradient GEMM)
+      if (!ld.a2) return fail(AXVS_ERR_ARG, "training GEMM: the affine loader needs its second operand");
+      if (gen) hipLaunchKernelGGL((tr_gemm_nt_kernel<2, 0, true, false, false, true>), grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
+      else hipLaunchKernelGGL((tr_gemm_nt_kernel<2, 0, false, false, false, true>), grid, dim3(512), gemm_nt_lds<2>(), st, X, W, Y, M, N, K, ld, e);
+      return AXVS_OK;
+    }
     if (g_train_amp) {                // torch.autocast: one 16-bit piece per operand (1: bf16, 2: fp16), whatever the caller's `exact`
 #define AXVS_NT1(F16_)                                                                                                                              \
   do {                                                                                                                                              \
