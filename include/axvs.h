@@ -85,7 +85,8 @@ const char* axvs_profile_stage_name(int i);
  *      products in the forward too; 2: three-piece input-gradient GEMMs as well), "train_amp" (default 0; 1 / 2: the X W^T GEMMs
  *      of the training tier -- forward, input gradients, weight gradients -- multiply ONE bf16 / fp16 piece per operand with fp32 accumulation:
  *      the products torch.autocast gives the reference's nn.Linear; the Python layer sets it for calls made under autocast and
- *      for the backward of their graphs), "train_spatial_wgs" (default 512: workgroups the
+ *      for the backward of their graphs), "train_attn_split" (default 1: the training tier's attention forward on split-precision
+ *      16-bit MFMAs with a frame's score tiles in registers, axis length <= 128; 0: the fp32 MFMA kernel), "train_spatial_wgs" (default 512: workgroups the
  *      training tier's attention kernels are spread over -- measured flat from 512 to 8192 at the metric shape);
  *      "msda_gemm" (default 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
  *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels). */
