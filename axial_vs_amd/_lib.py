@@ -98,6 +98,7 @@ SIGNATURES = {
     "axvs_version": (C.c_int, []),
     "axvs_last_error": (C.c_char_p, []),
     "axvs_set_status_buffer": (C.c_int, [_fp]),
+    "axvs_set_sync_buffer": (C.c_int, [_fp, C.c_size_t]),
     "axvs_profile_stages": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "axvs_profile_stage_count": (C.c_int, []),
     "axvs_profile_stage_name": (C.c_char_p, [C.c_int]),

@@ -50,6 +50,12 @@ thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kern
 // 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels of axvs_gemm.h.
 thread_local int g_msda_gemm = 4;
 thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
+// Merged q/k/v + trajectory launches (temporal_fused_kernel<..., MQ>): one launch per axial pass.  The sibling row tiles of a
+// sequence hand K / V^T over inside the launch through arrival counters the CALLER provides (axvs_set_sync_buffer: device words
+// that are zero when registered; every launch leaves them zero) -- without a registered buffer the passes run as two launches.
+thread_local unsigned* g_sync = nullptr;
+thread_local size_t g_sync_words = 0;
+thread_local int g_no_merge_qkv = 0;     // option "no_merge_qkv": keep qkv_fused_kernel + trajectory kernel as two launches (A/B, tests)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
 
@@ -289,38 +295,39 @@ int launch_attn(const TrajWs& w, float* attn, int S, int N, int T, int L, int he
 // nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel
 template <bool BF>
 int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L, int T,
-                    float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr, int vrow = 0, const NextQkv* nq = nullptr) {
+                    float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr, int vrow = 0, const NextQkv* nq = nullptr,
+                    const OwnQkv* oq = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
   const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? 2 : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
-  if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
+  if ((vrow || nq || oq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v / own q,k,v need 64-row tiles");
   if (fa == nullptr && (tiles64 < 128 || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
     switch (T) {
-      case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 3: return launch_temporal_n<BF, 3, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 4: return launch_temporal_n<BF, 4, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 5: return launch_temporal_n<BF, 5, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 6: return launch_temporal_n<BF, 6, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 7: return launch_temporal_n<BF, 7, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 8: return launch_temporal_n<BF, 8, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 9: return launch_temporal_n<BF, 9, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 10: return launch_temporal_n<BF, 10, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 11: return launch_temporal_n<BF, 11, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-      case 12: return launch_temporal_n<BF, 12, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+      case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 3: return launch_temporal_n<BF, 3, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 4: return launch_temporal_n<BF, 4, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 5: return launch_temporal_n<BF, 5, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 6: return launch_temporal_n<BF, 6, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 7: return launch_temporal_n<BF, 7, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 8: return launch_temporal_n<BF, 8, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 9: return launch_temporal_n<BF, 9, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 10: return launch_temporal_n<BF, 10, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 11: return launch_temporal_n<BF, 11, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+      case 12: return launch_temporal_n<BF, 12, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
       default: break;
     }
   }
   switch (T) {
-    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 6: return launch_temporal_n<BF, 6, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);     // x tile: T * 16 KiB of LDS
-    case 7: return launch_temporal_n<BF, 7, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 8: return launch_temporal_n<BF, 8, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 1: return launch_temporal_n<BF, 1, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 2: return launch_temporal_n<BF, 2, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 3: return launch_temporal_n<BF, 3, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 4: return launch_temporal_n<BF, 4, 4>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 5: return launch_temporal_n<BF, 5, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 6: return launch_temporal_n<BF, 6, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);     // x tile: T * 16 KiB of LDS
+    case 7: return launch_temporal_n<BF, 7, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 8: return launch_temporal_n<BF, 8, 2>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
     default: return fail(AXVS_ERR_ARG, "fused temporal kernel supports T <= 8");
   }
 }
@@ -332,7 +339,8 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
              float* attn, const TrajPacked& p, const TrajWs& w, RowMap rm, int S, int T, int L, int C, int heads,
              hipStream_t st, int pass = 0, const FfnArgs* ffn = nullptr, float* ffn_out = nullptr, bool* ffn_done = nullptr,
              const PosGen* posgen = nullptr, const NextQkv* nq = nullptr /* the kernel also emits q, k, v of the next pass */,
-             bool have_qkv = false /* w.q16 / k16 / vt16 already hold q, k and row-form v (written by the previous pass's kernel) */) {
+             bool have_qkv = false /* w.q16 / k16 / vt16 already hold q, k and row-form v (written by the previous pass's kernel) */,
+             bool may_merge = false /* the caller's sequences may use the registered sync words (one trajectory call at a time per buffer) */) {
   static const char* const kNames[3][8] = {
       {"qkv_proj", "spatial_attn", "proj_q", "proj_kv", "temporal_attn", "proj", "temporal_fused", "traj_fused"},
       {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused", "h.traj_fused"},
@@ -352,6 +360,20 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const bool vrow = fuse_attn && can_vrow(T, L, Mp, with_ffn, have_qkv);
   if ((have_qkv || nq) && !vrow && !(nq && fuse_attn && traj_mt4(T, traj_tiles64(Mp, N), with_ffn)))
     return fail(AXVS_ERR_ARG, "internal: fused q/k/v hand-over outside the 64-row fused tier");
+  // one launch per pass: the trajectory kernel computes q, k, v of its own rows (OwnQkv).  Needs the 64-row fused kernels with
+  // T <= 4, frames of a multiple of 16 keys (16-byte / 8-byte V^T stores) and at most 96 (register budget), byte offsets of K / V^T
+  // below 4 GiB (buffer addressing), one registered arrival counter per sequence.  Bit-identical to the two-launch form.
+  const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv && !g_spatial_only &&
+                     g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= 3 &&
+                     traj_mt4(T, traj_tiles64(Mp, N), with_ffn) && 2 * (long long)Cp * Mp * 2 < (1ll << 32);
+  if (merge) {
+    const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status};
+    int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr, 0, nullptr, &oq);
+    if (rc != AXVS_OK) return rc;
+    if (with_ffn) *ffn_done = true;
+    mark(st, with_ffn ? "w.qkv+traj+ffn" : pass == 1 ? "h.qkv+traj" : pass == 2 ? "w.qkv+traj" : "qkv+traj");
+    return AXVS_OK;
+  }
   if (have_qkv) goto qkv_done;
   // q, k, v projections -> blocked 16-bit, q pre-multiplied by scale*log2(e) for the exp2 softmax
   if (!g_generic_only && C == 256 && heads == 8 && qsrc == ksrc) {
@@ -609,7 +631,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   }
   if (which != 2) {
     rc = run_traj<BF>(src, src, src, pos, src, which == 1 ? out : buf1, h_attn, p.th, tw, rmh, B * W, T, H, C, heads, st, 1, nullptr, nullptr, nullptr, ph,
-                      fuse_qkv ? &nq : nullptr);
+                      fuse_qkv ? &nq : nullptr, false, true);
     if (rc != AXVS_OK) return rc;
     if (which == 1) return last_launch_status();
   } else {
@@ -620,7 +642,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   const FfnArgs fa{p.w1, p.w2, p.b1, p.b2, p.g1, p.be1, p.g2, p.be2, F};
   bool ffn_done = false;
   rc = run_traj<BF>(buf1, buf1, buf1, pos, buf1, buf2, w_attn, p.tw, fuse_qkv ? tw2 : tw, rmw, B * H, T, W, C, heads, st, 2, &fa, out, &ffn_done, pw,
-                    nullptr, fuse_qkv);
+                    nullptr, fuse_qkv, true);
   if (rc != AXVS_OK) return rc;
   if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
@@ -1103,6 +1125,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_merge_qkv")) { g_no_merge_qkv = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
@@ -1110,6 +1133,13 @@ const char* axvs_last_error(void) { return g_err; }
 
 int axvs_set_status_buffer(int* device_word) {
   g_status = device_word;
+  return AXVS_OK;
+}
+
+int axvs_set_sync_buffer(unsigned* device_words, size_t n_words) {
+  if (device_words != nullptr && n_words == 0) return fail(AXVS_ERR_ARG, "empty sync buffer");
+  g_sync = device_words;
+  g_sync_words = device_words ? n_words : 0;
   return AXVS_OK;
 }
 

@@ -312,6 +312,29 @@ struct WtBuf {
   }
 };
 
+// ---- hand-off between workgroups of ONE launch (the merged q/k/v + trajectory kernels): bytes stored write-through (sc1) by one
+//      workgroup are read by its sibling workgroups with sc1 loads -- served by the L2 / the memory side, never by a CU's own L1,
+//      which no other CU's store refreshes.  Protocol (MI355X_MICROARCH.md, "inter-workgroup visibility"): every storing wave
+//      waits vmcnt(0), workgroup barrier, ONE lane adds to the counter; a consumer wave polls the counter with an sc1 load and
+//      issues its sc1 loads of the bytes only after the poll matched.
+struct ScBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ explicit ScBuf(const void* base)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000)) {}
+  // 16 bytes at base + voff + soff (soff wave-uniform); aux 16 = sc1
+  __device__ __forceinline__ u16x8 load16(unsigned voff, unsigned soff) const {
+    return __builtin_bit_cast(u16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 16));
+  }
+};
+// one dword, sc1, waited for (the poll of a counter another workgroup adds to)
+__device__ __forceinline__ unsigned ld_sc1_u32(const unsigned* p) {
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// every vector-memory operation of this wave has completed (stores acknowledged)
+__device__ __forceinline__ void vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- in-kernel phase stamps: diagnostic builds only (-DAXVS_STAMPS); the shipped library contains none ----
 #ifdef AXVS_STAMPS
 static __device__ unsigned long long g_stamps[64 * 64];   // per translation unit; g_stamps[slot * 64 + (workgroup % 8) * 8 + wave]

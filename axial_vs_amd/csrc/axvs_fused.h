@@ -374,9 +374,10 @@ constexpr size_t temporal_tile_bytes() {
   if (FFN || QKVN) epi += (size_t)8 * MT * 16 * 32 * sizeof(u16);
   return xt > epi ? xt : epi;
 }
-template <int T, int MT, bool FFN = false, bool QKVN = false>
-constexpr size_t temporal_lds_bytes(int F = 0) {   // tiles | bpq, bv2, bp | FFN parameters
-  return temporal_tile_bytes<T, MT, FFN, QKVN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0);
+template <int T, int MT, bool FFN = false, bool QKVN = false, int MQ = 0>
+constexpr size_t temporal_lds_bytes(int F = 0) {   // tiles | bpq, bv2, bp | FFN parameters | MQ: bq, bk, bv
+  return temporal_tile_bytes<T, MT, FFN, QKVN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0) +
+         (MQ ? 3 * 256 * sizeof(float) : 0);
 }
 
 // QKVN: what the trajectory kernel of one pass needs to emit q, k, v of the NEXT pass from its own output rows (they are in LDS
@@ -393,6 +394,22 @@ struct NextQkv {
   int wt;                 // write-through stores (byte offsets < 4 GiB)
   int* status;
 };
+
+// MQ ("merged q/k/v"): the trajectory kernel of a pass computes q, k, v of its OWN 64 rows first (the body of qkv_fused_kernel:
+// rows gathered through the RowMap, operand tiles in the not yet used x-tile space), keeps q in registers, stores K / V^T
+// write-through, tells the other row tiles of its sequence through `sync[sequence]` and reads THEIR K / V^T with sc1 loads once
+// all of them have arrived -- one launch per pass instead of two, q never leaves the CU (WC/temporal_attention.py:42-57,197-213).
+struct OwnQkv {
+  const float* src;       // fp32 token rows, addressed through the kernel's RowMap
+  const float* pos;       // nullable; read when pg.mode == 0
+  PosGen pg;
+  const u16 *Wq, *Wk, *Wv;
+  const float *bq, *bk, *bv;
+  float qscale;           // head_dim^-0.5 * log2(e)
+  unsigned* sync;         // [sequences] arrival counters: zero before the launch, zero again after it (see the kernel)
+  int* status;            // nullable: bit 0 <- an operand left the fp16 range, bit 2 <- a hand-off wait ran out
+};
+constexpr unsigned kSyncSpinLimit = 1u << 22;    // polls (with s_sleep) before a hand-off wait gives up: ~ 1 s
 
 template <int MT>
 __device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // element offset in the x tile
@@ -444,7 +461,12 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
 //       16-byte rows from any tile shape (QKVN below); MT = 4, NKS <= 2 only.
 // QKVN: after the residual, q / k / v of the NEXT pass are computed from the 64 output rows still in LDS (NextQkv) and stored in
 //       that pass's sequence order.
-template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, bool VROW = false, bool QKVN = false>
+// MQ: 1 = the kernel computes q, k, v of its own rows first (OwnQkv; 64-row tiles, frames of a multiple of 16 keys); 2 = the same
+//     for frames of exactly 64 keys, where a row tile IS one frame of its sequence: that frame's K / V^T fragments are the
+//     accumulators of the k / v sweeps (same 16-bit values as the stored ones), so its QK^T / softmax / AV run first, from registers,
+//     while the sibling tiles' K / V^T stores drain (frames are visited in the order own, own + 1, ... mod T; x-tile blocks are
+//     independent, so the result does not depend on the order).
+template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, bool VROW = false, bool QKVN = false, int MQ = 0>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
                                                              const u16* __restrict__ Wpq, const float* __restrict__ bpq,
                                                              const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
@@ -457,14 +479,18 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */,
                                                              int spatial_only = 0 /* measurement: stop after the QK^T / AV half */,
                                                              const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
-                                                             const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{}) {
+                                                             const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{},
+                                                             OwnQkv oq = OwnQkv{}) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
+  static_assert(MQ == 0 || (MT == 4 && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64-row tiles, block-transposed V");
+  static_assert(MQ != 2 || (NKS == 2 && T >= 2), "own frame first: a 64-row tile is one 64-key frame");
   static_assert(!VROW || (MT == 4 && NKS >= 1 && NKS <= 2), "row-major V is staged in a 64-row x-tile block: 64 keys per frame at most");
   static_assert(!QKVN || (MT == 4 && !FFN && NKS > 0), "the next pass's q/k/v ride in the 64-row kernel without the FFN");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
   float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN, QKVN>());   // bpq | bv2 | bp
+  float* const sqkvb = sbias + 3 * C + (FFN ? fa.F + 5 * C : 0);   // MQ: bq | bk | bv
   FfnLds fl;
   if constexpr (FFN) {
     fl.ytile = xt;
@@ -524,15 +550,173 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const long long nsf = Mp / L;                               // frame slots (sequences x frames)
     const u16* Vh = VROW ? VT16 + (long long)wave * Mp * 32 : VT16 + (long long)wave * nsf * NKS * 1024;
     u16x8 qf[MT];
+    // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
+    // the L2 latency of both hides behind MFMA + softmax work
+    u16x8 kb[2][2 * NKS], vf[2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
+    if constexpr (MQ != 0) {
+      // ---- q, k, v of my own 64 rows (WC/temporal_attention.py:42-44 with query = key = src + pos, value = src, :200-203): the body
+      //      of qkv_fused_kernel on this tile's rows.  The operand tiles live in the x-tile space, which nothing uses yet. ----
+      constexpr int KBSq = ROWS * 32;
+      u16* const tqk = xt;                       // (src + pos) tile [8][64][32]
+      u16* const tv = xt + 8 * KBSq;             // src tile
+      load_wfrags<2, 8>(wf, oq.Wq, C, 0, wave * 32, fi, fg);
+      float bias3[3];                            // biases requested now, parked in LDS behind the row gather
+      if (tid < C) {
+        bias3[0] = oq.bq[tid]; bias3[1] = oq.bk[tid]; bias3[2] = oq.bv[tid];
+      }
+      {
+        // thread -> (row, float4 column); RowMap arithmetic once per wave: lane k computes the k-th of the wave's 8 rows (rows
+        // wave + 8k; rows past the sequence's end are clamped copies), v_readlane broadcasts
+        int off_lo, off_hi, coords = 0;
+        {
+          const int myrow = wave + 8 * (lane & 7);
+          const int mym = (int)m0 + min(myrow, nvalid - 1);
+          const long long myoff = (oq.pg.mode ? nat_row_coords(rm, mym, oq.pg.l_is_h, &coords) : nat_row(rm, mym)) * C;
+          off_lo = (int)(myoff & 0xffffffffll);
+          off_hi = (int)(myoff >> 32);
+        }
+        PosGenLane pl;
+        if (oq.pg.mode) pl.init(oq.pg, lane * 4);
+        float amax = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float4 a[4], p[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = half * 4 + i;
+            const long long off = (((long long)__builtin_amdgcn_readlane(off_hi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(off_lo, k)) + lane * 4;
+            a[i] = *reinterpret_cast<const float4*>(oq.src + off);
+            if (oq.pg.mode) p[i] = pl.eval(oq.pg, __builtin_amdgcn_readlane(coords, k));      // sine embedding generated, not read
+            else p[i] = oq.pos ? *reinterpret_cast<const float4*>(oq.pos + off) : float4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = wave + 8 * (half * 4 + i);
+            const int n = lane * 4, kbq = n >> 5, k = n & 31;
+            const int o = (kbq * ROWS + row) * 32 + swz_chunk(row, k >> 3) * 8 + (k & 7);
+            *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{a[i].x, a[i].y, a[i].z, a[i].w});
+            *reinterpret_cast<u16x4*>(tqk + o) = cvt4<BF>(f32x4{a[i].x + p[i].x, a[i].y + p[i].y, a[i].z + p[i].z, a[i].w + p[i].w});
+            if (!BF) {
+              amax = fmaximum(amax, fmaximum(fmaximum(fabsf(a[i].x), fabsf(a[i].y)), fmaximum(fabsf(a[i].z), fabsf(a[i].w))));
+              amax = fmaximum(amax, fmaximum(fmaximum(fabsf(a[i].x + p[i].x), fabsf(a[i].y + p[i].y)), fmaximum(fabsf(a[i].z + p[i].z), fabsf(a[i].w + p[i].w))));
+            }
+          }
+          lds_fence();
+        }
+        if (!BF && oq.status != nullptr && !(amax <= 65504.f)) atomicOr(oq.status, 1);
+      }
+      if (tid < C) {
+        sqkvb[tid] = bias3[0];
+        sqkvb[C + tid] = bias3[1];
+        sqkvb[2 * C + tid] = bias3[2];
+      }
+      lds_fence();
+      stage_small();
+      AXVS_STAMP(16);
+      __syncthreads();
+      AXVS_STAMP(17);
+      int bb[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int row = mt * 16 + fi;
+        bb[mt] = row * 32 + swz_chunk(row, fg) * 8;
+      }
+      const WtBuf wkb(K16), wvb(VT16);
+      {   // q: stays in registers as the B operand of QK^T (the values qkv_fused_kernel would store and this kernel load back)
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sweep8<BF, MT, true>(acc, wf, tqk, bb, KBSq, oq.Wk, C, wave * 32, fi, fg);
+        const float4 b0 = *reinterpret_cast<const float4*>(sqkvb + wave * 32 + fg * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(sqkvb + wave * 32 + 16 + fg * 4);
+        const float sc_ = oq.qscale;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v[8] = {(acc[0][mt][0] + b0.x) * sc_, (acc[0][mt][1] + b0.y) * sc_, (acc[0][mt][2] + b0.z) * sc_, (acc[0][mt][3] + b0.w) * sc_,
+                        (acc[1][mt][0] + b1.x) * sc_, (acc[1][mt][1] + b1.y) * sc_, (acc[1][mt][2] + b1.z) * sc_, (acc[1][mt][3] + b1.w) * sc_};
+          qf[mt] = cvt8<BF>(v);
+        }
+      }
+      AXVS_STAMP(18);
+      {   // k: rows of K16 (perm32 channel order: 16 contiguous bytes per lane), write-through
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sweep8<BF, MT, true>(acc, wf, tqk, bb, KBSq, oq.Wv, C, wave * 32, fi, fg);
+        const float4 b0 = *reinterpret_cast<const float4*>(sqkvb + C + wave * 32 + fg * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(sqkvb + C + wave * 32 + 16 + fg * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v[8] = {acc[0][mt][0] + b0.x, acc[0][mt][1] + b0.y, acc[0][mt][2] + b0.z, acc[0][mt][3] + b0.w,
+                        acc[1][mt][0] + b1.x, acc[1][mt][1] + b1.y, acc[1][mt][2] + b1.z, acc[1][mt][3] + b1.w};
+          const u16x8 k8 = cvt8<BF>(v);
+          if constexpr (MQ == 2) kb[0][mt] = k8;                  // my rows ARE the keys of my frame
+          if (mt * 16 + fi < nvalid) wkb.store16((unsigned)((((long long)wave * Mp + m0 + mt * 16 + fi) * 32 + fg * 8) * 2), k8);
+        }
+      }
+      AXVS_STAMP(19);
+      {   // v with the operands swapped (tokens on the D rows) -> block-transposed V^T, write-through
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sweep8<BF, MT, false, true>(acc, wf, tv, bb, KBSq, oq.Wv, C, 0, fi, fg);
+        if (L % 32 == 0) {
+          // tile pairs (mt, mt+1) are the two 16-key halves of one 32-key step: 16 contiguous bytes per lane
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float b = sqkvb[2 * C + wave * 32 + nt * 16 + fi];
+#pragma unroll
+            for (int mp = 0; mp < MT; mp += 2) {
+              float v[8] = {acc[nt][mp][0] + b, acc[nt][mp][1] + b, acc[nt][mp][2] + b, acc[nt][mp][3] + b,
+                            acc[nt][mp + 1][0] + b, acc[nt][mp + 1][1] + b, acc[nt][mp + 1][2] + b, acc[nt][mp + 1][3] + b};
+              const u16x8 v8 = cvt8<BF>(v);
+              if constexpr (MQ == 2) vf[nt][mp >> 1] = v8;
+              if (mp * 16 < nvalid) {
+                const unsigned mt0 = (unsigned)m0 + mp * 16;
+                const unsigned sf = mt0 / (unsigned)L;
+                const int ks = (int)(mt0 - sf * L) >> 5;
+                const long long d = ((((long long)wave * nsf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + fg * 8;
+                wvb.store16((unsigned)(d * 2), v8);
+              }
+            }
+          }
+        } else {   // frames of an odd multiple of 16 keys (the host admits L % 16 == 0 only)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const float b = sqkvb[2 * C + wave * 32 + nt * 16 + fi];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              if (mt * 16 < nvalid) {
+                const unsigned mt0 = (unsigned)m0 + mt * 16;
+                const unsigned sf = mt0 / (unsigned)L;
+                const int l = (int)(mt0 - sf * L) + fg * 4;
+                const int ks = l >> 5, pp = fg * 8 + ((l >> 4) & 1) * 4;
+                const long long d = ((((long long)wave * nsf + sf) * NKS + ks) * 2 + nt) * 512 + fi * 32 + pp;
+                f32x4 v = acc[nt][mt];
+                v[0] += b; v[1] += b; v[2] += b; v[3] += b;
+                wvb.store8((unsigned)(d * 2), cvt4<BF>(v));
+                // the frame's last 16-key tile also clears the padding half of its 32-key step (finite values for probability 0)
+                if ((int)(mt0 - sf * L) + 16 == L) wvb.store8((unsigned)((d ^ 4) * 2), u16x4{0, 0, 0, 0});
+              }
+            }
+          }
+        }
+      }
+      AXVS_STAMP(20);
+    } else {
 #pragma unroll
     for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + min(qt * 16 + fi, nvalid - 1)) * 32 + fg * 8);
+    }
     const bool ragged = L != NKS * 32;
     u16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = H16<BF>::from_f32(1.f);
-    // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
-    // the L2 latency of both hides behind MFMA + softmax work
-    u16x8 kb[2][2 * NKS], vf[2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
     // per-lane fragment pointers, advanced by one frame per iteration (all index math hoisted out of the loop:
     // frame slot sf = seq0 / L + f because N = T * L)
     const u16* kp[2 * NKS];
@@ -560,18 +744,74 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) vtr[nd] = (4 * fg + (fi >> 2)) * 32 + 8 * (fi & 3) + 4 * (nd ^ (fg & 1));
     }
+    // MQ: K / V^T written by the sibling tiles of this launch are read with sc1 buffer loads (per-lane byte offset + a
+    // wave-uniform frame offset), and only after the hand-off below
+    [[maybe_unused]] const ScBuf kbuf(K16), vbuf(VT16);
+    [[maybe_unused]] unsigned kvo[2 * NKS], vvo = 0;
+    [[maybe_unused]] const unsigned kstep_b = (unsigned)L * 64u, vstep_b = NKS * 2048u;
+    [[maybe_unused]] unsigned* const cnt = MQ != 0 ? oq.sync + m0 / N : nullptr;      // my sequence's arrival counter
+    [[maybe_unused]] const unsigned tps_u = (unsigned)((N + ROWS - 1) / ROWS);
+    // arrive: my K / V^T stores are complete (every wave drained its own, then the barrier); the counter wraps back to 0 with the
+    // last of the 2 * tiles arrivals + departures, so it is zero again when the launch ends
+    auto arrive = [&]() {
+      vm_drain();
+      __syncthreads();
+      if (tid == 0) atomicInc(cnt, 2 * tps_u - 1);
+    };
+    auto wait_siblings = [&]() {            // every wave polls for itself (one dword, sc1) and loads only after its poll matched
+      unsigned spins = 0;
+      while (ld_sc1_u32(cnt) < tps_u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSyncSpinLimit) {
+          if (oq.status != nullptr && lane == 0) atomicOr(oq.status, 4);
+          break;
+        }
+      }
+    };
+    if constexpr (MQ != 0) {
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt)
+        kvo[kt] = (unsigned)((((long long)wave * Mp + seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8) * 2);
+      vvo = (unsigned)((((long long)wave * nsf + seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8) * 2);
+      if constexpr (MQ == 1) {
+        arrive();
+        AXVS_STAMP(21);
+        wait_siblings();
+        AXVS_STAMP(22);
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = kbuf.load16(kvo[kt], 0);
+      }
+    } else {
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+    }
     AXVS_STAMP(11);
-    stage_small();                       // behind the cold Q / K loads of the first frame instead of in front of the barrier
+    if constexpr (MQ == 0) stage_small();   // behind the cold Q / K loads of the first frame instead of in front of the barrier
     // One frame.  PAR = f & 1 as a compile-time constant (the K fragment sets alternate; register arrays need static indices).
     // LAST: the sequence's last frame -- no K prefetch for a next one, and the first GEMM phase's weight fragments (Wpq rows of
     // my head) are requested as soon as the score registers are free, so their L2 latency hides behind the last AV products and
     // the barrier instead of following them.
-    auto frame = [&](const int f, auto par_tag, auto last_tag) {
+    // MQ: `fnext` is the frame visited after f (its K fragments are requested here); OWN (MQ == 2, first frame): K / V^T fragments
+    // of frame f are already in kb[PAR] / vf (this tile's own rows) and the hand-off with the sibling tiles happens inside the frame,
+    // between the softmax and the AV products -- the own K / V^T stores drain behind the scores, the siblings' K fragments of
+    // frame fnext arrive behind the AV products.
+    auto frame = [&](const int f, const int fnext, auto par_tag, auto last_tag, auto own_tag) {
       constexpr int PAR = decltype(par_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;
+      constexpr bool OWN = decltype(own_tag)::value;
       u16x8 vr[NVL];
+      if constexpr (MQ != 0) {
+        if constexpr (!OWN) {
+#pragma unroll
+          for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = vbuf.load16(vvo + (ks * 2 + nd) * 1024, (unsigned)f * vstep_b);
+          if constexpr (!LAST) {
+#pragma unroll
+            for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = kbuf.load16(kvo[kt], (unsigned)fnext * kstep_b);
+          }
+        }
+      } else {
       if constexpr (VROW) {
 #pragma unroll
         for (int n = 0; n < NVL; ++n) {
@@ -590,6 +830,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+      }
       }
       f32x4 sc[MT][2 * NKS];
 #pragma unroll
@@ -656,6 +897,12 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
               for (int e = 0; e < 4; ++e) vf[nd][ks][4 * hj + e] = (u16)t4[e];
             }
       }
+      if constexpr (OWN) {
+        arrive();                          // (the barrier also ends every wave's use of the q/k/v operand tiles in the x-tile space)
+        wait_siblings();
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = kbuf.load16(kvo[kt], (unsigned)fnext * kstep_b);
+      }
       if constexpr (LAST) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
       f32x4 xa[MT][2];
 #pragma unroll
@@ -684,16 +931,33 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     {
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
+      if constexpr (MQ == 2) {
+        // my tile is frame `fown` of its sequence: visit own, own + 1, ... (mod T)
+        const int fown = (int)(m0 - seq0) / L;
+        auto fr = [&](int i) { const int f = fown + i; return f >= T ? f - T : f; };
+        frame(fr(0), fr(1), I0{}, std::false_type{}, std::true_type{});
+        int i = 1;
+#pragma nounroll
+        for (; i + 2 <= T - 1; i += 2) {
+          frame(fr(i), fr(i + 1), I1{}, std::false_type{}, std::false_type{});
+          frame(fr(i + 1), fr(i + 2), I0{}, std::false_type{}, std::false_type{});
+        }
+        if constexpr (((T - 2) & 1) != 0) frame(fr(T - 2), fr(T - 1), std::integral_constant<int, (T - 2) & 1>{}, std::false_type{}, std::false_type{});
+        frame(fr(T - 1), 0, std::integral_constant<int, (T - 1) & 1>{}, std::true_type{}, std::false_type{});
+      } else {
       int f = 0;
 #pragma nounroll
       for (; f + 2 <= T - 1; f += 2) {
-        frame(f, I0{}, std::false_type{});
-        frame(f + 1, I1{}, std::false_type{});
+        frame(f, f + 1, I0{}, std::false_type{}, std::false_type{});
+        frame(f + 1, f + 2, I1{}, std::false_type{}, std::false_type{});
       }
-      if constexpr (((T - 1) & 1) != 0) frame(T - 2, I0{}, std::false_type{});
-      frame(T - 1, std::integral_constant<int, (T - 1) & 1>{}, std::true_type{});
+      if constexpr (((T - 1) & 1) != 0) frame(T - 2, T - 1, I0{}, std::false_type{}, std::false_type{});
+      frame(T - 1, 0, std::integral_constant<int, (T - 1) & 1>{}, std::true_type{}, std::false_type{});
+      }
     }
-    if (spatial_only) return;            // bench.py times QK^T / softmax / AV alone with this (nothing is written)
+    if constexpr (MQ == 0) {
+      if (spatial_only) return;          // bench.py times QK^T / softmax / AV alone with this (nothing is written)
+    }
   } else {
   // ---- stage the x tile: T*8 blocks of ROWS rows x 64 B, contiguous in global memory ----
   {
@@ -721,6 +985,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   if constexpr (NKS == 0) stage_small();   // (with the spatial half in the kernel this happened before its first frame)
   __syncthreads();
+  if constexpr (MQ != 0) {                 // depart: every wave of this workgroup is past its poll
+    const int tps = (N + ROWS - 1) / ROWS;
+    if (tid == 0) atomicInc(oq.sync + m0 / N, 2 * (unsigned)tps - 1);
+  }
 
   AXVS_STAMP(1);
   // per-lane query bookkeeping

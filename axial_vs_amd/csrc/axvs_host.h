@@ -75,6 +75,7 @@ struct TrajWs {
 
 struct FfnArgs;   // axvs_fused.h
 struct NextQkv;   // axvs_fused.h
+struct OwnQkv;    // axvs_fused.h
 
 // nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel.  `fa` non-null: the
 // layer's FFN rides along (needs nks > 0 and 64-row tiles).  vrow: w.vt16 holds V row-major in K's layout (64-row tiles, nks <= 2).
@@ -82,6 +83,6 @@ struct NextQkv;   // axvs_fused.h
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
                       int L, float scale, hipStream_t st, const FfnArgs* fa, int flags /* bit 0: write-through output rows, bit 1: stop after the spatial half */,
-                      int vrow, const NextQkv* nq);
+                      int vrow, const NextQkv* nq, const OwnQkv* oq /* non-null: the kernel computes q, k, v of its own rows first (merged launch) */);
 
 }  // namespace axvs

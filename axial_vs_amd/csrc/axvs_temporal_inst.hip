@@ -13,23 +13,37 @@
 
 namespace axvs {
 
-template <bool BF, int T, int MT, int NKS, bool FFN, bool VROW, bool QKVN>
+template <bool BF, int T, int MT, int NKS, bool FFN, bool VROW, bool QKVN, int MQ = 0>
 static int launch_one(unsigned grid, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                      float scale, hipStream_t st, const FfnArgs* fa, int wt, const NextQkv* nq) {
-  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, VROW, QKVN>;
+                      float scale, hipStream_t st, const FfnArgs* fa, int wt, const NextQkv* nq, const OwnQkv* oq = nullptr) {
+  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, VROW, QKVN, MQ>;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern))) return rc;
-  const size_t lds = temporal_lds_bytes<T, MT, FFN, QKVN>(FFN ? fa->F : 0);
+  const size_t lds = temporal_lds_bytes<T, MT, FFN, QKVN, MQ>(FFN ? fa->F : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale,
                      w.q16, w.k16, w.vt16, FFN ? *fa : FfnArgs{}, p.wk2t, wt & 1, wt >> 1, FFN ? nullptr : p.post_ln_g,
-                     FFN ? nullptr : p.post_ln_b, QKVN ? *nq : NextQkv{});
+                     FFN ? nullptr : p.post_ln_b, QKVN ? *nq : NextQkv{}, MQ ? *oq : OwnQkv{});
   return AXVS_OK;
 }
 
 template <bool BF, int T, int MT, int NKS>
 static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                             float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq) {
+                             float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq, const OwnQkv* oq) {
   // with the spatial half in the kernel every sequence gets its own ceil(N / rows) tiles (see temporal_fused_kernel)
   const unsigned grid = NKS > 0 ? (unsigned)((Mp / N) * ((N + MT * 16 - 1) / (MT * 16))) : (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
+  if constexpr (NKS > 0 && NKS <= 3 && MT == 4 && T <= 4) {
+    if (oq) {                           // merged q/k/v + trajectory launch (the caller checked: no row-form V, no next-pass q/k/v)
+      if (vrow || nq) return fail(AXVS_ERR_ARG, "internal: merged q/k/v excludes row-form V / next-pass q,k,v");
+      if constexpr (NKS == 2 && T >= 2) {
+        if (L == 64) {                  // a 64-row tile is one frame: own frame first, from registers
+          if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+          return launch_one<BF, T, MT, NKS, false, false, false, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+        }
+      }
+      if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+      return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+    }
+  }
+  if (oq) return fail(AXVS_ERR_ARG, "internal: merged q/k/v needs the in-kernel spatial half on 64-row tiles, T <= 4");
   if constexpr (NKS > 0 && MT == 4) {
     if constexpr (NKS <= 2) {           // V in row form (staged in the x tile: 64 keys per frame at most)
       if (vrow && fa) return launch_one<BF, T, MT, NKS, true, true, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
@@ -47,20 +61,20 @@ static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* 
 
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq) {
+                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq, const OwnQkv* oq) {
   switch (nks) {
-    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
-    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq);
+    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
     default: return fail(AXVS_ERR_ARG, "bad nks");
   }
 }
 
 template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, AXVS_INST_MT>(
     int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int, int,
-    const NextQkv*);
+    const NextQkv*, const OwnQkv*);
 
 }  // namespace axvs
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import math
+import threading
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -54,6 +55,26 @@ def _workspace(device: torch.device, nbytes: int) -> Tensor:
 
 def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# Arrival counters of the one-launch-per-pass kernels (include/axvs.h, axvs_set_sync_buffer): zero when registered, left zero by
+# every launch.  One set per (device, stream) -- calls on different streams may run concurrently (pixel_decoder runs two levels
+# side by side) -- registered with the library per calling thread, re-registered only when the (device, stream) changes.
+_SYNC_WORDS = 16384
+_sync_buffers: Dict[Tuple[int, int], Tensor] = {}
+_sync_tls = threading.local()
+
+
+def _select_sync_words(device: torch.device) -> None:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    if getattr(_sync_tls, "key", None) == key:
+        return
+    buf = _sync_buffers.get(key)
+    if buf is None:
+        buf = _sync_buffers[key] = torch.zeros(_SYNC_WORDS, dtype=torch.int32, device=torch.device("cuda", idx))
+    _lib.check(_lib.lib().axvs_set_sync_buffer(buf.data_ptr(), _SYNC_WORDS), "axvs_set_sync_buffer")
+    _sync_tls.key = key
 
 
 def _dev_f32(t: Tensor, what: str) -> Tensor:
@@ -429,6 +450,7 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             ha = torch.empty(B * W * self.n_heads, T * H, T, H, dtype=torch.float32, device=s.device)
             wa = torch.empty(B * H * self.n_heads, T * W, T, W, dtype=torch.float32, device=s.device)
         packed = self._pack()
+        _select_sync_words(s.device)
         tag = _sine_tag(pos) if self.use_generated_pos else None
         if tag is not None:
             sp = _lib.AxvsSinePos3D(tag.temperature, int(tag.normalize), tag.scale, tag.level.data_ptr() if tag.level is not None else None)
@@ -460,6 +482,7 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         F = self.linear1.out_features
         out = torch.empty_like(xs)
         packed = self._pack()
+        _select_sync_words(xs.device)
         ws = _workspace(xs.device, L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, 0, 0))
         _lib.check(L.axvs_axial_pass_fwd(xs.data_ptr(), ps.data_ptr(), out.data_ptr(), packed.data_ptr(), int(which), B, T, H, W, C_,
                                          self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(), _stream(xs.device)),

@@ -65,7 +65,23 @@ const char* axvs_last_error(void);
  *   bit 0  AXVS_STATUS_FP16_RANGE: a q/k/v operand of the C = 256 fused kernels (src or src + pos) exceeded the fp16 range
  *          (|x| > 65504) or was NaN -- with f16 MFMA operands the result would silently contain inf / NaN; use AXVS_BF16. */
 #define AXVS_STATUS_FP16_RANGE 1
+/*   bit 2  AXVS_STATUS_SYNC_TIMEOUT: a workgroup of a merged q/k/v + trajectory launch (axvs_set_sync_buffer) gave up waiting for
+ *          its sibling row tiles (~1 s): the sync words were not zero at launch.  The outputs of that call are invalid; zero the
+ *          words again (hipMemset) before the next call. */
+#define AXVS_STATUS_SYNC_TIMEOUT 4
 int axvs_set_status_buffer(int* device_word);
+
+/* Synchronisation words of the ONE-LAUNCH-PER-PASS form of the axial layer (axvs_axial_layer_fwd[_sine3d], axvs_axial_pass_fwd;
+ * C = 256, 8 heads, T <= 4, axis lengths that are multiples of 16 up to 96).  Reference: WC/temporal_attention.py:197-213 -- the
+ * q/k/v Linear layers and the trajectory attention of a pass.  With a buffer registered, the trajectory kernel of a pass computes
+ * q, k, v of its own 64 rows itself and the row tiles of one sequence hand K / V^T to each other INSIDE the launch, through one
+ * arrival counter per sequence (B*W for the height pass, B*H for the width pass) taken from `device_words`; without one (the
+ * default) every pass is a q/k/v launch followed by a trajectory launch.  Both forms give bit-identical results.
+ * Contract: `device_words` are n_words 32-bit words of device memory that are ZERO when registered (hipMemset once); every launch
+ * leaves them zero again.  One buffer serves one stream at a time: calls that may run concurrently (different streams) need
+ * different buffers.  Registration is per calling thread, like the status word; (NULL, 0) unregisters.  A call with more
+ * sequences than n_words runs the two-launch form. */
+int axvs_set_sync_buffer(unsigned* device_words, size_t n_words);
 
 /* ---- optional per-stage timing of axvs_axial_layer_fwd (used by bench.py; thread-local).
  *      events: array of `capacity` hipEvent_t created by the caller, or NULL to switch off.  While set, the layer
