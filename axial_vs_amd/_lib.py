@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -228,14 +229,21 @@ def current_amp() -> int:
     return _AMP_MODE
 
 
+_AMP_LOCK = threading.RLock()
+
+
 class train_amp:
-    """Context manager: the library's X W^T GEMMs of the training tier run with `mode` (0 off, 1 bf16, 2 fp16) inside."""
+    """Context manager: the library's X W^T GEMMs of the training tier run with `mode` (0 off, 1 bf16, 2 fp16) inside.
+    The option is process-wide in the library (forward and backward threads must agree on it), so training-tier calls are
+    serialised on a lock while one holds the option: a concurrent call from another thread (a second model, a DataParallel
+    replica) waits instead of running its GEMMs at the other call's precision."""
 
     def __init__(self, mode: int):
         self.mode = int(mode)
 
     def __enter__(self):
         global _AMP_MODE
+        _AMP_LOCK.acquire()
         self.prev = _AMP_MODE
         _AMP_MODE = self.mode
         if self.mode != self.prev:
@@ -245,6 +253,9 @@ class train_amp:
     def __exit__(self, *exc):
         global _AMP_MODE
         _AMP_MODE = self.prev
-        if self.mode != self.prev:
-            lib().axvs_set_option(b"train_amp", self.prev)
+        try:
+            if self.mode != self.prev:
+                check(lib().axvs_set_option(b"train_amp", self.prev), "axvs_set_option")
+        finally:
+            _AMP_LOCK.release()
         return False

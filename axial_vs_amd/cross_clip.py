@@ -153,7 +153,7 @@ class CrossClipTrackingModule(nn.Module):
     # ---- packing -------------------------------------------------------------------------------------------------
     def _dtype(self) -> str:
         from . import modules
-        return self.mfma_dtype or modules._DEFAULT_DTYPE
+        return self.mfma_dtype or modules.default_operand_dtype()
 
     def _pack(self):
         dt = self._dtype()
@@ -194,9 +194,10 @@ class CrossClipTrackingModule(nn.Module):
         """train() mode (CC:53-57 instead of :58-70): differentiable, BatchNorm on batch statistics, outputs stay on the GPU."""
         from .cc_training import cc_module_train
         logits, masks = cc_module_train(self, clip_query, panoptic_features)
-        nl = self.num_layers
-        cls_all = [logits[i] for i in range(nl)]
-        mask_all = [masks[i] for i in range(nl)]
+        # unbind: ONE autograd node that stacks the per-layer gradients once (indexing layer by layer would add a full-size zero
+        # tensor per layer in backward: 4 x 3.2 GB at the shipped VIPSeg shape)
+        cls_all = list(logits.unbind(0))
+        mask_all = list(masks.unbind(0))
         # (_set_aux_loss resamples the auxiliary masks to the last layer's size, CC:324-331: every layer has that size already)
         aux = [{"pred_logits": a, "pred_masks": b} for a, b in zip(cls_all[:-1], mask_all[:-1])]
         return {"pred_logits": cls_all[-1], "pred_masks": mask_all[-1], "aux_outputs": aux}
@@ -287,7 +288,7 @@ class TubeLinkCrossClipHead(nn.Module):
 
     def _dtype(self) -> str:
         from . import modules
-        return self.mfma_dtype or modules._DEFAULT_DTYPE
+        return self.mfma_dtype or modules.default_operand_dtype()
 
     def _pack(self):
         dt = self._dtype()

@@ -55,6 +55,7 @@ thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass'
 // that are zero when registered; every launch leaves them zero) -- without a registered buffer the passes run as two launches.
 thread_local unsigned* g_sync = nullptr;
 thread_local size_t g_sync_words = 0;
+thread_local int g_merge_qkv_any = 0;    // option "merge_qkv_any": merged launches at every grid size (A/B; see run_traj)
 thread_local int g_no_merge_qkv = 0;     // option "no_merge_qkv": keep qkv_fused_kernel + trajectory kernel as two launches (A/B, tests)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
@@ -363,9 +364,15 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   // one launch per pass: the trajectory kernel computes q, k, v of its own rows (OwnQkv).  Needs the 64-row fused kernels with
   // T <= 4, frames of a multiple of 16 keys (16-byte / 8-byte V^T stores) and at most 96 (register budget), byte offsets of K / V^T
   // below 4 GiB (buffer addressing), one registered arrival counter per sequence.  Bit-identical to the two-launch form.
+  // Frames of 64 keys (a row tile IS a frame: its own K / V^T fragments never leave the registers, MQ = 2) gain at every size
+  // measured (4 - 9 % from [1,2,256,64,64] to [8,4,256,64,64]); other frame lengths (MQ = 1) gain while the grid stays within
+  // ~2 rounds of the chip (-3.5 % at 576 tiles, -7.5 % at 240) and LOSE beyond (+2.5 % at 1152 tiles, +8 % at 4608: sibling
+  // tiles start staggered there and every tile waits for the last one) -- option "merge_qkv_any" lifts the limit for A/B runs.
+  const bool own_frame = L == 64 && T >= 2;
   const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv && !g_spatial_only &&
                      g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= 3 &&
-                     traj_mt4(T, traj_tiles64(Mp, N), with_ffn) && 2 * (long long)Cp * Mp * 2 < (1ll << 32);
+                     traj_mt4(T, traj_tiles64(Mp, N), with_ffn) && 2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
+                     (own_frame || traj_tiles64(Mp, N) <= 640 || g_merge_qkv_any);
   if (merge) {
     const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status};
     int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr, 0, nullptr, &oq);
@@ -1126,6 +1133,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_merge_qkv")) { g_no_merge_qkv = value; return AXVS_OK; }
+  if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }

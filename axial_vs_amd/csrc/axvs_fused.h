@@ -553,16 +553,46 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
     // the L2 latency of both hides behind MFMA + softmax work
     u16x8 kb[2][2 * NKS], vf[2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
+    // MQ: K / V^T written by the sibling tiles of this launch are read with sc1 buffer loads (per-lane byte offset + a
+    // wave-uniform frame offset), and only after the hand-off
+    [[maybe_unused]] const ScBuf kbuf(K16), vbuf(VT16);
+    [[maybe_unused]] unsigned kvo[2 * NKS], vvo = 0;
+    [[maybe_unused]] const unsigned kstep_b = (unsigned)L * 64u, vstep_b = NKS * 2048u;
+    [[maybe_unused]] unsigned* const cnt = MQ != 0 ? oq.sync + m0 / N : nullptr;      // my sequence's arrival counter
+    [[maybe_unused]] const unsigned tps_u = (unsigned)((N + ROWS - 1) / ROWS);
+    [[maybe_unused]] u16x8 vown[2][NKS];          // MQ == 2: V^T fragments of my own frame
+    auto wait_siblings = [&]() {            // every wave polls for itself (one dword, sc1) and loads only after its poll matched
+      unsigned spins = 0;
+      while (ld_sc1_u32(cnt) < tps_u) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSyncSpinLimit) {
+          if (oq.status != nullptr && lane == 0) atomicOr(oq.status, 4);
+          break;
+        }
+      }
+    };
     if constexpr (MQ != 0) {
       // ---- q, k, v of my own 64 rows (WC/temporal_attention.py:42-44 with query = key = src + pos, value = src, :200-203): the body
-      //      of qkv_fused_kernel on this tile's rows.  The operand tiles live in the x-tile space, which nothing uses yet. ----
+      //      of qkv_fused_kernel on this tile's rows.  The operand tiles live in the x-tile space, which nothing uses yet.
+      //      Order: v, k -- their stores are what the sibling tiles wait for -- then the hand-off signal, then q (which never
+      //      leaves the CU): the q sweep and, for MQ == 2, the own frame's scores run while the signals travel. ----
       constexpr int KBSq = ROWS * 32;
       u16* const tqk = xt;                       // (src + pos) tile [8][64][32]
       u16* const tv = xt + 8 * KBSq;             // src tile
-      load_wfrags<2, 8>(wf, oq.Wq, C, 0, wave * 32, fi, fg);
-      float bias3[3];                            // biases requested now, parked in LDS behind the row gather
+      load_wfrags<2, 8>(wf, oq.Wv, C, 0, wave * 32, fi, fg);
+      // every small parameter is requested now and parked in LDS behind the row gather (their latency hides behind it)
+      float sm3[3], sq3[3], sf5[5], sf1[2];
       if (tid < C) {
-        bias3[0] = oq.bq[tid]; bias3[1] = oq.bk[tid]; bias3[2] = oq.bv[tid];
+        sq3[0] = oq.bq[tid]; sq3[1] = oq.bk[tid]; sq3[2] = oq.bv[tid];
+        sm3[0] = bpq[tid]; sm3[1] = bpkv[C + tid]; sm3[2] = bp[tid];
+        if constexpr (FFN) {
+          sf5[0] = fa.b2[tid]; sf5[1] = fa.g1[tid]; sf5[2] = fa.be1[tid]; sf5[3] = fa.g2[tid]; sf5[4] = fa.be2[tid];
+        }
+      }
+      if constexpr (FFN) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (tid + i * 512 < fa.F) sf1[i] = fa.b1[tid + i * 512];      // (d_ffn > 1024: the rest follows the gather)
       }
       {
         // thread -> (row, float4 column); RowMap arithmetic once per wave: lane k computes the k-th of the wave's 8 rows (rows
@@ -606,12 +636,24 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         if (!BF && oq.status != nullptr && !(amax <= 65504.f)) atomicOr(oq.status, 1);
       }
       if (tid < C) {
-        sqkvb[tid] = bias3[0];
-        sqkvb[C + tid] = bias3[1];
-        sqkvb[2 * C + tid] = bias3[2];
+        sqkvb[tid] = sq3[0]; sqkvb[C + tid] = sq3[1]; sqkvb[2 * C + tid] = sq3[2];
+        sbias[tid] = sm3[0]; sbias[C + tid] = sm3[1]; sbias[2 * C + tid] = sm3[2];
+        if constexpr (FFN) {
+          float* q = fl.par + fa.F;
+          q[tid] = sf5[0]; q[256 + tid] = sf5[1]; q[512 + tid] = sf5[2]; q[768 + tid] = sf5[3]; q[1024 + tid] = sf5[4];
+        }
       }
       lds_fence();
-      stage_small();
+      if constexpr (FFN) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (tid + i * 512 < fa.F) fl.par[tid + i * 512] = sf1[i];
+        lds_fence();
+        for (int i = tid + 1024; i < fa.F; i += 512) {
+          fl.par[i] = fa.b1[i];
+          lds_fence();
+        }
+      }
       AXVS_STAMP(16);
       __syncthreads();
       AXVS_STAMP(17);
@@ -622,50 +664,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         bb[mt] = row * 32 + swz_chunk(row, fg) * 8;
       }
       const WtBuf wkb(K16), wvb(VT16);
-      {   // q: stays in registers as the B operand of QK^T (the values qkv_fused_kernel would store and this kernel load back)
-        f32x4 acc[2][MT];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sweep8<BF, MT, true>(acc, wf, tqk, bb, KBSq, oq.Wk, C, wave * 32, fi, fg);
-        const float4 b0 = *reinterpret_cast<const float4*>(sqkvb + wave * 32 + fg * 4);
-        const float4 b1 = *reinterpret_cast<const float4*>(sqkvb + wave * 32 + 16 + fg * 4);
-        const float sc_ = oq.qscale;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float v[8] = {(acc[0][mt][0] + b0.x) * sc_, (acc[0][mt][1] + b0.y) * sc_, (acc[0][mt][2] + b0.z) * sc_, (acc[0][mt][3] + b0.w) * sc_,
-                        (acc[1][mt][0] + b1.x) * sc_, (acc[1][mt][1] + b1.y) * sc_, (acc[1][mt][2] + b1.z) * sc_, (acc[1][mt][3] + b1.w) * sc_};
-          qf[mt] = cvt8<BF>(v);
-        }
-      }
-      AXVS_STAMP(18);
-      {   // k: rows of K16 (perm32 channel order: 16 contiguous bytes per lane), write-through
-        f32x4 acc[2][MT];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sweep8<BF, MT, true>(acc, wf, tqk, bb, KBSq, oq.Wv, C, wave * 32, fi, fg);
-        const float4 b0 = *reinterpret_cast<const float4*>(sqkvb + C + wave * 32 + fg * 4);
-        const float4 b1 = *reinterpret_cast<const float4*>(sqkvb + C + wave * 32 + 16 + fg * 4);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float v[8] = {acc[0][mt][0] + b0.x, acc[0][mt][1] + b0.y, acc[0][mt][2] + b0.z, acc[0][mt][3] + b0.w,
-                        acc[1][mt][0] + b1.x, acc[1][mt][1] + b1.y, acc[1][mt][2] + b1.z, acc[1][mt][3] + b1.w};
-          const u16x8 k8 = cvt8<BF>(v);
-          if constexpr (MQ == 2) kb[0][mt] = k8;                  // my rows ARE the keys of my frame
-          if (mt * 16 + fi < nvalid) wkb.store16((unsigned)((((long long)wave * Mp + m0 + mt * 16 + fi) * 32 + fg * 8) * 2), k8);
-        }
-      }
-      AXVS_STAMP(19);
       {   // v with the operands swapped (tokens on the D rows) -> block-transposed V^T, write-through
         f32x4 acc[2][MT];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        sweep8<BF, MT, false, true>(acc, wf, tv, bb, KBSq, oq.Wv, C, 0, fi, fg);
+        sweep8<BF, MT, true, true>(acc, wf, tv, bb, KBSq, oq.Wk, C, wave * 32, fi, fg);
         if (L % 32 == 0) {
           // tile pairs (mt, mt+1) are the two 16-key halves of one 32-key step: 16 contiguous bytes per lane
 #pragma unroll
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
               float v[8] = {acc[nt][mp][0] + b, acc[nt][mp][1] + b, acc[nt][mp][2] + b, acc[nt][mp][3] + b,
                             acc[nt][mp + 1][0] + b, acc[nt][mp + 1][1] + b, acc[nt][mp + 1][2] + b, acc[nt][mp + 1][3] + b};
               const u16x8 v8 = cvt8<BF>(v);
-              if constexpr (MQ == 2) vf[nt][mp >> 1] = v8;
+              if constexpr (MQ == 2) vown[nt][mp >> 1] = v8;     // my rows ARE the keys of my frame
               if (mp * 16 < nvalid) {
                 const unsigned mt0 = (unsigned)m0 + mp * 16;
                 const unsigned sf = mt0 / (unsigned)L;
@@ -708,7 +713,62 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
           }
         }
       }
+      AXVS_STAMP(18);
+      {   // k: rows of K16 (perm32 channel order: 16 contiguous bytes per lane), write-through
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sweep8<BF, MT, true>(acc, wf, tqk, bb, KBSq, oq.Wq, C, wave * 32, fi, fg);
+        const float4 b0 = *reinterpret_cast<const float4*>(sqkvb + C + wave * 32 + fg * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(sqkvb + C + wave * 32 + 16 + fg * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v[8] = {acc[0][mt][0] + b0.x, acc[0][mt][1] + b0.y, acc[0][mt][2] + b0.z, acc[0][mt][3] + b0.w,
+                        acc[1][mt][0] + b1.x, acc[1][mt][1] + b1.y, acc[1][mt][2] + b1.z, acc[1][mt][3] + b1.w};
+          const u16x8 k8 = cvt8<BF>(v);
+          if constexpr (MQ == 2) kb[0][mt] = k8;
+          if (mt * 16 + fi < nvalid) wkb.store16((unsigned)((((long long)wave * Mp + m0 + mt * 16 + fi) * 32 + fg * 8) * 2), k8);
+        }
+      }
+      AXVS_STAMP(19);
+      // hand-off, producer side: my K / V^T stores are complete (every wave drains its own, then the barrier), ONE lane adds to the
+      // sequence's counter.  (The counter wraps back to 0 with the last of the 2 * tiles arrivals + departures: zero again at the end.)
+      vm_drain();
       AXVS_STAMP(20);
+      __syncthreads();
+      if (tid == 0) atomicInc(cnt, 2 * tps_u - 1);
+      AXVS_STAMP(21);
+      {   // q: stays in registers as the B operand of QK^T (the values qkv_fused_kernel would store and this kernel load back)
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sweep8<BF, MT, false>(acc, wf, tqk, bb, KBSq, oq.Wq, C, 0, fi, fg);
+        const float4 b0 = *reinterpret_cast<const float4*>(sqkvb + wave * 32 + fg * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(sqkvb + wave * 32 + 16 + fg * 4);
+        const float sc_ = oq.qscale;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v[8] = {(acc[0][mt][0] + b0.x) * sc_, (acc[0][mt][1] + b0.y) * sc_, (acc[0][mt][2] + b0.z) * sc_, (acc[0][mt][3] + b0.w) * sc_,
+                        (acc[1][mt][0] + b1.x) * sc_, (acc[1][mt][1] + b1.y) * sc_, (acc[1][mt][2] + b1.z) * sc_, (acc[1][mt][3] + b1.w) * sc_};
+          qf[mt] = cvt8<BF>(v);
+        }
+      }
+      AXVS_STAMP(22);
+      __syncthreads();                           // every wave is done with the operand tiles: the x tile may be written
+#pragma unroll
+      for (int kt = 0; kt < 2 * NKS; ++kt)
+        kvo[kt] = (unsigned)((((long long)wave * Mp + seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8) * 2);
+      vvo = (unsigned)((((long long)wave * nsf + seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8) * 2);
+      if constexpr (MQ == 1) {
+        wait_siblings();
+        AXVS_STAMP(23);
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = kbuf.load16(kvo[kt], 0);
+      }
     } else {
 #pragma unroll
     for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + min(qt * 16 + fi, nvalid - 1)) * 32 + fg * 8);
@@ -744,44 +804,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) vtr[nd] = (4 * fg + (fi >> 2)) * 32 + 8 * (fi & 3) + 4 * (nd ^ (fg & 1));
     }
-    // MQ: K / V^T written by the sibling tiles of this launch are read with sc1 buffer loads (per-lane byte offset + a
-    // wave-uniform frame offset), and only after the hand-off below
-    [[maybe_unused]] const ScBuf kbuf(K16), vbuf(VT16);
-    [[maybe_unused]] unsigned kvo[2 * NKS], vvo = 0;
-    [[maybe_unused]] const unsigned kstep_b = (unsigned)L * 64u, vstep_b = NKS * 2048u;
-    [[maybe_unused]] unsigned* const cnt = MQ != 0 ? oq.sync + m0 / N : nullptr;      // my sequence's arrival counter
-    [[maybe_unused]] const unsigned tps_u = (unsigned)((N + ROWS - 1) / ROWS);
-    // arrive: my K / V^T stores are complete (every wave drained its own, then the barrier); the counter wraps back to 0 with the
-    // last of the 2 * tiles arrivals + departures, so it is zero again when the launch ends
-    auto arrive = [&]() {
-      vm_drain();
-      __syncthreads();
-      if (tid == 0) atomicInc(cnt, 2 * tps_u - 1);
-    };
-    auto wait_siblings = [&]() {            // every wave polls for itself (one dword, sc1) and loads only after its poll matched
-      unsigned spins = 0;
-      while (ld_sc1_u32(cnt) < tps_u) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSyncSpinLimit) {
-          if (oq.status != nullptr && lane == 0) atomicOr(oq.status, 4);
-          break;
-        }
-      }
-    };
-    if constexpr (MQ != 0) {
-#pragma unroll
-      for (int kt = 0; kt < 2 * NKS; ++kt)
-        kvo[kt] = (unsigned)((((long long)wave * Mp + seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8) * 2);
-      vvo = (unsigned)((((long long)wave * nsf + seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8) * 2);
-      if constexpr (MQ == 1) {
-        arrive();
-        AXVS_STAMP(21);
-        wait_siblings();
-        AXVS_STAMP(22);
-#pragma unroll
-        for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = kbuf.load16(kvo[kt], 0);
-      }
-    } else {
+    if constexpr (MQ == 0) {
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
     }
@@ -791,21 +814,27 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     // LAST: the sequence's last frame -- no K prefetch for a next one, and the first GEMM phase's weight fragments (Wpq rows of
     // my head) are requested as soon as the score registers are free, so their L2 latency hides behind the last AV products and
     // the barrier instead of following them.
-    // MQ: `fnext` is the frame visited after f (its K fragments are requested here); OWN (MQ == 2, first frame): K / V^T fragments
-    // of frame f are already in kb[PAR] / vf (this tile's own rows) and the hand-off with the sibling tiles happens inside the frame,
-    // between the softmax and the AV products -- the own K / V^T stores drain behind the scores, the siblings' K fragments of
-    // frame fnext arrive behind the AV products.
-    auto frame = [&](const int f, const int fnext, auto par_tag, auto last_tag, auto own_tag) {
+#ifdef AXVS_STAMPS
+    int nvis_ = 0;
+#endif
+    // MQ: `fnext` is the frame visited after f (its K fragments are requested here).  OWN (MQ == 2, first frame): K / V^T fragments
+    // of frame f are this tile's own rows (kb[PAR] / vown, from the sweeps); the wait for the sibling tiles sits right behind the
+    // score MFMAs, and the K AND V^T fragments of frame fnext are requested there, so that they arrive behind the softmax and the
+    // AV products of the own frame.  VPRE: the V^T fragments of frame f were requested by the frame before (the one after OWN).
+    auto frame = [&](const int f, const int fnext, auto par_tag, auto last_tag, auto own_tag, auto vpre_tag) {
       constexpr int PAR = decltype(par_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr bool OWN = decltype(own_tag)::value;
+      constexpr bool VPRE = decltype(vpre_tag)::value;
       u16x8 vr[NVL];
       if constexpr (MQ != 0) {
         if constexpr (!OWN) {
+          if constexpr (!VPRE) {
 #pragma unroll
-          for (int nd = 0; nd < 2; ++nd)
+            for (int nd = 0; nd < 2; ++nd)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = vbuf.load16(vvo + (ks * 2 + nd) * 1024, (unsigned)f * vstep_b);
+              for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = vbuf.load16(vvo + (ks * 2 + nd) * 1024, (unsigned)f * vstep_b);
+          }
           if constexpr (!LAST) {
 #pragma unroll
             for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = kbuf.load16(kvo[kt], (unsigned)fnext * kstep_b);
@@ -837,6 +866,17 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       for (int kt = 0; kt < 2 * NKS; ++kt) {
 #pragma unroll
         for (int qt = 0; qt < MT; ++qt) sc[qt][kt] = H16<BF>::mfma(kb[PAR][kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});   // D[key][query]
+      }
+      if constexpr (OWN) {                 // hand-off, consumer side: K / V^T of the next frame, from the sibling tiles
+        AXVS_STAMP(23);
+        wait_siblings();
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = kbuf.load16(kvo[kt], (unsigned)fnext * kstep_b);
+#pragma unroll
+        for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = vbuf.load16(vvo + (ks * 2 + nd) * 1024, (unsigned)fnext * vstep_b);
+        AXVS_STAMP(11);
       }
       if (ragged) {
 #pragma unroll
@@ -897,22 +937,16 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
               for (int e = 0; e < 4; ++e) vf[nd][ks][4 * hj + e] = (u16)t4[e];
             }
       }
-      if constexpr (OWN) {
-        arrive();                          // (the barrier also ends every wave's use of the q/k/v operand tiles in the x-tile space)
-        wait_siblings();
-#pragma unroll
-        for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = kbuf.load16(kvo[kt], (unsigned)fnext * kstep_b);
-      }
       if constexpr (LAST) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
       f32x4 xa[MT][2];
 #pragma unroll
       for (int nd = 0; nd < 2; ++nd) {
 #pragma unroll
-        for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf[nd][0], pf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f});   // D[d][query]
+        for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(OWN ? vown[nd][0] : vf[nd][0], pf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f});   // D[d][query]
 #pragma unroll
         for (int ks = 1; ks < NKS; ++ks) {
 #pragma unroll
-          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(vf[nd][ks], pf[qt][ks], xa[qt][nd]);
+          for (int qt = 0; qt < MT; ++qt) xa[qt][nd] = H16<BF>::mfma(OWN ? vown[nd][ks] : vf[nd][ks], pf[qt][ks], xa[qt][nd]);
         }
       }
       // x tile block (frame f, k-block = my head): row = query, 16-byte chunk g holds channels in perm32 order
@@ -925,34 +959,44 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       }
       lds_fence();                       // per frame: the LDS stores of several frames must never pile up (4-bit lgkmcnt)
 #ifdef AXVS_STAMPS
-      if (f == 0) { AXVS_STAMP(12); } else if (f == 1) { AXVS_STAMP(13); } else if (f == 2) { AXVS_STAMP(14); } else { AXVS_STAMP(15); }
+      {   // by visit order (MQ == 2 starts with its own frame)
+        const int v_ = MQ == 2 ? nvis_++ : f;
+        if (v_ == 0) { AXVS_STAMP(12); } else if (v_ == 1) { AXVS_STAMP(13); } else if (v_ == 2) { AXVS_STAMP(14); } else { AXVS_STAMP(15); }
+      }
 #endif
     };
     {
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
+      using F_ = std::false_type;
+      using T_ = std::true_type;
       if constexpr (MQ == 2) {
         // my tile is frame `fown` of its sequence: visit own, own + 1, ... (mod T)
         const int fown = (int)(m0 - seq0) / L;
         auto fr = [&](int i) { const int f = fown + i; return f >= T ? f - T : f; };
-        frame(fr(0), fr(1), I0{}, std::false_type{}, std::true_type{});
-        int i = 1;
+        frame(fr(0), fr(1), I0{}, F_{}, T_{}, F_{});
+        if constexpr (T > 2) {
+          frame(fr(1), fr(2), I1{}, F_{}, F_{}, T_{});
+          int i = 2;
 #pragma nounroll
-        for (; i + 2 <= T - 1; i += 2) {
-          frame(fr(i), fr(i + 1), I1{}, std::false_type{}, std::false_type{});
-          frame(fr(i + 1), fr(i + 2), I0{}, std::false_type{}, std::false_type{});
+          for (; i + 2 <= T - 1; i += 2) {
+            frame(fr(i), fr(i + 1), I0{}, F_{}, F_{}, F_{});
+            frame(fr(i + 1), fr(i + 2), I1{}, F_{}, F_{}, F_{});
+          }
+          if constexpr (((T - 3) & 1) != 0) frame(fr(T - 2), fr(T - 1), std::integral_constant<int, (T - 2) & 1>{}, F_{}, F_{}, F_{});
+          frame(fr(T - 1), 0, std::integral_constant<int, (T - 1) & 1>{}, T_{}, F_{}, F_{});
+        } else {
+          frame(fr(1), 0, I1{}, T_{}, F_{}, T_{});
         }
-        if constexpr (((T - 2) & 1) != 0) frame(fr(T - 2), fr(T - 1), std::integral_constant<int, (T - 2) & 1>{}, std::false_type{}, std::false_type{});
-        frame(fr(T - 1), 0, std::integral_constant<int, (T - 1) & 1>{}, std::true_type{}, std::false_type{});
       } else {
       int f = 0;
 #pragma nounroll
       for (; f + 2 <= T - 1; f += 2) {
-        frame(f, f + 1, I0{}, std::false_type{}, std::false_type{});
-        frame(f + 1, f + 2, I1{}, std::false_type{}, std::false_type{});
+        frame(f, f + 1, I0{}, F_{}, F_{}, F_{});
+        frame(f + 1, f + 2, I1{}, F_{}, F_{}, F_{});
       }
-      if constexpr (((T - 1) & 1) != 0) frame(T - 2, T - 1, I0{}, std::false_type{}, std::false_type{});
-      frame(T - 1, 0, std::integral_constant<int, (T - 1) & 1>{}, std::true_type{}, std::false_type{});
+      if constexpr (((T - 1) & 1) != 0) frame(T - 2, T - 1, I0{}, F_{}, F_{}, F_{});
+      frame(T - 1, 0, std::integral_constant<int, (T - 1) & 1>{}, T_{}, F_{}, F_{});
       }
     }
     if constexpr (MQ == 0) {
@@ -1308,7 +1352,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   AXVS_STAMP(10);
 #if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)
-  if constexpr (QKVN) AXVS_STAMP_FLUSH_AT(32, 24);      // the height-pass kernel's stamps: slots 32 .. 55 (the width pass's stay in 0 .. 15)
+  if constexpr (QKVN || (MQ != 0 && !FFN)) AXVS_STAMP_FLUSH_AT(32, 24);      // the height-pass kernel's stamps: slots 32 .. 55 (the width pass's stay in 0 .. 23)
+  else if constexpr (MQ != 0) AXVS_STAMP_FLUSH(24);
   else AXVS_STAMP_FLUSH(16);
 #endif
 }

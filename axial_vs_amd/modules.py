@@ -37,6 +37,12 @@ def set_default_dtype(name: str) -> None:
     _DEFAULT_DTYPE = name
 
 
+def default_operand_dtype() -> str:
+    """16-bit operand type of the modules that have no fp32 tier (everything but the axial layer / TemporalEncoder): the default,
+    or 'f16' when the default is 'f32'."""
+    return "f16" if _DEFAULT_DTYPE == "f32" else _DEFAULT_DTYPE
+
+
 # ---------------------------------------------------------------------------------------------
 # plumbing
 # ---------------------------------------------------------------------------------------------
@@ -286,7 +292,7 @@ class TrajectoryAttention(nn.Module):
         self._packed_key = None
 
     def _dtype(self) -> str:
-        return self.mfma_dtype or _DEFAULT_DTYPE
+        return self.mfma_dtype or default_operand_dtype()
 
     def _pack(self) -> Tensor:
         dt = self._dtype()
@@ -389,6 +395,9 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
 
     def _pack(self) -> Tensor:
         dt = self._dtype()
+        if dt == "f32":
+            raise NotImplementedError("axial_vs_amd: the fp32 tier (mfma_dtype='f32', head_dim 64) has no packed weights and no "
+                                      "per-pass entry point (forward_pass / dist.offaxis_forward run on the 16-bit tier)")
         key = _param_key(self, dt)
         if self._packed is None or key != self._packed_key:
             if abs(self.norm1.eps - 1e-5) > 0 or abs(self.norm2.eps - 1e-5) > 0:
@@ -513,7 +522,7 @@ class TemporalTrajectoryAttentionLayer(nn.Module):
         self._packed_key = None
 
     def _dtype(self) -> str:
-        return self.mfma_dtype or _DEFAULT_DTYPE
+        return self.mfma_dtype or default_operand_dtype()
 
     def _pack(self) -> Tensor:
         dt = self._dtype()
@@ -574,6 +583,16 @@ class TemporalEncoder(nn.Module):
             self.temporal_layers = nn.ModuleList([TemporalAxialTrajectoryAttentionLayer(
                 d_model, d_ffn, dropout, attn_drop, activation, n_heads, mfma_dtype) for _ in range(num_temporal_layer)])
         # any other string: no layers are created, exactly like the reference (:85-88)
+
+    def prepack(self) -> None:
+        """Pack (or re-pack after a weight change) every layer's weights NOW, on the current stream.  A caller that is about to run
+        this encoder on several streams at once calls it first: the pack kernels and the packed buffer's allocation then belong to
+        the stream every fork waits on, instead of to whichever stream reaches `_pack()` first."""
+        if self.training:
+            return
+        for layer in getattr(self, "temporal_layers", ()):
+            if layer._dtype() != "f32":
+                layer._pack()
 
     def forward(self, src: Tensor, pos: Tensor):
         """

@@ -132,7 +132,7 @@ class MSDeformAttn(nn.Module):
 
     def _dtype(self) -> str:
         from . import modules
-        return self.mfma_dtype or modules._DEFAULT_DTYPE
+        return self.mfma_dtype or modules.default_operand_dtype()
 
     def _pack(self):
         dt = self._dtype()
@@ -268,7 +268,7 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def _dtype(self) -> str:
         from . import modules
-        return self.mfma_dtype or modules._DEFAULT_DTYPE
+        return self.mfma_dtype or modules.default_operand_dtype()
 
     def _pack(self):
         dt = self._dtype()

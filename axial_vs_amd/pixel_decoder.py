@@ -128,6 +128,9 @@ class MSDeformAttnTransformerEncoder(nn.Module):
                 starts = [sum(sizes[:j]) for j in range(nt)]
                 ins = [output[:, starts[j]:starts[j] + sizes[j]].contiguous() for j in range(nt)]
                 layer = self.temporal_layers[i]
+                # weights are packed on THIS stream before the fork (both streams' launches read the same packed buffer)
+                if hasattr(layer, "prepack"):
+                    layer.prepack()
                 res = _run_levels_concurrently([(lambda j=j: layer(src=ins[j], pos=pos_3d[j])) for j in range(nt)])
                 for j in range(nt):
                     lvl, h_attn, w_attn = res[j]
@@ -177,6 +180,10 @@ class TemporalTransformerEncoder(nn.Module):
         parts = [p.contiguous() for p in torch.split(src, sizes, dim=1)[:nt]]
         h_attn = w_attn = None
         for temporal_layer in self.temporal_layers:
+            # weights are packed on the CALLER's stream before the fork: the side stream's level and this stream's level share the
+            # packed buffer, and nothing else would order one stream's q/k/v launches behind the other stream's pack kernels
+            if hasattr(temporal_layer, "prepack"):
+                temporal_layer.prepack()
             res = _run_levels_concurrently([(lambda j=j: temporal_layer(src=parts[j], pos=pos_3d[j])) for j in range(nt)])
             for j in range(nt):
                 parts[j], h_attn, w_attn = res[j]
@@ -268,7 +275,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def _dtype(self) -> str:
         from . import modules
-        return self.mfma_dtype or modules._DEFAULT_DTYPE
+        return self.mfma_dtype or modules.default_operand_dtype()
 
     def _pack_projs(self):
         dt = self._dtype()

@@ -83,7 +83,7 @@ class MultiScaleDeformableAxialTrajectoryAttention(nn.Module):
 
     def _dtype(self) -> str:
         from . import modules
-        return self.mfma_dtype or modules._DEFAULT_DTYPE
+        return self.mfma_dtype or modules.default_operand_dtype()
 
     def _pack(self) -> Tensor:
         dt = self._dtype()

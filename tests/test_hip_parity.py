@@ -1141,7 +1141,8 @@ def test_small_problem_kernels_are_bit_identical_to_the_large_problem_ones(shape
     finally:
         _lib.lib().axvs_set_option(b"no_small_tiles", 0)
     print(f"{shape}: {names_small[1:]} vs {names_big[1:]}: max/max {rel_err(out_small.cpu(), ref):.2e}")
-    assert "norm1+ffn+norm2" in names_small and "w.traj_fused+ffn" in names_big
+    # (the 64-row kernels run one launch per pass here: q/k/v merged into the trajectory kernel, see test_merged_qkv_*)
+    assert "norm1+ffn+norm2" in names_small and ("w.traj_fused+ffn" in names_big or "w.qkv+traj+ffn" in names_big)
     assert torch.equal(out_small, out_big)
     assert rel_err(out_small.cpu(), ref) < TOL_F16
 
@@ -1179,7 +1180,9 @@ def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_default_kernels(shape
     print(f"{shape}: {names[None][1:]} | {names['qkv_fusion'][1:]} | max/max {e:.2e} relL2 {e2:.2e}")
     if W <= 64:      # (the last shape's width pass has 96 keys per frame: V^T form, separate q/k/v launch)
         assert "h.traj_fused+w.qkv" in names["qkv_fusion"] and "w.qkv_proj" not in names["qkv_fusion"], names["qkv_fusion"]
-    assert "w.qkv_proj" in names[None] and "w.qkv_proj" in names["vrow"]
+    # default: one launch per pass when the frames are multiples of 16 keys (merged q/k/v), else q/k/v + trajectory launches
+    # (row-form V exists for <= 64 keys per frame: a 96-key width pass ignores the option and runs the default, merged, launch)
+    assert ("w.qkv_proj" in names[None] or "w.qkv+traj+ffn" in names[None]) and ("w.qkv_proj" in names["vrow"] or W > 64)
     for opt in ("qkv_fusion", "vrow"):
         assert torch.equal(outs[None], outs[opt]), opt
         assert torch.equal(gen[None], gen[opt]), opt
@@ -1211,3 +1214,136 @@ def test_f32_tier_handles_operands_beyond_the_fp16_range():
     enc = ax.TemporalEncoder(C, F, n_heads=8, temporal_attn_type="axial-trajectory", num_temporal_layer=2, mfma_dtype="f32").eval().cuda()
     o2 = enc(dev(src), dev(pos))[0]
     assert torch.isfinite(o2).all()
+
+
+# ---- one launch per pass: q/k/v merged into the trajectory kernel (round 4; include/axvs.h, axvs_set_sync_buffer) ----------------
+MERGE_SHAPES = [(1, 4, 256, 64, 64, 1024),     # the metric shape: a row tile is one frame, own frame first (MQ = 2)
+                (2, 4, 256, 64, 64, 1024),     # BASELINE config 2
+                (1, 2, 256, 64, 64, 512), (1, 3, 256, 64, 32, 1024),      # T = 2, 3; width pass with 32-key frames (two frames per tile)
+                (1, 4, 256, 48, 80, 1024),     # frames of 48 / 80 keys: odd multiples of 16 (8-byte V^T stores, padded key steps)
+                (1, 4, 256, 96, 96, 1024),     # BASELINE config 5's clip size: 1.5 tiles per frame
+                (3, 1, 256, 64, 64, 1024)]     # T = 1: one tile per sequence, nobody to wait for
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", MERGE_SHAPES)
+def test_merged_qkv_launch_is_bit_identical_to_two_launches(shape):
+    """WC/temporal_attention.py:197-213: per pass, the q/k/v Linear layers and the trajectory attention.  With sync words registered
+    (the Python modules do) a pass is ONE launch: the trajectory kernel computes q, k, v of its own 64 rows, keeps q in registers and
+    hands K / V^T to the sibling row tiles of its sequence inside the launch.  Same MFMA fragments in the same order as
+    qkv_fused_kernel + temporal_fused_kernel, so: the same bits -- on fresh inputs call after call (the K / V^T buffers are re-used,
+    stale lines of the previous call sit in the L2s), with positions generated and read, and the counters are zero afterwards."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib, modules
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 17)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    pt = pg.clone()
+    L = _lib.lib()
+    for it in range(4):
+        g = torch.Generator(device="cuda").manual_seed(1000 + it)
+        src = torch.randn(B * T, H * W, C, device="cuda", generator=g)
+        for pos in (pg, pt):
+            _lib.check(L.axvs_set_option(b"no_merge_qkv", 1), "axvs_set_option")
+            try:
+                two = layer(src, pos)[0].clone()
+                names_two = _stage_names()
+            finally:
+                L.axvs_set_option(b"no_merge_qkv", 0)
+            one = layer(src, pos)[0].clone()
+            names_one = _stage_names()
+            assert torch.equal(one, two), (it, pos is pg)
+    assert "h.qkv_proj" in names_two and "w.qkv_proj" in names_two, names_two
+    merged_h = "h.qkv+traj" in names_one
+    merged_w = any(n.startswith("w.qkv+traj") for n in names_one)
+    print(f"{shape}: {names_two[1:]} -> {names_one[1:]}")
+    # 64-row tiles need >= 128 of them (or the FFN riding along): every shape here has at least one merged pass
+    assert merged_h or merged_w, names_one
+    sync = modules._sync_buffers[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
+    torch.cuda.synchronize()
+    assert int(sync.abs().sum()) == 0, "arrival counters must be zero again after every launch"
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 17)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    e = rel_err(layer(dev(src), dev(pos))[0].cpu(), ref)
+    assert e < TOL_F16, e
+
+
+@pytest.mark.gpu
+def test_merged_qkv_through_the_c_abi_and_without_sync_words():
+    """The C-ABI contract of the merged launches: axvs_set_sync_buffer(words, n) opts a calling thread in; (NULL, 0) -- the default
+    for a C caller -- keeps every pass at two launches; a buffer with fewer words than the pass has sequences falls back too."""
+    import ctypes as C_
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib, modules
+    B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 3)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 3)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    s, p = dev(src), dev(pos)
+    want = layer(s, p)[0].clone()
+    assert "h.qkv+traj" in _stage_names()
+    L = _lib.lib()
+    packed = layer._pack()
+    ws = torch.empty(L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C, 8, F, 0, 0), dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def call():
+        out = torch.empty_like(s)
+        _lib.check(L.axvs_axial_layer_fwd(s.data_ptr(), p.data_ptr(), out.data_ptr(), packed.data_ptr(), B, T, H, W, C, 8, F, 0,
+                                          ws.data_ptr(), ws.numel(), None, None, st), "axvs_axial_layer_fwd")
+        return out, _stage_names()
+
+    try:
+        _lib.check(L.axvs_set_sync_buffer(None, 0), "axvs_set_sync_buffer")
+        out, names = call()
+        assert "h.qkv_proj" in names and "h.qkv+traj" not in names, names
+        assert torch.equal(out, want)
+        words = torch.zeros(64, dtype=torch.int32, device="cuda")        # 64 sequences per pass at this shape: exactly enough
+        _lib.check(L.axvs_set_sync_buffer(words.data_ptr(), 64), "axvs_set_sync_buffer")
+        out, names = call()
+        assert "h.qkv+traj" in names and "w.qkv+traj+ffn" in names, names
+        assert torch.equal(out, want)
+        torch.cuda.synchronize()
+        assert int(words.abs().sum()) == 0
+        _lib.check(L.axvs_set_sync_buffer(words.data_ptr(), 63), "axvs_set_sync_buffer")   # one word short: two launches
+        out, names = call()
+        assert "h.qkv_proj" in names, names
+        assert torch.equal(out, want)
+        assert L.axvs_set_sync_buffer(words.data_ptr(), 0) != 0
+    finally:
+        L.axvs_set_sync_buffer(None, 0)
+        modules._sync_tls.key = None          # the modules re-register their own words on the next call
+
+
+@pytest.mark.gpu
+def test_merged_qkv_on_two_streams_at_once():
+    """Calls on different streams may overlap on the chip (the pixel decoder runs two pyramid levels side by side): every stream
+    has its own arrival counters.  Two streams run different clips through one layer concurrently, many times; every result has
+    to equal the single-stream one."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = 1, 4, 256, 32, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 9)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    xs = [torch.randn(B * T, H * W, C, device="cuda") for _ in range(2)]
+    want = [layer(x, pg)[0].clone() for x in xs]
+    assert any(n.startswith("w.qkv+traj") for n in _stage_names()), _stage_names()
+    layer._pack()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(20):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(layer(xs[k], pg)[0])
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for o in outs[k]:
+            assert torch.equal(o, want[k])

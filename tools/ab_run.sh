@@ -2,7 +2,7 @@
 # tools/ab_run.sh [rounds] -- per-kernel averages (rocprofv3 --kernel-trace --stats) of bench.py for every tools/ab/*.so, interleaved
 # `rounds` times on this box; summary in gpurun_out/ab_summary.txt
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 ROUNDS=${1:-2}
 shift
 OUT=$R/gpurun_out/ab

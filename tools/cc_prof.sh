@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of the cross-clip module at BASELINE config 4: tools/cc_prof.sh <tag>
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/ccprof_$1
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/cc_time.py > $OUT/log.txt 2>&1

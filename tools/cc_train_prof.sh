@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of a training step of the cross-clip module at BASELINE config 4: tools/cc_train_prof.sh <tag> [cc_train_time.py args, e.g. --shape 128,12,2,193,337,4]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/cctrainprof_$1
 shift
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per (kernel, grid) durations of the cross-clip training step: which launches are slow
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/cctraintrace
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/cc_train_time.py 3 "$@" > $OUT/log.txt 2>&1

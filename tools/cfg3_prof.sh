@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of the within-clip module at BASELINE config 3: tools/cfg3_prof.sh <tag>
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/cfg3prof_$1
 mkdir -p $OUT
 python3 $R/tools/cfg3_time.py 30 | tail -1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel average durations of the bench workload: tools/kstats.sh <tag> [bench args...]  -> gpurun_out/kstats_<tag>/
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 tag=$1; shift
 OUT=$R/gpurun_out/kstats_$tag
 mkdir -p $OUT

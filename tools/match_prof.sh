@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/matchprof
 mkdir -p $OUT
 python3 $R/tools/match_time.py | tail -3

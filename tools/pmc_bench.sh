@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes over bench.py (tuning helper); per-kernel counter averages
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_bench
 mkdir -p $OUT
 i=0

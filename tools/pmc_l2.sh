@@ -1,7 +1,7 @@
 #!/bin/bash
 # L2 hit rate per kernel (tuning helper)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_l2
 mkdir -p $OUT
 i=0

@@ -2,7 +2,7 @@
 # HBM traffic of one layer forward from the TCC counters (MI355X_MICROARCH.md "HBM"): separate --pmc passes for
 # FETCH_SIZE and WRITE_SIZE; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (corrected below).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_traffic
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes over bench.py (tuning helper); per-kernel counter averages
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_train
 mkdir -p $OUT
 i=0
@@ -33,7 +33,7 @@ for k, cs in agg.items():
             # kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; MFMA busy is summed over the chip's 1024 SIMDs
             "mfma_busy_frac": round(summary[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(g / 8 * 1024, 1), 4) if g else None,
         }
-json.dump({"command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --settle-ms 0 (3 passes, one counter set each)",
+json.dump({"command": "rocprofv3 --pmc <set> --kernel-trace -- python3 tools/train_time.py (one pass per counter set)",
            "per_kernel_per_launch": summary}, open("$OUT/summary.json", "w"), indent=1)
 for k, cs in agg.items():
     print(k)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # phase timelines + weight-stream ablation into gpurun_out/timeline.json (diagnostic builds: tools/diag_*.so)
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 J=$R/gpurun_out/timeline.json
 rm -f $J
 ORD=0,11,12,13,14,15,1,2,3,4,5,9,6,7,8,10

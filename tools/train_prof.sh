@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of a training step at BASELINE config 2: tools/train_prof.sh <tag>
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/trainprof_$1
 mkdir -p $OUT
 python3 $R/tools/train_time.py 10 | tail -2

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per (kernel, grid) durations of the layer's training step at BASELINE config 2: which launches are slow
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/traintrace
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/train_time.py 5 "$@" > $OUT/log.txt 2>&1

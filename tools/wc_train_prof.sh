@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel durations of a training step of the within-clip module at BASELINE config 3: tools/wc_train_prof.sh <tag>
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/wctrainprof_$1
 mkdir -p $OUT
 python3 $R/tools/wc_train_time.py 10
