@@ -33,7 +33,8 @@ thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
 thread_local int* g_status = nullptr;     // axvs_set_status_buffer: device word that kernels OR condition bits into
 thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
-thread_local int g_spatial_only = 0;     // option "spatial_only": the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten)
+thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
+                                         // 2 = the merged q/k/v + trajectory kernels return after their q/k/v part (the two-launch kernels treat it as 1)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
 thread_local int g_no_ffn_fusion = 0;    // option "no_ffn_fusion": keep the FFN in its own kernel
 thread_local int g_no_reassoc = 0;       // option "no_reassoc": generic tier computes k2, v2 = proj_kv(x) for every frame slot (the reference's form)
@@ -299,7 +300,7 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
                     float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr, int vrow = 0, const NextQkv* nq = nullptr,
                     const OwnQkv* oq = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
-  const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? 2 : 0);
+  const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? (oq ? g_spatial_only : 1) << 1 : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
   if ((vrow || nq || oq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v / own q,k,v need 64-row tiles");
@@ -369,7 +370,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   // ~2 rounds of the chip (-3.5 % at 576 tiles, -7.5 % at 240) and LOSE beyond (+2.5 % at 1152 tiles, +8 % at 4608: sibling
   // tiles start staggered there and every tile waits for the last one) -- option "merge_qkv_any" lifts the limit for A/B runs.
   const bool own_frame = L == 64 && T >= 2;
-  const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv && !g_spatial_only &&
+  const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv &&
                      g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= 3 &&
                      traj_mt4(T, traj_tiles64(Mp, N), with_ffn) && 2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
                      (own_frame || traj_tiles64(Mp, N) <= 640 || g_merge_qkv_any);

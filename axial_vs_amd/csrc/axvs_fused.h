@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
                                                              const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */,
                                                              int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */,
-                                                             int spatial_only = 0 /* measurement: stop after the QK^T / AV half */,
+                                                             int spatial_only = 0 /* measurement: 1 = stop after the QK^T / AV half; MQ kernels also 2 = stop after their q/k/v part */,
                                                              const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
                                                              const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{},
                                                              OwnQkv oq = OwnQkv{}) {
@@ -740,6 +740,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       __syncthreads();
       if (tid == 0) atomicInc(cnt, 2 * tps_u - 1);
       AXVS_STAMP(21);
+      if (spatial_only == 2) {                   // measurement: stop behind the q/k/v part (bench.py subtracts this from spatial_only = 1)
+        if (tid == 0) atomicInc(cnt, 2 * tps_u - 1);      // depart at once: nobody polls, the counter still ends at zero
+        return;
+      }
       {   // q: stays in registers as the B operand of QK^T (the values qkv_fused_kernel would store and this kernel load back)
         f32x4 acc[2][MT];
 #pragma unroll
@@ -1032,6 +1036,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   if constexpr (MQ != 0) {                 // depart: every wave of this workgroup is past its poll
     const int tps = (N + ROWS - 1) / ROWS;
     if (tid == 0) atomicInc(oq.sync + m0 / N, 2 * (unsigned)tps - 1);
+    if (spatial_only) return;              // measurement: q/k/v + QK^T / softmax / AV (nothing else is written)
   }
 
   AXVS_STAMP(1);

@@ -155,6 +155,14 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def rccl_version():
+        """version of the RCCL library torch was built against (backend "nccl" IS RCCL on ROCm); None if it cannot be queried"""
+        try:
+            v = torch.cuda.nccl.version()
+            return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception:
+            return None
+
     def timed(step, steps, warmup, settle_ms=0.0):
         """[`settle_ms` of untimed steady running -- the secondary measurements start after host-side set-up gaps in which the GPU
         clocks drop --,] `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; MAX over
@@ -294,9 +302,11 @@ def main():
                                f"heads={heads}, d_ffn={F}, fp32 in/out, {args.dtype} MFMA operands",
                    "shape_per_gpu": [B, T, C, H, W],
                    "pos": "tensor read from HBM" if args.tensor_pos else "PositionEmbeddingSine3D, evaluated in-kernel",
-                   "launch": "python per step" if graphed is None else "hipGraph replay (4 kernels)",
+                   "launch": "python per step" if graphed is None else "hipGraph replay",
                    "settle_ms": args.settle_ms,
-                   "ranks": world, "collective_backend": ("RCCL" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                   "ranks": world, "n_ranks_seen": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+                   "collective_backend": ("RCCL" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                   "rccl_version": rccl_version(),
                    "parallelism": f"dp{world} (clips sharded over ranks"
                    + (", RCCL all-gather of outputs overlapped)" if (args.gather and gathered is not None) else ", no collective)")},
     }
@@ -374,10 +384,52 @@ def main():
                                     "shape_per_gpu": [B5, T5, C5, H5, W5], "steps": steps5,
                                     "mfma_frac_per_gpu": round(fl5 / (el / steps5) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                     "what": "BASELINE config 5 ([B=64,T=4,C=256,H=W=96] over 8 GPUs): each rank runs its 8-clip share, no collective"}
+            # BASELINE config 5 AS WORDED: the same share run through axial_vs_amd.dist.sharded_forward -- the local clips in 4 groups,
+            # every group's all-gather of its output maps issued right behind its kernels (RCCL over xGMI on a node; the collective of
+            # group i crosses the links while group i + 1 computes) -- with fp32 maps and with maps cast to f16 (half the link bytes).
+            # One rank: there is nothing to gather and the number equals cfg5_share's.
+            try:
+                from axial_vs_amd import dist as axd
+                fn5 = lambda a, b: layer5(a, b)[0]
+                link_peak = 7 * 153.0                                      # GB/s into one GPU over its 7 xGMI links
+                g5 = {}
+                for key5, gdt in (("fp32_map", None), ("f16_map", torch.float16)):
+                    el5, full5 = timed(lambda: axd.sharded_forward(fn5, src5, pos5, replicated_inputs=False, gather_dtype=gdt, chunks=4),
+                                       steps5, 3, settle_ms=min(args.settle_ms, 100.0))
+                    assert torch.isfinite(full5.float()).all() and full5.shape[0] == (world * B5 * T5 if world > 1 else B5 * T5)
+                    mb_in = (world - 1) * B5 * T5 * H5 * W5 * C5 * (4 if gdt is None else 2) / 1e6      # bytes INTO each rank per step
+                    g5[key5] = {"value": round(world * B5 * T5 * steps5 / el5, 1), "unit": "frames/s", "ms_per_step": round(el5 / steps5 * 1e3, 4),
+                                "inbound_MB_per_rank_per_step": round(mb_in, 1),
+                                "inbound_GBs_per_rank": round(mb_in / 1e3 / (el5 / steps5), 1),
+                                "frac_of_7x153_GBs": round(mb_in / 1e3 / (el5 / steps5) / link_peak, 3),
+                                "mfma_frac_per_gpu": round(fl5 / (el5 / steps5) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                    del full5
+                g5["ranks"] = world
+                g5["collective_backend"] = (("RCCL" if args.backend == "nccl" else args.backend) if world > 1 else None)
+                g5["what"] = ("BASELINE config 5 as worded: [B=64,T=4,C=256,H=W=96] batch-sharded over the ranks (8 clips each), output maps "
+                              "reassembled on every rank by all-gathers issued per group of 2 clips behind the group's kernels "
+                              "(axial_vs_amd.dist.sharded_forward, chunks=4); value = frames/s over all ranks including the gather")
+                extras["cfg5_gather"] = g5
+            except Exception as e:          # a secondary measurement never costs the headline line
+                extras["cfg5_gather"] = {"error": str(e)[:200]}
             del layer5, src5, pos5, o5
             torch.cuda.empty_cache()
         except RuntimeError as e:           # e.g. out of memory on a shared debugging GPU
             extras["cfg5_share"] = {"error": str(e)[:200]}
+        # the literal (src, pos) drop-in surface: `pos` as a plain tensor (a caller that swaps TemporalEncoder alone and builds the
+        # embedding with the reference's own module): the layer reads it from HBM in both passes instead of evaluating it
+        try:
+            ptens = pos.clone()
+            stp = max(20, min(args.steps, 300))
+            elp, op = timed(lambda: layer(src, ptens)[0], stp, 5, settle_ms=min(args.settle_ms, 100.0))
+            assert torch.isfinite(op).all()
+            extras["tensor_pos"] = {"value": round(world * B * T * stp / elp, 1), "unit": "frames/s", "ms_per_step": round(elp / stp * 1e3, 5),
+                                    "mfma_frac": round(layer_flops(B, T, H, W, C, F) / (elp / stp) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                    "what": "the headline workload with `pos` handed over as a plain [B,T,H,W,C] tensor (read from HBM by both "
+                                            "passes: +33.5 MB per layer) instead of a PositionEmbeddingSine3D product the layer evaluates in-kernel"}
+            del ptens, op
+        except RuntimeError as e:
+            extras["tensor_pos"] = {"error": str(e)[:200]}
 
     if rank == 0:
         # ---- roofline: HIP events on the launch stream (torch's current stream), averaged over the same K steps ----
@@ -429,14 +481,34 @@ def main():
             return S * (N * C * C * (4 + 4 * T) + 4 * N * N * C + 4 * N * T * C)
         f_ffn = 4 * B * T * H * W * C * F
         stage_flops = {"h.qkv_proj": f_qkv(B * W, H), "w.qkv_proj": f_qkv(B * H, W), "h.traj_fused": f_traj(B * W, H),
-                       "w.traj_fused": f_traj(B * H, W), "w.traj_fused+ffn": f_traj(B * H, W) + f_ffn, "norm1+ffn+norm2": f_ffn}
+                       "w.traj_fused": f_traj(B * H, W), "w.traj_fused+ffn": f_traj(B * H, W) + f_ffn, "norm1+ffn+norm2": f_ffn,
+                       # one launch per pass (q/k/v merged into the trajectory kernel)
+                       "h.qkv+traj": f_qkv(B * W, H) + f_traj(B * W, H), "w.qkv+traj": f_qkv(B * H, W) + f_traj(B * H, W),
+                       "w.qkv+traj+ffn": f_qkv(B * H, W) + f_traj(B * H, W) + f_ffn}
         stage_frac = {k: round(stage_flops[k] / (v * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) for k, v in kernels.items()
                       if k in stage_flops and v > 0}
         # the north star's sub-target: QK^T / softmax / AV alone.  Option "spatial_only" makes the fused trajectory kernels return
         # after that half (same launch, same loads of q / k / V^T, x tile written to LDS, nothing else): its duration against
         # 4 S N^2 C FLOPs per pass.  Only meaningful when both passes run the fully fused kernels.
         qk_av = None
-        if "h.traj_fused" in kernels and ("w.traj_fused+ffn" in kernels or "w.traj_fused" in kernels):
+        if "h.qkv+traj" in kernels and any(k.startswith("w.qkv+traj") for k in kernels):
+            # merged launches: the kernel stopped after QK^T / softmax / AV (spatial_only = 1) minus the kernel stopped after its q/k/v
+            # part (spatial_only = 2) -- the hand-off wait for the sibling tiles' K / V^T is part of the difference
+            def stopped(mode):
+                _lib.check(L.axvs_set_option(b"spatial_only", mode), "axvs_set_option")
+                try:
+                    return stage_times(lambda: layer(src, pos), reps)
+                finally:
+                    _lib.check(L.axvs_set_option(b"spatial_only", 0), "axvs_set_option")
+            s1, s2 = stopped(1), stopped(2)
+            wk = [k for k in s1 if k.startswith("w.qkv+traj")][0]
+            t_h, t_w = s1["h.qkv+traj"] - s2["h.qkv+traj"], s1[wk] - s2[wk]
+            fl_h, fl_w = 4 * (B * W) * (T * H) ** 2 * C, 4 * (B * H) * (T * W) ** 2 * C
+            qk_av = {"frac": round((fl_h + fl_w) / ((t_h + t_w) * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "h_us": round(t_h, 2), "w_us": round(t_w, 2),
+                     "h_us_qkv_part": s2["h.qkv+traj"], "w_us_qkv_part": s2[wk], "gflop": round((fl_h + fl_w) / 1e9, 2),
+                     "what": "merged q/k/v + trajectory kernels: launch stopped after QK^T/softmax/AV minus launch stopped after the q/k/v part "
+                             "(events; includes the hand-off wait for the sibling tiles), 4*S*N^2*C FLOPs per pass"}
+        elif "h.traj_fused" in kernels and ("w.traj_fused+ffn" in kernels or "w.traj_fused" in kernels):
             _lib.check(L.axvs_set_option(b"spatial_only", 1), "axvs_set_option")
             try:
                 sp = stage_times(lambda: layer(src, pos), reps)

@@ -187,8 +187,8 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "10", "--warmup", "3",
-           "--no-cpu-baseline", "--no-extras", "--settle-ms", "20"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+           "--no-cpu-baseline", "--settle-ms", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]            # rank 0 alone prints
@@ -196,3 +196,14 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     assert j["n_gpus"] == 2 and j["steps"] == 10 and j["warmup"] == 3 and j["scaling"] == "weak" and j["value"] > 0
     assert abs(j["value"] - 2 * 4 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3      # whole-job frames/s: both ranks' clips / max-over-ranks time
     print("bench.py --gpus 2 (two ranks sharing cuda:0 over gloo):", j["value"], j["unit"], j["ms_per_step"], "ms per step")
+    # what the first 8-GPU run will be read by: the world size torch.distributed reports, and BASELINE config 5 as worded -- the
+    # [8,4,256,96,96] share per rank THROUGH the chunked all-gather of the output maps (fp32 and f16 maps) -- next to the
+    # headline with `pos` as a plain tensor
+    assert j["config"]["n_ranks_seen"] == 2 and "rccl_version" in j["config"]
+    g5 = j["extras"]["cfg5_gather"]
+    assert "error" not in g5, g5
+    assert g5["ranks"] == 2 and g5["fp32_map"]["value"] > 0 and g5["f16_map"]["value"] > 0
+    assert g5["fp32_map"]["inbound_MB_per_rank_per_step"] == pytest.approx(8 * 4 * 96 * 96 * 256 * 4 / 1e6, rel=1e-3)     # one other rank's maps
+    assert g5["f16_map"]["inbound_MB_per_rank_per_step"] == pytest.approx(8 * 4 * 96 * 96 * 256 * 2 / 1e6, rel=1e-3)
+    assert j["extras"]["tensor_pos"]["value"] > 0
+    print("cfg5_gather:", g5["fp32_map"], g5["f16_map"])
