@@ -13,6 +13,9 @@ sd = mod.state_dict(); sd.update(orc.random_weights(shapes, 0)); mod.load_state_
 mod = mod.cuda(); mod.eval_outputs_on_cpu = False
 cq = torch.randn(1, 128, 4, 256, device="cuda")
 pf = torch.nn.functional.normalize(torch.randn(1, 128, 16, 64, 64, device="cuda"), dim=1)
+for kv in sys.argv[1:]:          # library options: key=value (axvs_set_option)
+    k, v = kv.split("=")
+    _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), k)
 for _ in range(5): mod(cq, pf)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

@@ -14,17 +14,18 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in sorted(glob.glob("$OUT/*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void axvs::", "")
-        if "at::" in k or "rocclr" in k or "pack" in k: continue
+        if "at::" in k or "rocclr" in k or "pack" in k or "pos3d" in k: continue
         a = agg[k][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
-# launches per layer forward: every forward launches qkv_fused_kernel exactly twice
-nq = max((max(c[1] for c in cs.values()) for k, cs in agg.items() if "qkv_fused_kernel" in k), default=2)
+# launches per layer forward: the FFN-carrying trajectory kernel (or, failing that, the least-launched axvs kernel) runs once per forward
+cnt = {k: max(c[1] for c in cs.values()) for k, cs in agg.items()}
+nfwd = min(cnt.values())
 tot_r = tot_w = 0.0
 rows = {}
 for k, cs in agg.items():
     fs = cs.get("FETCH_SIZE", [0, 1]); ws = cs.get("WRITE_SIZE", [0, 1])
     rd = fs[0] / max(fs[1], 1) * 1024 * 2      # KB -> bytes, x2 gfx950 correction for wide coalesced reads
     wr = ws[0] / max(ws[1], 1) * 1024
-    n = round(2 * max(c[1] for c in cs.values()) / nq)
+    n = round(cnt[k] / nfwd)
     rows[k[:60]] = {"read_MB_per_launch": round(rd / 1e6, 2), "write_MB_per_launch": round(wr / 1e6, 2), "launches_per_layer": n}
     tot_r += rd * n; tot_w += wr * n
 res = {"per_kernel": rows, "layer_read_MB": round(tot_r / 1e6, 1), "layer_write_MB": round(tot_w / 1e6, 1),
