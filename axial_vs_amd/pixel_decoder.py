@@ -433,6 +433,19 @@ class WithinClipTrackingModule(nn.Module):
                     transformer_spatial_in_features=m.SPATIAL_IN_FEATURES, transformer_temporal_in_features=m.TEMPORAL_IN_FEATURES,
                     num_clip_frames=cfg.INPUT.NUM_CLIP_FRAMES, cross_clip_training=cfg.MODEL.MAXTRON.CROSS_CLIP_TRACKING_MODULE.ENABLE)
 
+    def set_stack_precision(self, precision: str = "f16") -> "WithinClipTrackingModule":
+        """Operand precision of the axial-trajectory (temporal) layers of the stack: 'f16' (default: 16-bit MFMA operands, every
+        layer inside 1e-3 on its own, the free-running stack at 1.4e-3 max-norm / <= 1e-3 relative L2 on the temporal levels at
+        BASELINE config 3) or 'f32' (the layers' fp32 tier: the stack then holds 1e-3 in max-norm too, at several times the time --
+        the reference runs this stack in fp32 end to end, WC/msdeformattn.py:244-273).  Returns self."""
+        if precision not in ("f16", "bf16", "f32"):
+            raise ValueError(f"unknown precision {precision!r}")
+        from .modules import TemporalAxialTrajectoryAttentionLayer
+        for m in self.modules():
+            if isinstance(m, TemporalAxialTrajectoryAttentionLayer):
+                m.mfma_dtype = precision
+        return self
+
     def forward_features(self, features):
         within_clip_features, axial_height_attn, axial_width_attn = self.within_clip_tracking_module.forward_features(features)
         for k in within_clip_features:

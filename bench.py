@@ -576,9 +576,24 @@ def main():
                         wc.forward_features(dict(feats3))
                     torch.cuda.synchronize(dev)
                 el = (time.perf_counter() - t3) / n3
+                # the same module with the axial-trajectory layers on their fp32 tier: the setting under which the free-running
+                # stack holds 1e-3 in max-norm too (tests/test_hip_parity.py: ..._fp32_stack_holds_the_bar_in_max_norm)
+                wc.set_stack_precision("f32")
+                with torch.no_grad():
+                    for _ in range(3):
+                        wc.forward_features(dict(feats3))
+                    torch.cuda.synchronize(dev)
+                    t3 = time.perf_counter()
+                    for _ in range(10):
+                        wc.forward_features(dict(feats3))
+                    torch.cuda.synchronize(dev)
+                el32 = (time.perf_counter() - t3) / 10
                 extras["wc_cfg3"] = {"ms_per_forward": round(el * 1e3, 3), "value": round(4 / el, 1), "unit": "frames/s",
+                                     "ms_per_forward_f32_stack": round(el32 * 1e3, 3),
                                      "what": "BASELINE config 3: WithinClipTrackingModule.forward_features, res3/4/5 = [4,192,64,64] / [4,384,32,32] / "
-                                             "[4,768,16,16], 2 stages x (1 deformable spatial layer + 2 axial-trajectory layers on res5 and res4)"}
+                                             "[4,768,16,16], 2 stages x (1 deformable spatial layer + 2 axial-trajectory layers on res5 and res4); "
+                                             "ms_per_forward: 16-bit operands (<= 1e-3 per layer and in relative L2, 1.4e-3 max-norm over the stack); "
+                                             "ms_per_forward_f32_stack: set_stack_precision('f32'), <= 1e-3 in max-norm as well"}
                 del wc, feats3
             except RuntimeError as e:
                 extras["wc_cfg3"] = {"error": str(e)[:200]}

@@ -730,7 +730,8 @@ def test_within_clip_module_golden(name):
         # something here is the L2 one; the full-size decoder (test_within_clip_module_full_size_golden) holds TOL_STACK in max-norm.
         # measured (round 3): relL2 <= 1.01e-3, max-norm <= 2.2e-3 on the temporal levels of the toy decoders
         assert e2 < (TOL_F16 if k == "res3" else 1.3e-3), k
-        assert e < (TOL_F16 if k == "res3" else 3.5e-3), k
+        # measured (round 4, all three toy fixtures): max-norm 1.3e-3 .. 2.2e-3 on the temporal levels
+        assert e < (TOL_F16 if k == "res3" else 2.5e-3), k
 
 
 def _full_size_decoder(m, w):
@@ -778,6 +779,26 @@ def test_within_clip_module_full_size_golden():
         print(f"full-size decoder {k}: max/max {e:.2e} relL2 {e2:.2e}")
         assert e < (TOL_F16 if k == "res3" else TOL_STACK) and e2 < TOL_F16, k
         np.testing.assert_allclose(checks(o)[1:], z["chk_" + k][1:], rtol=5e-3)
+
+
+def test_within_clip_module_full_size_fp32_stack_holds_the_bar_in_max_norm():
+    """BASELINE config 3 inside the north star's 1e-3 in MAX-NORM as well: `set_stack_precision("f32")` runs the axial-trajectory
+    layers of the stack on their fp32 tier (the reference runs the whole stack in fp32, WC/msdeformattn.py:244-273); the 16-bit
+    default holds 1e-3 per layer and in relative L2, and TOL_STACK = 1.5e-3 max-norm end to end (test above).  Cost: about 4x
+    the time of the default (bench.py, extras.wc_cfg3.ms_per_forward_f32_stack)."""
+    z, m = load("g8_pixel_decoder_full_T4_S2")
+    mod = _full_size_decoder(m, weights(z, m)).set_stack_precision("f32")
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    feats = {k: torch.randn(m["B"] * m["T"], m["chans"][k], *m["sizes"][k], generator=g) for k in m["chans"]}
+    out, _, _ = mod.forward_features({k: v.cuda() for k, v in feats.items()})
+    for k in m["chans"]:
+        sb = m["sub"][k]
+        o = out[k].cpu()
+        e, e2 = rel_err(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k])), rel_l2(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]))
+        print(f"full-size decoder, fp32 temporal layers, {k}: max/max {e:.2e} relL2 {e2:.2e}")
+        assert e < TOL_F16 and e2 < TOL_F16, k
+    with pytest.raises(ValueError):
+        mod.set_stack_precision("fp8")
 
 
 @pytest.mark.parametrize("name", ["g8_pixel_decoder_full_T4_S2", "g8_pixel_decoder_T3_S1"])

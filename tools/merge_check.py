@@ -73,7 +73,11 @@ def run(shape, reps, timing=True):
 
 
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:]]
+    for kv in [x for x in sys.argv[1:] if "=" in x]:       # library options: key=value
+        k, v = kv.split("=")
+        opt(k, int(v))
+        print("option", k, v)
+    a = [int(x) for x in sys.argv[1:] if "=" not in x]
     shapes = [tuple(a[:4])] if len(a) >= 4 else [(1, 4, 64, 64), (2, 4, 64, 64), (1, 2, 64, 64), (1, 3, 32, 64), (1, 4, 48, 80), (1, 4, 96, 96), (1, 1, 64, 64), (3, 4, 16, 32)]
     reps = a[4] if len(a) >= 5 else 6
     bad = 0
