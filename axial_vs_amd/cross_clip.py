@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import _lib
-from .modules import _dev_f32, _param_key, _require_eval, _stream, _traj_struct, _workspace, _guarded
+from .modules import _dev_f32, _param_key, _require_eval, _select_sync_words, _stream, _traj_struct, _workspace, _guarded
 
 
 class _LayerNormCF(nn.Module):
@@ -230,6 +230,7 @@ class CrossClipTrackingModule(nn.Module):
         masks = torch.empty(nl, B, Q, TV, H, W, dtype=torch.float32, device=dev)
         last = torch.empty_like(cq)
         pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
+        _select_sync_words(dev)          # the layers' trajectory attention runs q/k/v + attention as one launch (include/axvs.h)
         _lib.check(L.axvs_cc_module_fwd(cq.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
                                         nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
                    "axvs_cc_module_fwd")
@@ -363,6 +364,7 @@ class TubeLinkCrossClipHead(nn.Module):
         masks = torch.empty(nl, B, T, Q, h, w, dtype=torch.float32, device=dev)
         last = torch.empty_like(cur)
         pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
+        _select_sync_words(dev)
         _lib.check(L.axvs_tl_cc_module_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
                                            nl, B, Q, Tc, T // Tc, h, w, K1, Cm, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
                    "axvs_tl_cc_module_fwd")

@@ -57,6 +57,7 @@ thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass'
 thread_local unsigned* g_sync = nullptr;
 thread_local size_t g_sync_words = 0;
 thread_local int g_merge_qkv_any = 0;    // option "merge_qkv_any": merged launches at every grid size (A/B; see run_traj)
+thread_local int g_merge_small = 0;      // option "merge_small": 16-row-tile problems merge as well (built and bit-identical; measured a wash, see run_traj)
 thread_local int g_no_merge_qkv = 0;     // option "no_merge_qkv": keep qkv_fused_kernel + trajectory kernel as two launches (A/B, tests)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
@@ -303,7 +304,8 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
   const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? (oq ? g_spatial_only : 1) << 1 : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
-  if ((vrow || nq || oq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v / own q,k,v need 64-row tiles");
+  if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
+  if (oq && !(nks > 0 && T <= 4)) return fail(AXVS_ERR_ARG, "internal: own q,k,v need the in-kernel spatial half and T <= 4");
   if (fa == nullptr && (tiles64 < 128 || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
     switch (T) {
       case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
@@ -369,11 +371,17 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   // measured (4 - 9 % from [1,2,256,64,64] to [8,4,256,64,64]); other frame lengths (MQ = 1) gain while the grid stays within
   // ~2 rounds of the chip (-3.5 % at 576 tiles, -7.5 % at 240) and LOSE beyond (+2.5 % at 1152 tiles, +8 % at 4608: sibling
   // tiles start staggered there and every tile waits for the last one) -- option "merge_qkv_any" lifts the limit for A/B runs.
-  const bool own_frame = L == 64 && T >= 2;
+  // Problems with few rows run 16-row tiles (launch_temporal: fewer than 128 tiles of 64 rows and no FFN riding along -- pyramid
+  // levels of 32 x 32 and below, the cross-clip queries).  Their merged form exists (MQ = 1 on 16-row tiles, bit-identical) but
+  // every 16-row workgroup then streams the 384 KB of q/k/v weights itself, which costs what the launch and the q round trip save:
+  // layer at [1,4,256,32,32] 59.0 vs 59.2 us, [1,4,256,16,16] 53.1 vs 56.0, [3,4,256,16,32] 105.3 vs 97.8 (768 tiles: siblings
+  // start staggered), cross-clip module 236.1 vs 237.3, BASELINE config 3 0.997 vs 0.989 ms -- off unless option "merge_small".
+  const bool mt4 = traj_mt4(T, traj_tiles64(Mp, N), with_ffn);
+  const bool own_frame = mt4 && L == 64 && T >= 2;
   const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv &&
-                     g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= 3 &&
-                     traj_mt4(T, traj_tiles64(Mp, N), with_ffn) && 2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
-                     (own_frame || traj_tiles64(Mp, N) <= 640 || g_merge_qkv_any);
+                     g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= (mt4 ? 3 : 4) &&
+                     2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
+                     (!mt4 || own_frame || traj_tiles64(Mp, N) <= 640 || g_merge_qkv_any) && (mt4 || g_merge_small);
   if (merge) {
     const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status};
     int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr, 0, nullptr, &oq);
@@ -759,7 +767,8 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
     p.t.post_ln_g = p.norm_w;
     p.t.post_ln_b = p.norm_b;
   }
-  int rc = run_traj<BF>(x, x, x, nullptr, x, ln_in_kernel ? w.t2 : w.t1, nullptr, p.t, w.tw, rm, B, Tc, Q, 256, 8, st, 0);
+  int rc = run_traj<BF>(x, x, x, nullptr, x, ln_in_kernel ? w.t2 : w.t1, nullptr, p.t, w.tw, rm, B, Tc, Q, 256, 8, st, 0, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, false, true);
   if (rc != AXVS_OK) return rc;
   if (!ln_in_kernel) {
     hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, w.t1, p.norm_w, p.norm_b, w.t2, (u16*)nullptr, R, 256,
@@ -1135,6 +1144,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_merge_qkv")) { g_no_merge_qkv = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
+  if (key && !strcmp(key, "merge_small")) { g_merge_small = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
@@ -1906,10 +1916,11 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
     const int n4 = Cout / 4, lanes = n4 < 256 ? n4 : 256, rg = 256 / lanes;
     hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nblk, N), dim3(256), 2 * (size_t)rg * Cout * sizeof(float), st, y, partial, HW, Cout, groups);
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((N * groups + 3) / 4)), dim3(256), 0, st, partial, stats, nblk, groups, N * groups);
+  // (the per-group sums of the blocks' partials are formed by the apply kernel itself: no launch of their own)
+  (void)stats;
   const dim3 ag((unsigned)((HW + 63) / 64), (unsigned)((Cout + 63) / 64), N);
-  if (out_layout == 0) hipLaunchKernelGGL((gn_apply_kernel<true>), ag, dim3(256), 0, st, y, stats, g, be, out, HW, Cout, groups, eps, (long long)0, (long long)Cout * HW);
-  else hipLaunchKernelGGL((gn_apply_kernel<false>), ag, dim3(256), 0, st, y, stats, g, be, out, HW, Cout, groups, eps, out_ld, out_batch_stride);
+  if (out_layout == 0) hipLaunchKernelGGL((gn_apply_kernel<true>), ag, dim3(256), 0, st, y, (const float*)partial, nblk, g, be, out, HW, Cout, groups, eps, (long long)0, (long long)Cout * HW);
+  else hipLaunchKernelGGL((gn_apply_kernel<false>), ag, dim3(256), 0, st, y, (const float*)partial, nblk, g, be, out, HW, Cout, groups, eps, out_ld, out_batch_stride);
   mark(st, "glue.group_norm");
   return last_launch_status();
 }

@@ -482,8 +482,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{},
                                                              OwnQkv oq = OwnQkv{}) {
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
-  static_assert(MQ == 0 || (MT == 4 && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64-row tiles, block-transposed V");
-  static_assert(MQ != 2 || (NKS == 2 && T >= 2), "own frame first: a 64-row tile is one 64-key frame");
+  static_assert(MQ == 0 || ((MT == 4 || MT == 1) && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64- or 16-row tiles, block-transposed V");
+  static_assert(MQ != 2 || (MT == 4 && NKS == 2 && T >= 2), "own frame first: a 64-row tile is one 64-key frame");
   static_assert(!VROW || (MT == 4 && NKS >= 1 && NKS <= 2), "row-major V is staged in a 64-row x-tile block: 64 keys per frame at most");
   static_assert(!QKVN || (MT == 4 && !FFN && NKS > 0), "the next pass's q/k/v ride in the 64-row kernel without the FFN");
   constexpr int C = 256, ROWS = MT * 16;
@@ -595,11 +595,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
           if (tid + i * 512 < fa.F) sf1[i] = fa.b1[tid + i * 512];      // (d_ffn > 1024: the rest follows the gather)
       }
       {
-        // thread -> (row, float4 column); RowMap arithmetic once per wave: lane k computes the k-th of the wave's 8 rows (rows
+        // thread -> (row, float4 column); RowMap arithmetic once per wave: lane k computes the k-th of the wave's ROWS / 8 rows (rows
         // wave + 8k; rows past the sequence's end are clamped copies), v_readlane broadcasts
+        constexpr int RPWq = ROWS / 8;               // rows per wave: 8 (64-row tiles) or 2 (16-row tiles)
+        constexpr int GRPq = RPWq >= 4 ? 4 : RPWq;   // rows of a wave in flight together
         int off_lo, off_hi, coords = 0;
         {
-          const int myrow = wave + 8 * (lane & 7);
+          const int myrow = wave + 8 * (lane & (RPWq - 1));
           const int mym = (int)m0 + min(myrow, nvalid - 1);
           const long long myoff = (oq.pg.mode ? nat_row_coords(rm, mym, oq.pg.l_is_h, &coords) : nat_row(rm, mym)) * C;
           off_lo = (int)(myoff & 0xffffffffll);
@@ -609,19 +611,19 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         if (oq.pg.mode) pl.init(oq.pg, lane * 4);
         float amax = 0.f;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          float4 a[4], p[4];
+        for (int half = 0; half < RPWq / GRPq; ++half) {
+          float4 a[GRPq], p[GRPq];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int k = half * 4 + i;
+          for (int i = 0; i < GRPq; ++i) {
+            const int k = half * GRPq + i;
             const long long off = (((long long)__builtin_amdgcn_readlane(off_hi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(off_lo, k)) + lane * 4;
             a[i] = *reinterpret_cast<const float4*>(oq.src + off);
             if (oq.pg.mode) p[i] = pl.eval(oq.pg, __builtin_amdgcn_readlane(coords, k));      // sine embedding generated, not read
             else p[i] = oq.pos ? *reinterpret_cast<const float4*>(oq.pos + off) : float4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int row = wave + 8 * (half * 4 + i);
+          for (int i = 0; i < GRPq; ++i) {
+            const int row = wave + 8 * (half * GRPq + i);
             const int n = lane * 4, kbq = n >> 5, k = n & 31;
             const int o = (kbq * ROWS + row) * 32 + swz_chunk(row, k >> 3) * 8 + (k & 7);
             *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{a[i].x, a[i].y, a[i].z, a[i].w});
@@ -671,13 +673,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
           for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         sweep8<BF, MT, true, true>(acc, wf, tv, bb, KBSq, oq.Wk, C, wave * 32, fi, fg);
-        if (L % 32 == 0) {
+        if (MT >= 2 && L % 32 == 0) {
           // tile pairs (mt, mt+1) are the two 16-key halves of one 32-key step: 16 contiguous bytes per lane
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             const float b = sqkvb[2 * C + wave * 32 + nt * 16 + fi];
 #pragma unroll
-            for (int mp = 0; mp < MT; mp += 2) {
+            for (int mp = 0; mp + 1 < MT; mp += 2) {
               float v[8] = {acc[nt][mp][0] + b, acc[nt][mp][1] + b, acc[nt][mp][2] + b, acc[nt][mp][3] + b,
                             acc[nt][mp + 1][0] + b, acc[nt][mp + 1][1] + b, acc[nt][mp + 1][2] + b, acc[nt][mp + 1][3] + b};
               const u16x8 v8 = cvt8<BF>(v);
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
               }
             }
           }
-        } else {   // frames of an odd multiple of 16 keys (the host admits L % 16 == 0 only)
+        } else {   // 16-key pieces: frames of an odd multiple of 16 keys (the host admits L % 16 == 0 only), and every 16-row tile
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             const float b = sqkvb[2 * C + wave * 32 + nt * 16 + fi];
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                 v[0] += b; v[1] += b; v[2] += b; v[3] += b;
                 wvb.store8((unsigned)(d * 2), cvt4<BF>(v));
                 // the frame's last 16-key tile also clears the padding half of its 32-key step (finite values for probability 0)
-                if ((int)(mt0 - sf * L) + 16 == L) wvb.store8((unsigned)((d ^ 4) * 2), u16x4{0, 0, 0, 0});
+                if (L % 32 != 0 && (int)(mt0 - sf * L) + 16 == L) wvb.store8((unsigned)((d ^ 4) * 2), u16x4{0, 0, 0, 0});
               }
             }
           }

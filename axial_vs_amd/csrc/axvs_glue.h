@@ -90,38 +90,44 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
-// one wave per (n, g): lanes stride over the blocks, then a fixed-order butterfly
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk, int G, int NG) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;          // (n, g)
-  if (i >= NG) return;
-  const int n = i / G, g = i - n * G;
-  float s = 0.f, q = 0.f;
-  for (int b = lane; b < nblk; b += 64) {
-    const float* p = partial + (((long long)n * nblk + b) * G + g) * 2;
-    s += p[0]; q += p[1];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o, 64);
-    q += __shfl_xor(q, o, 64);
-  }
-  if (lane == 0) {
-    stats[(long long)i * 2] = s;
-    stats[(long long)i * 2 + 1] = q;
-  }
-}
-
+// (Round 4: the second stage -- per (n, g): lanes stride over the blocks' partials, then a fixed-order butterfly -- is the first thing
+//  gn_apply_kernel does for the groups its 64 channels touch, instead of a launch of its own: 3 launches per GroupNorm -> 2.)
 // GroupNorm apply: out = (y - mean_g) * rstd_g * gamma_c + beta_c; token rows in, token rows (in place allowed) or NCHW out.
 // Workgroup = 64 pixels x 64 channels of one sample, transposed through LDS for the NCHW store.
 template <bool OUT_NCHW>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ partial, int nblk,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ out, int HW, int C, int G, float eps, long long out_ld,
                                                        long long out_batch_stride) {
   __shared__ float tile[64][65];
+  __shared__ float gmu[64], grs[64];                   // mean / rstd of the (at most 33: channels per group >= 2) groups of my 64 channels
   const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
   const int cg = C / G;
   const float cnt = (float)HW * cg;
+  {
+    // statistics of my groups from the blocks' partial sums, in a fixed order (every workgroup that needs a group computes the same
+    // bits): one wave per group, lanes stride over the blocks, xor butterfly
+    const int g_first = c0 / cg, g_last = min(c0 + 63, C - 1) / cg, lane = tid & 63;
+    for (int g = g_first + (tid >> 6); g <= g_last; g += 4) {
+      float s = 0.f, q = 0.f;
+      for (int b = lane; b < nblk; b += 64) {
+        const float* p = partial + (((long long)n * nblk + b) * G + g) * 2;
+        s += p[0]; q += p[1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+      }
+      if (lane == 0) {
+        const float mu = s / cnt;
+        gmu[g - g_first] = mu;
+        grs[g - g_first] = rsqrtf(fmaxf(q / cnt - mu * mu, 0.f) + eps);
+      }
+    }
+    __syncthreads();
+  }
+  const int g_first = c0 / cg;
   // read: thread -> (pixel row, 16 channels) as float4 x 4: 64 rows x 16 float4
   for (int i = tid; i < 64 * 16; i += 256) {
     const int r = i >> 4, c4 = (i & 15) * 4;
@@ -132,10 +138,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int g = (c + k) / cg;
-        const float mu = stats[((long long)n * G + g) * 2] / cnt;
-        const float var = fmaxf(stats[((long long)n * G + g) * 2 + 1] / cnt - mu * mu, 0.f);
-        o[k] = (o[k] - mu) * rsqrtf(var + eps) * gamma[c + k] + beta[c + k];
+        const int g = (c + k) / cg - g_first;
+        o[k] = (o[k] - gmu[g]) * grs[g] * gamma[c + k] + beta[c + k];
       }
       v = float4{o[0], o[1], o[2], o[3]};
       if (!OUT_NCHW) *reinterpret_cast<float4*>(out + (long long)n * out_batch_stride + (long long)p * out_ld + c) = v;

@@ -1368,3 +1368,34 @@ def test_merged_qkv_on_two_streams_at_once():
     for k in (0, 1):
         for o in outs[k]:
             assert torch.equal(o, want[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 4, 256, 32, 32, 1024), (1, 4, 256, 16, 16, 1024), (2, 3, 256, 32, 16, 512)])
+def test_merged_qkv_on_16_row_tiles_is_bit_identical(shape):
+    """Problems with few rows run the trajectory kernels on 16-row tiles; their one-launch-per-pass form (option `merge_small`:
+    measured no faster -- every 16-row workgroup streams the q/k/v weights itself -- so it is opt-in) must give the same bits as
+    q/k/v launch + trajectory launch, like the 64-row form does."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 23)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    L = _lib.lib()
+    for it in range(3):
+        g = torch.Generator(device="cuda").manual_seed(2000 + it)
+        src = torch.randn(B * T, H * W, C, device="cuda", generator=g)
+        for pos in (pg, pg.clone()):
+            two = layer(src, pos)[0].clone()
+            names_two = _stage_names()
+            _lib.check(L.axvs_set_option(b"merge_small", 1), "axvs_set_option")
+            try:
+                one = layer(src, pos)[0].clone()
+                names_one = _stage_names()
+            finally:
+                L.axvs_set_option(b"merge_small", 0)
+            assert torch.equal(one, two), it
+    assert "h.qkv_proj" in names_two and "h.qkv+traj" in names_one and "w.qkv+traj" in names_one, (names_two, names_one)
