@@ -39,35 +39,11 @@ struct H16<true> {
   }
 };
 
-// ---- 16-bit VALU helpers for the reassociated temporal half (axvs_fused.h): fp32 accumulate dot of 8 element pairs, and
-//      acc += a * x on 8 packed elements.  fp16: v_dot2_f32_f16 / v_pk_fma_f16; bf16 (non-default operand type): fp32 math.
+// ---- 16-bit VALU helper for the reassociated temporal half (axvs_fused.h): acc += a * x on 8 packed elements.
+//      fp16: v_pk_fma_f16; bf16 (non-default operand type): fp32 math.  (The per-row dot products of that half run on the
+//      matrix pipe since round 4: diagonal of a 16 x 16 x 32 MFMA.)
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 struct H2x4 { h16x2 v[4]; };
-
-template <bool BF>
-__device__ __forceinline__ float dot8_acc(f32x4 a_lo, f32x4 a_hi, u16x8 x, float acc) {
-  if constexpr (!BF) {
-    const H2x4 xs = __builtin_bit_cast(H2x4, x);
-    const h16x2 a0 = {(_Float16)a_lo[0], (_Float16)a_lo[1]}, a1 = {(_Float16)a_lo[2], (_Float16)a_lo[3]};
-    const h16x2 a2 = {(_Float16)a_hi[0], (_Float16)a_hi[1]}, a3 = {(_Float16)a_hi[2], (_Float16)a_hi[3]};
-    acc = __builtin_amdgcn_fdot2(a0, xs.v[0], acc, false);
-    acc = __builtin_amdgcn_fdot2(a1, xs.v[1], acc, false);
-    acc = __builtin_amdgcn_fdot2(a2, xs.v[2], acc, false);
-    acc = __builtin_amdgcn_fdot2(a3, xs.v[3], acc, false);
-    return acc;
-  } else {     // v_dot2c_f32_bf16 (gfx950): the multiplier is rounded to bf16 like the f16 path rounds it to f16
-    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
-    struct B2x4 { b16x2 v[4]; };
-    const B2x4 xs = __builtin_bit_cast(B2x4, x);
-    const b16x2 a0 = {(__bf16)a_lo[0], (__bf16)a_lo[1]}, a1 = {(__bf16)a_lo[2], (__bf16)a_lo[3]};
-    const b16x2 a2 = {(__bf16)a_hi[0], (__bf16)a_hi[1]}, a3 = {(__bf16)a_hi[2], (__bf16)a_hi[3]};
-    acc = __builtin_amdgcn_fdot2_f32_bf16(a0, xs.v[0], acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(a1, xs.v[1], acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(a2, xs.v[2], acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(a3, xs.v[3], acc, false);
-    return acc;
-  }
-}
 
 // acc (8 packed 16-bit values) += a * x.  fp16: four v_pk_fma_f16 (running sum kept in fp16: the result is an MFMA operand and
 // would be rounded to 16 bits anyway; T <= 5 terms).  bf16: fp32 math, rounded per call.

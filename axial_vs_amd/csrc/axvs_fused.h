@@ -1092,10 +1092,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     q2f[mt] = cvt8<BF>(v);
   }
   float lg[T][MT];
+  f32x4 lacc[T][MT];                                        // MFMA tiles whose diagonals are the logits (see below)
 #pragma unroll
   for (int f = 0; f < T; ++f)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) lg[f][mt] = 0.f;
+    for (int mt = 0; mt < MT; ++mt) lacc[f][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     constexpr int PD = T <= 4 ? 2 : 1;                      // groups of x fragments in flight ahead of their use
     u16x8 xg[PD + 1][T];                                    // x fragments of group g live in xg[g % (PD + 1)] (no copies)
@@ -1120,16 +1121,32 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
           for (int f = 0; f < T; ++f)
             xg[(g + PD) % (PD + 1)][f] = *reinterpret_cast<const u16x8*>(xt + bfr[(g + PD) % MT] + f * FS + ((g + PD) / MT) * KBS);
         }
+        {   // logit_f += u . x_f over the 32 channels of block kb, for the 16 rows of tile mt: the DIAGONAL of a 16 x 16 x 32 MFMA with
+            // A = u (rows = tokens: the accumulators of the qk MFMAs, converted, ARE that fragment) and B = x_f.  15 of 16 outputs are
+            // unused, but the matrix pipe is mostly idle in this phase while the VALU was its bottleneck (round 4: 512 v_dot2 per wave
+            // replaced by 128 MFMAs; -1.9 us on the width-pass kernel, and no register spills any more)
+          float v8[8] = {qk[0][mt][0], qk[0][mt][1], qk[0][mt][2], qk[0][mt][3], qk[1][mt][0], qk[1][mt][1], qk[1][mt][2], qk[1][mt][3]};
+          const u16x8 ua = cvt8<BF>(v8);
 #pragma unroll
-        for (int f = 0; f < T; ++f) lg[f][mt] = dot8_acc<BF>(qk[0][mt], qk[1][mt], xg[g % (PD + 1)][f], lg[f][mt]);
+          for (int f = 0; f < T; ++f) lacc[f][mt] = H16<BF>::mfma(ua, xg[g % (PD + 1)][f], lacc[f][mt]);
+        }
         __builtin_amdgcn_sched_barrier(0);                  // keeps the LDS reads of later groups from being hoisted (lgkmcnt)
       }
     }
   }
+  {
+    // lane (fi, fg) holds D[4 fg + r][fi]: the diagonal element of row fi sits in lane (fi, fi >> 2), component fi & 3; every
+    // lane of column fi fetches it from there
+    const int sel = fi & 3, srcl = (fi + 16 * (fi >> 2)) * 4;
 #pragma unroll
-  for (int f = 0; f < T; ++f)
+    for (int f = 0; f < T; ++f)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) lg[f][mt] = groups_sum(lg[f][mt]);
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 a = lacc[f][mt];
+        const float d = sel == 0 ? a[0] : sel == 1 ? a[1] : sel == 2 ? a[2] : a[3];
+        lg[f][mt] = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(d)));
+      }
+  }
   AXVS_STAMP(3);
   // softmax over frames
 #pragma unroll
