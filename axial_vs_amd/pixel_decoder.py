@@ -436,7 +436,7 @@ class WithinClipTrackingModule(nn.Module):
     def set_stack_precision(self, precision: str = "f16") -> "WithinClipTrackingModule":
         """Operand precision of the axial-trajectory (temporal) layers of the stack: 'f16' (default: 16-bit MFMA operands, every
         layer inside 1e-3 on its own, the free-running stack at 1.4e-3 max-norm / <= 1e-3 relative L2 on the temporal levels at
-        BASELINE config 3) or 'f32' (the layers' fp32 tier: the stack then holds 1e-3 in max-norm too, at several times the time --
+        BASELINE config 3) or 'f32' (the layers' fp32 tier: the stack then holds 1e-3 in max-norm too, at about 2.6x the time --
         the reference runs this stack in fp32 end to end, WC/msdeformattn.py:244-273).  Returns self."""
         if precision not in ("f16", "bf16", "f32"):
             raise ValueError(f"unknown precision {precision!r}")

@@ -607,7 +607,13 @@ def main():
                 s_t = src.detach().clone().requires_grad_(True)
                 g_t = torch.ones_like(s_t)
 
+                def zero_grads():        # what optimizer.zero_grad() (set_to_none=True, torch's default) does in a training loop:
+                    s_t.grad = None      # without it autograd ADDS every new gradient to last step's (33 more elementwise kernels)
+                    for p_ in tl.parameters():
+                        p_.grad = None
+
                 def train_step():
+                    zero_grads()
                     tl(s_t, pos)[0].backward(g_t)
 
                 def time_train():
@@ -623,6 +629,7 @@ def main():
                 el = time_train()                       # default: activations kept between forward and backward
 
                 def train_step_amp():
+                    zero_grads()
                     with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
                         y_t = tl(s_t, pos)[0]
                     y_t.backward(g_t)
@@ -634,7 +641,7 @@ def main():
                 extras["train_step"] = {"ms_per_step": round(el * 1e3, 3), "value": round(B * T / el, 1), "unit": "frames/s",
                                         "ms_per_step_recompute": round(el_rec * 1e3, 3),
                                         "ms_per_step_autocast_bf16": round(el_amp * 1e3, 3),
-                                        "what": "forward + backward of one layer through the training tier (axvs_axial_layer_train_fwd/_bwd), "
+                                        "what": "forward + backward of one layer through the training tier (axvs_axial_layer_train_fwd/_bwd), gradients reset to None before every step as optimizer.zero_grad() does (round 4; rounds 1-3 let autograd accumulate: +0.12 ms of torch add kernels), "
                                                 "dropout 0.1 / attn_drop 0.1; ms_per_step: activations kept in HBM between forward and backward "
                                                 "(the default, as the reference under autograd), ms_per_step_recompute: layer.recompute = True "
                                                 "(backward rebuilds them).  Linear layers on the library's own split-precision bf16 MFMA GEMMs "

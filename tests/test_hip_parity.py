@@ -784,7 +784,7 @@ def test_within_clip_module_full_size_golden():
 def test_within_clip_module_full_size_fp32_stack_holds_the_bar_in_max_norm():
     """BASELINE config 3 inside the north star's 1e-3 in MAX-NORM as well: `set_stack_precision("f32")` runs the axial-trajectory
     layers of the stack on their fp32 tier (the reference runs the whole stack in fp32, WC/msdeformattn.py:244-273); the 16-bit
-    default holds 1e-3 per layer and in relative L2, and TOL_STACK = 1.5e-3 max-norm end to end (test above).  Cost: about 4x
+    default holds 1e-3 per layer and in relative L2, and TOL_STACK = 1.5e-3 max-norm end to end (test above).  Cost: about 2.6x
     the time of the default (bench.py, extras.wc_cfg3.ms_per_forward_f32_stack)."""
     z, m = load("g8_pixel_decoder_full_T4_S2")
     mod = _full_size_decoder(m, weights(z, m)).set_stack_precision("f32")
