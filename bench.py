@@ -178,12 +178,19 @@ def main():
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
+        # HIP events on the launch stream around the SAME K steps: the roofline's kernel time is taken over the timed region itself
+        # (a separate event loop behind the per-stage measurements ran at the lower clocks their host syncs leave behind: 107 us
+        #  against 96 us for the same 20 steps)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for _ in range(steps):
             out = step()
+        ev1.record()
         torch.cuda.synchronize(dev)
         barrier()
         elapsed = time.perf_counter() - t0
+        timed.last_event_ms = ev0.elapsed_time(ev1)
         if world > 1:
             tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -288,6 +295,7 @@ def main():
             step()
         torch.cuda.synchronize(dev)
     elapsed, out = timed(step, args.steps, args.warmup)
+    main_event_ms = timed.last_event_ms          # device time of exactly those K steps (this rank's stream)
     assert torch.isfinite(out).all()
     frames = world * B * T * args.steps
     value = frames / elapsed
@@ -460,14 +468,8 @@ def main():
 
         reps = min(args.steps, 50)
         kernels = stage_times(lambda: layer(src, pos), reps)
-        # whole-forward duration with events bracketing K back-to-back forwards (no host sync inside)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            step()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        fwd_ms = e0.elapsed_time(e1) / args.steps
+        # whole-forward duration: the HIP events that bracketed the K timed steps (no host sync inside)
+        fwd_ms = main_event_ms / args.steps
         flops = layer_flops(B, T, H, W, C, F)
         achieved = flops / (fwd_ms * 1e-3) / 1e12
         dom = max(kernels, key=kernels.get)
