@@ -49,9 +49,10 @@ def default_operand_dtype() -> str:
 _workspaces: Dict[Tuple[str, int], Tensor] = {}
 
 
-def _workspace(device: torch.device, nbytes: int) -> Tensor:
-    """Grow-only scratch buffer per (device, stream) from torch's caching allocator."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+def _workspace(device: torch.device, nbytes: int, stream_handle: Optional[int] = None) -> Tensor:
+    """Grow-only scratch buffer per (device, stream) from torch's caching allocator.  `stream_handle`: the current stream's handle
+    when the caller has it already (torch.cuda.current_stream costs ~4 us per call)."""
+    key = (str(device), stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
@@ -71,9 +72,9 @@ _sync_buffers: Dict[Tuple[int, int], Tensor] = {}
 _sync_tls = threading.local()
 
 
-def _select_sync_words(device: torch.device) -> None:
+def _select_sync_words(device: torch.device, stream_handle: Optional[int] = None) -> None:
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    key = (idx, stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream)
     if getattr(_sync_tls, "key", None) == key:
         return
     buf = _sync_buffers.get(key)
@@ -459,20 +460,21 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             ha = torch.empty(B * W * self.n_heads, T * H, T, H, dtype=torch.float32, device=s.device)
             wa = torch.empty(B * H * self.n_heads, T * W, T, W, dtype=torch.float32, device=s.device)
         packed = self._pack()
-        _select_sync_words(s.device)
+        sh = _stream(s.device)                     # the current stream's handle, looked up once per call
+        _select_sync_words(s.device, sh)
         tag = _sine_tag(pos) if self.use_generated_pos else None
         if tag is not None:
             sp = _lib.AxvsSinePos3D(tag.temperature, int(tag.normalize), tag.scale, tag.level.data_ptr() if tag.level is not None else None)
-            ws = _workspace(s.device, L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, int(self.return_attn), 1))
+            ws = _workspace(s.device, L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, int(self.return_attn), 1), sh)
             _lib.check(L.axvs_axial_layer_fwd_sine3d(s.data_ptr(), C.byref(sp), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
                                                      self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(),
-                                                     _ptr(ha), _ptr(wa), _stream(s.device)), "axvs_axial_layer_fwd_sine3d")
+                                                     _ptr(ha), _ptr(wa), sh), "axvs_axial_layer_fwd_sine3d")
             return out, ha, wa
         nws = L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, int(self.return_attn), 0)
-        ws = _workspace(s.device, nws)
+        ws = _workspace(s.device, nws, sh)
         _lib.check(L.axvs_axial_layer_fwd(s.data_ptr(), p.data_ptr(), out.data_ptr(), packed.data_ptr(), B, T, H, W, C_,
                                           self.n_heads, F, _lib.DTYPES[self._dtype()], ws.data_ptr(), ws.numel(),
-                                          _ptr(ha), _ptr(wa), _stream(s.device)), "axvs_axial_layer_fwd")
+                                          _ptr(ha), _ptr(wa), sh), "axvs_axial_layer_fwd")
         return out, ha, wa
 
 
