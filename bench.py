@@ -444,27 +444,44 @@ def main():
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
         nst = L.axvs_profile_stages(None, 0)
-        evs = (ctypes.c_void_p * nst)()
-        for i in range(nst):
-            e = ctypes.c_void_p()
-            assert hip.hipEventCreate(ctypes.byref(e)) == 0
-            evs[i] = e.value
+        ev_sets = []
+        for _ in range(2):                 # two event sets, used alternately: a forward is read while the next one already runs
+            evs_ = (ctypes.c_void_p * nst)()
+            for i in range(nst):
+                e = ctypes.c_void_p()
+                assert hip.hipEventCreate(ctypes.byref(e)) == 0
+                evs_[i] = e.value
+            ev_sets.append(evs_)
 
         def stage_times(fn, reps):
-            """per-stage mean durations (us) from the events the library records between its launches"""
-            acc = [0.0] * nst
-            L.axvs_profile_stages(evs, nst)
-            for _ in range(reps):
+            """per-stage mean durations (us) from the events the library records between its launches.  The GPU never idles between
+            the measured forwards (forward k is read while k + 1 runs; a host sync after every forward let the clocks drop and
+            inflated the stages by ~15 %), and a short settling run precedes them."""
+            for _ in range(200):
                 fn()
-                torch.cuda.synchronize(dev)
-                for i in range(1, L.axvs_profile_stage_count()):
+            acc = [0.0] * nst
+            n_st, prev = 0, None
+
+            def read(evs_):
+                assert hip.hipEventSynchronize(evs_[n_st - 1]) == 0
+                for i in range(1, n_st):
                     ms = ctypes.c_float()
-                    assert hip.hipEventElapsedTime(ctypes.byref(ms), evs[i - 1], evs[i]) == 0
+                    assert hip.hipEventElapsedTime(ctypes.byref(ms), evs_[i - 1], evs_[i]) == 0
                     acc[i] += ms.value / reps
+            for r in range(reps):
+                evs_ = ev_sets[r & 1]
+                L.axvs_profile_stages(evs_, nst)
+                fn()
+                n_st = L.axvs_profile_stage_count()
+                if prev is not None:
+                    read(prev)
+                prev = evs_
+            read(prev)
             L.axvs_profile_stages(None, 0)
-            n = L.axvs_profile_stage_count()
-            return {L.axvs_profile_stage_name(i).decode(): round(acc[i] * 1e3, 2) for i in range(1, n)}
+            torch.cuda.synchronize(dev)
+            return {L.axvs_profile_stage_name(i).decode(): round(acc[i] * 1e3, 2) for i in range(1, n_st)}
 
         reps = min(args.steps, 50)
         kernels = stage_times(lambda: layer(src, pos), reps)
