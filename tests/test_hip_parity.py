@@ -1244,6 +1244,8 @@ MERGE_SHAPES = [(1, 4, 256, 64, 64, 1024),     # the metric shape: a row tile is
                 (1, 4, 256, 48, 80, 1024),     # frames of 48 / 80 keys: odd multiples of 16 (8-byte V^T stores, padded key steps)
                 (1, 4, 256, 96, 96, 1024),     # BASELINE config 5's clip size: 1.5 tiles per frame
                 (3, 1, 256, 64, 64, 1024),     # T = 1: one tile per sequence, nobody to wait for
+                (1, 3, 256, 80, 48, 512),      # sequences of 240 / 144 rows: the last tile of a sequence holds 48 / 16 rows (clamped copies
+                                               # computed, never stored, their K / V^T never written)
                 (1, 4, 256, 64, 36, 1024)]     # 36 sequences in the height pass: not a multiple of 8, so the tiles of a sequence are NOT
                                                # gathered on one XCD (sibling hand-off across XCDs); width pass (36 keys): two launches
 
