@@ -241,3 +241,41 @@ def test_reference_extension_stand_in_exposes_the_two_entry_points():
     b = list(inspect.signature(MSDA.ms_deform_attn_backward).parameters)
     assert f == ["value", "value_spatial_shapes", "value_level_start_index", "sampling_locations", "attention_weights", "im2col_step"]
     assert b == ["value", "value_spatial_shapes", "value_level_start_index", "sampling_locations", "attention_weights", "grad_output", "im2col_step"]
+
+
+def test_default_dtype_f32_falls_back_to_16_bit_where_there_is_no_fp32_tier():
+    """`set_default_dtype("f32")` selects the fp32 tier of the axial layer; modules without such a tier (TrajectoryAttention, the
+    cross-clip module, deformable attention, ...) keep 16-bit operands instead of failing on an unknown dtype (round-3 advisor)."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import modules
+    prev = modules._DEFAULT_DTYPE
+    try:
+        modules.set_default_dtype("f32")
+        assert modules.default_operand_dtype() == "f16"
+        assert ax.TrajectoryAttention(64, 8)._dtype() == "f16"
+        layer = ax.TemporalAxialTrajectoryAttentionLayer(64, 128, n_heads=8)
+        assert layer._dtype() == "f32"
+        with pytest.raises(NotImplementedError):
+            layer._pack()                      # the fp32 tier has no packed weights / per-pass entry point
+        modules.set_default_dtype("bf16")
+        assert modules.default_operand_dtype() == "bf16" and layer._dtype() == "bf16"
+        with pytest.raises(ValueError):
+            modules.set_default_dtype("fp8")
+    finally:
+        modules.set_default_dtype(prev)
+
+
+def test_stack_precision_setter_reaches_every_axial_layer():
+    """`WithinClipTrackingModule.set_stack_precision`: the operand precision of the axial-trajectory layers of the stack (the fp32
+    setting is what holds 1e-3 in max-norm over the free-running stack of BASELINE config 3; GPU test
+    test_within_clip_module_full_size_fp32_stack_holds_the_bar_in_max_norm)."""
+    import axial_vs_amd as ax
+    z, m = load("g8_pixel_decoder_T2_S2")
+    mod = _decoder_from_meta(m)
+    layers = [x for x in mod.modules() if isinstance(x, ax.TemporalAxialTrajectoryAttentionLayer)]
+    assert layers and all(l.mfma_dtype is None for l in layers)
+    assert mod.set_stack_precision("f32") is mod and all(l._dtype() == "f32" for l in layers)
+    mod.set_stack_precision("f16")
+    assert all(l._dtype() == "f16" for l in layers)
+    with pytest.raises(ValueError):
+        mod.set_stack_precision("fp8")
