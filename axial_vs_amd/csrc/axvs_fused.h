@@ -170,9 +170,14 @@ __device__ __forceinline__ void ffn_stage_params(const FfnLds& l, const float* _
 // `row_off(r)`: element offset of tile row r in `out`, or < 0 for a row that does not exist (ragged last tile).
 // GELU: the hidden activation is the exact (erf) GELU of F.gelu instead of ReLU (WC/temporal_attention.py:9-17) -- a template flag so
 // that the ReLU kernels (every shipped config, and the width-pass kernel that carries this body) keep their code as it is.
-template <bool BF, class RowOff, bool GELU = false>
+// PRE / `pre`: the wave's 8 input rows (row 8 wave + rr, float4 column `lane`) handed over in registers -- the caller then
+// has NOT written them to xtile, and norm1 below skips reading them back (the fused width-pass kernel: its residual epilogue and
+// this norm1 walk the same rows; one LDS round trip per row less).
+struct NoRows { float4 v[8]; };
+template <bool BF, class RowOff, bool GELU = false, bool PRE = false>
 __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], const u16* __restrict__ W1, const u16* __restrict__ W2,
-                                         float* __restrict__ out, RowOff row_off, int F, int rot, int crot, int tid, int wt = 0) {
+                                         float* __restrict__ out, RowOff row_off, int F, int rot, int crot, int tid, int wt = 0,
+                                         const NoRows& pre = NoRows{}) {
   constexpr int C = 256, KB = 8;
   const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const float* sb1 = l.par;
@@ -189,7 +194,9 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const int r = wave * 8 + rr;
-      const float4 v = *reinterpret_cast<const float4*>(l.xtile + r * kEpiLd + lane * 4);
+      float4 v;
+      if constexpr (PRE) v = pre.v[rr];
+      else v = *reinterpret_cast<const float4*>(l.xtile + r * kEpiLd + lane * 4);
       const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
       const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
       const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
@@ -1278,6 +1285,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   u16* const tv = reinterpret_cast<u16*>(etile + ROWS * kEpiLd);
   PosGenLane npl;
   float namax = 0.f;
+  [[maybe_unused]] NoRows yrows;                   // FFN: the wave's rows after the residual
   if constexpr (QKVN) {
     if (nq.pg.mode) npl.init(nq.pg, lane * 4);
   }
@@ -1310,7 +1318,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         y = float4{d0 * rstd * g.x + b.x, d1 * rstd * g.y + b.y, d2 * rstd * g.z + b.z, d3 * rstd * g.w + b.w};
       }
     }
-    if constexpr (FFN) *reinterpret_cast<float4*>(etile + row * kEpiLd + lane * 4) = y;    // stays in LDS: input row of the FFN half
+    if constexpr (FFN) yrows.v[i] = y;             // stays on the CU: input row of the FFN half, handed to its norm1 in registers
     else if (row < nvalid) {
       if (wt) WtBuf(out).store16((unsigned)(roff[i] * 4), y);
       else *reinterpret_cast<float4*>(out + roff[i]) = y;
@@ -1373,9 +1381,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
   if constexpr (FFN) {
-    lds_fence();                                    // my rows are complete (ffn_body's norm1 reads the rows of its own wave)
-    ffn_body<BF>(fl, wf, fa.W1, fa.W2, out,
-                 [=](int row) { return row < nvalid ? roff[row % RPW] - lane * 4 : -1ll; }, fa.F, 0, crot, tid, wt);   // rows of this wave
+    static_assert(RPW == 8, "the FFN half walks 8 rows per wave");
+    auto row_off_ = [=](int row) { return row < nvalid ? roff[row % RPW] - lane * 4 : -1ll; };       // rows of this wave
+    ffn_body<BF, decltype(row_off_), false, true>(fl, wf, fa.W1, fa.W2, out, row_off_, fa.F, 0, crot, tid, wt, yrows);
   }
   AXVS_STAMP(10);
 #if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)
