@@ -1403,3 +1403,29 @@ def test_merged_qkv_on_16_row_tiles_is_bit_identical(shape):
                 L.axvs_set_option(b"merge_small", 0)
             assert torch.equal(one, two), it
     assert "h.qkv_proj" in names_two and "h.qkv+traj" in names_one and "w.qkv+traj" in names_one, (names_two, names_one)
+
+
+@pytest.mark.gpu
+def test_merged_qkv_launches_replay_from_a_hip_graph():
+    """The merged q/k/v + trajectory launches inside a captured HIP graph: the arrival counters are left zero by every launch, so a
+    replay needs no memset node; replay == eager, bitwise, also after the inputs change, and the counters are zero afterwards."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import modules
+    B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 29)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    a = torch.randn(B * T, H * W, C, device="cuda")
+    b = torch.randn(B * T, H * W, C, device="cuda")
+    pt = pg.clone()            # (GraphedForward replays on its own copies of the inputs: a plain `pos` tensor there, so here too)
+    want_a, want_b = layer(a, pt)[0].clone(), layer(b, pt)[0].clone()
+    assert "h.qkv+traj" in _stage_names()
+    g = ax.GraphedForward(layer, a, pt)
+    for _ in range(3):
+        assert torch.equal(g()[0], want_a)
+    assert torch.equal(g(b, pt)[0], want_b)
+    torch.cuda.synchronize()
+    for buf in modules._sync_buffers.values():
+        assert int(buf.abs().sum()) == 0
