@@ -15,6 +15,7 @@
 #include "axvs_common.h"
 #include "axvs_fused.h"
 #include "axvs_ffn_split.h"
+#include "axvs_ffn_wide.h"
 #include "axvs_gemm.h"
 #include "axvs_misc.h"
 #include "axvs_gemm_nt.h"
@@ -32,6 +33,7 @@ thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
 thread_local int* g_status = nullptr;     // axvs_set_status_buffer: device word that kernels OR condition bits into
+thread_local int g_ffn_wide = 0;         // option "ffn_wide": 0 = 128-row FFN tiles when they save a round of the chip (ffn_wide_pays), 1 = always, 2 = never
 thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
                                          // 2 = the merged q/k/v + trajectory kernels return after their q/k/v part (the two-launch kernels treat it as 1)
@@ -505,6 +507,13 @@ qkv_done:
   return AXVS_OK;
 }
 
+// A 128-row FFN tile takes 33 us where a 64-row tile takes 18 (one workgroup per CU; measured stand-alone, tools/ffn_wide_check.py):
+// the wide kernel pays when its rounds of the 256-CU chip are so much fewer (21504 rows: 1 x 33 against 2 x 18).
+bool ffn_wide_pays(long long M) {
+  const long long r64 = ((M + kRows - 1) / kRows + 255) / 256, r128 = ((M + kWideRows - 1) / kWideRows + 255) / 256;
+  return r64 > 1 && r128 * 11 < r64 * 6;
+}
+
 // norm1 -> linear1 -> ReLU -> linear2 -> +residual -> norm2 on fp32 rows X[M][C] (X is clobbered by the generic path)
 template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
@@ -520,6 +529,20 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
     }
     hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
                        p.g2, p.be2, out, M, F / 256);
+    mark(st, "norm1+ffn+norm2");
+    return AXVS_OK;
+  }
+  if (ffn_kernel_is_fused(C, heads, F) && F <= 2048 && (g_ffn_wide == 1 || (g_ffn_wide == 0 && ffn_wide_pays(M)))) {
+    // more 64-row tiles than CUs: 128-row tiles when that saves a round of the chip (axvs_ffn_wide.h; bit-identical)
+    const size_t lds = ffn_wide_lds_bytes(F);
+    const dim3 wgrid((unsigned)((M + kWideRows - 1) / kWideRows));
+    if (g_ffn_gelu) {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_wide_kernel<BF, true>))) return rc;
+      hipLaunchKernelGGL((ffn_wide_kernel<BF, true>), wgrid, dim3(512), lds, st, (const float*)X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+    } else {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_wide_kernel<BF>))) return rc;
+      hipLaunchKernelGGL((ffn_wide_kernel<BF>), wgrid, dim3(512), lds, st, (const float*)X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+    }
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }
@@ -952,7 +975,7 @@ MsdaPacked carve_msda(Carver& c, int C, int heads, int L, int P) {
   const size_t Cp = (size_t)heads * 32, nq = (size_t)3 * heads * L * P;
   MsdaPacked m;
   m.wv = c.take<u16>(3 * Cp * C);          // split precision: (hi | lo | hi) along K
-  m.wq = c.take<u16>(3 * nq * C);
+  m.wq = c.take<u16>(3 * ((nq + 15) & ~(size_t)15) * C);      // (weight rows are stored in groups of 16: wblk_off)
   m.wo = c.take<u16>(3 * (size_t)C * Cp);
   m.bv = c.take<float>(Cp);
   m.bq = c.take<float>(nq);
@@ -1140,6 +1163,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
+  if (key && !strcmp(key, "ffn_wide")) { g_ffn_wide = value; return AXVS_OK; }
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_merge_qkv")) { g_no_merge_qkv = value; return AXVS_OK; }
@@ -1850,7 +1874,7 @@ int axvs_msda_core_bwd(const float* value, const int* spatial_shapes, const floa
 // ---- pixel-decoder glue ----
 size_t axvs_conv1x1_gn_packed_bytes(int Cin, int Cout) {
   Carver c(nullptr);
-  c.take<u16>(3 * (size_t)Cin * Cout);
+  c.take<u16>(3 * (size_t)Cin * ((Cout + 15) & ~15));
   c.take<float>(Cout); c.take<float>(Cout); c.take<float>(Cout);
   return c.off;
 }
@@ -1860,7 +1884,7 @@ int axvs_conv1x1_gn_pack(const AxvsConvGnParams* p, void* packed, int Cin, int C
   if (Cin <= 0 || Cin % 32 || Cout <= 0 || Cout % 4) return fail(AXVS_ERR_ARG, "Cin=%d must be a multiple of 32, Cout=%d of 4", Cin, Cout);
   if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
   Carver c(packed);
-  u16* w = c.take<u16>(3 * (size_t)Cin * Cout);
+  u16* w = c.take<u16>(3 * (size_t)Cin * ((Cout + 15) & ~15));
   float* b = c.take<float>(Cout); float* g = c.take<float>(Cout); float* be = c.take<float>(Cout);
   hipStream_t st = static_cast<hipStream_t>(stream);
   PackDim nd{Cout, Cout, 0, 0, 0}, kd{Cin, Cin, 0, 0, 0};
@@ -1892,7 +1916,7 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
   if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
   hipStream_t st = static_cast<hipStream_t>(stream);
   Carver pc(const_cast<void*>(packed));
-  const u16* w = pc.take<u16>(3 * (size_t)Cin * Cout);
+  const u16* w = pc.take<u16>(3 * (size_t)Cin * ((Cout + 15) & ~15));
   const float* b = pc.take<float>(Cout); const float* g = pc.take<float>(Cout); const float* be = pc.take<float>(Cout);
   Carver wc(workspace);
   const long long M = (long long)N * HW;

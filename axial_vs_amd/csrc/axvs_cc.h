@@ -4,7 +4,7 @@
 
 namespace axvs {
 
-// conv weight [Cout][Cin][3] fp32 -> blocked 16-bit [3*Cin/32][Cout][32] with k = tap*Cin + ci
+// conv weight [Cout][Cin][3] fp32 -> blocked 16-bit weight layout (wblk_off) with k = tap*Cin + ci
 template <bool BF>
 __global__ void pack_conv3_kernel(const float* __restrict__ W, u16* __restrict__ out, int Cout, int Cin) {
   long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -15,7 +15,7 @@ __global__ void pack_conv3_kernel(const float* __restrict__ W, u16* __restrict__
   int n = t % Cout;
   int kb = t / Cout;
   int k = kb * 32 + kk, tap = k / Cin, ci = k - tap * Cin;
-  out[idx] = H16<BF>::from_f32(W[((long long)n * Cin + ci) * 3 + tap]);
+  out[wblk_off(Cout, n, k)] = H16<BF>::from_f32(W[((long long)n * Cin + ci) * 3 + tap]);
 }
 
 // eval-mode BatchNorm folded into a per-channel multiplier / bias:  y = (x - mean) / sqrt(var + eps) * w + b

@@ -195,6 +195,17 @@ __device__ __forceinline__ long long blk_off(long long R, long long r, int k) {
   return ((long long)(k >> 5) * R + r) * kBlk + (k & 31);
 }
 
+// Blocked 16-bit WEIGHT matrix [K/32][Rp/16][4 chunks][16 rows][8] (Rp = R rounded up to 16): the 1 KiB of a (k-block, 16 rows)
+// block is stored in MFMA-FRAGMENT order, so that lane (i = lane & 15, g = lane >> 4) of a fragment load -- row i, 8 k-values of
+// chunk g -- reads bytes [16 lane, 16 lane + 16) of the block: consecutive lanes, consecutive addresses.  With plain 64-byte rows
+// ([K/32][R][32], the activation layout above) the same load makes 4 consecutive lanes touch 4 different 64-byte segments, and the
+// L2 -> CU weight stream of the N-split kernels ran ~ 1.5x slower for it (tools/hw/ffn_overlap.hip: 3.9 k vs 2.6 k cycles per FFN
+// phase).  Every packer (axvs_misc.h) writes and every weight reader (w_frag, the GEMM kernels) addresses through this function.
+__device__ __forceinline__ long long wblk_off(long long R, long long r, int k) {
+  const long long Rp = (R + 15) & ~15ll;
+  return ((long long)(k >> 5) * Rp + (r & ~15ll)) * kBlk + ((k >> 3) & 3) * 128 + (r & 15) * 8 + (k & 7);
+}
+
 // LDS image of a [rows][32] 16-bit tile (64-byte rows) read as MFMA fragments with ds_read_b128:
 // lane (i = lane&15, g = lane>>4) reads the 16-byte chunk g of row i.  XOR-ing the chunk index with
 // kSwz[(row>>2)&3] makes the four 16-lane ds_read_b128 groups hit 16 distinct 16-byte slots.

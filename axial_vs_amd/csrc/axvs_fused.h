@@ -24,12 +24,19 @@ __device__ __forceinline__ u16x8 act_frag(const u16* tile, int kb, int mt, int f
   return *reinterpret_cast<const u16x8*>(tile + act_off(kb, mt * 16 + fi, fg));
 }
 
-// A-operand fragment (weights) straight from the blocked global layout [K/32][NR][32]
+// A-operand fragment (weights) straight from the blocked weight layout (wblk_off: 16 bytes per lane, lanes in address order)
 __device__ __forceinline__ u16x8 w_frag(const u16* __restrict__ W, int NR, int kb, int nrow, int fg) {
 #ifdef AXVS_ABL_W   // diagnostic: every fragment load hits the same 1 KiB (L1-resident) -- results are wrong on purpose
-  return *reinterpret_cast<const u16x8*>(W + (nrow & 15) * 32 + fg * 8);
+  return *reinterpret_cast<const u16x8*>(W + fg * 128 + (nrow & 15) * 8);
 #endif
-  return *reinterpret_cast<const u16x8*>(W + ((long long)kb * NR + nrow) * 32 + fg * 8);
+  return *reinterpret_cast<const u16x8*>(W + wblk_off(NR, nrow, kb * 32 + fg * 8));
+}
+
+// the same fragment addressed as (16-row block, lane): with a wave-uniform block index (rows `nrow16`, a multiple of 16, and `kb` in
+// SGPRs) the load is `global_load_dwordx4 v, v_lane16, s[base]` -- ONE address VGPR for all fragments of a phase
+__device__ __forceinline__ u16x8 w_frag_u(const u16* __restrict__ W, int NR, int kb, int nrow16, int lane) {
+  const long long blk = ((long long)kb * ((NR + 15) & ~15) + nrow16) * 32;
+  return *reinterpret_cast<const u16x8*>(W + blk + lane * 8);
 }
 
 // store 4 consecutive channels (D layout: n = 16*nt16 + 4*fg + r) of token `row` into an activation tile

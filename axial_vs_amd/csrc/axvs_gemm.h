@@ -226,8 +226,11 @@ __device__ __forceinline__ void gemm64_body(const ALoad& al, const u16* __restri
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
   const int lrow = tid >> 2, lg = tid & 3;                 // staging: one 16-byte chunk per thread and operand
-  const int wrow = min(n0 + lrow, Nout - 1);
   const int st_off = lrow * 32 + swz_chunk(lrow, lg) * 8;
+  // weights: thread t of a wave takes bytes [16 t, 16 t + 16) of its (k-block, 16 rows) block (wblk_off: fragment order)
+  const int wlrow = wave * 16 + (lane & 15), wlg = lane >> 4;
+  const int wrow = min(n0 + wlrow, Nout - 1);
+  const int wst_off = wlrow * 32 + swz_chunk(wlrow, wlg) * 8;
   const int fi = lane & 15, fg = lane >> 4;
 
   f32x4 acc[2][2];
@@ -248,7 +251,7 @@ __device__ __forceinline__ void gemm64_body(const ALoad& al, const u16* __restri
   for (int u = 0; u < PF; ++u) {
     const int k = min(u, nkb - 1) * 32 + lg * 8;
     rx[u] = Raw::fetch(al, m0 + lrow, k);
-    rw[u] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, k));
+    rw[u] = *reinterpret_cast<const u16x8*>(Wp + wblk_off(Nout, wrow, k - lg * 8 + wlg * 8));
   }
   for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
 #pragma unroll
@@ -258,12 +261,12 @@ __device__ __forceinline__ void gemm64_body(const ALoad& al, const u16* __restri
         u16* bx = sX[kb & 1];
         u16* bw = sW[kb & 1];
         *reinterpret_cast<u16x8*>(bx + st_off) = Raw::conv(rx[u]);
-        *reinterpret_cast<u16x8*>(bw + st_off) = rw[u];
+        *reinterpret_cast<u16x8*>(bw + wst_off) = rw[u];
         __syncthreads();                    // also orders these writes after the reads of this buffer two steps ago
         {
           const int k = min(kb + PF, nkb - 1) * 32 + lg * 8;   // unconditional (clamped) prefetch keeps vmcnt bookkeeping simple
           rx[u] = Raw::fetch(al, m0 + lrow, k);
-          rw[u] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, wrow, k));
+          rw[u] = *reinterpret_cast<const u16x8*>(Wp + wblk_off(Nout, wrow, k - lg * 8 + wlg * 8));
         }
         u16x8 fx[2], fw[2];
 #pragma unroll
@@ -321,7 +324,7 @@ __device__ __forceinline__ void gemm_direct_body(const ALoad& al, const u16* __r
     const int k = (kbase + min(d, nkb - 1)) * 32 + fg * 8;
     xb[d] = Raw::fetch(al, m0 + fi, k);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wa[d][nt] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, nrow[nt], k));
+    for (int nt = 0; nt < NT; ++nt) wa[d][nt] = *reinterpret_cast<const u16x8*>(Wp + wblk_off(Nout, nrow[nt], k));
   }
   f32x4 acc[NT];
 #pragma unroll
@@ -340,7 +343,7 @@ __device__ __forceinline__ void gemm_direct_body(const ALoad& al, const u16* __r
           const int k = (kbase + min(kb0 + u + D, nkb - 1)) * 32 + fg * 8;
           xb[u] = Raw::fetch(al, m0 + fi, k);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) wa[u][nt] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, nrow[nt], k));
+          for (int nt = 0; nt < NT; ++nt) wa[u][nt] = *reinterpret_cast<const u16x8*>(Wp + wblk_off(Nout, nrow[nt], k));
         }
       }
     }
@@ -355,7 +358,7 @@ __device__ __forceinline__ void gemm_direct_body(const ALoad& al, const u16* __r
         const int k = (kbase + min(kb0 + u + D, nkb - 1)) * 32 + fg * 8;   // unconditional (clamped) refill of the slot just used
         xb[u] = Raw::fetch(al, m0 + fi, k);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wa[u][nt] = *reinterpret_cast<const u16x8*>(Wp + blk_off(Nout, nrow[nt], k));
+        for (int nt = 0; nt < NT; ++nt) wa[u][nt] = *reinterpret_cast<const u16x8*>(Wp + wblk_off(Nout, nrow[nt], k));
       }
     }
   }

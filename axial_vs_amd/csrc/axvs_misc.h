@@ -5,7 +5,7 @@
 
 namespace axvs {
 
-// ---------------- weight packing: fp32 nn.Linear [Nout, K] -> blocked 16-bit [Kp/32][Np][32] ----------------
+// ---------------- weight packing: fp32 nn.Linear [Nout, K] -> blocked 16-bit weight layout (wblk_off, axvs_common.h) ----------------
 // Either dimension may be "head structured": `parts` consecutive groups of (heads x d) channels, each head padded
 // from d to 32 (zero rows / columns), so that kernels always see 32-wide head blocks.
 // Stored position p (0..31) of a permuted head block holds channel perm32(p): the order in which an MFMA D tile pair
@@ -43,7 +43,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ W, u16* __restrict_
   int kb = t / nd.padded;
   int no = nd.to_orig(n), ko = kd.to_orig(kb * 32 + kk);
   float v = (no >= 0 && ko >= 0) ? W[(long long)no * kd.orig + ko] : 0.f;
-  out[((long long)kb * n_total + n_off + n) * 32 + kk] = H16<BF>::from_f32(v);
+  out[wblk_off(n_total, n_off + n, kb * 32 + kk)] = H16<BF>::from_f32(v);
 }
 
 // split-precision weights for the (hi | hi | lo) activations of ALoad*Split3: out blocked [3*Kp/32][N][32], K parts (hi | lo | hi)
@@ -61,8 +61,8 @@ __global__ void pack_weight_split3_kernel(const float* __restrict__ W, u16* __re
   float v = (no >= 0 && ko >= 0) ? W[(long long)no * kd.orig + ko] : 0.f;
   const u16 hi = H16<BF>::from_f32(v);
   const u16 lo = H16<BF>::from_f32(v - H16<BF>::to_f32(hi));
-  const long long part = (long long)(kd.padded / 32) * n_total * 32;
-  const long long o = ((long long)kb * n_total + n_off + n) * 32 + kk;
+  const long long part = (long long)(kd.padded / 32) * ((n_total + 15) & ~15) * 32;
+  const long long o = wblk_off(n_total, n_off + n, kb * 32 + kk);
   out[o] = hi;
   out[part + o] = lo;
   out[2 * part + o] = hi;
@@ -78,7 +78,7 @@ __global__ void pack_wk2t_kernel(const float* __restrict__ W, u16* __restrict__ 
   const int p = idx & 31;
   const long long r = idx >> 5;
   const int c = (int)(r % C), h = (int)(r / C);
-  out[idx] = H16<BF>::from_f32(W[(long long)(h * 32 + perm32(p)) * C + c]);
+  out[wblk_off((long long)heads * C, r, p)] = H16<BF>::from_f32(W[(long long)(h * 32 + perm32(p)) * C + c]);
 }
 
 // Per-head weight copies for the REASSOCIATED temporal half of the shape-generic tier (any T; d = 32, C = heads * 32):
@@ -93,7 +93,7 @@ __global__ void pack_wk2n_kernel(const float* __restrict__ W, u16* __restrict__ 
   const long long r = idx >> 5;
   const int n = (int)(r % C), h = (int)(r / C);
   const int ch = (n & ~31) + perm32(n & 31);
-  out[idx] = H16<BF>::from_f32(W[(long long)(h * 32 + d) * C + ch]);
+  out[(long long)h * C * 32 + wblk_off(C, n, d)] = H16<BF>::from_f32(W[(long long)(h * 32 + d) * C + ch]);
 }
 template <bool BF>
 __global__ void pack_wv2h_kernel(const float* __restrict__ W, u16* __restrict__ out, int C, int heads) {
@@ -104,7 +104,7 @@ __global__ void pack_wv2h_kernel(const float* __restrict__ W, u16* __restrict__ 
   const int r = (int)(t & 31);
   t >>= 5;
   const int KB = C / 32, kb = (int)(t % KB), h = (int)(t / KB);
-  out[idx] = H16<BF>::from_f32(W[(long long)(C + h * 32 + r) * C + kb * 32 + perm32(kk)]);
+  out[(long long)h * C * 32 + wblk_off(32, r, kb * 32 + kk)] = H16<BF>::from_f32(W[(long long)(C + h * 32 + r) * C + kb * 32 + perm32(kk)]);
 }
 
 // Reassociated temporal attention over any number of frames (WC/temporal_attention.py:66-73 with proj_kv applied once instead

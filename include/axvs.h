@@ -105,10 +105,13 @@ const char* axvs_profile_stage_name(int i);
  *      16-bit MFMAs with a frame's score tiles in registers, axis length <= 128; 0: the fp32 MFMA kernel), "train_spatial_wgs" (default 512: workgroups the
  *      training tier's attention kernels are spread over -- measured flat from 512 to 8192 at the metric shape);
  *      "msda_gemm" (default 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
- *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels). */
+ *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels);
+ *      "ffn_wide" (default 0: the stand-alone FFN runs on 128-row tiles when that saves a round of the chip; 1: always; 2: never --
+ *      bit-identical either way). */
 int axvs_set_option(const char* key, int value);
 
-/* ---- weight packing (once per load_state_dict; result is opaque, device-resident) ---- */
+/* ---- weight packing (once per load_state_dict; result is opaque, device-resident: 16-bit operands in MFMA-fragment order,
+ *      16 rows x 32 k-values per KiB, so that a wave's fragment load reads consecutive addresses in lane order) ---- */
 size_t axvs_traj_packed_bytes(int C, int heads);
 int axvs_traj_pack(const AxvsTrajParams* p, void* packed, int C, int heads, int dtype, void* stream);
 size_t axvs_axial_layer_packed_bytes(int C, int heads, int d_ffn);

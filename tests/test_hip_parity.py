@@ -356,6 +356,44 @@ def test_ffn_tail_unit_and_determinism():
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("F", [1024, 512, 2048])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_ffn_on_128_row_tiles_is_bit_identical_to_the_64_row_kernel(F, dtype):
+    """Round 4: with more 64-row tiles than CUs the stand-alone FFN runs on 128-row tiles when that saves a round of the chip
+    (ffn_wide_kernel: every weight fragment multiplies two 64-row halves; option `ffn_wide` 1 = always, 2 = never).  The row count
+    decides, so the two kernels have to produce the same bits -- whole tiles, a ragged last tile, a single row, ReLU and GELU."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    C = 256
+    L = _lib.lib()
+    for act in ("relu", "gelu"):
+        w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 13)
+        layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8, activation=act, mfma_dtype=dtype).eval()
+        layer.load_state_dict(w, strict=True)
+        packed = layer.cuda()._pack()
+        _lib.check(L.axvs_set_option(b"ffn_gelu", int(act == "gelu")), "axvs_set_option")
+        try:
+            for M in (21504, 128 * 3 + 1, 64, 1, 16384 + 129):
+                g = torch.Generator().manual_seed(M)
+                xs = (torch.randn(M, C, generator=g) * 1.7 + 0.3).cuda()
+                ws = torch.empty(L.axvs_ffn_workspace_bytes(M, C, F), dtype=torch.uint8, device="cuda")
+                outs = []
+                for mode in (2, 1):
+                    _lib.check(L.axvs_set_option(b"ffn_wide", mode), "axvs_set_option")
+                    out = torch.full_like(xs, float("nan"))
+                    _lib.check(L.axvs_ffn_fwd(xs.data_ptr(), out.data_ptr(), packed.data_ptr(), M, C, 8, F, _lib.DTYPES[dtype], ws.data_ptr(),
+                                              ws.numel(), torch.cuda.current_stream().cuda_stream), "axvs_ffn_fwd")
+                    outs.append(out)
+                assert torch.equal(outs[0], outs[1]), (act, M)
+                if act == "relu" and M == 21504:
+                    y = orc._layer_norm(xs.cpu().double(), w, "norm1")
+                    ref = orc._layer_norm(y + orc._linear(torch.relu(orc._linear(y, w, "linear1")), w, "linear2"), w, "norm2")
+                    assert rel_err(outs[1].cpu(), ref) < (2e-3 / 4 if dtype == "f16" else 8e-3)
+        finally:
+            L.axvs_set_option(b"ffn_wide", 0)
+            L.axvs_set_option(b"ffn_gelu", 0)
+
+
 def test_layer_determinism_stress():
     import axial_vs_amd as ax
     z, m = load("g2_axial_B1_T4_C256_H64_W64")

@@ -32,6 +32,8 @@ with torch.no_grad():
     dt = (time.perf_counter() - t0) / n
 print(f"cfg3 within-clip module forward: {dt*1e3:.3f} ms ({m['B']*m['T']/dt:.0f} frames/s)")
 
+if os.environ.get("AXVS_CFG3_NO_GRAPH"):
+    sys.exit(0)
 # the same forward replayed from a captured HIP graph (two streams inside: the temporal levels of a stage run side by side)
 keys = list(feats)
 def fn(*ts):
