@@ -136,6 +136,9 @@ SIGNATURES = {
     "axvs_axial_layer_workspace_bytes_ex": (C.c_size_t, [C.c_int] * 9),
     "axvs_axial_layer_sine3d_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "axvs_axial_layer_fwd_sine3d": (C.c_int, [_fp, C.POINTER(AxvsSinePos3D), _fp, _fp] + [C.c_int] * 8 + [_fp, C.c_size_t, _fp, _fp, _fp]),
+    "axvs_axial_layer_strided_ok": (C.c_int, [C.c_int] * 3),
+    "axvs_axial_layer_workspace_bytes_strided": (C.c_size_t, [C.c_int] * 7 + [C.c_longlong]),
+    "axvs_axial_layer_fwd_sine3d_strided": (C.c_int, [_fp, C.POINTER(AxvsSinePos3D), _fp, _fp] + [C.c_int] * 8 + [C.c_longlong, _fp, C.c_size_t, _fp]),
     "axvs_ffn_workspace_bytes": (C.c_size_t, [C.c_longlong, C.c_int, C.c_int]),
     "axvs_ffn_fwd": (C.c_int, [_fp, _fp, _fp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),
     "axvs_cc_layer_packed_bytes": (C.c_size_t, []),

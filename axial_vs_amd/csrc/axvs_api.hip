@@ -33,6 +33,7 @@ thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
 thread_local int* g_status = nullptr;     // axvs_set_status_buffer: device word that kernels OR condition bits into
+thread_local long long g_row_span = 0;   // rows spanned by the layer's row-addressed tensors when their frames are strided (0: natural)
 thread_local int g_ffn_wide = 0;         // option "ffn_wide": 0 = 128-row FFN tiles when they save a round of the chip (ffn_wide_pays), 1 = always, 2 = never
 thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
@@ -303,7 +304,7 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
                     float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr, int vrow = 0, const NextQkv* nq = nullptr,
                     const OwnQkv* oq = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
-  const int wt = ((!g_no_wt_stores && Mp * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? (oq ? g_spatial_only : 1) << 1 : 0);
+  const int wt = ((!g_no_wt_stores && (g_row_span ? g_row_span : Mp) * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? (oq ? g_spatial_only : 1) << 1 : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
   if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
@@ -517,18 +518,19 @@ bool ffn_wide_pays(long long M) {
 // norm1 -> linear1 -> ReLU -> linear2 -> +residual -> norm2 on fp32 rows X[M][C] (X is clobbered by the generic path)
 template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
-            hipStream_t st, float* part = nullptr /* [F/256][M][256] fp32: enables the chunk-per-workgroup form for few rows */) {
+            hipStream_t st, float* part = nullptr /* [F/256][M][256] fp32: enables the chunk-per-workgroup form for few rows */,
+            RowStride rs = RowStride{0, 0} /* X and out rows: frames of rs.hw rows, rs.hw + rs.extra rows apart (fused kernels only) */) {
   if (part != nullptr && ffn_split_applies(C, heads, F, M)) {
     const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 256);
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true>))) return rc;
-      hipLaunchKernelGGL((ffn_split_kernel<BF, true>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F);
+      hipLaunchKernelGGL((ffn_split_kernel<BF, true>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
     } else {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF>))) return rc;
-      hipLaunchKernelGGL((ffn_split_kernel<BF>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F);
+      hipLaunchKernelGGL((ffn_split_kernel<BF>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
     }
     hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
-                       p.g2, p.be2, out, M, F / 256);
+                       p.g2, p.be2, out, M, F / 256, rs);
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }
@@ -538,10 +540,10 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
     const dim3 wgrid((unsigned)((M + kWideRows - 1) / kWideRows));
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_wide_kernel<BF, true>))) return rc;
-      hipLaunchKernelGGL((ffn_wide_kernel<BF, true>), wgrid, dim3(512), lds, st, (const float*)X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+      hipLaunchKernelGGL((ffn_wide_kernel<BF, true>), wgrid, dim3(512), lds, st, (const float*)X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs);
     } else {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_wide_kernel<BF>))) return rc;
-      hipLaunchKernelGGL((ffn_wide_kernel<BF>), wgrid, dim3(512), lds, st, (const float*)X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+      hipLaunchKernelGGL((ffn_wide_kernel<BF>), wgrid, dim3(512), lds, st, (const float*)X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs);
     }
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
@@ -552,14 +554,15 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
     const dim3 fgrid((unsigned)((M + kRows - 1) / kRows));
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF, true>))) return rc;
-      hipLaunchKernelGGL((ffn_fused_kernel<BF, true>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+      hipLaunchKernelGGL((ffn_fused_kernel<BF, true>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs);
     } else {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>))) return rc;
-      hipLaunchKernelGGL((ffn_fused_kernel<BF>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F);
+      hipLaunchKernelGGL((ffn_fused_kernel<BF>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs);
     }
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }
+  if (rs.hw) return fail(AXVS_ERR_ARG, "internal: strided frames need the fused FFN kernels");
   const unsigned lnblocks = (unsigned)((M + 3) / 4);
   hipLaunchKernelGGL((layernorm_kernel<BF>), dim3(lnblocks), dim3(256), 0, st, X, p.g1, p.be1, tmp, y16, M, C, 1e-5f);
   mark(st, "norm1");
@@ -615,23 +618,26 @@ PosGen make_posgen(const AxvsSinePos3D& sp, int T, int H, int W, int C, int l_is
 template <bool BF>
 int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void* packed, int B, int T, int H, int W, int C,
                       int heads, int F, void* ws, float* h_attn, float* w_attn, hipStream_t st, const AxvsSinePos3D* sine = nullptr,
-                      int which = 0 /* 0: whole layer; 1: height pass only (out = src + height_attn); 2: width pass + norm1 + FFN + norm2 on src */) {
+                      int which = 0 /* 0: whole layer; 1: height pass only (out = src + height_attn); 2: width pass + norm1 + FFN + norm2 on src */,
+                      long long fs = 0 /* > 0: frames of src / out (and of the row-addressed temporaries) are fs rows apart; out may be src */) {
   Carver pc(const_cast<void*>(packed));
   LayerPacked p = carve_layer(pc, C, heads, F);
   const long long M = (long long)B * T * H * W;
+  const long long span = fs ? ((long long)B * T - 1) * fs + (long long)H * W : M;      // rows spanned by a row-addressed tensor
+  struct SpanGuard { SpanGuard(long long v) { g_row_span = v; } ~SpanGuard() { g_row_span = 0; } } span_guard(fs ? span : 0);
   Carver wc(ws);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
   TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
   // second q / k / v set: the height-pass kernel writes the width pass's operands while other tiles still read its own
-  const bool fuse_qkv = plan.fuse_qkv && which == 0;
+  const bool fuse_qkv = plan.fuse_qkv && which == 0 && fs == 0;
   TrajWs tw2 = plan.fuse_qkv ? carve_traj_ws(wc, M, T, heads, true) : tw;
-  float* buf1 = wc.take<float>((size_t)M * C);
+  float* buf1 = wc.take<float>((size_t)span * C);
   float* const scratch1 = buf1;                // fp32 scratch of the generic FFN path (free once the width pass has read the rows)
-  float* buf2 = plan.need_buf2 ? wc.take<float>((size_t)M * C) : nullptr;
+  float* buf2 = plan.need_buf2 ? wc.take<float>((size_t)span * C) : nullptr;
   u16* y16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * C) : nullptr;
   u16* h16 = plan.need_ffn_tmp ? wc.take<u16>((size_t)M * F) : nullptr;
   float* ffn_part = plan.need_ffn_part ? wc.take<float>((size_t)(F / 256) * M * C) : nullptr;
-  const long long sB = (long long)T * H * W, sT = (long long)H * W;
+  const long long sB = fs ? (long long)T * fs : (long long)T * H * W, sT = fs ? fs : (long long)H * W;
 
   g_prof_next = 0;
   mark(st, "begin");
@@ -686,7 +692,7 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   if (ffn_done) return last_launch_status();   // the width-pass kernel ran norm1 -> FFN -> norm2 too and wrote `out`
 
   // norm1 -> FFN -> norm2                               :181-185, :217-218
-  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, scratch1, y16, h16, st, ffn_part);
+  int rc2 = run_ffn<BF>(buf2, out, p, M, C, heads, F, scratch1, y16, h16, st, ffn_part, fs ? RowStride{H * W, fs - (long long)H * W} : RowStride{0, 0});
   if (rc2 != AXVS_OK) return rc2;
   return last_launch_status();
 }
@@ -1261,14 +1267,15 @@ int axvs_traj_attn_fwd(const float* query, const float* key, const float* value,
   return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
 }
 
-size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, int heads, int d_ffn, int want_attn_maps, int sine_pos) {
+// span: rows spanned by a row-addressed temporary (= M unless the frames are strided)
+static size_t layer_ws_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn, int want_attn_maps, int sine_pos, long long span) {
   const long long M = (long long)B * T * H * W;
   Carver c(nullptr);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, d_ffn, want_attn_maps != 0);
   carve_traj_ws(c, M, T, heads, plan.lean_traj);
   if (plan.fuse_qkv) carve_traj_ws(c, M, T, heads, true);
-  c.take<float>((size_t)M * C);
-  if (plan.need_buf2) c.take<float>((size_t)M * C);
+  c.take<float>((size_t)span * C);
+  if (plan.need_buf2) c.take<float>((size_t)span * C);
   if (plan.need_ffn_tmp) {
     c.take<u16>((size_t)M * C);
     c.take<u16>((size_t)M * d_ffn);
@@ -1276,6 +1283,40 @@ size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, in
   if (plan.need_ffn_part) c.take<float>((size_t)(d_ffn / 256) * M * C);
   if (sine_pos && !sine_in_kernel(C, heads)) c.take<float>((size_t)M * C);     // materialised positions (tiers without in-kernel evaluation)
   return c.off;
+}
+size_t axvs_axial_layer_workspace_bytes_ex(int B, int T, int H, int W, int C, int heads, int d_ffn, int want_attn_maps, int sine_pos) {
+  return layer_ws_bytes(B, T, H, W, C, heads, d_ffn, want_attn_maps, sine_pos, (long long)B * T * H * W);
+}
+
+// frames of src / out `frame_stride_rows` rows apart (a level of the pixel decoder's concatenated token buffer, used in place): the
+// row-addressed temporaries take the same stride, i.e. span ((B T - 1) stride + H W) rows each
+size_t axvs_axial_layer_workspace_bytes_strided(int B, int T, int H, int W, int C, int heads, int d_ffn, long long frame_stride_rows) {
+  return layer_ws_bytes(B, T, H, W, C, heads, d_ffn, 0, 1, ((long long)B * T - 1) * frame_stride_rows + (long long)H * W);
+}
+
+int axvs_axial_layer_strided_ok(int C, int heads, int d_ffn) {
+  return !g_generic_only && sine_in_kernel(C, heads) && ffn_kernel_is_fused(C, heads, d_ffn) ? 1 : 0;
+}
+
+int axvs_axial_layer_fwd_sine3d_strided(const float* src, const AxvsSinePos3D* pos, float* out, const void* packed, int B, int T, int H, int W,
+                                        int C, int heads, int d_ffn, int dtype, long long frame_stride_rows, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  if (!src || !pos || !out || !packed || !workspace) return fail(AXVS_ERR_ARG, "null pointer");
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0) return fail(AXVS_ERR_ARG, "empty shape B=%d T=%d H=%d W=%d", B, T, H, W);
+  if (int rc = check_cfg(C, heads)) return rc;
+  if (d_ffn <= 0 || d_ffn % 32 != 0) return fail(AXVS_ERR_ARG, "d_ffn=%d must be a positive multiple of 32", d_ffn);
+  if (!axvs_axial_layer_strided_ok(C, heads, d_ffn)) return fail(AXVS_ERR_ARG, "strided frames need the fused tier (C = 256, 8 heads, d_ffn a multiple of 256)");
+  if (frame_stride_rows < (long long)H * W) return fail(AXVS_ERR_ARG, "frame stride %lld < H W = %d rows", frame_stride_rows, H * W);
+  if (T > 255 || H > 4095 || W > 4095) return fail(AXVS_ERR_ARG, "grid too large for generated positions");
+  const long long span = ((long long)B * T - 1) * frame_stride_rows + (long long)H * W;
+  if (span > 2147483647LL / 64) return fail(AXVS_ERR_ARG, "too many rows for 32-bit row indices");
+  if (dtype != AXVS_BF16 && dtype != AXVS_F16) return fail(AXVS_ERR_ARG, "unknown dtype %d", dtype);
+  const size_t need = axvs_axial_layer_workspace_bytes_strided(B, T, H, W, C, heads, d_ffn, frame_stride_rows);
+  if (workspace_bytes < need) return fail(AXVS_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == AXVS_BF16)
+    return axial_layer_fwd_t<true>(src, nullptr, out, packed, B, T, H, W, C, heads, d_ffn, workspace, nullptr, nullptr, st, pos, 0, frame_stride_rows);
+  return axial_layer_fwd_t<false>(src, nullptr, out, packed, B, T, H, W, C, heads, d_ffn, workspace, nullptr, nullptr, st, pos, 0, frame_stride_rows);
 }
 
 size_t axvs_axial_layer_workspace_bytes(int B, int T, int H, int W, int C, int heads, int d_ffn) {

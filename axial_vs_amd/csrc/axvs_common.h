@@ -97,6 +97,14 @@ __device__ __forceinline__ long long nat_row(const RowMap& rm, int mp) {
   return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
 }
 
+// Rows of a [frames, hw, C] tensor whose frames are `hw + extra` rows apart (a level of the pixel decoder's concatenated token
+// buffer, used in place): natural row m -> row index in the buffer.  hw = 0: contiguous rows.
+struct RowStride {
+  int hw;
+  long long extra;
+  __device__ __forceinline__ long long row(long long m) const { return hw ? m + (m / hw) * extra : m; }
+};
+
 // exact (erf) GELU: F.gelu / nn.GELU() defaults
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 

@@ -20,7 +20,7 @@ template <bool BF, bool GELU = false>
 __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict__ X, const u16* __restrict__ W1, const float* __restrict__ b1,
                                                         const u16* __restrict__ W2, const float* __restrict__ g1,
                                                         const float* __restrict__ be1, float* __restrict__ part /* [F/256][M][256] */,
-                                                        long long M, int F) {
+                                                        long long M, int F, RowStride rs) {
   constexpr int C = 256, KB = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   u16* ytile = reinterpret_cast<u16*>(smem_c);
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const long long m = min(m0 + wave * 8 + rr, M - 1);
-      rows[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+      rows[rr] = *reinterpret_cast<const float4*>(X + rs.row(m) * C + lane * 4);
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -103,13 +103,14 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ffn_finish_kernel(const float* __restrict__ X, const float* __restrict__ part, const float* __restrict__ b2,
                                                          const float* __restrict__ g1, const float* __restrict__ be1,
                                                          const float* __restrict__ g2, const float* __restrict__ be2,
-                                                         float* __restrict__ out, long long M, int nchunk) {
+                                                         float* __restrict__ out, long long M, int nchunk, RowStride rs) {
   constexpr int C = 256;
   const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (m >= M) return;
+  const long long mrow = rs.row(m);                     // X and out rows (the partial sums are in natural order)
   const float4 gg = *reinterpret_cast<const float4*>(g1 + lane * 4), bb = *reinterpret_cast<const float4*>(be1 + lane * 4);
-  const float4 v = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+  const float4 v = *reinterpret_cast<const float4*>(X + mrow * C + lane * 4);
   const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
   const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
   const float rstd = rsqrtf(wave_sum(a * a + b * b + cc * cc + d * d) * (1.f / C) + 1e-5f);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void ffn_finish_kernel(const float* __restrict
   const float d0 = u.x - mu2, d1 = u.y - mu2, d2 = u.z - mu2, d3 = u.w - mu2;
   const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
   const float4 g2v = *reinterpret_cast<const float4*>(g2 + lane * 4), be2v = *reinterpret_cast<const float4*>(be2 + lane * 4);
-  *reinterpret_cast<float4*>(out + m * C + lane * 4) =
+  *reinterpret_cast<float4*>(out + mrow * C + lane * 4) =
       float4{d0 * rstd2 * g2v.x + be2v.x, d1 * rstd2 * g2v.y + be2v.y, d2 * rstd2 * g2v.z + be2v.z, d3 * rstd2 * g2v.w + be2v.w};
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void ffn_wide_kernel(const float* __restrict__
                                                        const u16* __restrict__ W2, const float* __restrict__ b2,
                                                        const float* __restrict__ g1, const float* __restrict__ be1,
                                                        const float* __restrict__ g2, const float* __restrict__ be2,
-                                                       float* __restrict__ out, long long M, int F) {
+                                                       float* __restrict__ out, long long M, int F, RowStride rs) {
   constexpr int C = 256, KB = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   FfnLds l;                                            // (xtile unused here)
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512) void ffn_wide_kernel(const float* __restrict__
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const long long m = min(m0 + h * kRows + wave * 8 + rr, M - 1);
-        rows[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+        rows[rr] = *reinterpret_cast<const float4*>(X + rs.row(m) * C + lane * 4);
       }
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void ffn_wide_kernel(const float* __restrict__
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
         const long long m = min(m0 + h * kRows + wave * 8 + rr, M - 1);
-        xr[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+        xr[rr] = *reinterpret_cast<const float4*>(X + rs.row(m) * C + lane * 4);
       }
 #pragma unroll
       for (int rr = 0; rr < 8; ++rr) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512) void ffn_wide_kernel(const float* __restrict__
         const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
         const long long m = m0 + h * kRows + r;
         if (m < M)
-          *reinterpret_cast<float4*>(out + m * C + lane * 4) =
+          *reinterpret_cast<float4*>(out + rs.row(m) * C + lane * 4) =
               float4{d0 * rstd2 * g2v.x + be2v.x, d1 * rstd2 * g2v.y + be2v.y, d2 * rstd2 * g2v.z + be2v.z, d3 * rstd2 * g2v.w + be2v.w};
         if (rr == 3) lds_fence();
       }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ b2, const float* __restrict__ g1,
                                                         const float* __restrict__ be1, const float* __restrict__ g2,
                                                         const float* __restrict__ be2, float* __restrict__ out,
-                                                        long long M, int F) {
+                                                        long long M, int F, RowStride rs) {
   constexpr int C = 256, KB = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   FfnLds l;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
       const long long m = min(m0 + wave * 8 + rr, M - 1);
-      rows[rr] = *reinterpret_cast<const float4*>(X + m * C + lane * 4);
+      rows[rr] = *reinterpret_cast<const float4*>(X + rs.row(m) * C + lane * 4);
     }
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
     }
   }
   __syncthreads();                       // parameters staged
-  auto row_off = [=](int r) { return m0 + r < M ? (m0 + r) * C : -1ll; };
+  auto row_off = [=](int r) { return m0 + r < M ? rs.row(m0 + r) * C : -1ll; };
   ffn_body<BF, decltype(row_off), GELU>(l, w1f, W1, W2, out, row_off, F, rot, crot, tid);
 }
 

@@ -132,6 +132,12 @@ def _param_key(mod: nn.Module, dtype: str):
     return tuple(key)
 
 
+def _has_hooks(mod: nn.Module) -> bool:
+    """Forward (pre-)hooks registered on `mod` or globally: callers that bypass `forward()` for a faster data flow check this first."""
+    import torch.nn.modules.module as _m
+    return bool(mod._forward_hooks or mod._forward_pre_hooks or _m._global_forward_hooks or _m._global_forward_pre_hooks)
+
+
 def invalidate_pack(mod: nn.Module) -> None:
     """Forget cached parameter references / packed weights of `mod` and its children."""
     for m in mod.modules():
@@ -478,6 +484,38 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         return out, ha, wa
 
 
+    def can_run_in_place(self, pos: Tensor) -> bool:
+        """Whether `forward_level_in_place` applies: eval mode, 16-bit fused tier, generated positions, no attention maps."""
+        if self.training or self.return_attn or not self.use_generated_pos or self._dtype() == "f32" or _sine_tag(pos) is None:
+            return False
+        if _has_hooks(self):              # forward hooks see forward()'s per-level tensors: the split / cat data flow runs for them
+            return False
+        return bool(_lib.lib().axvs_axial_layer_strided_ok(self.linear1.in_features, self.n_heads, self.linear1.out_features))
+
+    @_guarded
+    def forward_level_in_place(self, tokens: Tensor, start: int, pos: Tensor) -> None:
+        """The layer applied IN PLACE to rows [start, start + H*W) of every frame of `tokens` [B*T, S, C] -- one level of the pixel
+        decoder's concatenated token buffer, where the reference splits the level out, runs the layer and concatenates again
+        (WC/msdeformattn.py:258-264): no copy out, no copy back.  `pos` [B, T, H, W, C] made by PositionEmbeddingSine3D."""
+        B, T, H, W = pos.shape[:4]
+        tag = _sine_tag(pos)
+        if tokens.dtype != torch.float32 or not tokens.is_cuda or not tokens.is_contiguous() or tokens.dim() != 3:
+            raise RuntimeError("tokens: contiguous fp32 [B*T, S, C] on the GPU")
+        BT, S, C_ = tokens.shape
+        if BT != B * T or start < 0 or start + H * W > S or pos.shape[-1] != C_ or tag is None:
+            raise RuntimeError(f"tokens {tuple(tokens.shape)} / start {start} do not match pos {tuple(pos.shape)}")
+        L = _lib.lib()
+        F = self.linear1.out_features
+        packed = self._pack()
+        sh = _stream(tokens.device)
+        _select_sync_words(tokens.device, sh)
+        sp = _lib.AxvsSinePos3D(tag.temperature, int(tag.normalize), tag.scale, tag.level.data_ptr() if tag.level is not None else None)
+        ws = _workspace(tokens.device, L.axvs_axial_layer_workspace_bytes_strided(B, T, H, W, C_, self.n_heads, F, S), sh)
+        base = tokens.data_ptr() + start * C_ * 4
+        _lib.check(L.axvs_axial_layer_fwd_sine3d_strided(base, C.byref(sp), base, packed.data_ptr(), B, T, H, W, C_, self.n_heads, F,
+                                                         _lib.DTYPES[self._dtype()], S, ws.data_ptr(), ws.numel(), sh),
+                   "axvs_axial_layer_fwd_sine3d_strided")
+
     @_guarded
     def forward_pass(self, x: Tensor, pos: Tensor, which: int) -> Tensor:
         """One axial pass on a LOCAL block [B,T,H,W,C] of the token grid (`pos`: the matching block of the embedding):
@@ -604,6 +642,16 @@ class TemporalEncoder(nn.Module):
         for layer in self.temporal_layers:
             src, height_traj_attn, width_traj_attn = layer(src, pos)
         return src, height_traj_attn, width_traj_attn
+
+    def can_run_in_place(self, pos: Tensor) -> bool:
+        layers = getattr(self, "temporal_layers", None)
+        return (not self.training and layers is not None and len(layers) > 0 and not _has_hooks(self)
+                and all(isinstance(l, TemporalAxialTrajectoryAttentionLayer) and l.can_run_in_place(pos) for l in layers))
+
+    def forward_level_in_place(self, tokens: Tensor, start: int, pos: Tensor) -> None:
+        """Every layer of the encoder applied in place to one level of the concatenated token buffer (see the layer's method)."""
+        for layer in self.temporal_layers:
+            layer.forward_level_in_place(tokens, start, pos)
 
 
 class TubeLinkTemporalEncoder(nn.Module):

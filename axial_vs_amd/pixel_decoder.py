@@ -62,6 +62,7 @@ def _conv_gn(in_channels: int, out_channels: int) -> nn.Sequential:
 
 
 _side_streams: Dict[str, "torch.cuda.Stream"] = {}
+_IN_PLACE_LEVELS = True      # eval: the temporal levels of a stage are processed in place in the token buffer (tests switch it off to compare)
 
 
 def _run_levels_concurrently(fns):
@@ -126,11 +127,17 @@ class MSDeformAttnTransformerEncoder(nn.Module):
                 # (WC/msdeformattn.py:258-264) would also copy the large level that passes through
                 nt = self.transformer_num_temporal_feature_levels
                 starts = [sum(sizes[:j]) for j in range(nt)]
-                ins = [output[:, starts[j]:starts[j] + sizes[j]].contiguous() for j in range(nt)]
                 layer = self.temporal_layers[i]
                 # weights are packed on THIS stream before the fork (both streams' launches read the same packed buffer)
                 if hasattr(layer, "prepack"):
                     layer.prepack()
+                if _IN_PLACE_LEVELS and output.is_contiguous() and hasattr(layer, "can_run_in_place") \
+                        and all(layer.can_run_in_place(pos_3d[j]) for j in range(nt)):
+                    # the levels are read and written where they lie in the token buffer (frames S rows apart): no copies at all
+                    _run_levels_concurrently([(lambda j=j: (layer.forward_level_in_place(output, starts[j], pos_3d[j]),))
+                                              for j in range(nt)])
+                    continue
+                ins = [output[:, starts[j]:starts[j] + sizes[j]].contiguous() for j in range(nt)]
                 res = _run_levels_concurrently([(lambda j=j: layer(src=ins[j], pos=pos_3d[j])) for j in range(nt)])
                 for j in range(nt):
                     lvl, h_attn, w_attn = res[j]
@@ -177,6 +184,15 @@ class TemporalTransformerEncoder(nn.Module):
                 for j in range(nt):
                     parts[j], h_attn, w_attn = temporal_layer(src=parts[j].contiguous(), pos=pos_3d[j])
             return torch.cat(parts, dim=1), h_attn, w_attn
+        if _IN_PLACE_LEVELS and all(hasattr(tl, "can_run_in_place") and tl.can_run_in_place(pos_3d[j])
+                                    for tl in self.temporal_layers for j in range(nt)):
+            out = src.contiguous().clone()              # (the caller's buffer is left alone); the levels are processed where they lie
+            starts = [sum(sizes[:j]) for j in range(nt)]
+            for temporal_layer in self.temporal_layers:
+                temporal_layer.prepack()
+                _run_levels_concurrently([(lambda j=j: (temporal_layer.forward_level_in_place(out, starts[j], pos_3d[j]),))
+                                          for j in range(nt)])
+            return out, None, None
         parts = [p.contiguous() for p in torch.split(src, sizes, dim=1)[:nt]]
         h_attn = w_attn = None
         for temporal_layer in self.temporal_layers:

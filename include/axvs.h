@@ -182,6 +182,16 @@ int axvs_axial_layer_fwd_sine3d(const float* src, const AxvsSinePos3D* pos, floa
                                 int W, int C, int heads, int d_ffn, int dtype, void* workspace, size_t workspace_bytes,
                                 float* h_attn, float* w_attn, void* stream);
 
+/* ---- the same layer on a [B*T, H*W, C] VIEW whose frames are `frame_stride_rows` rows (of C floats) apart -- one level of the pixel
+ *      decoder's concatenated [B*T, sum(H_l W_l), C] token buffer (WC/msdeformattn.py:258-264 splits the levels out, runs the
+ *      temporal encoder on each and concatenates them again; here the level is read and written where it lies).  `out` may be
+ *      `src` (in place).  Generated positions only, no attention maps; fused tier only (axvs_axial_layer_strided_ok). */
+int axvs_axial_layer_strided_ok(int C, int heads, int d_ffn);
+size_t axvs_axial_layer_workspace_bytes_strided(int B, int T, int H, int W, int C, int heads, int d_ffn, long long frame_stride_rows);
+int axvs_axial_layer_fwd_sine3d_strided(const float* src, const AxvsSinePos3D* pos, float* out, const void* packed, int B, int T, int H,
+                                        int W, int C, int heads, int d_ffn, int dtype, long long frame_stride_rows, void* workspace,
+                                        size_t workspace_bytes, void* stream);
+
 /* ---- the layer's feed-forward tail alone: out = norm2(y + linear2(relu(linear1(y)))), y = norm1(x)
  *      WC/temporal_attention.py:181-185 + :217.  x/out fp32 [M, C]; weights from a packed AxvsAxialLayerParams. */
 size_t axvs_ffn_workspace_bytes(long long M, int C, int d_ffn);

@@ -772,6 +772,59 @@ def test_within_clip_module_golden(name):
         assert e < (TOL_F16 if k == "res3" else 2.5e-3), k
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 256, 64, 64, 1024, 5376), (1, 4, 256, 32, 32, 1024, 5376), (1, 4, 256, 16, 16, 1024, 5376),
+                                   (2, 2, 256, 25, 43, 1024, 1500), (1, 3, 256, 20, 12, 512, 240), (2, 4, 256, 96, 64, 1024, 6144 + 77)])
+def test_layer_in_place_on_a_level_of_the_token_buffer_is_bit_identical(shape):
+    """Round 4: `forward_level_in_place` / axvs_axial_layer_fwd_sine3d_strided runs the layer on rows [start, start + H W) of every
+    frame of a [B T, S, C] buffer, in place (the pixel decoder's concatenated levels: no split, no cat).  Same kernels, only the
+    frame stride of the row maps differs: the level must come out with the same bits as the contiguous call, and the rest of the
+    buffer must be untouched -- 64-row merged kernels, 16-row tiles + chunked FFN, ragged tiles, stride == level size."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F, S = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 17)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pos = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    g = torch.Generator().manual_seed(3)
+    tokens = torch.randn(B * T, S, C, generator=g).cuda()
+    for start in (0, S - H * W):
+        before = tokens.clone()
+        ref = layer(before[:, start:start + H * W].contiguous(), pos)[0]
+        buf = before.clone()
+        assert layer.can_run_in_place(pos)
+        layer.forward_level_in_place(buf, start, pos)
+        assert torch.equal(buf[:, start:start + H * W], ref), start
+        assert torch.equal(buf[:, :start], before[:, :start]) and torch.equal(buf[:, start + H * W:], before[:, start + H * W:]), start
+
+
+@pytest.mark.parametrize("name", ["g8_pixel_decoder_full_T4_S2", "g8_pixel_decoder_T3_S1", "g8_pixel_decoder_T2_S2_temporal_only"])
+def test_decoder_in_place_levels_equal_the_split_and_cat_path(name):
+    """The decoder's eval path processes the temporal levels in place in the token buffer; switched off it splits the levels out and
+    writes them back (the reference's data flow).  Both must give the same bits."""
+    from axial_vs_amd import pixel_decoder as pd
+    z, m = load(name)
+    w = weights(z, m)
+    if m.get("full_size"):
+        mod = _full_size_decoder(m, w)
+    else:
+        from test_cabi_cpu import _decoder_from_meta
+        mod = _decoder_from_meta(m).eval()
+        mod.within_clip_tracking_module.load_state_dict(w, strict=True)
+        mod = mod.cuda()
+    g = torch.Generator().manual_seed(m["seed"] + 1)
+    feats = {k: torch.randn(m["B"] * m["T"], m["chans"][k], *m["sizes"][k], generator=g).cuda() for k in m["chans"]}
+    out_a, _, _ = mod.forward_features(dict(feats))         # (the module updates the dict it is given, like the reference)
+    out_a = {k: v.clone() for k, v in out_a.items()}
+    pd._IN_PLACE_LEVELS = False
+    try:
+        out_b, _, _ = mod.forward_features(dict(feats))
+    finally:
+        pd._IN_PLACE_LEVELS = True
+    for k in out_a:
+        assert torch.equal(out_a[k], out_b[k]), k
+
+
 def _full_size_decoder(m, w):
     from test_cabi_cpu import _decoder_from_meta
     mod = _decoder_from_meta(dict(m, d_ffn=m["d_ffn"]), cross_clip_training=True).eval()

@@ -18,6 +18,11 @@ from axial_vs_amd import _lib
 for a in sys.argv[2:]:
     if "=" in a:
         k, v = a.split("=")
+        if k == "inplace":                    # inplace=0: the temporal levels are split out of / written back into the token buffer
+            from axial_vs_amd import pixel_decoder as _pd
+            _pd._IN_PLACE_LEVELS = bool(int(v))
+            print("in-place levels", bool(int(v)))
+            continue
         _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), "axvs_set_option")
         print("option", k, v)
 with torch.no_grad():
