@@ -211,6 +211,9 @@ __device__ __forceinline__ long long blk_off(long long R, long long r, int k) {
 // phase).  Every packer (axvs_misc.h) writes and every weight reader (w_frag, the GEMM kernels) addresses through this function.
 __device__ __forceinline__ long long wblk_off(long long R, long long r, int k) {
   const long long Rp = (R + 15) & ~15ll;
+#ifdef AXVS_WEIGHT_ROWS   // diagnostic (tools/ab_variants.py): rounds 1-3's plain 64-byte rows, for same-box A/B runs of the access pattern
+  return ((long long)(k >> 5) * Rp + r) * kBlk + (k & 31);
+#endif
   return ((long long)(k >> 5) * Rp + (r & ~15ll)) * kBlk + ((k >> 3) & 3) * 128 + (r & 15) * 8 + (k & 7);
 }
 
