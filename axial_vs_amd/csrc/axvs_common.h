@@ -212,6 +212,7 @@ __device__ __forceinline__ long long blk_off(long long R, long long r, int k) {
 __device__ __forceinline__ long long wblk_off(long long R, long long r, int k) {
   const long long Rp = (R + 15) & ~15ll;
 #ifdef AXVS_WEIGHT_ROWS   // diagnostic (tools/ab_variants.py): rounds 1-3's plain 64-byte rows, for same-box A/B runs of the access pattern
+                          // (w_frag_u / ffn_wide_kernel assume the fragment order: run such a build with option ffn_wide = 2)
   return ((long long)(k >> 5) * Rp + r) * kBlk + (k & 31);
 #endif
   return ((long long)(k >> 5) * Rp + (r & ~15ll)) * kBlk + ((k >> 3) & 3) * 128 + (r & 15) * 8 + (k & 7);

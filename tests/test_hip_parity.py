@@ -623,6 +623,38 @@ def test_msda_reference_boxes_and_errors():
         mod(dev(q), dev(ref), dev(src[:, :-1]), shapes)
 
 
+@pytest.mark.parametrize("L_P", [(1, 3), (3, 3), (1, 1), (2, 5)])
+def test_msda_with_weight_row_counts_that_are_not_multiples_of_16(L_P):
+    """Round 4 packs weights in blocks of 16 output rows (MFMA-fragment order, wblk_off): a projection whose row count is not a
+    multiple of 16 -- the deformable attention's offsets | logits GEMM has 3 * heads * levels * points rows: 72, 216, 24, 240 here --
+    is padded inside the packed buffer.  The module against the fp64 oracle, on the 64 x 64 kernels (`msda_gemm` 0) and the default."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    L, P = L_P
+    shapes = [(12, 10), (6, 5), (3, 4)][:L]
+    g = torch.Generator().manual_seed(100 * L + P)
+    mod = ax.MSDeformAttn(d_model=256, n_levels=L, n_heads=8, n_points=P).eval()
+    with torch.no_grad():
+        mod.sampling_offsets.weight.copy_((torch.rand(mod.sampling_offsets.weight.shape, generator=g) - 0.5) * 0.2)
+        mod.attention_weights.weight.copy_((torch.rand(mod.attention_weights.weight.shape, generator=g) - 0.5) * 0.5)
+    w = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    S = sum(h * w_ for h, w_ in shapes)
+    src = torch.randn(2, S, 256, generator=g)
+    q = torch.randn(2, S, 256, generator=g)
+    ref = torch.rand(2, S, L, 2, generator=g)
+    want = orc.msda_module(q.double(), ref.double(), src.double(), shapes, {k: v.double() for k, v in w.items()}, 8, L, P)
+    mod = mod.cuda()
+    for opt in (0, 4):
+        _lib.check(_lib.lib().axvs_set_option(b"msda_gemm", opt), "axvs_set_option")
+        try:
+            out = mod(dev(q), dev(ref), dev(src), shapes).cpu()
+        finally:
+            _lib.lib().axvs_set_option(b"msda_gemm", 4)
+        e = rel_err(out, want)
+        print(f"L={L} P={P} msda_gemm={opt}: {e:.2e}")
+        assert e < TOL_F16
+
+
 from golden_util import MSDA_ENCLAYER, msda_enclayer_case  # noqa: E402
 
 
