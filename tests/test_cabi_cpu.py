@@ -279,3 +279,20 @@ def test_stack_precision_setter_reaches_every_axial_layer():
     assert all(l._dtype() == "f16" for l in layers)
     with pytest.raises(ValueError):
         mod.set_stack_precision("fp8")
+
+
+def test_forward_hooks_keep_the_split_and_cat_data_flow():
+    """The decoder's eval path runs the temporal levels in place in the token buffer, bypassing `TemporalEncoder.forward()`; a
+    module with forward (pre-)hooks must keep the reference's data flow, where the hooks see the per-level tensors."""
+    import axial_vs_amd as ax
+    from axial_vs_amd.modules import _has_hooks
+    enc = ax.TemporalEncoder(256, 1024, temporal_attn_type="axial-trajectory", num_temporal_layer=2).eval()
+    assert not _has_hooks(enc) and not any(_has_hooks(l) for l in enc.temporal_layers)
+    h = enc.register_forward_hook(lambda m, a, o: None)
+    assert _has_hooks(enc) and not enc.can_run_in_place(torch.zeros(1, 2, 4, 4, 256))
+    h.remove()
+    assert not _has_hooks(enc)
+    h = enc.temporal_layers[1].register_forward_pre_hook(lambda m, a: None)
+    assert _has_hooks(enc.temporal_layers[1])
+    h.remove()
+    assert not enc.train().can_run_in_place(torch.zeros(1, 2, 4, 4, 256))      # train() mode: autograd needs the out-of-place path
