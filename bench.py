@@ -67,6 +67,12 @@ def main():
     ap.add_argument("--gather", action="store_true", help="make the all-gather of the outputs part of the timed steps (default: reported under extras)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-qkav", action="store_true",
+                    help="skip the QK^T/AV sub-target probe: it launches the layer's kernels TRUNCATED (option spatial_only), which must "
+                         "not be averaged into a rocprofv3 --stats summary of this command (tools/kstats.sh passes this flag)")
+    ap.add_argument("--no-stages", action="store_true",
+                    help="skip the per-launch event split (roofline.stage_us): with --no-extras --no-qkav the LAST --steps launches of "
+                         "every layer kernel in a kernel trace are then exactly the timed region (tools/kstats.sh)")
     ap.add_argument("--graph", action="store_true", help="replay a captured HIP graph per step instead of launching from Python")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--settle-ms", type=float, default=300.0,
@@ -484,12 +490,12 @@ def main():
             return {L.axvs_profile_stage_name(i).decode(): round(acc[i] * 1e3, 2) for i in range(1, n_st)}
 
         reps = min(args.steps, 50)
-        kernels = stage_times(lambda: layer(src, pos), reps)
+        kernels = {} if args.no_stages else stage_times(lambda: layer(src, pos), reps)
         # whole-forward duration: the HIP events that bracketed the K timed steps (no host sync inside)
         fwd_ms = main_event_ms / args.steps
         flops = layer_flops(B, T, H, W, C, F)
         achieved = flops / (fwd_ms * 1e-3) / 1e12
-        dom = max(kernels, key=kernels.get)
+        dom = max(kernels, key=kernels.get) if kernels else None
         # algorithmic FLOPs per launch (SURVEY 8d terms) -> per-kernel fraction of the MFMA peak, from the same HIP events
 
         def f_qkv(S, Lx):
@@ -510,7 +516,9 @@ def main():
         # after that half (same launch, same loads of q / k / V^T, x tile written to LDS, nothing else): its duration against
         # 4 S N^2 C FLOPs per pass.  Only meaningful when both passes run the fully fused kernels.
         qk_av = None
-        if "h.qkv+traj" in kernels and any(k.startswith("w.qkv+traj") for k in kernels):
+        if args.no_qkav:
+            pass
+        elif "h.qkv+traj" in kernels and any(k.startswith("w.qkv+traj") for k in kernels):
             # merged launches: the kernel stopped after QK^T / softmax / AV (spatial_only = 1) minus the kernel stopped after its q/k/v
             # part (spatial_only = 2) -- the hand-off wait for the sibling tiles' K / V^T is part of the difference
             def stopped(mode):
@@ -556,6 +564,15 @@ def main():
             "stage_us": kernels, "stage_frac": stage_frac, "dominant_stage": dom,
             "qk_av_frac": qk_av["frac"] if qk_av else None, "qk_av": qk_av,
         }
+        if qk_av:
+            # the builder's own ceiling for this half, so that the fraction is read against it and not against the bare 0.30 target:
+            # an exact per-frame softmax at head_dim 32 issues ~7.5 VALU slots per score (max, subtract, quarter-rate v_exp_f32, sum,
+            # convert) against 128 MFMA FLOPs -- ~1.9 k VALU cycles per wave and frame for 0.5 k MFMA cycles
+            qk_av["cap"] = 0.27
+            qk_av["cap_source"] = ("DESIGN.md section 4 'QK^T/AV sub-target' + profiles/r3_valu_issue_rates.txt: exact segmented softmax at head_dim 32 "
+                                   "is VALU-issue-bound (v_exp_f32 8.2 cycles, sub 2.2, cvt 2.1, max 1.1-4.25 per score vs 16.7 per 16x16x32 MFMA); "
+                                   "0.27 of the dense 16-bit MFMA peak even with perfect MFMA/VALU overlap")
+            qk_av["frac_of_cap"] = round(qk_av["frac"] / 0.27, 3)
 
         # ---- BASELINE config 4: the cross-clip tracking module (launch/HBM-write bound: report us and GB/s) ----
         if not args.no_extras and world == 1:

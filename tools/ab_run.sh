@@ -10,8 +10,9 @@ rm -rf $OUT; mkdir -p $OUT
 for r in $(seq 1 $ROUNDS); do
   for so in $R/tools/ab/*.so; do
     n=$(basename $so .so)
-    AXVS_LIB_PATH=$so rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${n}_$r -- python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extras "$@" > $OUT/${n}_$r.log 2>&1
-    cp $OUT/${n}_$r/*/*kernel_stats.csv $OUT/${n}_$r.stats.csv; rm -rf $OUT/${n}_$r
+    AXVS_LIB_PATH=$so rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${n}_$r -- python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-extras --no-qkav --no-stages "$@" > $OUT/${n}_$r.log 2>&1
+    # averages over the timed region only (the last 300 launches of every layer kernel in the raw trace)
+    python3 $R/tools/trace_reduce.py $OUT/${n}_$r $OUT/${n}_$r.log --out $OUT/${n}_$r.stats.csv > /dev/null; rm -rf $OUT/${n}_$r
   done
 done
 python3 - <<PY > $R/gpurun_out/ab_summary.txt
@@ -19,11 +20,10 @@ import csv, glob, collections, json, os
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/*.stats.csv")):
     n = os.path.basename(f)[:-len(".stats.csv")].rsplit("_", 1)[0]
-    rows = [r for r in csv.DictReader(open(f)) if "axvs" in r["Name"] and int(r["Calls"]) >= 100]
-    per_step = min(int(r["Calls"]) for r in rows)          # the least-launched kernel runs once per forward
+    rows = [r for r in csv.DictReader(l for l in open(f) if not l.startswith("#"))]
     for r in rows:
         k = r["Name"].replace("void axvs::", "").split("(")[0][:52]
-        res[n][k].append(float(r["AverageNs"]) / 1e3 * round(int(r["Calls"]) / per_step))
+        res[n][k].append(float(r["AverageNs"]) / 1e3 * int(r["CallsPerStep"]))
 for f in sorted(glob.glob("$OUT/*.log")):
     n = os.path.basename(f).rsplit("_", 1)[0]
     for l in open(f):

@@ -3,10 +3,14 @@
 # FETCH_SIZE and WRITE_SIZE; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (corrected below).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/pmc_traffic
-mkdir -p $OUT
+# usage: tools/pmc_traffic.sh [--shape B,T,C,H,W] [tag]   (default: the metric shape -> gpurun_out/pmc_traffic/traffic.json)
+SHAPE=1,4,256,64,64
+if [ "$1" = "--shape" ]; then SHAPE=$2; shift 2; fi
+TAG=${1:-}
+OUT=$R/gpurun_out/pmc_traffic$TAG
+rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --settle-ms 0 > $OUT/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-qkav --no-stages --settle-ms 0 --shape $SHAPE > $OUT/$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
@@ -32,6 +36,8 @@ res = {"per_kernel": rows, "layer_read_MB": round(tot_r / 1e6, 1), "layer_write_
        "layer_total_MB": round((tot_r + tot_w) / 1e6, 1),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B)"}
 print(json.dumps(res, indent=1))
-res["workload"] = "axial layer fwd B=1 T=4 C=256 H=W=64 d_ffn=1024 f16"
+res["workload"] = "axial layer fwd [B,T,C,H,W] = [$SHAPE] d_ffn=1024 f16"
+B_, T_, C_, H_, W_ = (int(v) for v in "$SHAPE".split(","))
+res["algorithmic_MB"] = round((3 * B_ * T_ * H_ * W_ * C_ * 4 + 2 * (2 * (7 * C_ * C_ + 8 * C_) + 2 * C_ * 1024 + 1024 + 5 * C_)) / 1e6, 1)
 json.dump(res, open("$OUT/traffic.json", "w"), indent=1)
 PY
