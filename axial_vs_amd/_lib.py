@@ -99,6 +99,7 @@ SIGNATURES = {
     "axvs_version": (C.c_int, []),
     "axvs_last_error": (C.c_char_p, []),
     "axvs_set_status_buffer": (C.c_int, [_fp]),
+    "axvs_check_status": (C.c_int, []),
     "axvs_set_sync_buffer": (C.c_int, [_fp, C.c_size_t]),
     "axvs_profile_stages": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "axvs_profile_stage_count": (C.c_int, []),
@@ -206,9 +207,15 @@ def lib() -> C.CDLL:
     return _lib
 
 
+ERR_STATE = -4          # include/axvs.h AXVS_ERR_STATE: an earlier merged launch reported a hand-off timeout
+_state_handler = None   # set by axial_vs_amd.modules: puts the sync words / status word back in order before the error is raised
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().axvs_last_error().decode(errors="replace")
+        if rc == ERR_STATE and _state_handler is not None:
+            _state_handler()
         raise RuntimeError(f"axial_vs_amd: {what} failed (code {rc}): {msg}")
 
 
@@ -249,8 +256,13 @@ class train_amp:
         _AMP_LOCK.acquire()
         self.prev = _AMP_MODE
         _AMP_MODE = self.mode
-        if self.mode != self.prev:
-            check(lib().axvs_set_option(b"train_amp", self.mode), "axvs_set_option")
+        try:
+            if self.mode != self.prev:
+                check(lib().axvs_set_option(b"train_amp", self.mode), "axvs_set_option")
+        except BaseException:       # __exit__ will not run: put the mode back and let the other threads in
+            _AMP_MODE = self.prev
+            _AMP_LOCK.release()
+            raise
         return self
 
     def __exit__(self, *exc):

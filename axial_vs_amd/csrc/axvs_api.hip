@@ -32,7 +32,10 @@ constexpr int kMaxStages = 32;
 thread_local const char* g_stage_names[kMaxStages] = {};
 thread_local int g_generic_only = 0;
 thread_local int g_attn_waves = 0;
-thread_local int* g_status = nullptr;     // axvs_set_status_buffer: device word that kernels OR condition bits into
+thread_local int* g_status = nullptr;     // axvs_set_status_buffer: word that kernels OR condition bits into (device memory, or pinned host memory)
+thread_local volatile int* g_status_host = nullptr;   // the same word when the HOST can read it (pinned host memory): the entry points of the
+                                          // axial layer then refuse to run on top of a reported hand-off timeout (status_gate)
+thread_local unsigned g_sync_spin_limit = axvs::kSyncSpinLimit;   // option "sync_spin_limit": polls before a hand-off wait gives up (tests shorten it)
 thread_local long long g_row_span = 0;   // rows spanned by the layer's row-addressed tensors when their frames are strided (0: natural)
 thread_local int g_ffn_wide = 0;         // option "ffn_wide": 0 = 128-row FFN tiles when they save a round of the chip (ffn_wide_pays), 1 = always, 2 = never
 thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
@@ -89,6 +92,18 @@ int check_cfg(int C, int heads) {
   if (C <= 0 || heads <= 0 || C % heads != 0) return fail(AXVS_ERR_ARG, "C=%d must be a positive multiple of heads=%d", C, heads);
   if (C % 32 != 0) return fail(AXVS_ERR_ARG, "C=%d must be a multiple of 32", C);
   if (C / heads > 32) return fail(AXVS_ERR_ARG, "head_dim=%d > 32 is not supported yet", C / heads);
+  return AXVS_OK;
+}
+
+// Fail loudly (round 5): a hand-off wait of a merged launch that ran out has set AXVS_STATUS_SYNC_TIMEOUT; that launch's outputs are
+// garbage and its arrival counters are left non-zero.  When the status word is host-readable the NEXT call of an axial-layer entry
+// point on this thread returns AXVS_ERR_STATE instead of computing on top of it (no synchronisation: the word is read as it is).
+int status_gate() {
+  if (g_status_host != nullptr && (*g_status_host & AXVS_STATUS_SYNC_TIMEOUT))
+    return fail(AXVS_ERR_STATE, "an earlier merged q/k/v + trajectory launch gave up waiting for its sibling row tiles (status bit 2, "
+                                "AXVS_STATUS_SYNC_TIMEOUT): its outputs are invalid and its sync words are not zero.  Synchronise, zero the sync words "
+                                "(axvs_set_sync_buffer contract), clear the status word, then call again -- or run two launches per pass "
+                                "(axvs_set_sync_buffer(NULL, 0) / option no_merge_qkv)");
   return AXVS_OK;
 }
 
@@ -353,6 +368,8 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
       {"h.qkv_proj", "h.spatial_attn", "h.proj_q", "h.proj_kv", "h.temporal_attn", "h.proj", "h.temporal_fused", "h.traj_fused"},
       {"w.qkv_proj", "w.spatial_attn", "w.proj_q", "w.proj_kv", "w.temporal_attn", "w.proj", "w.temporal_fused", "w.traj_fused"}};
   const char* const* nm = kNames[pass];
+  if (may_merge)      // never compute on top of a reported hand-off timeout (host-readable status word; no synchronisation)
+    if (int rc = status_gate()) return rc;
   const int N = T * L, Cp = heads * 32, d = C / heads;
   const long long Mp = (long long)S * N;
   if (Mp * T > 2147483647LL / 2) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
@@ -386,7 +403,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
                      2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
                      (!mt4 || own_frame || traj_tiles64(Mp, N) <= 640 || g_merge_qkv_any) && (mt4 || g_merge_small);
   if (merge) {
-    const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status};
+    const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status, g_sync_spin_limit};
     int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr, 0, nullptr, &oq);
     if (rc != AXVS_OK) return rc;
     if (with_ffn) *ffn_done = true;
@@ -1176,14 +1193,26 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
+  if (key && !strcmp(key, "sync_spin_limit")) { g_sync_spin_limit = value > 0 ? (unsigned)value : axvs::kSyncSpinLimit; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }
 const char* axvs_last_error(void) { return g_err; }
 
 int axvs_set_status_buffer(int* device_word) {
   g_status = device_word;
+  g_status_host = nullptr;
+  if (device_word != nullptr) {
+    // a word in pinned host memory (hipHostMalloc: device-visible at the same address) can be read by the host without a copy
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, device_word) == hipSuccess && at.type == hipMemoryTypeHost && at.hostPointer != nullptr)
+      g_status_host = static_cast<volatile int*>(at.hostPointer);
+    else
+      (void)hipGetLastError();      // (an unregistered pointer leaves an error behind: not ours to report)
+  }
   return AXVS_OK;
 }
+
+int axvs_check_status(void) { return status_gate(); }
 
 int axvs_set_sync_buffer(unsigned* device_words, size_t n_words) {
   if (device_words != nullptr && n_words == 0) return fail(AXVS_ERR_ARG, "empty sync buffer");

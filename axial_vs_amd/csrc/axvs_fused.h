@@ -422,8 +422,9 @@ struct OwnQkv {
   float qscale;           // head_dim^-0.5 * log2(e)
   unsigned* sync;         // [sequences] arrival counters: zero before the launch, zero again after it (see the kernel)
   int* status;            // nullable: bit 0 <- an operand left the fp16 range, bit 2 <- a hand-off wait ran out
+  unsigned spin_limit;    // polls (with s_sleep) before a hand-off wait gives up (kSyncSpinLimit; option "sync_spin_limit")
 };
-constexpr unsigned kSyncSpinLimit = 1u << 22;    // polls (with s_sleep) before a hand-off wait gives up: ~ 1 s
+constexpr unsigned kSyncSpinLimit = 1u << 22;    // ~ 1 s
 
 template <int MT>
 __device__ __forceinline__ int xt_off(int f, int kb, int row, int c) {   // element offset in the x tile
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       unsigned spins = 0;
       while (ld_sc1_u32(cnt) < tps_u) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > kSyncSpinLimit) {
+        if (++spins > oq.spin_limit) {
           if (oq.status != nullptr && lane == 0) atomicOr(oq.status, 4);
           break;
         }

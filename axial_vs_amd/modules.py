@@ -74,11 +74,33 @@ _sync_tls = threading.local()
 
 def _select_sync_words(device: torch.device, stream_handle: Optional[int] = None) -> None:
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    override = getattr(_sync_tls, "override", None)
+    if override is not None:             # GraphedForward: the graph being warmed up / captured owns its counters (see there)
+        sh = stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream
+        key = ("graph", idx, sh, id(override))
+        if getattr(_sync_tls, "key", None) == key:
+            return
+        buf = override["map"].get((idx, sh))
+        if buf is None and override["pool"]:         # one pre-zeroed set per stream the module uses (pixel_decoder: two)
+            buf = override["map"][(idx, sh)] = override["pool"].pop()
+        if buf is None:                              # more streams than sets: this one runs two launches per pass (same bits)
+            _lib.check(_lib.lib().axvs_set_sync_buffer(None, 0), "axvs_set_sync_buffer")
+        else:
+            _lib.check(_lib.lib().axvs_set_sync_buffer(buf.data_ptr(), buf.numel()), "axvs_set_sync_buffer")
+        _sync_tls.key = key
+        return
     key = (idx, stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream)
     if getattr(_sync_tls, "key", None) == key:
         return
     buf = _sync_buffers.get(key)
     if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            # A first use of this stream INSIDE a graph capture (a caller's own torch.cuda.graph around a module): an allocation here
+            # would land in the graph's private pool and its zero-fill would become a graph node instead of running now.  No sync words
+            # for this capture: the passes run as two launches (same bits).  GraphedForward allocates its words before capturing.
+            _lib.check(_lib.lib().axvs_set_sync_buffer(None, 0), "axvs_set_sync_buffer")
+            _sync_tls.key = ("capture-without-words", idx)
+            return
         buf = _sync_buffers[key] = torch.zeros(_SYNC_WORDS, dtype=torch.int32, device=torch.device("cuda", idx))
     _lib.check(_lib.lib().axvs_set_sync_buffer(buf.data_ptr(), _SYNC_WORDS), "axvs_set_sync_buffer")
     _sync_tls.key = key
@@ -207,56 +229,105 @@ def _sine_tag(pos: Tensor) -> Optional[SineTag]:
     return tag
 
 
-_status_words: Dict[str, Tensor] = {}
-_status_current: List[Optional[str]] = [None]      # device whose word the library currently holds (it keeps ONE pointer per thread)
+# ---- the status word: ALWAYS registered (round 5) ----------------------------------------------------------------------------------
+# One int32 per device in PINNED HOST memory (device-visible at the same address): the kernels OR condition bits into it only when a
+# condition fires (bit 0: an operand left the fp16 range; bit 2: a hand-off wait of a merged launch ran out -- include/axvs.h), so it
+# costs nothing on the normal path (profiles/r5_pinned_status_probe.txt), and the host reads it without a copy or a synchronisation.
+# Fail loudly: with a host-readable word the library refuses the NEXT axial-layer call on this thread (AXVS_ERR_STATE -> RuntimeError
+# here, after `_on_sync_timeout` has put the counters back in order); `check_status()` is the explicit form.
+_status_words: Dict[int, Tensor] = {}
+# (which device's word the library currently holds is remembered per calling thread, like the library's own pointer: _sync_tls.status_idx)
+_range_check_enabled: List[bool] = [False]
+
+
+def _status_word(idx: int) -> Tensor:
+    w = _status_words.get(idx)
+    if w is None:
+        w = _status_words[idx] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return w
 
 
 def _select_status_word(device: torch.device) -> None:
-    """The library holds a single status pointer; with range checks enabled on several devices, hand it the word of the device
-    the next call launches on (a word of another device would be a cross-device atomic: a fault without peer access, and the
-    flag would land on the wrong device).  A device without a registered word gets none."""
-    if not _status_words:
-        return
+    """The library holds a single status pointer per thread: hand it the word of the device the next call launches on."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = f"cuda:{idx}"
-    if _status_current[0] == key:
+    if getattr(_sync_tls, "status_idx", None) == idx:
         return
-    w = _status_words.get(key)
-    _lib.check(_lib.lib().axvs_set_status_buffer(w.data_ptr() if w is not None else None), "axvs_set_status_buffer")
-    _status_current[0] = key
+    _lib.check(_lib.lib().axvs_set_status_buffer(_status_word(idx).data_ptr()), "axvs_set_status_buffer")
+    _sync_tls.status_idx = idx
+
+
+def _on_sync_timeout() -> None:
+    """A merged launch reported AXVS_STATUS_SYNC_TIMEOUT: wait for the devices concerned, zero their arrival counters (the timed-out
+    launch left them non-zero), clear the bit.  The caller raises afterwards; the next call starts from a clean state."""
+    for idx, w in _status_words.items():
+        if int(w[0]) & 4:
+            torch.cuda.synchronize(idx)
+            for (kidx, _), buf in list(_sync_buffers.items()):
+                if kidx == idx:
+                    buf.zero_()
+            torch.cuda.synchronize(idx)
+            w[0] = int(w[0]) & ~4
+
+
+_lib._state_handler = _on_sync_timeout
+
+
+def check_status(device=None, synchronize: bool = True) -> None:
+    """Raise RuntimeError if a merged q/k/v + trajectory launch on `device` (default: every device used so far) gave up waiting for
+    its sibling row tiles -- the outputs of that forward are invalid.  `synchronize=True` waits for the launches still in flight
+    first; False reads the word as it is (free).  The counters are zeroed and the bit cleared before the error is raised."""
+    if device is None:
+        idxs = list(_status_words)
+    else:
+        dev = torch.device(device)
+        idxs = [dev.index if dev.index is not None else torch.cuda.current_device()]
+    hit = []
+    for idx in idxs:
+        w = _status_words.get(idx)
+        if w is None:
+            continue
+        if synchronize:
+            torch.cuda.synchronize(idx)
+        if int(w[0]) & 4:
+            hit.append(idx)
+    if hit:
+        _on_sync_timeout()
+        raise RuntimeError(f"axial_vs_amd: a merged q/k/v + trajectory launch on cuda:{hit} gave up waiting for its sibling row tiles "
+                           "(AXVS_STATUS_SYNC_TIMEOUT): the outputs of that forward are invalid.  The arrival counters have been "
+                           "zeroed; run again, or keep two launches per pass with axvs_set_option('no_merge_qkv', 1)")
 
 
 def enable_range_check(device="cuda") -> None:
-    """Register a device status word with libaxvs: the fused q/k/v loaders then flag operands outside the fp16 range (the f16
-    operand mode would turn them into inf silently).  Asynchronous -- read it with `range_check_report()`."""
+    """The fused q/k/v loaders flag operands outside the fp16 range (the f16 operand mode would turn them into inf silently) in the
+    status word -- always registered since round 5; this call only arms `range_check_report()` (kept for the round-1 API)."""
     dev = torch.device(device)
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
-    w = _status_words.get(str(dev))
-    if w is None:
-        w = _status_words[str(dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().axvs_set_status_buffer(w.data_ptr()), "axvs_set_status_buffer")
-    _status_current[0] = str(dev)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    _status_word(idx)
+    _range_check_enabled[0] = True
 
 
 def range_check_report(device="cuda", reset: bool = True) -> bool:
-    """True if a fused loader saw an operand beyond the fp16 range since the last reset (synchronises the device)."""
+    """True if a fused loader saw an operand beyond the fp16 range since the last reset (synchronises the device).  A hand-off
+    timeout recorded in the same word is NOT swallowed: it raises (check_status)."""
     dev = torch.device(device)
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
-    w = _status_words.get(str(dev))
-    if w is None:
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if not _range_check_enabled[0]:
         raise RuntimeError("axial_vs_amd: call enable_range_check() first")
-    hit = bool(int(w.item()) & 1)
+    torch.cuda.synchronize(idx)
+    w = _status_word(idx)
+    v = int(w[0])
     if reset:
-        w.zero_()
-    return hit
+        w[0] = v & ~1
+    if v & 4:
+        check_status(dev, synchronize=False)
+    return bool(v & 1)
 
 
 def disable_range_check() -> None:
-    _status_words.clear()
-    _status_current[0] = None
-    _lib.check(_lib.lib().axvs_set_status_buffer(None), "axvs_set_status_buffer")
+    """Disarm `range_check_report()`; the status word itself stays registered (it also carries the hand-off timeout bit)."""
+    _range_check_enabled[0] = False
+    for w in _status_words.values():
+        w[0] = int(w[0]) & ~1
 
 
 def _traj_struct(m: "TrajectoryAttention", keep: list) -> _lib.AxvsTrajParams:
@@ -484,13 +555,33 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         return out, ha, wa
 
 
-    def can_run_in_place(self, pos: Tensor) -> bool:
-        """Whether `forward_level_in_place` applies: eval mode, 16-bit fused tier, generated positions, no attention maps."""
+    # in-place levels: the row-addressed temporaries of the layer take the FRAME STRIDE of the token buffer (sparse buffers of
+    # (B*T - 1) * stride + H*W rows).  A small level inside a long buffer would blow the workspace up (B*T = 32 frames of 21504
+    # tokens: 680 MB per temporary for a 32 x 32 level against 32 MB): beyond this overhead the split / cat data flow runs.
+    _IN_PLACE_WS_OVERHEAD = 256 << 20
+
+    def can_run_in_place(self, pos: Tensor, frame_stride_rows: Optional[int] = None) -> bool:
+        """Whether `forward_level_in_place` applies: eval mode, 16-bit fused tier, generated positions, no attention maps -- and, when
+        the caller names the frame stride of its token buffer, row indices within 32 bits and a workspace not more than
+        `_IN_PLACE_WS_OVERHEAD` bytes above the contiguous call's."""
         if self.training or self.return_attn or not self.use_generated_pos or self._dtype() == "f32" or _sine_tag(pos) is None:
             return False
         if _has_hooks(self):              # forward hooks see forward()'s per-level tensors: the split / cat data flow runs for them
             return False
-        return bool(_lib.lib().axvs_axial_layer_strided_ok(self.linear1.in_features, self.n_heads, self.linear1.out_features))
+        L = _lib.lib()
+        C_, F = self.linear1.in_features, self.linear1.out_features
+        if not L.axvs_axial_layer_strided_ok(C_, self.n_heads, F):
+            return False
+        if frame_stride_rows is not None:
+            B, T, H, W = pos.shape[:4]
+            span = (B * T - 1) * int(frame_stride_rows) + H * W
+            if span > (2 ** 31 - 1) // 64:
+                return False
+            strided = L.axvs_axial_layer_workspace_bytes_strided(B, T, H, W, C_, self.n_heads, F, int(frame_stride_rows))
+            natural = L.axvs_axial_layer_workspace_bytes_ex(B, T, H, W, C_, self.n_heads, F, 0, 1)
+            if strided > natural + self._IN_PLACE_WS_OVERHEAD:
+                return False
+        return True
 
     @_guarded
     def forward_level_in_place(self, tokens: Tensor, start: int, pos: Tensor) -> None:
@@ -643,10 +734,10 @@ class TemporalEncoder(nn.Module):
             src, height_traj_attn, width_traj_attn = layer(src, pos)
         return src, height_traj_attn, width_traj_attn
 
-    def can_run_in_place(self, pos: Tensor) -> bool:
+    def can_run_in_place(self, pos: Tensor, frame_stride_rows: Optional[int] = None) -> bool:
         layers = getattr(self, "temporal_layers", None)
         return (not self.training and layers is not None and len(layers) > 0 and not _has_hooks(self)
-                and all(isinstance(l, TemporalAxialTrajectoryAttentionLayer) and l.can_run_in_place(pos) for l in layers))
+                and all(isinstance(l, TemporalAxialTrajectoryAttentionLayer) and l.can_run_in_place(pos, frame_stride_rows) for l in layers))
 
     def forward_level_in_place(self, tokens: Tensor, start: int, pos: Tensor) -> None:
         """Every layer of the encoder applied in place to one level of the concatenated token buffer (see the layer's method)."""
@@ -780,17 +871,30 @@ class GraphedForward:
         self.module = module
         self.inputs = tuple(t.detach().clone() for t in inputs)
         dev = self.inputs[0].device
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture requires
-            for _ in range(max(warmup, 1)):
-                module(*self.inputs)
-        torch.cuda.current_stream(dev).wait_stream(side)
+        # The graph owns its arrival counters (merged q/k/v + trajectory launches): allocated and zeroed NOW, eagerly -- an allocation
+        # during the capture would come from the graph's private pool with its zero-fill recorded as a graph node instead of executed,
+        # and every graph captured on torch's shared capture stream would bake the same pointer in (graphs replayed concurrently on
+        # different streams must not share counters: include/axvs.h, "one buffer serves one stream at a time").
+        self._sync = [torch.zeros(_SYNC_WORDS, dtype=torch.int32, device=dev) for _ in range(4)]
         torch.cuda.synchronize(dev)
-        before = set(_workspaces)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = module(*self.inputs)
+        prev_override = getattr(_sync_tls, "override", None)
+        # (warm-up and capture run on different streams: each gets its own set; sets left in the pool are simply kept)
+        _sync_tls.override = {"pool": list(self._sync), "map": {}}
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture requires
+                for _ in range(max(warmup, 1)):
+                    module(*self.inputs)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            before = set(_workspaces)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = module(*self.inputs)
+        finally:
+            _sync_tls.override = prev_override
+            _sync_tls.key = None                          # the next eager call registers its own (device, stream) words again
         # scratch buffers allocated on the capture stream belong to this graph (its private pool): they go with it
         self._ws_keys = [k for k in _workspaces if k not in before]
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import _lib
-from .modules import PositionEmbeddingSine3D, TemporalEncoder, _dev_f32, _param_key, _require_eval, _stream, _workspace, _guarded
+from .modules import PositionEmbeddingSine3D, TemporalEncoder, _dev_f32, _has_hooks, _param_key, _require_eval, _stream, _workspace, _guarded
 from .msda import MSDeformAttn, MSDeformAttnTransformerEncoderLayer
 
 
@@ -131,8 +131,11 @@ class MSDeformAttnTransformerEncoder(nn.Module):
                 # weights are packed on THIS stream before the fork (both streams' launches read the same packed buffer)
                 if hasattr(layer, "prepack"):
                     layer.prepack()
+                # (a forward hook on the spatial layer or on this encoder may have captured `output`: the in-place levels would
+                #  mutate the tensor it holds, so hooked modules keep the reference's split / cat data flow)
                 if _IN_PLACE_LEVELS and output.is_contiguous() and hasattr(layer, "can_run_in_place") \
-                        and all(layer.can_run_in_place(pos_3d[j]) for j in range(nt)):
+                        and not _has_hooks(spatial_layer) and not _has_hooks(self) \
+                        and all(layer.can_run_in_place(pos_3d[j], frame_stride_rows=output.shape[1]) for j in range(nt)):
                     # the levels are read and written where they lie in the token buffer (frames S rows apart): no copies at all
                     _run_levels_concurrently([(lambda j=j: (layer.forward_level_in_place(output, starts[j], pos_3d[j]),))
                                               for j in range(nt)])
@@ -184,7 +187,7 @@ class TemporalTransformerEncoder(nn.Module):
                 for j in range(nt):
                     parts[j], h_attn, w_attn = temporal_layer(src=parts[j].contiguous(), pos=pos_3d[j])
             return torch.cat(parts, dim=1), h_attn, w_attn
-        if _IN_PLACE_LEVELS and all(hasattr(tl, "can_run_in_place") and tl.can_run_in_place(pos_3d[j])
+        if _IN_PLACE_LEVELS and all(hasattr(tl, "can_run_in_place") and tl.can_run_in_place(pos_3d[j], frame_stride_rows=src.shape[1])
                                     for tl in self.temporal_layers for j in range(nt)):
             out = src.contiguous().clone()              # (the caller's buffer is left alone); the levels are processed where they lie
             starts = [sum(sizes[:j]) for j in range(nt)]

@@ -33,6 +33,7 @@ extern "C" {
 #define AXVS_ERR_ARG (-1)       /* bad shape / null pointer / unsupported configuration */
 #define AXVS_ERR_WORKSPACE (-2) /* workspace too small */
 #define AXVS_ERR_LAUNCH (-3)    /* HIP launch failure */
+#define AXVS_ERR_STATE (-4)     /* an EARLIER call on this thread's status word reported AXVS_STATUS_SYNC_TIMEOUT (see below) */
 
 /* fp32 parameters of one TrajectoryAttention (WC/temporal_attention.py:21-33,
  * TL/mmdet/models/plugins/msdeformattn_pixel_decoder.py:653-665).  Device pointers.
@@ -60,16 +61,25 @@ typedef struct AxvsAxialLayerParams {
 int axvs_version(void);
 const char* axvs_last_error(void);
 
-/* Asynchronous condition bits.  The entry points never synchronise, so conditions only a kernel can see are OR-ed into a device
- * word the caller registers (per calling thread; NULL disables) and reads back when it likes:
+/* Asynchronous condition bits.  The entry points never synchronise, so conditions only a kernel can see are OR-ed into a word
+ * the caller registers (per calling thread; NULL disables) and reads back when it likes.  The word may live in device memory
+ * or in PINNED HOST memory (hipHostMalloc: device-visible at the same address; the kernels touch it only when a condition
+ * fires, so it costs nothing on the normal path -- profiles/r5_pinned_status_probe.txt).  With a host-readable word the
+ * library FAILS LOUDLY: every later call of an axial-layer entry point on this thread returns AXVS_ERR_STATE while bit 2 is set
+ * (axvs_check_status() reports the same without launching anything).  The Python modules always register a pinned word.
  *   bit 0  AXVS_STATUS_FP16_RANGE: a q/k/v operand of the C = 256 fused kernels (src or src + pos) exceeded the fp16 range
  *          (|x| > 65504) or was NaN -- with f16 MFMA operands the result would silently contain inf / NaN; use AXVS_BF16. */
 #define AXVS_STATUS_FP16_RANGE 1
 /*   bit 2  AXVS_STATUS_SYNC_TIMEOUT: a workgroup of a merged q/k/v + trajectory launch (axvs_set_sync_buffer) gave up waiting for
- *          its sibling row tiles (~1 s): the sync words were not zero at launch.  The outputs of that call are invalid; zero the
- *          words again (hipMemset) before the next call. */
+ *          its sibling row tiles (~1 s; option "sync_spin_limit" = number of polls): the sync words were not zero at launch, or the
+ *          sibling tiles were not scheduled (the hand-off relies on the tiles of a sequence being dispatched in order onto a GPU
+ *          that can hold them: true on a whole MI355X, not under CU masking).  The outputs of that call are INVALID and its sync
+ *          words are left non-zero: synchronise, zero the words (hipMemset), clear the status word, then call again. */
 #define AXVS_STATUS_SYNC_TIMEOUT 4
 int axvs_set_status_buffer(int* device_word);
+/* 0, or AXVS_ERR_STATE when the registered status word is host-readable and has AXVS_STATUS_SYNC_TIMEOUT set (reads the word as it
+ * is: synchronise first to see launches still in flight).  A word in device memory cannot be inspected: returns 0. */
+int axvs_check_status(void);
 
 /* Synchronisation words of the ONE-LAUNCH-PER-PASS form of the axial layer (axvs_axial_layer_fwd[_sine3d], axvs_axial_pass_fwd;
  * C = 256, 8 heads, T <= 4, axis lengths that are multiples of 16 up to 96).  Reference: WC/temporal_attention.py:197-213 -- the
@@ -107,7 +117,8 @@ const char* axvs_profile_stage_name(int i);
  *      "msda_gemm" (default 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
  *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels);
  *      "ffn_wide" (default 0: the stand-alone FFN runs on 128-row tiles when that saves a round of the chip; 1: always; 2: never --
- *      bit-identical either way). */
+ *      bit-identical either way); "sync_spin_limit" (polls before a hand-off wait of a merged launch gives up and sets
+ *      AXVS_STATUS_SYNC_TIMEOUT; default 2^22, about one second; 0 restores the default). */
 int axvs_set_option(const char* key, int value);
 
 /* ---- weight packing (once per load_state_dict; result is opaque, device-resident: 16-bit operands in MFMA-fragment order,

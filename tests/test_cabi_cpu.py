@@ -296,3 +296,56 @@ def test_forward_hooks_keep_the_split_and_cat_data_flow():
     assert _has_hooks(enc.temporal_layers[1])
     h.remove()
     assert not enc.train().can_run_in_place(torch.zeros(1, 2, 4, 4, 256))      # train() mode: autograd needs the out-of-place path
+
+
+def test_status_check_and_state_error_are_part_of_the_abi():
+    """Round 5: AXVS_ERR_STATE / axvs_check_status / option sync_spin_limit exist; without a registered word the check passes, and
+    registering NULL (no GPU call involved) keeps it that way."""
+    from axial_vs_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "axvs.h")).read()
+    assert "#define AXVS_ERR_STATE (-4)" in hdr and _lib.ERR_STATE == -4
+    assert L.axvs_set_status_buffer(None) == 0
+    assert L.axvs_check_status() == 0
+    assert L.axvs_set_option(b"sync_spin_limit", 1000) == 0 and L.axvs_set_option(b"sync_spin_limit", 0) == 0
+
+
+def test_train_amp_context_releases_its_lock_when_the_option_call_fails(monkeypatch):
+    """advisor (round 4): __enter__ took the lock and set the mode before a failing option call; __exit__ never ran."""
+    from axial_vs_amd import _lib
+
+    def boom(rc, what):
+        raise RuntimeError("option call failed")
+    prev = _lib.current_amp()
+    monkeypatch.setattr(_lib, "check", boom)
+    with pytest.raises(RuntimeError):
+        with _lib.train_amp(1 if prev != 1 else 2):
+            pass
+    monkeypatch.undo()
+    assert _lib.current_amp() == prev
+    assert _lib._AMP_LOCK.acquire(blocking=False)       # free again (an RLock held by this thread would also succeed: check the count)
+    _lib._AMP_LOCK.release()
+    import threading
+    got = []
+    def other():
+        ok = _lib._AMP_LOCK.acquire(timeout=2)
+        got.append(ok)
+        if ok:
+            _lib._AMP_LOCK.release()
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    assert got == [True], "another thread must be able to take the lock"
+
+
+def test_in_place_levels_fall_back_when_the_strided_workspace_explodes():
+    """advisor (round 4): a small level inside a long token buffer (B*T = 32 frames of 21504 tokens, a 32 x 32 level) would take
+    ~680 MB per row-addressed temporary in place against 32 MB in the natural layout: can_run_in_place says no, the split / cat
+    data flow runs; BASELINE config 3's stride is fine."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import modules
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(256, 1024, n_heads=8).eval()
+    pos_small = modules.tag_sine3d(torch.zeros(1, 4, 32, 32, 256), 10000.0, True, 6.283185307179586)
+    assert layer.can_run_in_place(pos_small) and layer.can_run_in_place(pos_small, frame_stride_rows=64 * 64 + 32 * 32 + 16 * 16)
+    pos_many = modules.tag_sine3d(torch.zeros(8, 4, 32, 32, 256), 10000.0, True, 6.283185307179586)
+    assert not layer.can_run_in_place(pos_many, frame_stride_rows=21504)
+    assert not layer.can_run_in_place(pos_many, frame_stride_rows=2 ** 22)      # row indices beyond 32 bits / 64

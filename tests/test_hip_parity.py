@@ -1552,3 +1552,151 @@ def test_merged_qkv_launches_replay_from_a_hip_graph():
     torch.cuda.synchronize()
     for buf in modules._sync_buffers.values():
         assert int(buf.abs().sum()) == 0
+
+
+# ---- round 5: a hand-off timeout fails loudly (include/axvs.h AXVS_STATUS_SYNC_TIMEOUT / AXVS_ERR_STATE) ------------------------------
+@pytest.mark.gpu
+def test_hand_off_timeout_fails_loudly_and_recovers():
+    """One arrival counter of the merged q/k/v + trajectory launch is poisoned (not zero at launch, against the contract of
+    axvs_set_sync_buffer) and the spin limit shortened: the waiting tiles give up and compute on stale K / V^T.  That must not pass
+    silently: the always-registered status word (pinned host memory) carries bit 2, check_status() raises, the NEXT layer call is
+    refused by the library itself (AXVS_ERR_STATE -> RuntimeError), the counters are zeroed by the handler, and afterwards both the
+    two-launch and the merged form give the golden result again."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib, modules
+    B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 23)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 23)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    s, p = dev(src), dev(pos)
+    good = layer(s, p)[0].clone()
+    assert "h.qkv+traj" in _stage_names()
+    ax.check_status()                                            # clean so far
+    L = _lib.lib()
+    sync = modules._sync_buffers[(torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)]
+    torch.cuda.synchronize()
+    _lib.check(L.axvs_set_option(b"sync_spin_limit", 2000), "axvs_set_option")
+    try:
+        sync[5] = 1000                                           # sequence 5 of the height pass starts from a non-zero counter
+        layer(s, p)                                              # launches fine: nothing is known yet (no synchronisation in the call)
+        torch.cuda.synchronize()
+        assert int(modules._status_words[torch.cuda.current_device()][0]) & 4
+        with pytest.raises(RuntimeError, match="AXVS_STATUS_SYNC_TIMEOUT"):
+            layer(s, p)                                          # the library refuses to run on top of it
+        torch.cuda.synchronize()
+        assert int(sync.abs().sum()) == 0, "the handler zeroes the counters"
+        assert not int(modules._status_words[torch.cuda.current_device()][0]) & 4
+        # the explicit form
+        sync[7] = 1000
+        layer(s, p)
+        with pytest.raises(RuntimeError, match="sibling row tiles"):
+            ax.check_status()
+        ax.check_status()                                        # reported once, state clean again
+    finally:
+        L.axvs_set_option(b"sync_spin_limit", 0)
+    _lib.check(L.axvs_set_option(b"no_merge_qkv", 1), "axvs_set_option")
+    try:
+        two = layer(s, p)[0].clone()
+        assert "h.qkv_proj" in _stage_names()
+    finally:
+        L.axvs_set_option(b"no_merge_qkv", 0)
+    one = layer(s, p)[0]
+    assert "h.qkv+traj" in _stage_names()
+    assert torch.equal(two, good) and torch.equal(one, good)
+    assert rel_err(one.cpu(), ref) < TOL_F16
+    ax.check_status()
+
+
+@pytest.mark.gpu
+def test_range_report_does_not_swallow_a_timeout():
+    """range_check_report() used to test bit 0 and zero the whole word: a recorded hand-off timeout (bit 2) disappeared unreported."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import modules
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(256, 512, n_heads=8).eval().cuda()
+    layer(torch.randn(2, 256, 256, device="cuda"), ax.PositionEmbeddingSine3D(128, normalize=True).channels_last(1, 2, 16, 16, "cuda"))
+    torch.cuda.synchronize()
+    wd = modules._status_words[torch.cuda.current_device()]
+    ax.enable_range_check()
+    try:
+        wd[0] = 5                                                # both conditions recorded
+        with pytest.raises(RuntimeError, match="AXVS_STATUS_SYNC_TIMEOUT"):
+            ax.range_check_report()
+        assert int(wd[0]) == 0
+        assert not ax.range_check_report()
+    finally:
+        ax.disable_range_check()
+
+
+@pytest.mark.gpu
+def test_merged_qkv_on_two_streams_with_grids_far_beyond_one_round():
+    """Two merged launches side by side on two streams, each with 2048 row tiles per pass ([8,4,256,64,64]: eight rounds of the
+    chip): the tiles of a sequence are consecutive workgroups of one kernel, so whichever kernel gets a free CU continues its own
+    partially dispatched sequence -- no wait can outlast the sequences already running.  Results equal the one-at-a-time results bit
+    for bit, no timeout is recorded, every counter is zero afterwards."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import modules
+    B, T, C, H, W, F = 8, 4, 256, 64, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 31)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pos = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    xs = [torch.randn(B * T, H * W, C, device="cuda") for _ in range(2)]
+    want = [layer(x, pos)[0].clone() for x in xs]
+    assert "h.qkv+traj" in _stage_names()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        outs = [None, None]
+        for i, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for _ in range(2):
+                    outs[i] = layer(xs[i], pos)[0]
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(outs[i], want[i]), (rep, i)
+    ax.check_status()
+    for buf in modules._sync_buffers.values():
+        assert int(buf.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_graphed_forwards_own_their_sync_words():
+    """Every GraphedForward allocates and zeroes its arrival counters eagerly, before the capture (an allocation inside the capture
+    would come from the graph's private pool with its zero-fill recorded as a node): two graphs never share counters, replays are
+    bit-equal to eager, and a first use of a stream inside a caller's own capture falls back to two launches instead of allocating."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import modules
+    B, T, C, H, W, F = 1, 4, 256, 64, 64, 1024
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 37)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pt = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda").clone()
+    a, b = torch.randn(B * T, H * W, C, device="cuda"), torch.randn(B * T, H * W, C, device="cuda")
+    want_a, want_b = layer(a, pt)[0].clone(), layer(b, pt)[0].clone()
+    n_before = len(modules._sync_buffers)
+    g1, g2 = ax.GraphedForward(layer, a, pt), ax.GraphedForward(layer, b, pt)
+    assert len(modules._sync_buffers) == n_before, "no (device, stream) set may be created while a graph is built"
+    p1 = {t.data_ptr() for t in g1._sync}
+    assert not p1 & {t.data_ptr() for t in g2._sync}
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):                                           # replayed concurrently on two streams
+        with torch.cuda.stream(s1):
+            o1 = g1()[0]
+        with torch.cuda.stream(s2):
+            o2 = g2()[0]
+        torch.cuda.synchronize()
+        assert torch.equal(o1, want_a) and torch.equal(o2, want_b)
+    for t in g1._sync + g2._sync:
+        assert int(t.abs().sum()) == 0
+    assert torch.equal(layer(a, pt)[0], want_a)                  # eager calls re-register their own words
+    assert "h.qkv+traj" in _stage_names()
+    ax.check_status()
