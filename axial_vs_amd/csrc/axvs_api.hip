@@ -64,6 +64,9 @@ thread_local unsigned* g_sync = nullptr;
 thread_local size_t g_sync_words = 0;
 thread_local int g_merge_qkv_any = 0;    // option "merge_qkv_any": merged launches at every grid size (A/B; see run_traj)
 thread_local int g_merge_small = 0;      // option "merge_small": 16-row-tile problems merge as well (built and bit-identical; measured a wash, see run_traj)
+thread_local int g_out_dtype = 0;        // option "layer_out_dtype": 0 = the layer's output rows are fp32 (the reference's type); 1 / 2 = the kernel that ends the layer
+                                         // (norm2 epilogue of the FFN) writes them as f16 / bf16 -- the map a batch-sharded caller gathers over the links
+                                         // (BASELINE config 5 is worded "bf16"), written once instead of cast by a second pass
 thread_local int g_no_merge_qkv = 0;     // option "no_merge_qkv": keep qkv_fused_kernel + trajectory kernel as two launches (A/B, tests)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
@@ -319,7 +322,8 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
                     float scale, hipStream_t st, int nks = 0, const FfnArgs* fa = nullptr, int vrow = 0, const NextQkv* nq = nullptr,
                     const OwnQkv* oq = nullptr) {
   // output rows are addressed through the RowMap: the largest byte offset is that of the natural [rows, 256] fp32 tensor
-  const int wt = ((!g_no_wt_stores && (g_row_span ? g_row_span : Mp) * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? (oq ? g_spatial_only : 1) << 1 : 0);
+  const int wt = ((!g_no_wt_stores && (g_row_span ? g_row_span : Mp) * 256 * 4 < (1ll << 32)) ? 1 : 0) | (g_spatial_only && nks > 0 ? (oq ? g_spatial_only : 1) << 1 : 0) |
+                 (fa != nullptr && g_out_dtype ? (g_out_dtype == 1 ? kOutF16 : kOutBf16) : 0);
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
   if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
@@ -537,7 +541,10 @@ template <bool BF>
 int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int heads, int F, float* tmp, u16* y16, u16* h16,
             hipStream_t st, float* part = nullptr /* [F/256][M][256] fp32: enables the chunk-per-workgroup form for few rows */,
             RowStride rs = RowStride{0, 0} /* X and out rows: frames of rs.hw rows, rs.hw + rs.extra rows apart (fused kernels only) */) {
-  if (part != nullptr && ffn_split_applies(C, heads, F, M)) {
+  const int oflags = g_out_dtype ? (g_out_dtype == 1 ? kOutF16 : kOutBf16) : 0;
+  if (oflags && !(ffn_kernel_is_fused(C, heads, F) && ffn_lds_bytes(F) <= 160 * 1024))
+    return fail(AXVS_ERR_ARG, "layer_out_dtype: a 16-bit output map needs the fused FFN tier (C = 256, 8 heads, d_ffn a multiple of 256 up to 4096)");
+  if (!oflags && part != nullptr && ffn_split_applies(C, heads, F, M)) {
     const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 256);
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true>))) return rc;
@@ -551,7 +558,7 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }
-  if (ffn_kernel_is_fused(C, heads, F) && F <= 2048 && (g_ffn_wide == 1 || (g_ffn_wide == 0 && ffn_wide_pays(M)))) {
+  if (!oflags && ffn_kernel_is_fused(C, heads, F) && F <= 2048 && (g_ffn_wide == 1 || (g_ffn_wide == 0 && ffn_wide_pays(M)))) {
     // more 64-row tiles than CUs: 128-row tiles when that saves a round of the chip (axvs_ffn_wide.h; bit-identical)
     const size_t lds = ffn_wide_lds_bytes(F);
     const dim3 wgrid((unsigned)((M + kWideRows - 1) / kWideRows));
@@ -571,10 +578,10 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
     const dim3 fgrid((unsigned)((M + kRows - 1) / kRows));
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF, true>))) return rc;
-      hipLaunchKernelGGL((ffn_fused_kernel<BF, true>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs);
+      hipLaunchKernelGGL((ffn_fused_kernel<BF, true>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs, oflags);
     } else {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<BF>))) return rc;
-      hipLaunchKernelGGL((ffn_fused_kernel<BF>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs);
+      hipLaunchKernelGGL((ffn_fused_kernel<BF>), fgrid, dim3(512), lds, st, X, p.w1, p.b1, p.w2, p.b2, p.g1, p.be1, p.g2, p.be2, out, M, F, rs, oflags);
     }
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
@@ -642,6 +649,8 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
   const long long M = (long long)B * T * H * W;
   const long long span = fs ? ((long long)B * T - 1) * fs + (long long)H * W : M;      // rows spanned by a row-addressed tensor
   struct SpanGuard { SpanGuard(long long v) { g_row_span = v; } ~SpanGuard() { g_row_span = 0; } } span_guard(fs ? span : 0);
+  if (g_out_dtype && (fs != 0 || which == 1))
+    return fail(AXVS_ERR_ARG, "layer_out_dtype: a 16-bit output map exists for the whole layer / its width pass on contiguous frames only");
   Carver wc(ws);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
   TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
@@ -1193,6 +1202,11 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
+  if (key && !strcmp(key, "layer_out_dtype")) {
+    if (value < 0 || value > 2) return fail(AXVS_ERR_ARG, "layer_out_dtype: 0 (fp32), 1 (f16) or 2 (bf16)");
+    g_out_dtype = value;
+    return AXVS_OK;
+  }
   if (key && !strcmp(key, "sync_spin_limit")) { g_sync_spin_limit = value > 0 ? (unsigned)value : axvs::kSyncSpinLimit; return AXVS_OK; }
   return fail(AXVS_ERR_ARG, "unknown option");
 }

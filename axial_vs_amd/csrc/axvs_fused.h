@@ -142,6 +142,10 @@ __device__ __forceinline__ void load_wfrags(u16x8 (&wf)[NT][KB], const u16* __re
 #define FSTAMP_FLUSH(n)
 #endif
 
+// flag bits of the `wt` argument of ffn_body / the kernels that carry it: bit 0 = write-through (sc1) output rows; bits 4, 5 = the
+// output rows are 16-bit (f16 / bf16) instead of fp32 (`out` then points at a [rows][256] 16-bit map)
+constexpr int kOutF16 = 16, kOutBf16 = 32, kOut16Mask = kOutF16 | kOutBf16;
+
 struct FfnLds {
   float* xtile;   // [64][kEpiLd] fp32
   u16* ytile;     // [8][64][32]
@@ -305,7 +309,13 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
       const long long off = row_off(r);
       if (off >= 0) {
         const float4 y = float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
-        if (wt) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);       // the next kernel reads these rows from other XCDs
+        if (wt & kOut16Mask) {      // the layer's output map in 16 bits (option "layer_out_dtype"): rows of 512 B, written here instead of by a cast pass
+          const f32x4 yv = {y.x, y.y, y.z, y.w};
+          const u16x4 h = (wt & kOutBf16) ? cvt4<true>(yv) : cvt4<false>(yv);
+          u16* o16 = reinterpret_cast<u16*>(out);
+          if (wt & 1) WtBuf(o16).store8((unsigned)((off + lane * 4) * 2), h);
+          else *reinterpret_cast<u16x4*>(o16 + off + lane * 4) = h;
+        } else if (wt & 1) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);       // the next kernel reads these rows from other XCDs
         else *reinterpret_cast<float4*>(out + off + lane * 4) = y;
       }
       if (i == 3) lds_fence();
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ b2, const float* __restrict__ g1,
                                                         const float* __restrict__ be1, const float* __restrict__ g2,
                                                         const float* __restrict__ be2, float* __restrict__ out,
-                                                        long long M, int F, RowStride rs) {
+                                                        long long M, int F, RowStride rs, int oflags = 0 /* kOutF16 / kOutBf16 */) {
   constexpr int C = 256, KB = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   FfnLds l;
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   }
   __syncthreads();                       // parameters staged
   auto row_off = [=](int r) { return m0 + r < M ? rs.row(m0 + r) * C : -1ll; };
-  ffn_body<BF, decltype(row_off), GELU>(l, w1f, W1, W2, out, row_off, F, rot, crot, tid);
+  ffn_body<BF, decltype(row_off), GELU>(l, w1f, W1, W2, out, row_off, F, rot, crot, tid, oflags);
 }
 
 
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              const u16* __restrict__ K16 = nullptr,
                                                              const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
                                                              const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */,
-                                                             int wt = 0 /* write-through output rows (byte offsets < 4 GiB) */,
+                                                             int wt = 0 /* bit 0: write-through output rows (byte offsets < 4 GiB); FFN: bits 4 / 5 = 16-bit output map (kOutF16 / kOutBf16) */,
                                                              int spatial_only = 0 /* measurement: 1 = stop after the QK^T / AV half; MQ kernels also 2 = stop after their q/k/v part */,
                                                              const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
                                                              const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{},
@@ -1328,7 +1338,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
     if constexpr (FFN) yrows.v[i] = y;             // stays on the CU: input row of the FFN half, handed to its norm1 in registers
     else if (row < nvalid) {
-      if (wt) WtBuf(out).store16((unsigned)(roff[i] * 4), y);
+      if (wt & 1) WtBuf(out).store16((unsigned)(roff[i] * 4), y);
       else *reinterpret_cast<float4*>(out + roff[i]) = y;
     }
   }

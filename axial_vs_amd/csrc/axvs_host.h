@@ -82,7 +82,7 @@ struct OwnQkv;    // axvs_fused.h
 // `nq` non-null: the kernel also emits q, k, v of the next pass (64-row tiles, no FFN).
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa, int flags /* bit 0: write-through output rows, bit 1: stop after the spatial half */,
+                      int L, float scale, hipStream_t st, const FfnArgs* fa, int flags /* bit 0: write-through output rows, bits 1-2: stop after the spatial half / the q,k,v part, bits 4-5: 16-bit output map of the FFN-carrying kernel (kOutF16 / kOutBf16) */,
                       int vrow, const NextQkv* nq, const OwnQkv* oq /* non-null: the kernel computes q, k, v of its own rows first (merged launch) */);
 
 }  // namespace axvs

@@ -20,7 +20,7 @@ static int launch_one(unsigned grid, const TrajWs& w, const TrajPacked& p, const
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern))) return rc;
   const size_t lds = temporal_lds_bytes<T, MT, FFN, QKVN, MQ>(FFN ? fa->F : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale,
-                     w.q16, w.k16, w.vt16, FFN ? *fa : FfnArgs{}, p.wk2t, wt & 1, wt >> 1, FFN ? nullptr : p.post_ln_g,
+                     w.q16, w.k16, w.vt16, FFN ? *fa : FfnArgs{}, p.wk2t, (wt & 1) | (FFN ? wt & kOut16Mask : 0), (wt >> 1) & 3, FFN ? nullptr : p.post_ln_g,
                      FFN ? nullptr : p.post_ln_b, QKVN ? *nq : NextQkv{}, MQ ? *oq : OwnQkv{});
   return AXVS_OK;
 }

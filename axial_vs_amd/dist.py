@@ -69,6 +69,15 @@ def gather_clips(out_local: Tensor, n_clips_total: int, frames: int, group=None,
     return torch.cat([buf[k * mx: k * mx + sizes[k]] for k in range(world)], dim=0)
 
 
+def chunked_clip_order(total: int, world: int, chunks: int) -> List[int]:
+    """Clip index (rank-major numbering: rank r owns clips [r*b, (r+1)*b), b = total / world) at every position of the map that
+    `sharded_forward(..., replicated_inputs=False, chunks=k)` returns: the map is ordered (group, rank, clip in group) so that every
+    group's all-gather has ONE contiguous destination.  `full.view(chunks, world, cb * T, ...)[c, r]` is rank r's group c."""
+    b = total // world
+    cb = b // chunks
+    return [r * b + c * cb + i for c in range(chunks) for r in range(world) for i in range(cb)]
+
+
 def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, pos: Tensor, group=None,
                     gather: bool = True, replicated_inputs: bool = True, gather_dtype: Optional[torch.dtype] = None,
                     chunks: int = 1) -> Tensor:
@@ -76,48 +85,76 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
 
     ``replicated_inputs``: src / pos hold the whole batch on every rank (cut locally); otherwise they are already the
     local shard and ``pos.shape[0]`` is the local clip count (the total is summed over ranks).
-    ``gather_dtype``: see `gather_clips`.  ``chunks`` > 1 (equal shards only): the local clips are run in that many groups and
-    every group's all-gather is issued asynchronously right behind its kernels, so the collective of group i crosses the links
-    while group i + 1 computes; the groups land in their places of the full map (no reorder copy).
+    ``gather_dtype``: see `gather_clips`; a `layer_fn` that already returns that type (the layer's ``out_dtype``: the 16-bit map
+    written by the kernel epilogue) is not cast again.
+    ``chunks`` > 1 (equal shards only): the local clips are run in that many groups and every group's all-gather is issued
+    asynchronously right behind its kernels, so the collective of group i crosses the links while group i + 1 computes.  Every group
+    is ONE `all_gather_into_tensor` into a contiguous slice of the full map -- no list-form all_gather (ProcessGroupNCCL flattens
+    those into a temporary and copies every slice out again: (world - 1) / world of the map in extra HBM reads and writes per step):
+      * replicated inputs: the clips are dealt to the ranks group by group -- rank r computes clips {c * world * cb + r * cb + i}
+        (cb = clips per group) -- so group c of all ranks IS rows [c * world * cb * T, (c + 1) * world * cb * T) of the map in natural
+        clip order;
+      * pre-sharded inputs (rank r holds its own clips): the map comes back ordered (group, rank, clip in group);
+        `chunked_clip_order(total, world, chunks)` names the clip at every position (also attached as `full.clip_order`).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     T = pos.shape[1]
+    tag = getattr(pos, "_axvs_sine3d", None)
+    if tag is not None and tag.version != pos._version:
+        tag = None
+
+    def retag(p_c: Tensor) -> Tensor:
+        if tag is None:
+            return p_c
+        from .modules import tag_sine3d
+        return tag_sine3d(p_c.contiguous(), tag.temperature, tag.normalize, tag.scale, tag.level)
+
+    equal = True
     if replicated_inputs:
         total = pos.shape[0]
-        s_loc, p_loc = local_slice(src, pos, rank, world)
     else:
-        s_loc, p_loc = src, pos
-        cnt = torch.tensor([pos.shape[0]], device=src.device, dtype=torch.int64)
+        # every rank learns every rank's clip count (one tiny all-gather): the total, and whether the shards are equal -- all ranks
+        # must take the same branch below
+        mine = torch.tensor([pos.shape[0]], device=src.device, dtype=torch.int64)
+        counts = mine.new_empty(world)
         if world > 1:
-            dist.all_reduce(cnt, group=group)
-        total = int(cnt.item())
-    b_loc = p_loc.shape[0]
-    if gather and world > 1 and chunks > 1 and total % world == 0 and b_loc % chunks == 0 and b_loc > 0:
-        cb = b_loc // chunks                                  # clips per group
+            dist.all_gather_into_tensor(counts, mine, group=group)
+        else:
+            counts = mine
+        cl = counts.tolist()
+        total = int(sum(cl))
+        equal = len(set(cl)) == 1
+    b_each = total // world if world else total
+    if gather and world > 1 and chunks > 1 and equal and total % world == 0 and b_each % chunks == 0 and b_each > 0:
+        cb = b_each // chunks                                 # clips per group
         full = None
         works = []
         for c in range(chunks):
-            sl = slice(c * cb * T, (c + 1) * cb * T)
-            p_c = p_loc[c * cb:(c + 1) * cb]
-            tag = getattr(p_loc, "_axvs_sine3d", None)
-            if tag is not None and tag.version == p_loc._version:
-                from .modules import tag_sine3d
-                p_c = tag_sine3d(p_c.contiguous(), tag.temperature, tag.normalize, tag.scale, tag.level)
-            o = layer_fn(s_loc[sl], p_c)
+            if replicated_inputs:                             # group c of rank r: clips [c * world * cb + r * cb, ... + cb) of the batch
+                c0 = c * world * cb + rank * cb
+                s_c, p_c = src[c0 * T:(c0 + cb) * T], retag(pos[c0:c0 + cb])
+            else:                                             # my own clips, in order
+                s_c, p_c = src[c * cb * T:(c + 1) * cb * T], retag(pos[c * cb:(c + 1) * cb])
+            o = layer_fn(s_c.contiguous(), p_c)
             if gather_dtype is not None and o.dtype != gather_dtype:
                 o = o.to(gather_dtype)
             if full is None:
                 full = o.new_empty((total * T,) + tuple(o.shape[1:]))
-            # rank r's group c lives at rows (r * b_loc + c * cb) * T of the full map
-            outs = [full[(r * b_loc + c * cb) * T:(r * b_loc + (c + 1) * cb) * T] for r in range(world)]
-            works.append(dist.all_gather(outs, o.contiguous(), group=group, async_op=True))
+            dst = full[c * world * cb * T:(c + 1) * world * cb * T]        # contiguous: ranks side by side inside the group's slice
+            works.append(dist.all_gather_into_tensor(dst, o.contiguous(), group=group, async_op=True))
         for wk in works:
             wk.wait()
+        if not replicated_inputs:
+            full.clip_order = chunked_clip_order(total, world, chunks)
         return full
+    if replicated_inputs:
+        s_loc, p_loc = local_slice(src, pos, rank, world)
+    else:
+        s_loc, p_loc = src, pos
     out_local = layer_fn(s_loc, p_loc) if s_loc.shape[0] else s_loc.new_empty(s_loc.shape)
     if not gather or world == 1:
-        return out_local if gather_dtype is None else out_local.to(gather_dtype)
+        return out_local if gather_dtype is None or out_local.dtype == gather_dtype else out_local.to(gather_dtype)
     return gather_clips(out_local, total, T, group, dtype=gather_dtype)
 
 
@@ -167,6 +204,7 @@ def offaxis_forward(pass_fn: Callable[[Tensor, Tensor, int], Tensor], src: Tenso
     out_rows = pass_fn(y_rows, pos[:, :, h0:h0 + hb].contiguous(), 1)
     if not gather:
         return out_rows
-    parts = [torch.empty_like(out_rows) for _ in range(world)]
-    dist.all_gather(parts, out_rows.contiguous(), group=group)
-    return torch.cat(parts, dim=2).reshape(B * T, H * W, C)
+    # one contiguous all-gather ([world, B, T, hb, W, C]); the row blocks are then interleaved into the map with ONE copy
+    every = out_rows.new_empty((world * out_rows.shape[0],) + tuple(out_rows.shape[1:]))      # (concatenated form: gloo knows no other)
+    dist.all_gather_into_tensor(every, out_rows.contiguous(), group=group)
+    return every.view((world,) + tuple(out_rows.shape)).permute(1, 2, 0, 3, 4, 5).reshape(B * T, H * W, C)

@@ -458,6 +458,9 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
         self.mfma_dtype = mfma_dtype
         self.return_attn = False
         self.use_generated_pos = True   # a `pos` made by PositionEmbeddingSine3D is evaluated in-kernel instead of read (SineTag)
+        # eval mode: None = fp32 output rows (the reference's type); torch.float16 / torch.bfloat16 = the layer's last kernel writes the
+        # map in 16 bits (what a batch-sharded caller sends over the links: axial_vs_amd.dist, BASELINE config 5)
+        self.out_dtype: Optional[torch.dtype] = None
         # train() mode: False (default) keeps the activations between forward and backward like the reference under autograd does
         # (44 C floats per token and layer: 0.74 GB at the metric shape -- sized for 288 GB of HBM); True: backward rebuilds them
         # from (src, pos, seed) first (+1 forward, nothing kept)
@@ -531,11 +534,27 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             raise RuntimeError(f"src {tuple(src.shape)} does not match pos {tuple(pos.shape)}")
         L = _lib.lib()
         F = self.linear1.out_features
+        if self.out_dtype is not None:
+            # the output map in 16 bits, written by the epilogue of the kernel that ends the layer (library option "layer_out_dtype")
+            code = {torch.float16: 1, torch.bfloat16: 2}.get(self.out_dtype)
+            if code is None:
+                raise ValueError("out_dtype: None (fp32, the reference's type), torch.float16 or torch.bfloat16")
+            if self.return_attn:
+                raise NotImplementedError("axial_vs_amd: out_dtype and return_attn exclude each other")
+            out = torch.empty(s.shape, dtype=self.out_dtype, device=s.device)
+            _lib.check(L.axvs_set_option(b"layer_out_dtype", code), "axvs_set_option")
+            try:
+                return self._launch(L, s, p, pos, out, None, None, B, T, H, W, C_, F)
+            finally:
+                L.axvs_set_option(b"layer_out_dtype", 0)
         out = torch.empty_like(s)
         ha = wa = None
         if self.return_attn:
             ha = torch.empty(B * W * self.n_heads, T * H, T, H, dtype=torch.float32, device=s.device)
             wa = torch.empty(B * H * self.n_heads, T * W, T, W, dtype=torch.float32, device=s.device)
+        return self._launch(L, s, p, pos, out, ha, wa, B, T, H, W, C_, F)
+
+    def _launch(self, L, s, p, pos, out, ha, wa, B, T, H, W, C_, F):
         packed = self._pack()
         sh = _stream(s.device)                     # the current stream's handle, looked up once per call
         _select_sync_words(s.device, sh)

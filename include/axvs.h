@@ -117,7 +117,10 @@ const char* axvs_profile_stage_name(int i);
  *      "msda_gemm" (default 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
  *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels);
  *      "ffn_wide" (default 0: the stand-alone FFN runs on 128-row tiles when that saves a round of the chip; 1: always; 2: never --
- *      bit-identical either way); "sync_spin_limit" (polls before a hand-off wait of a merged launch gives up and sets
+ *      bit-identical either way); "layer_out_dtype" (default 0: axvs_axial_layer_fwd* / axvs_axial_pass_fwd(pass = 1) / axvs_traj_layer_fwd / axvs_ffn_fwd write
+ *      their output rows as fp32, the reference's type; 1 / 2: `out` is a [rows, C] f16 / bf16 map, written by the epilogue of the
+ *      kernel that ends the layer -- the map a batch-sharded caller gathers over xGMI (BASELINE config 5: "bf16"), without a cast
+ *      pass; fused FFN tier only, contiguous frames only); "sync_spin_limit" (polls before a hand-off wait of a merged launch gives up and sets
  *      AXVS_STATUS_SYNC_TIMEOUT; default 2^22, about one second; 0 restores the default). */
 int axvs_set_option(const char* key, int value);
 

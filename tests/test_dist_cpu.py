@@ -47,6 +47,18 @@ def _worker(rank, world, port, q):
             want = ref if dt is None else ref.to(dt)
             assert out.dtype == want.dtype
             q.put((rank, 8, float((out.float() - want.float()).abs().max()), tuple(out.shape)))
+        # pre-sharded inputs, chunked: every group's gather lands in ONE contiguous slice; the map is ordered (group, rank, clip)
+        # and `clip_order` names the clip at every position
+        s_loc, p_loc = axd.local_slice(src, pos, rank, world)
+        out = axd.sharded_forward(fn, s_loc, p_loc, gather=True, replicated_inputs=False, chunks=2)
+        order = out.clip_order
+        assert order == axd.chunked_clip_order(8, world, 2) and sorted(order) == list(range(8))
+        want = ref.reshape(8, T, H * W, C)[order].reshape(8 * T, H * W, C)
+        q.put((rank, 8, float((out - want).abs().max()), tuple(out.shape)))
+        # a layer_fn that already returns the 16-bit map (the kernel epilogue's out_dtype) is not cast again
+        fn16 = lambda s, p: fn(s, p).to(torch.float16)
+        out = axd.sharded_forward(fn16, src, pos, gather=True, chunks=2, gather_dtype=torch.float16)
+        q.put((rank, 8, float((out.float() - ref.to(torch.float16).float()).abs().max()), tuple(out.shape)))
     finally:
         dist.destroy_process_group()
 
@@ -59,11 +71,11 @@ def test_sharded_forward_matches_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world * (len(CASES) + 4))]
+    res = [q.get(timeout=300) for _ in range(world * (len(CASES) + 6))]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert len(res) == world * (len(CASES) + 4)
+    assert len(res) == world * (len(CASES) + 6)
     for rank, B, err, shape in res:
         assert shape == (B * 2, 20, 64)
         assert err < 1e-5, (rank, B, err)   # sharding never mixes clips (the 16-bit maps are compared with the cast reference)
@@ -122,3 +134,12 @@ def test_oracle_axial_pass_composes_to_the_layer():
     ref = orc.axial_layer(src, pos, w, 8, want_attn=False)[0]
     y = orc.axial_pass(orc.axial_pass(src.reshape(B, T, H, W, C), pos, w, 0), pos, w, 1)
     assert float((y.reshape(B * T, H * W, C) - ref).abs().max()) < 1e-5
+
+
+def test_no_list_form_all_gather_on_the_batch_sharded_path():
+    """round-4 review: ProcessGroupNCCL flattens list-form all_gather into a temporary and copies every slice out -- the batch-sharded
+    path must only use all_gather_into_tensor on contiguous destinations (the gloo stand-in of the all-to-all keeps its own)."""
+    import inspect
+    from axial_vs_amd import dist as axd
+    for f in (axd.sharded_forward, axd.gather_clips, axd.offaxis_forward):
+        assert "dist.all_gather(" not in inspect.getsource(f), f.__name__

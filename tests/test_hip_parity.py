@@ -1700,3 +1700,31 @@ def test_graphed_forwards_own_their_sync_words():
     assert torch.equal(layer(a, pt)[0], want_a)                  # eager calls re-register their own words
     assert "h.qkv+traj" in _stage_names()
     ax.check_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 4, 256, 64, 64, 1024), (2, 4, 256, 96, 96, 1024), (1, 2, 256, 32, 32, 1024), (1, 4, 256, 16, 24, 512),
+                                   (1, 5, 256, 64, 64, 1024)])
+def test_layer_writes_its_output_map_in_16_bits(shape):
+    """layer.out_dtype (library option layer_out_dtype): the kernel that ends the layer -- the width-pass kernel with the FFN riding along,
+    or the stand-alone fused FFN kernel -- writes the [rows, C] output map as f16 / bf16 itself, the type a batch-sharded caller sends
+    over the links (BASELINE config 5: "bf16").  Same values as the fp32 map rounded once (round-to-nearest-even, like Tensor.half())."""
+    import axial_vs_amd as ax
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 41)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    src = torch.randn(B * T, H * W, C, device="cuda")
+    for pos in (ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda"),):
+        full = layer(src, pos)[0]
+        for dt in (torch.float16, torch.bfloat16):
+            layer.out_dtype = dt
+            try:
+                got = layer(src, pos)[0]
+            finally:
+                layer.out_dtype = None
+            assert got.dtype == dt and got.shape == full.shape
+            assert torch.equal(got, full.to(dt)), (shape, dt, float((got.float() - full).abs().max()))
+        again = layer(src, pos)[0]
+        assert again.dtype == torch.float32 and torch.equal(again, full)
