@@ -225,12 +225,19 @@ void pack_traj(const AxvsTrajParams& p, const TrajPacked& t, int C, int heads, h
 
 // ---------------- one trajectory attention over sequence-ordered rows ----------------
 // lean: the fully fused tier only round-trips q, k and V^T (x, the T-expanded attention output, stays in LDS)
-TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = false) {
+// rows of the q/k/v row space of `M` token rows in frames of L rows: the fused trajectory tier pads every frame to a multiple of 16
+// rows (RowMap, "padded frames"), so that 16-row MFMA tiles never straddle frames
+inline int pad16(int L) { return (L + 15) & ~15; }
+inline long long padded_rows(long long M, int L) { return L > 0 && L % 16 ? M / L * pad16(L) : M; }
+
+// Mq: capacity of q16 / k16 / vt16 in rows (>= Mp: padded_rows of the longest frame the caller will run)
+TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = false, long long Mq = 0) {
   const size_t Cp = (size_t)heads * 32;
+  if (Mq < Mp) Mq = Mp;
   TrajWs w{};
-  w.q16 = c.take<u16>(Cp * Mp);
-  w.k16 = c.take<u16>(Cp * Mp);
-  w.vt16 = c.take<u16>(2 * Cp * Mp);      // block-transposed V (frames padded to a multiple of 32 keys: at most 2x)
+  w.q16 = c.take<u16>(Cp * Mq);
+  w.k16 = c.take<u16>(Cp * Mq);
+  w.vt16 = c.take<u16>(2 * Cp * Mq);      // block-transposed V (frames padded to a multiple of 32 keys: at most 2x)
   if (lean) return w;
   w.v16 = c.take<u16>(Cp * Mp);
   w.x16 = c.take<u16>(Cp * Mp * T);
@@ -374,16 +381,28 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const char* const* nm = kNames[pass];
   if (may_merge)      // never compute on top of a reported hand-off timeout (host-readable status word; no synchronisation)
     if (int rc = status_gate()) return rc;
-  const int N = T * L, Cp = heads * 32, d = C / heads;
-  const long long Mp = (long long)S * N;
-  if (Mp * T > 2147483647LL / 2) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
-  const int M = (int)Mp;
+  const int Lreal = L;
+  const int Cp = heads * 32, d = C / heads;
+  const long long Mreal = (long long)S * T * L;
+  if (Mreal * T > 2147483647LL / 4) return fail(AXVS_ERR_ARG, "too many tokens for 32-bit row indices");
   const float scale = 1.0f / sqrtf((float)d);
   const float kLog2e = 1.4426950408889634f;
 
-  const bool fuse_attn = qsrc == ksrc && vsrc == qsrc && can_fuse_attn(C, heads, T, L, attn != nullptr, Mp);
+  const bool fuse_attn = qsrc == ksrc && vsrc == qsrc && can_fuse_attn(C, heads, T, L, attn != nullptr, Mreal);
+  const bool with_ffn = fuse_attn && ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F, Mreal);
+  // The fused tier runs in the PADDED row space (RowMap): frames of roundup16(L) rows, the last ones of each frame clamped copies
+  // that are computed and never stored -- every 16-row MFMA tile then lies inside one frame, K / V^T are stored 16 / 8 bytes per lane
+  // and the merged launch applies for any frame length (the shipped VIPSeg maps: 49 x 85, 25 x 43).  Every other tier is dense.
+  if (fuse_attn && L % 16 != 0 && !have_qkv && !nq) {
+    L = pad16(L);
+    rm.Lv = Lreal;
+    rm.L = L;
+    rm.N = T * L;
+  }
+  const int N = T * L;
+  const long long Mp = (long long)S * N;
+  const int M = (int)Mp;
   const int nks_fused = (L + 31) / 32;
-  const bool with_ffn = fuse_attn && ffn != nullptr && can_fuse_ffn_into_pass(T, ffn->F, Mp);
   // row-form V (K's layout, 16-byte stores from any producer) on the 64-row fused kernels with at most 64 keys per frame
   const bool vrow = fuse_attn && can_vrow(T, L, Mp, with_ffn, have_qkv);
   if ((have_qkv || nq) && !vrow && !(nq && fuse_attn && traj_mt4(T, traj_tiles64(Mp, N), with_ffn)))
@@ -613,7 +632,7 @@ int traj_attn_fwd_t(const float* query, const float* key, const float* value, fl
   Carver pc(const_cast<void*>(packed));
   TrajPacked p = carve_traj(pc, C, heads);
   Carver wc(ws);
-  TrajWs w = carve_traj_ws(wc, (long long)S * T * L, T, heads);
+  TrajWs w = carve_traj_ws(wc, (long long)S * T * L, T, heads, false, padded_rows((long long)S * T * L, L));
   // the fused kernels always add a residual: feed zeros here (TrajectoryAttention.forward itself has none)
   float* zeros = wc.take<float>((size_t)S * T * L * C);
   if (hipMemsetAsync(zeros, 0, (size_t)S * T * L * C * sizeof(float), st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "memset failed");
@@ -653,7 +672,8 @@ int axial_layer_fwd_t(const float* src, const float* pos, float* out, const void
     return fail(AXVS_ERR_ARG, "layer_out_dtype: a 16-bit output map exists for the whole layer / its width pass on contiguous frames only");
   Carver wc(ws);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, F, h_attn != nullptr || w_attn != nullptr);
-  TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj);
+  const long long Mq = std::max(padded_rows(M, H), padded_rows(M, W));      // q/k/v row space: frames padded to multiples of 16 rows
+  TrajWs tw = carve_traj_ws(wc, M, T, heads, plan.lean_traj, Mq);
   // second q / k / v set: the height-pass kernel writes the width pass's operands while other tiles still read its own
   const bool fuse_qkv = plan.fuse_qkv && which == 0 && fs == 0;
   TrajWs tw2 = plan.fuse_qkv ? carve_traj_ws(wc, M, T, heads, true) : tw;
@@ -733,7 +753,7 @@ int traj_layer_fwd_t(const float* src, const float* pos, float* out, const void*
   LayerPacked pf = carve_ffn(pc, C, F);
   const long long M = (long long)B * T * HW;
   Carver wc(ws);
-  TrajWs tw = carve_traj_ws(wc, M, T, heads);
+  TrajWs tw = carve_traj_ws(wc, M, T, heads, false, padded_rows(M, HW));
   float* x = wc.take<float>((size_t)M * C);
   float* tmp = wc.take<float>((size_t)M * C);
   u16* y16 = wc.take<u16>((size_t)M * C);
@@ -785,9 +805,9 @@ struct CCLayerWs {
   float *t1, *t2, *y;
   u16* cat16;
 };
-CCLayerWs carve_cc_layer_ws(Carver& c, long long R, int Tc) {
+CCLayerWs carve_cc_layer_ws(Carver& c, long long R, int Tc, int Q) {
   CCLayerWs w;
-  w.tw = carve_traj_ws(c, R, Tc, 8);
+  w.tw = carve_traj_ws(c, R, Tc, 8, false, padded_rows(R, Q));      // (Tube-Link: 100 queries per clip -> frames of 112 rows)
   w.t1 = c.take<float>((size_t)R * 256);
   w.t2 = c.take<float>((size_t)R * 256);
   w.y = c.take<float>((size_t)R * 256);
@@ -810,7 +830,7 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   CCLayerPacked p = carve_cc_layer(pc);
   const long long R = (long long)B * Q * Tc;
   Carver wc(ws);
-  CCLayerWs w = carve_cc_layer_ws(wc, R, Tc);
+  CCLayerWs w = carve_cc_layer_ws(wc, R, Tc, Q);
   g_prof_next = 0;
   mark(st, "begin");
   // trajectory attention over (t q) tokens of each video, read in place from [B,Q,Tc,C]:  row (b; t,q) -> b*Q*Tc + q*Tc + t
@@ -1290,7 +1310,7 @@ int axvs_axial_layer_pack(const AxvsAxialLayerParams* p, void* packed, int C, in
 
 size_t axvs_traj_attn_workspace_bytes(int S, int T, int L, int C, int heads) {
   Carver c(nullptr);
-  carve_traj_ws(c, (long long)S * T * L, T, heads);
+  carve_traj_ws(c, (long long)S * T * L, T, heads, false, padded_rows((long long)S * T * L, L));
   c.take<float>((size_t)S * T * L * C);
   return c.off;
 }
@@ -1315,7 +1335,7 @@ static size_t layer_ws_bytes(int B, int T, int H, int W, int C, int heads, int d
   const long long M = (long long)B * T * H * W;
   Carver c(nullptr);
   const LayerPlan plan = plan_layer(B, T, H, W, C, heads, d_ffn, want_attn_maps != 0);
-  carve_traj_ws(c, M, T, heads, plan.lean_traj);
+  carve_traj_ws(c, M, T, heads, plan.lean_traj, std::max(padded_rows(M, H), padded_rows(M, W)));
   if (plan.fuse_qkv) carve_traj_ws(c, M, T, heads, true);
   c.take<float>((size_t)span * C);
   if (plan.need_buf2) c.take<float>((size_t)span * C);
@@ -1448,7 +1468,7 @@ int axvs_traj_layer_pack(const AxvsTrajLayerParams* p, void* packed, int C, int 
 size_t axvs_traj_layer_workspace_bytes(int B, int T, int HW, int C, int heads, int d_ffn) {
   const long long M = (long long)B * T * HW;
   Carver c(nullptr);
-  carve_traj_ws(c, M, T, heads);
+  carve_traj_ws(c, M, T, heads, false, padded_rows(M, HW));
   c.take<float>((size_t)M * C);
   c.take<float>((size_t)M * C);
   c.take<u16>((size_t)M * C);
@@ -1533,7 +1553,7 @@ int axvs_cc_layer_pack(const AxvsCCLayerParams* p, void* packed, int dtype, void
 
 size_t axvs_cc_layer_workspace_bytes(int B, int Q, int Tc) {
   Carver c(nullptr);
-  carve_cc_layer_ws(c, (long long)B * Q * Tc, Tc);
+  carve_cc_layer_ws(c, (long long)B * Q * Tc, Tc, Q);
   return c.off;
 }
 

@@ -85,16 +85,29 @@ __device__ __forceinline__ u16x4 cvt4(f32x4 v) {
 //   nat = b*sB + t*sT + l*sL + o*sO           (rows; multiply by C for elements)
 // height pass: L=H, Loff=W, sL=W, sO=1.  width pass: L=W, Loff=H, sL=1, sO=W.
 // identity ([S,N,C] input): Loff=1, sB=N, sT=L, sL=1, sO=0.
+// PADDED FRAMES (round 5; the fused trajectory tier only): a frame whose length is not a multiple of 16 (the shipped VIPSeg maps:
+// 49 x 85, 25 x 43) occupies L = roundup16(Lv) rows of the sequence-order row space, of which the first Lv exist; rows l >= Lv are
+// clamped copies of row Lv - 1 that are computed and never stored (like the rows past a sequence's end).  Every frame then starts at
+// a multiple of 16 rows, so a 16-row MFMA tile never straddles two frames: K rows and V^T fragments are stored 16 / 8 bytes per lane
+// for ANY frame length, and the row tiles of a pass can hand K / V^T over inside one launch.  Lv == 0: every row exists (L = Lv).
 struct RowMap {
   int N, L, Loff;
   long long sB, sT, sL, sO;
+  int Lv;
 };
 
 __device__ __forceinline__ long long nat_row(const RowMap& rm, int mp) {
   int s = mp / rm.N, n = mp - s * rm.N;
   int b = s / rm.Loff, o = s - b * rm.Loff;
   int t = n / rm.L, l = n - t * rm.L;
+  if (rm.Lv) l = min(l, rm.Lv - 1);
   return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
+}
+// does sequence-order row mp exist (padded frames: rows l >= Lv of a frame do not)?
+__device__ __forceinline__ bool row_exists(const RowMap& rm, int mp) {
+  if (!rm.Lv) return true;
+  const int n = mp % rm.N;
+  return n % rm.L < rm.Lv;
 }
 
 // Rows of a [frames, hw, C] tensor whose frames are `hw + extra` rows apart (a level of the pixel decoder's concatenated token
@@ -150,6 +163,7 @@ __device__ __forceinline__ long long nat_row_coords(const RowMap& rm, int mp, in
   int s = mp / rm.N, n = mp - s * rm.N;
   int b = s / rm.Loff, o = s - b * rm.Loff;
   int t = n / rm.L, l = n - t * rm.L;
+  if (rm.Lv) l = min(l, rm.Lv - 1);
   *packed = t | ((l_is_h ? l : o) << 8) | ((l_is_h ? o : l) << 20);
   return b * rm.sB + t * rm.sT + l * rm.sL + o * rm.sO;
 }

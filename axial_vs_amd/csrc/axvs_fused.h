@@ -11,6 +11,12 @@
 
 #include "axvs_common.h"
 
+// The width-pass kernel's FFN half: 1 = wave-specialised body (ffn_body_ws: linear1 and linear2 on different waves, round 5);
+// 0 = the lockstep body of rounds 1-4 (ffn_body).  Same bits either way; a build switch for same-box A/B runs (tools/ab_variants.py).
+#ifndef AXVS_FFN_WS
+#define AXVS_FFN_WS 1
+#endif
+
 namespace axvs {
 
 constexpr int kRows = 64;                       // token rows per workgroup
@@ -325,6 +331,220 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
   FSTAMP_FLUSH(13);
 }
 
+// =====================================================================================================
+// The same norm1 -> FFN -> norm2 with the two GEMMs on DIFFERENT waves (round 5, "wave-specialised"; used by the width-pass kernel).
+// ffn_body above runs all 8 waves in lockstep: linear1 phase (matrix pipe), activation epilogue (VALU, pipe idle), barrier, linear2
+// phase, barrier -- per 256-unit chunk; its stamps (profiles/r4_phase_timeline_merged.json) put 4 x (1.3 k epilogue + barriers) and
+// ~6 k of weight stalls beside 16.4 k cycles of MFMA work.  Here waves 0-3 ("A") only ever run linear1 -- 64 hidden units of the chunk
+// each, all 64 rows -- and waves 4-7 ("B") only ever run linear2 -- 64 output channels each -- one chunk behind, through a two-slot h
+// ring in LDS: step s = { A: linear1(chunk s) -> ReLU -> h[s];  B: linear2(chunk s - 1) from h[s - 1] }, ONE barrier per step.  A SIMD
+// hosts one A and one B wave (waves w and w + 4), so A's activation epilogue runs beside B's MFMAs, and each wave streams ONE weight
+// matrix continuously through a 4-k-step ring of fragments (W1 rows for A, W2 rows for B: the same bytes per CU as before).
+// The fp32 residual y does not fit LDS beside two h slots: A's waves carry it in registers (their 64 channels x 64 rows, the
+// accumulator layout; A has no long-lived accumulators) from a staging tile written by norm1, and hand it back for norm2.
+// Same MFMA sequence per output element as ffn_body (k-blocks in order; the chunk partials `part` summed in chunk order): the SAME
+// BITS, so the row count may still decide which FFN kernel runs.
+// LDS: ytile 32 KiB | stage 65 KiB fp32 (its first 32 KiB double as h slot 1) | h slot 0 32 KiB  -- the footprint of ffn_body.
+// =====================================================================================================
+struct FfnLdsWs {
+  u16* ytile;     // [8][64][32] 16-bit y = norm1(x): B operand of linear1
+  float* stage;   // [64][kEpiLd] fp32: y on its way to A's registers, later y + linear2 + b2 on its way to norm2
+  u16* h0;        // [8][64][32] h ring slot 0; slot 1 = (u16*)stage
+  float* par;     // b1[F] | b2 | g1 | be1 | g2 | be2
+};
+
+template <bool BF, class RowOff>
+__device__ __forceinline__ void ffn_body_ws(const FfnLdsWs& l, const u16* __restrict__ W1, const u16* __restrict__ W2,
+                                            float* __restrict__ out, RowOff row_off, int F, int tid, int wt, const NoRows& pre) {
+  constexpr int C = 256;
+  const int lane = tid & 63, fi = lane & 15, fg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (SGPR): fragment addresses split into s[base] + lane (w_frag_u)
+  const bool isA = wave < 4;              // waves w and w + 4 sit on the same SIMD: one producer, one consumer each
+  const int wq = wave & 3;                // my block of 64 hidden units (A) / 64 output channels (B)
+  const float* sb1 = l.par;
+  const float* sb2 = l.par + F;
+  const float *sg1 = sb2 + C, *sbe1 = sb2 + 2 * C, *sg2 = sb2 + 3 * C, *sbe2 = sb2 + 4 * C;
+  const int nchunk = F / 256, G = nchunk * 8;      // k-steps of my GEMM over all chunks
+  u16* const h1 = reinterpret_cast<u16*>(l.stage);
+  // chunk c -> h slot: the LAST chunk uses slot 0, so that `stage` (= slot 1) is free again while B still reads the last chunk
+  auto hslot = [&](int c) { return ((nchunk - 1 - c) & 1) ? h1 : l.h0; };
+  FSTAMP_DECL;
+  FSTAMP(0);
+
+  // my fragment of k-step g (chunk g / 8, k-block g % 8), 16-row block nt of my 64 rows of the weight matrix
+  auto wfrag = [&](int g, int nt) {
+    g = min(g, G - 1);                     // (the ring's last refills re-load the last k-step: branch-free vmcnt bookkeeping)
+    const int c = g >> 3, kb = g & 7;
+    // everything but the lane is wave-uniform: `global_load_dwordx4 v, v_lane16, s[base]` -- ONE address VGPR for the whole ring (per-lane
+    // 64-bit fragment pointers get hoisted out of the step loop by LICM, 32 pairs of them, and spill this 256-VGPR kernel)
+    const u16* const Wm = isA ? W1 : W2;
+    const int NR = isA ? F : C, kbg = isA ? kb : c * 8 + kb, row16 = (isA ? c * 256 : 0) + wq * 64 + nt * 16;
+    return w_frag_u(Wm, NR, kbg, row16, lane);
+  };
+  u16x8 ring[4][4];                        // [k-step slot][nt]: 4 k-steps of fragments in flight
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) ring[sl][nt] = wfrag(sl, nt);
+
+  // ---- norm1, row-wise (all 8 waves, 8 rows each, rows handed over in registers): y fp32 -> stage, y 16-bit -> ytile ----
+  {
+    const float4 gg = *reinterpret_cast<const float4*>(sg1 + lane * 4), bb = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr;
+      const float4 v = pre.v[rr];
+      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+      const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+      const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
+      const f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
+      *reinterpret_cast<float4*>(l.stage + r * kEpiLd + lane * 4) = float4{y[0], y[1], y[2], y[3]};
+      act_store4<BF>(l.ytile, lane * 4, r, y);
+      if (rr == 3) lds_fence();
+    }
+  }
+  FSTAMP(1);
+  __syncthreads();
+  FSTAMP(2);
+  // ---- A: my 64 channels of y, all 64 rows, into registers (accumulator layout: channel 64 wq + 16 nt + 4 fg + r, row 16 mt + fi);
+  //      B: its running sum over the chunks.  ONE register array for both roles (`keep`), and one for the GEMM phase's accumulators
+  //      (`acc`: linear1 of a chunk for A, the chunk's linear2 partial for B): the roles differ in addresses, not in registers ----
+  f32x4 keep[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      keep[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (isA) {
+        const float4 t = *reinterpret_cast<const float4*>(l.stage + (mt * 16 + fi) * kEpiLd + wq * 64 + nt * 16 + fg * 4);
+        keep[nt][mt] = f32x4{t.x, t.y, t.z, t.w};
+      }
+    }
+    if (nt & 1) lds_fence();               // <= 8 LDS reads in flight (4-bit lgkmcnt)
+  }
+  __syncthreads();                         // every A wave holds its y: h slot 1 (inside `stage`) may be written
+  FSTAMP(3);
+
+  for (int s = 0; s <= nchunk; ++s) {
+    // A: linear1 of chunk s (B operand: the y tile) while s < nchunk;  B: linear2 of chunk s - 1 (B operand: its h slot) while s > 0
+    const bool active = isA ? s < nchunk : s > 0;
+    const int cs = isA ? s : s - 1;        // my chunk of this step
+    if (active) {
+      const u16* const tile = isA ? l.ytile : hslot(cs);
+      const int g0 = cs * 8;
+      f32x4 acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {   // one GEMM phase of 8 k-steps: acc[nt][mt] += ring(g0 + j)[nt] . B(tile, k-block j); slot j & 3 is refilled with k-step g0 + j + 4.
+          // Row tiles outermost: B fragment mt is dead after its 4 MFMAs and is re-loaded for the next k-step at once (12 MFMAs ahead of
+          // its next use; ONE set of 4 B fragments, no second buffer: the kernel sits at 256 VGPRs); the ring slot's 4 fragments are
+          // refilled behind their last use, between the MFMAs of the last row tile.
+        u16x8 bf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) bf[mt] = act_frag(tile, 0, mt, fi, fg);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              acc[nt][mt] = H16<BF>::mfma(ring[j & 3][nt], bf[mt], acc[nt][mt]);
+              if (mt == 3) ring[j & 3][nt] = wfrag(g0 + j + 4, nt);
+            }
+            if (j + 1 < 8) bf[mt] = act_frag(tile, j + 1, mt, fi, fg);
+            __builtin_amdgcn_sched_barrier(0);   // keeps the loads where they are: spread between the MFMAs, <= 4 LDS reads in flight
+          }
+        }
+      }
+      if (isA) {
+        // ---- + b1, ReLU -> h slot of chunk s (chunk-local hidden index 64 wq + ...) ----
+        u16* const hb = hslot(cs);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float4 bias = *reinterpret_cast<const float4*>(sb1 + cs * 256 + wq * 64 + nt * 16 + fg * 4);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            f32x4 v = acc[nt][mt];
+            v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
+            v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+            act_store4<BF>(hb, wq * 64 + nt * 16 + fg * 4, mt * 16 + fi, v);
+          }
+          lds_fence();
+        }
+      } else {
+        // ---- the chunk's partial (from zero) added to the running sum: the ordered sum of per-chunk partials that ffn_body and
+        //      ffn_split_kernel + ffn_finish_kernel produce, bit for bit ----
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) keep[a][b] = cs == 0 ? acc[a][b] : keep[a][b] + acc[a][b];
+      }
+    } else if (isA) {
+      // ---- last step (B still runs linear2 of the last chunk, from slot 0): y back into `stage`, accumulator layout ----
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) epi_put(l.stage, mt * 16 + fi, wq * 64 + nt * 16 + fg * 4, keep[nt][mt]);
+        lds_fence();
+      }
+    }
+    if (s == 0) FSTAMP(4);
+    if (s == 1) FSTAMP(5);
+    if (s == 2) FSTAMP(6);
+    if (s == 3) FSTAMP(7);
+    __syncthreads();
+    if (s == 0) FSTAMP(8);
+  }
+  FSTAMP(9);
+  // ---- B: stage (= y) += linear2 + b2, accumulator layout; then norm2 per whole row (all 8 waves) and one 1-KiB store per row ----
+  if (!isA) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = wq * 64 + nt * 16 + fg * 4;
+      const float4 b = *reinterpret_cast<const float4*>(sb2 + n);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float* p = l.stage + (mt * 16 + fi) * kEpiLd + n;
+        const float4 y = *reinterpret_cast<const float4*>(p);
+        *reinterpret_cast<float4*>(p) = float4{y.x + keep[nt][mt][0] + b.x, y.y + keep[nt][mt][1] + b.y, y.z + keep[nt][mt][2] + b.z,
+                                               y.w + keep[nt][mt][3] + b.w};
+      }
+      lds_fence();
+    }
+  }
+  FSTAMP(10);
+  __syncthreads();
+  FSTAMP(11);
+  {
+    const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i;
+      const float4 v = *reinterpret_cast<const float4*>(l.stage + r * kEpiLd + lane * 4);
+      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+      const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+      const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
+      const long long off = row_off(r);
+      if (off >= 0) {
+        const float4 y = float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
+        if (wt & kOut16Mask) {
+          const f32x4 yv = {y.x, y.y, y.z, y.w};
+          const u16x4 h = (wt & kOutBf16) ? cvt4<true>(yv) : cvt4<false>(yv);
+          u16* o16 = reinterpret_cast<u16*>(out);
+          if (wt & 1) WtBuf(o16).store8((unsigned)((off + lane * 4) * 2), h);
+          else *reinterpret_cast<u16x4*>(o16 + off + lane * 4) = h;
+        } else if (wt & 1) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);
+        else *reinterpret_cast<float4*>(out + off + lane * 4) = y;
+      }
+      if (i == 3) lds_fence();
+    }
+  }
+  FSTAMP(12);
+  FSTAMP_FLUSH(13);
+}
+
 constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kTileElems * sizeof(u16);   // x | y | h
 inline size_t ffn_lds_bytes(int F) { return kFfnTiles + (size_t)(F + 5 * 256) * sizeof(float); }
 
@@ -548,6 +768,8 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     nvalid = (int)min((long long)ROWS, Mp - m0);
   }
 
+  // padded frames (RowMap): L is the frame length of the row space (a multiple of 16), Lr the number of keys / rows that exist
+  [[maybe_unused]] const int Lr = rm.Lv ? rm.Lv : L;
   AXVS_STAMP_DECL;
   AXVS_STAMP(0);
   // biases (and the FFN half's parameters) -> LDS
@@ -795,7 +1017,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       __syncthreads();                           // every wave is done with the operand tiles: the x tile may be written
 #pragma unroll
       for (int kt = 0; kt < 2 * NKS; ++kt)
-        kvo[kt] = (unsigned)((((long long)wave * Mp + seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8) * 2);
+        kvo[kt] = (unsigned)((((long long)wave * Mp + seq0 + min(kt * 16 + fi, Lr - 1)) * 32 + fg * 8) * 2);
       vvo = (unsigned)((((long long)wave * nsf + seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8) * 2);
       if constexpr (MQ == 1) {
         wait_siblings();
@@ -807,7 +1029,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
     for (int qt = 0; qt < MT; ++qt) qf[qt] = *reinterpret_cast<const u16x8*>(Qh + (m0 + min(qt * 16 + fi, nvalid - 1)) * 32 + fg * 8);
     }
-    const bool ragged = L != NKS * 32;
+    const bool ragged = Lr != NKS * 32;
     u16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = H16<BF>::from_f32(1.f);
@@ -815,7 +1037,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     // frame slot sf = seq0 / L + f because N = T * L)
     const u16* kp[2 * NKS];
 #pragma unroll
-    for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] = Kh + (seq0 + min(kt * 16 + fi, L - 1)) * 32 + fg * 8;
+    for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] = Kh + (seq0 + min(kt * 16 + fi, Lr - 1)) * 32 + fg * 8;
     const u16* vp = Vh + (seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8;
     const int kstep = L * 32;
     // VROW: the frame's V rows go global -> registers -> the wave's own block [f][wave] of the x tile (free until the frame's x is
@@ -917,7 +1139,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int kt = 0; kt < 2 * NKS; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kt * 16 + fg * 4 + r >= L) {
+            if (kt * 16 + fg * 4 + r >= Lr) {
 #pragma unroll
               for (int qt = 0; qt < MT; ++qt) sc[qt][kt][r] = -INFINITY;
             }
@@ -1268,11 +1490,16 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // RowMap arithmetic (integer divisions) once per wave, lane i computing row i of the wave's RPW rows, then broadcast with
   // v_readlane -- instead of RPW unrolled copies of the same ~75-instruction sequence
   int rcoords = 0;                                  // QKVN: (t, h, w) of the wave's row (lane % RPW), packed (nat_row_coords)
+  [[maybe_unused]] int roff_lo = 0, roff_hi = 0;    // element offset of row (lane % RPW) of this wave, as two words (re-read with v_readlane)
+  unsigned rok;                                     // bit i: row i of this wave exists (inside its sequence, not a padding row of its frame) -> stored
   {
     const int myrow = wave * RPW + (lane % RPW);
     const int mym = (int)m0 + min(myrow, nvalid - 1);
+    rok = (unsigned)__builtin_amdgcn_ballot_w64(myrow < nvalid && row_exists(rm, mym)) & ((1u << RPW) - 1u);
     const long long myoff = (QKVN ? nat_row_coords(rm, mym, nq.pg.l_is_h, &rcoords) : nat_row(rm, mym)) * C;
     const int lo = (int)(myoff & 0xffffffffll), hi = (int)(myoff >> 32);
+    roff_lo = lo;
+    roff_hi = hi;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const long long o = ((long long)__builtin_amdgcn_readlane(hi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, i);
@@ -1282,7 +1509,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   // with the FFN half following, the sweep leaves the first linear1 fragment set behind
   constexpr int crot = 0;                          // fixed chunk order: results do not depend on the tile index (see ffn_fused_kernel)
+#if AXVS_FFN_WS
+  if constexpr (FFN) sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);      // (ffn_body_ws fetches its own fragment ring)
+#else
   if constexpr (FFN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, fa.W1, fa.F, crot * 256 + wave * 32, fi, fg);
+#endif
   else if constexpr (QKVN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, nq.Wq, C, wave * 32, fi, fg);       // leaves the next pass's Wq rows of my head behind
   else sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
   AXVS_STAMP(7);
@@ -1337,7 +1568,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       }
     }
     if constexpr (FFN) yrows.v[i] = y;             // stays on the CU: input row of the FFN half, handed to its norm1 in registers
-    else if (row < nvalid) {
+    else if ((rok >> i) & 1u) {
       if (wt & 1) WtBuf(out).store16((unsigned)(roff[i] * 4), y);
       else *reinterpret_cast<float4*>(out + roff[i]) = y;
     }
@@ -1400,8 +1631,21 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   if constexpr (FFN) {
     static_assert(RPW == 8, "the FFN half walks 8 rows per wave");
-    auto row_off_ = [=](int row) { return row < nvalid ? roff[row % RPW] - lane * 4 : -1ll; };       // rows of this wave
+#if AXVS_FFN_WS
+    // (row offsets re-assembled from the two lane-indexed words when norm2 stores: 2 VGPRs alive across the FFN half instead of 16)
+    auto row_off_ = [=](int row) {
+      const int i = row % RPW;
+      return ((rok >> i) & 1u) ? (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(roff_hi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(roff_lo, i)) : -1ll;
+    };
+#else
+    auto row_off_ = [=](int row) { return ((rok >> (row % RPW)) & 1u) ? roff[row % RPW] - lane * 4 : -1ll; };       // rows of this wave
+#endif
+#if AXVS_FFN_WS
+    const FfnLdsWs fw{fl.ytile, fl.xtile, fl.htile, fl.par};       // y tile | fp32 stage (= h slot 1) | h slot 0: ffn_body's footprint
+    ffn_body_ws<BF, decltype(row_off_)>(fw, fa.W1, fa.W2, out, row_off_, fa.F, tid, wt, yrows);
+#else
     ffn_body<BF, decltype(row_off_), false, true>(fl, wf, fa.W1, fa.W2, out, row_off_, fa.F, 0, crot, tid, wt, yrows);
+#endif
   }
   AXVS_STAMP(10);
 #if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)

@@ -47,16 +47,19 @@ def default_operand_dtype() -> str:
 # plumbing
 # ---------------------------------------------------------------------------------------------
 _workspaces: Dict[Tuple[str, int], Tensor] = {}
+_sync_tls = threading.local()       # per calling thread: which sync words / status word the library holds, graph-construction overrides
 
 
 def _workspace(device: torch.device, nbytes: int, stream_handle: Optional[int] = None) -> Tensor:
     """Grow-only scratch buffer per (device, stream) from torch's caching allocator.  `stream_handle`: the current stream's handle
     when the caller has it already (torch.cuda.current_stream costs ~4 us per call)."""
     key = (str(device), stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream)
-    buf = _workspaces.get(key)
+    ov = getattr(_sync_tls, "override", None)
+    store = _workspaces if ov is None else ov["ws"]      # a graph under construction owns its scratch (GraphedForward): graphs captured on
+    buf = store.get(key)                                 # torch's shared capture stream must not bake one common workspace in
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
+        store[key] = buf
     return buf
 
 
@@ -69,7 +72,6 @@ def _stream(device: torch.device) -> int:
 # side by side) -- registered with the library per calling thread, re-registered only when the (device, stream) changes.
 _SYNC_WORDS = 16384
 _sync_buffers: Dict[Tuple[int, int], Tensor] = {}
-_sync_tls = threading.local()
 
 
 def _select_sync_words(device: torch.device, stream_handle: Optional[int] = None) -> None:
@@ -898,7 +900,8 @@ class GraphedForward:
         torch.cuda.synchronize(dev)
         prev_override = getattr(_sync_tls, "override", None)
         # (warm-up and capture run on different streams: each gets its own set; sets left in the pool are simply kept)
-        _sync_tls.override = {"pool": list(self._sync), "map": {}}
+        self._ws: Dict[Tuple[str, int], Tensor] = {}        # ... and its scratch buffers (replays of different graphs may overlap in time)
+        _sync_tls.override = {"pool": list(self._sync), "map": {}, "ws": self._ws}
         try:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -907,19 +910,12 @@ class GraphedForward:
                     module(*self.inputs)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            before = set(_workspaces)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = module(*self.inputs)
         finally:
             _sync_tls.override = prev_override
             _sync_tls.key = None                          # the next eager call registers its own (device, stream) words again
-        # scratch buffers allocated on the capture stream belong to this graph (its private pool): they go with it
-        self._ws_keys = [k for k in _workspaces if k not in before]
-
-    def __del__(self):
-        for k in getattr(self, "_ws_keys", ()):
-            _workspaces.pop(k, None)
 
     def __call__(self, *inputs: Tensor):
         for dst, src in zip(self.inputs, inputs):

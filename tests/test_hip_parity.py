@@ -320,7 +320,13 @@ def test_ragged_axis_lengths_take_the_fused_tier(shape):
     names = _stage_names()
     # the FFN rides in the width-pass kernel when that kernel has >= 128 row tiles (half the chip); below that it is its own launch
     ffn_rides = T <= 4 and B * T * H * W >= 128 * 64
-    assert "h.traj_fused" in names and ("w.traj_fused+ffn" in names if ffn_rides else "w.traj_fused" in names), names
+    # (round 5: frames are padded to multiples of 16 rows in the q/k/v row space, so ragged shapes with T <= 4 on 64-row tiles also
+    #  take ONE launch per pass -- "h.qkv+traj" / "w.qkv+traj[+ffn]" -- where they used to take "h.qkv_proj" + "h.traj_fused")
+    assert "h.traj_fused" in names or "h.qkv+traj" in names, names
+    if ffn_rides:
+        assert "w.traj_fused+ffn" in names or "w.qkv+traj+ffn" in names, names
+    else:
+        assert "w.traj_fused" in names or "w.qkv+traj" in names, names
     assert not any("spatial_attn" in n for n in names), names
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
     print(f"{shape}: {names[1:]} max/max {e:.2e} relL2 {e2:.2e}")
@@ -1728,3 +1734,57 @@ def test_layer_writes_its_output_map_in_16_bits(shape):
             assert torch.equal(got, full.to(dt)), (shape, dt, float((got.float() - full).abs().max()))
         again = layer(src, pos)[0]
         assert again.dtype == torch.float32 and torch.equal(again, full)
+
+
+# ---- round 5: padded frames -- any frame length gets 16-byte K / 8-byte V^T stores and the merged launch --------------------------------
+RAGGED_MERGE_SHAPES = [(1, 2, 256, 49, 85, 1024),     # shipped VIPSeg res4 level (T = 2): 49 -> 64 rows per frame (a tile IS a frame: MQ = 2), 85 -> 96
+                       (1, 4, 256, 49, 85, 1024),
+                       (2, 2, 256, 25, 43, 1024),     # res5 level: 16-row tiles (two-launch form by default: merge_small is off)
+                       (1, 3, 256, 17, 127, 512),     # 17 -> 32 (15 padding rows per frame), 127 -> 128 keys: the widest fused frame
+                       (2, 4, 256, 23, 40, 1024),
+                       (1, 4, 256, 33, 70, 1024)]     # 33 -> 48: a frame of 2 full key tiles + 1 key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", RAGGED_MERGE_SHAPES)
+def test_ragged_frames_in_the_padded_row_space(shape):
+    """WC/temporal_attention.py:197-213 on the map sizes the shipped configs produce (49 x 85, 25 x 43: WC/msdeformattn.py:248-266).
+    Frames are padded to a multiple of 16 rows in the q/k/v row space (RowMap::Lv): padding rows are clamped copies, computed and
+    never stored, padding keys are masked.  Checks: <= 1e-3 of the float64 oracle; the merged and the two-launch form give the same
+    bits; a clip's result does not depend on its batch (bit-exact); repeated calls are bit-identical; the arrival counters are zero."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib, modules
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 71)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 71)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    s = dev(src)
+    pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
+    L = _lib.lib()
+    for pos_d in (dev(pos), pg):
+        one = layer(s, pos_d)[0].clone()
+        names_one = _stage_names()
+        _lib.check(L.axvs_set_option(b"no_merge_qkv", 1), "axvs_set_option")
+        try:
+            two = layer(s, pos_d)[0].clone()
+            names_two = _stage_names()
+        finally:
+            L.axvs_set_option(b"no_merge_qkv", 0)
+        assert torch.equal(one, two), (shape, names_one, names_two)
+        assert torch.equal(one, layer(s, pos_d)[0])
+        e, e2 = rel_err(one.cpu(), ref), rel_l2(one.cpu(), ref)
+        assert e < TOL_F16 and e2 < TOL_F16, (shape, e, e2)
+    print(f"{shape}: {names_two[1:]} -> {names_one[1:]}  max/max {e:.2e}")
+    assert not any("spatial_attn" in n for n in names_one), names_one
+    if B * T * H * W >= 128 * 64 and T <= 4:          # 64-row tiles: one launch per pass for any frame length
+        assert "h.qkv+traj" in names_one and any(n.startswith("w.qkv+traj") for n in names_one), names_one
+    if B > 1:                                          # batch sharding stays bit-exact
+        alone = layer(s[:T].contiguous(), pg[:1].contiguous() if False else ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(1, T, H, W, "cuda"))[0]
+        assert torch.equal(alone, layer(s, pg)[0][:T])
+    torch.cuda.synchronize()
+    ax.check_status()
+    for buf in modules._sync_buffers.values():
+        assert int(buf.abs().sum()) == 0
