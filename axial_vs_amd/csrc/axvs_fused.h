@@ -11,10 +11,16 @@
 
 #include "axvs_common.h"
 
-// The width-pass kernel's FFN half: 1 = wave-specialised body (ffn_body_ws: linear1 and linear2 on different waves, round 5);
-// 0 = the lockstep body of rounds 1-4 (ffn_body).  Same bits either way; a build switch for same-box A/B runs (tools/ab_variants.py).
+// The width-pass kernel's FFN half: 0 (shipped) = the lockstep body of rounds 1-4 (ffn_body); 1 = the wave-specialised body of round 5
+// (ffn_body_ws: linear1 and linear2 on different waves).  Same bits either way; a build switch for same-box A/B runs
+// (tools/ab_variants.py).  MEASURED SLOWER (profiles/r5_ffn_wave_specialised.txt: width-pass kernel 57.1 -> 60.2 us, config 5's share
+// +4 %): the FFN half is bound by the per-CU L2 -> register weight stream (~ 35 B/clk), not by the MFMA / VALU alternation the
+// specialisation removes, and the two-stage pipeline adds a fill and a drain step during which only half the waves stream.
 #ifndef AXVS_FFN_WS
-#define AXVS_FFN_WS 1
+#define AXVS_FFN_WS 0
+#endif
+#ifndef AXVS_WS_PRIO      // s_setprio level of the linear1 waves during their MFMA phases (0: none)
+#define AXVS_WS_PRIO 2
 #endif
 
 namespace axvs {
@@ -441,6 +447,12 @@ __device__ __forceinline__ void ffn_body_ws(const FfnLdsWs& l, const u16* __rest
           // Row tiles outermost: B fragment mt is dead after its 4 MFMAs and is re-loaded for the next k-step at once (12 MFMAs ahead of
           // its next use; ONE set of 4 B fragments, no second buffer: the kernel sits at 256 VGPRs); the ring slot's 4 fragments are
           // refilled behind their last use, between the MFMAs of the last row tile.
+        // A's MFMAs first: the two waves of a SIMD share its matrix pipe; at equal priority A and B would finish their phases together and
+        // A's activation epilogue would follow with the pipe idle (measured: the lockstep body's time again, + 3 us).  With A ahead, its
+        // epilogue runs beside the second half of B's MFMAs.
+#if AXVS_WS_PRIO
+        if (isA) __builtin_amdgcn_s_setprio(AXVS_WS_PRIO);
+#endif
         u16x8 bf[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) bf[mt] = act_frag(tile, 0, mt, fi, fg);
@@ -458,6 +470,9 @@ __device__ __forceinline__ void ffn_body_ws(const FfnLdsWs& l, const u16* __rest
           }
         }
       }
+#if AXVS_WS_PRIO
+      if (isA) __builtin_amdgcn_s_setprio(0);
+#endif
       if (isA) {
         // ---- + b1, ReLU -> h slot of chunk s (chunk-local hidden index 64 wq + ...) ----
         u16* const hb = hslot(cs);
