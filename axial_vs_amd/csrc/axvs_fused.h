@@ -79,10 +79,12 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[NT][MT], const u16x8 (&w
 
 // Same, but while computing with `wf` it also issues the loads of the NEXT phase's fragments, NT per k-step, so the
 // 1-KiB weight loads are spread between the MFMAs instead of arriving as one burst that backs up the address path.
-template <bool BF, int NT, int MT, int KB, int NTN>
+struct NoKStamps {};
+struct KStamps8 { unsigned long long t[8]; };
+template <bool BF, int NT, int MT, int KB, int NTN, class KS = NoKStamps>
 __device__ __forceinline__ void gemm_phase_pf(f32x4 (&acc)[NT][MT], const u16x8 (&wf)[NT][KB], const u16* tile, int fi, int fg,
                                               int rot, u16x8 (&wnext)[NTN][KB], const u16* __restrict__ Wn, int NRn, int kb0n,
-                                              int nrow0n, int rotn) {
+                                              int nrow0n, int rotn, [[maybe_unused]] KS* ks = nullptr /* diagnostic: per-k-step stamps */) {
   u16x8 bcur[MT], bnxt[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) bcur[mt] = act_frag(tile, rot & (KB - 1), mt, fi, fg);
@@ -101,6 +103,12 @@ __device__ __forceinline__ void gemm_phase_pf(f32x4 (&acc)[NT][MT], const u16x8 
       for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], bcur[mt], acc[nt][mt]);
     // one k-step of B fragments ahead, never more: keeps the LDS reads in flight far below the 4-bit lgkmcnt limit
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!std::is_same<KS, NoKStamps>::value) {
+      if (ks) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ks->t[j])::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) bcur[mt] = bnxt[mt];
   }
@@ -239,8 +247,14 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
+  KStamps8 kst1{}, kst2{};
+#endif
   for (int ci = 0; ci < nchunk; ++ci) {
     const int c = (ci + crot) % nchunk;                 // hidden-unit chunk handled in this iteration
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
+    if (ci == AXVS_STAMPS_FFNK) { FSTAMP(14); }
+#endif
     const int cn = (min(ci + 1, nchunk - 1) + crot) % nchunk;
     // ---- linear1 + ReLU: my 32 hidden units of the chunk, all 64 rows; meanwhile fetch this chunk's linear2 fragments ----
     f32x4 acc1[2][4];
@@ -248,7 +262,11 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
+    gemm_phase_pf<BF, 2, 4, KB, 2, KStamps8>(acc1, w1f, l.ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot, ci == AXVS_STAMPS_FFNK ? &kst1 : nullptr);
+#else
     gemm_phase_pf<BF, 2, 4, KB, 2>(acc1, w1f, l.ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot);
+#endif
     if (ci == 0) FSTAMP(3);
     if (ci > 0) __syncthreads();                         // every wave is done reading the previous chunk's h
 #pragma unroll
@@ -281,11 +299,16 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) part[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
+    if (ci == AXVS_STAMPS_FFNK) { FSTAMP(13); }
+    gemm_phase_pf<BF, 2, 4, KB, 2, KStamps8>(part, w2f, l.htile, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot, ci == AXVS_STAMPS_FFNK ? &kst2 : nullptr);
+#else
     gemm_phase_pf<BF, 2, 4, KB, 2>(part, w2f, l.htile, fi, fg, rot, w1f, W1, F, 0, cn * 256 + wave * 32, rot);
+#endif
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc2[a][b] = ci == 0 ? part[a][b] : acc2[a][b] + part[a][b];
+        for (int b = 0; b < 4; ++b) acc2[a][b] = ci == 0 ? part[a][b] : acc2[a][b] + part[a][b];
     if (ci == 0) FSTAMP(6);
     if (ci == 1) FSTAMP(7);
     if (ci == 2) FSTAMP(8);
@@ -334,7 +357,14 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     }
   }
   FSTAMP(12);
-  FSTAMP_FLUSH(13);
+  FSTAMP_FLUSH(16);
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
+  if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)
+    for (int i_ = 0; i_ < 8; ++i_) {
+      ::axvs::g_stamps[(16 + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = kst1.t[i_];
+      ::axvs::g_stamps[(24 + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = kst2.t[i_];
+    }
+#endif
 }
 
 // =====================================================================================================
