@@ -45,6 +45,25 @@ struct H16<true> {
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 struct H2x4 { h16x2 v[4]; };
 
+// fp32-accumulated dot product of 8 packed 16-bit pairs: four v_dot2_f32_f16 (v_dot2_f32_bf16).  Used by the hybrid form of the temporal
+// logits (axvs_fused.h, AXVS_LOGITS_VALU_KB): some channel blocks on the VALU beside the MFMA diagonals of the others.
+template <bool BF>
+__device__ __forceinline__ float dot8_acc(u16x8 a, u16x8 x, float acc) {
+  if constexpr (!BF) {
+    const H2x4 as = __builtin_bit_cast(H2x4, a), xs = __builtin_bit_cast(H2x4, x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2(as.v[i], xs.v[i], acc, false);
+    return acc;
+  } else {
+    typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+    struct B2x4 { b16x2 v[4]; };
+    const B2x4 as = __builtin_bit_cast(B2x4, a), xs = __builtin_bit_cast(B2x4, x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(as.v[i], xs.v[i], acc, false);
+    return acc;
+  }
+}
+
 // acc (8 packed 16-bit values) += a * x.  fp16: four v_pk_fma_f16 (running sum kept in fp16: the result is an MFMA operand and
 // would be rounded to 16 bits anyway; T <= 5 terms).  bf16: fp32 math, rounded per call.
 template <bool BF>

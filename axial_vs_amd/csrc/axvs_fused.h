@@ -19,6 +19,11 @@
 #ifndef AXVS_FFN_WS
 #define AXVS_FFN_WS 0
 #endif
+// Temporal logits: mask of the channel blocks kb (kb & mask != 0) whose per-row dot products run on the VALU (v_dot2_f32_f16) instead of
+// as the diagonal of a 16 x 16 x 32 MFMA (round 4).  0 (shipped): all eight on the matrix pipe.
+#ifndef AXVS_LOGITS_VALU_KB
+#define AXVS_LOGITS_VALU_KB 0
+#endif
 #ifndef AXVS_WS_PRIO      // s_setprio level of the linear1 waves during their MFMA phases (0: none)
 #define AXVS_WS_PRIO 2
 #endif
@@ -1387,6 +1392,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     q2f[mt] = cvt8<BF>(v);
   }
   float lg[T][MT];
+#if AXVS_LOGITS_VALU_KB
+  float lgv[T][MT];                                         // hybrid: the channel blocks with (kb & AXVS_LOGITS_VALU_KB) on the VALU (v_dot2), per-lane partials
+#pragma unroll
+  for (int f = 0; f < T; ++f)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) lgv[f][mt] = 0.f;
+#endif
   f32x4 lacc[T][MT];                                        // MFMA tiles whose diagonals are the logits (see below)
 #pragma unroll
   for (int f = 0; f < T; ++f)
@@ -1422,8 +1434,21 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
             // replaced by 128 MFMAs; -1.9 us on the width-pass kernel, and no register spills any more)
           float v8[8] = {qk[0][mt][0], qk[0][mt][1], qk[0][mt][2], qk[0][mt][3], qk[1][mt][0], qk[1][mt][1], qk[1][mt][2], qk[1][mt][3]};
           const u16x8 ua = cvt8<BF>(v8);
+#if AXVS_LOGITS_VALU_KB
+          if (kb & AXVS_LOGITS_VALU_KB) {
+            // this lane's 8 channels of the block (the same 8 in `ua` and in the x fragment: perm32 order) for token fi; the 4 lanes
+            // (fi, fg = 0..3) of a token are summed once at the end.  The matrix pipe carries the other blocks' diagonals meanwhile.
+#pragma unroll
+            for (int f = 0; f < T; ++f) {
+              lgv[f][mt] = dot8_acc<BF>(ua, xg[g % (PD + 1)][f], lgv[f][mt]);
+              asm volatile("" : "+v"(lgv[f][mt]));          // stays HERE, beside this block's MFMAs (left alone, the dot products of all blocks
+            }                                               // collect behind the last MFMA and their x fragments spill)
+          } else
+#endif
+          {
 #pragma unroll
           for (int f = 0; f < T; ++f) lacc[f][mt] = H16<BF>::mfma(ua, xg[g % (PD + 1)][f], lacc[f][mt]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);                  // keeps the LDS reads of later groups from being hoisted (lgkmcnt)
       }
@@ -1440,6 +1465,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         const f32x4 a = lacc[f][mt];
         const float d = sel == 0 ? a[0] : sel == 1 ? a[1] : sel == 2 ? a[2] : a[3];
         lg[f][mt] = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(d)));
+#if AXVS_LOGITS_VALU_KB
+        lg[f][mt] += groups_sum(lgv[f][mt]);                // + the VALU blocks: sum over the token's 4 lanes (v_permlane16/32_swap)
+#endif
       }
   }
   AXVS_STAMP(3);
