@@ -67,6 +67,8 @@ thread_local int g_merge_small = 0;      // option "merge_small": 16-row-tile pr
 thread_local int g_out_dtype = 0;        // option "layer_out_dtype": 0 = the layer's output rows are fp32 (the reference's type); 1 / 2 = the kernel that ends the layer
                                          // (norm2 epilogue of the FFN) writes them as f16 / bf16 -- the map a batch-sharded caller gathers over the links
                                          // (BASELINE config 5 is worded "bf16"), written once instead of cast by a second pass
+thread_local int g_no_persist = 0;       // option "no_persist": merged launches beyond ~2 rounds of the chip fall back to two launches per pass instead of the
+                                         // persistent team grid (A/B, tests)
 thread_local int g_no_merge_qkv = 0;     // option "no_merge_qkv": keep qkv_fused_kernel + trajectory kernel as two launches (A/B, tests)
 thread_local int g_no_attn_fusion = 0;   // option "no_attn_fusion": keep spatial_attn_kernel + temporal kernel separate   // option "attn_waves": cap on waves per attention workgroup (tuning)
    // option "generic_only": 1 = always use the shape-generic v1 kernels
@@ -90,6 +92,20 @@ struct Carver {  // bump allocator over a caller-owned buffer
     return p;
   }
 };
+
+// CUs of the current device (the persistent merged launches run one workgroup per CU: their LDS footprint admits no second one)
+int cu_count() {
+  static thread_local int dev_seen = -1, cus = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != dev_seen) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    cus = pr.multiProcessorCount;
+    dev_seen = dev;
+  }
+  return cus;
+}
 
 int check_cfg(int C, int heads) {
   if (C <= 0 || heads <= 0 || C % heads != 0) return fail(AXVS_ERR_ARG, "C=%d must be a positive multiple of heads=%d", C, heads);
@@ -421,16 +437,31 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   // start staggered), cross-clip module 236.1 vs 237.3, BASELINE config 3 0.997 vs 0.989 ms -- off unless option "merge_small".
   const bool mt4 = traj_mt4(T, traj_tiles64(Mp, N), with_ffn);
   const bool own_frame = mt4 && L == 64 && T >= 2;
+  // Beyond ~2 rounds of the chip (frames other than 64 keys) the merged form can run as a PERSISTENT grid: one workgroup per CU, a whole
+  // number of teams of `tps` consecutive workgroups, every team walking one sequence per iteration -- the siblings of a hand-off start
+  // together at every size (round 5; BASELINE config 5's share: 4608 tiles per pass).  Frames of 33 .. 96 keys (NKS 2, 3).
+  // -DAXVS_WITH_PERSIST builds only: such grids keep running two launches per pass in the shipped library.
+  const long long tiles = traj_tiles64(Mp, N);
+  const int tps = (N + 63) / 64;
+  int persist_grid = 0;
+#ifdef AXVS_WITH_PERSIST      // built, bit-identical, and 24 % slower than two launches at config 5's share (the tile loop spills: profiles/r5_persistent_merged.txt)
+  if (mt4 && !own_frame && tiles > 640 && !g_merge_qkv_any && !g_no_persist && nks_fused >= 2 && nks_fused <= 3 && tps <= cu_count())
+    persist_grid = cu_count() / tps * tps;
+#endif
   const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv &&
                      g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= (mt4 ? 3 : 4) &&
                      2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
-                     (!mt4 || own_frame || traj_tiles64(Mp, N) <= 640 || g_merge_qkv_any) && (mt4 || g_merge_small);
+                     (!mt4 || own_frame || tiles <= 640 || g_merge_qkv_any || persist_grid > 0) && (mt4 || g_merge_small);
   if (merge) {
-    const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status, g_sync_spin_limit};
+    const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status, g_sync_spin_limit,
+                    persist_grid};
     int rc = launch_temporal<BF>(w, p, res, with_ffn ? ffn_out : out, rm, Mp, N, L, T, scale, st, nks_fused, with_ffn ? ffn : nullptr, 0, nullptr, &oq);
     if (rc != AXVS_OK) return rc;
     if (with_ffn) *ffn_done = true;
-    mark(st, with_ffn ? "w.qkv+traj+ffn" : pass == 1 ? "h.qkv+traj" : pass == 2 ? "w.qkv+traj" : "qkv+traj");
+    if (persist_grid > 0 && persist_grid < tiles)      // "/p": the persistent team grid
+      mark(st, with_ffn ? "w.qkv+traj+ffn/p" : pass == 1 ? "h.qkv+traj/p" : pass == 2 ? "w.qkv+traj/p" : "qkv+traj/p");
+    else
+      mark(st, with_ffn ? "w.qkv+traj+ffn" : pass == 1 ? "h.qkv+traj" : pass == 2 ? "w.qkv+traj" : "qkv+traj");
     return AXVS_OK;
   }
   if (have_qkv) goto qkv_done;
@@ -1220,6 +1251,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_merge_qkv")) { g_no_merge_qkv = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
+  if (key && !strcmp(key, "no_persist")) { g_no_persist = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   if (key && !strcmp(key, "layer_out_dtype")) {

@@ -703,6 +703,7 @@ struct OwnQkv {
   unsigned* sync;         // [sequences] arrival counters: zero before the launch, zero again after it (see the kernel)
   int* status;            // nullable: bit 0 <- an operand left the fp16 range, bit 2 <- a hand-off wait ran out
   unsigned spin_limit;    // polls (with s_sleep) before a hand-off wait gives up (kSyncSpinLimit; option "sync_spin_limit")
+  int persist_grid;       // host side only: > 0 = launch the PERSIST instantiation with this many workgroups (a whole number of teams)
 };
 constexpr unsigned kSyncSpinLimit = 1u << 22;    // ~ 1 s
 
@@ -761,21 +762,27 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
 //     accumulators of the k / v sweeps (same 16-bit values as the stored ones), so its QK^T / softmax / AV run first, from registers,
 //     while the sibling tiles' K / V^T stores drain (frames are visited in the order own, own + 1, ... mod T; x-tile blocks are
 //     independent, so the result does not depend on the order).
-template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, bool VROW = false, bool QKVN = false, int MQ = 0>
+// PERSIST (round 5; MQ = 1 on 64-row tiles): the grid is a fixed number of workgroups (one per CU, a whole number of TEAMS of
+//     ceil(N / 64) consecutive workgroups) and every workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: a team processes the
+//     row tiles of ONE sequence in the same iteration, so the sibling tiles of the in-launch K / V^T hand-off start together at every
+//     grid size.  (Dispatched as one workgroup per tile, the siblings of a sequence start staggered once the grid exceeds ~2 rounds of
+//     the chip -- every tile then waits for the last of them: +8 % at 4608 tiles, DESIGN 4h -- and such grids ran two launches per pass.)
+template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, bool VROW = false, bool QKVN = false, int MQ = 0, bool PERSIST = false>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
-                                                             const u16* __restrict__ Wpq, const float* __restrict__ bpq,
-                                                             const u16* __restrict__ Wpkv, const float* __restrict__ bpkv,
-                                                             const u16* __restrict__ Wp, const float* __restrict__ bp,
+                                                             const u16* __restrict__ Wpq_a, const float* __restrict__ bpq,
+                                                             const u16* __restrict__ Wpkv_a, const float* __restrict__ bpkv,
+                                                             const u16* __restrict__ Wp_a, const float* __restrict__ bp,
                                                              const float* __restrict__ res /* required */, float* __restrict__ out,
-                                                             RowMap rm, long long Mp, int N, int L, float scale, const u16* __restrict__ Q16 = nullptr,
+                                                             RowMap rm, long long Mp, int N_a, int L_a, float scale, const u16* __restrict__ Q16 = nullptr,
                                                              const u16* __restrict__ K16 = nullptr,
-                                                             const u16* __restrict__ VT16 = nullptr, FfnArgs fa = FfnArgs{},
-                                                             const u16* __restrict__ Wk2T = nullptr /* [8*256][32], pack_wk2t_kernel */,
+                                                             const u16* __restrict__ VT16 = nullptr, FfnArgs fa_a = FfnArgs{},
+                                                             const u16* __restrict__ Wk2T_a = nullptr /* [8*256][32], pack_wk2t_kernel */,
                                                              int wt = 0 /* bit 0: write-through output rows (byte offsets < 4 GiB); FFN: bits 4 / 5 = 16-bit output map (kOutF16 / kOutBf16) */,
                                                              int spatial_only = 0 /* measurement: 1 = stop after the QK^T / AV half; MQ kernels also 2 = stop after their q/k/v part */,
                                                              const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
                                                              const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{},
-                                                             OwnQkv oq = OwnQkv{}) {
+                                                             OwnQkv oq_a = OwnQkv{}) {
+  static_assert(!PERSIST || (MQ == 1 && MT == 4), "the tile loop exists for the merged launch on 64-row tiles");
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
   static_assert(MQ == 0 || ((MT == 4 || MT == 1) && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64- or 16-row tiles, block-transposed V");
   static_assert(MQ != 2 || (MT == 4 && NKS == 2 && T >= 2), "own frame first: a 64-row tile is one 64-key frame");
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
   float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN, QKVN>());   // bpq | bv2 | bp
-  float* const sqkvb = sbias + 3 * C + (FFN ? fa.F + 5 * C : 0);   // MQ: bq | bk | bv
+  float* const sqkvb = sbias + 3 * C + (FFN ? fa_a.F + 5 * C : 0);   // MQ: bq | bk | bv
   FfnLds fl;
   if constexpr (FFN) {
     fl.ytile = xt;
@@ -793,19 +800,44 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     fl.htile = reinterpret_cast<u16*>(fl.xtile + ROWS * kEpiLd);
     fl.par = sbias + 3 * C;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fi = lane & 15, fg = lane >> 4;
+
   // XCD-aware tile order (speed only): blocks b and b+8 share an XCD, hence an L2.  With the spatial half in the kernel the
   // N/ROWS row tiles of one sequence all read that sequence's K / V -- put them on the same XCD so it is fetched once.
   // Row tiles: with the spatial half in the kernel a tile never straddles two sequences (its queries share one K / V): every
   // sequence gets ceil(N / ROWS) tiles, the last one partly filled -- any axis length works, rows past the sequence's end are
   // clamped copies that are computed and never stored.  Without it (x staged from HBM) tiles are plain ROWS-row slices.
-  long long tile = blockIdx.x;
+  [[maybe_unused]] long long ptile = blockIdx.x;                // PERSIST: the tile of this iteration
+  for (;;) {                                                    // PERSIST: one iteration per tile; every other kernel: exactly one (the body below is not indented)
+  // Thread index, frame geometry and weight pointers of this iteration.  PERSIST: each passed through an empty asm the compiler cannot see
+  // through -- inside a tile loop LLVM hoists everything loop-invariant out of the loop (per-lane LDS offsets, dozens of 64-bit
+  // fragment addresses, the divisions of the tile arithmetic) and keeps it in registers across the whole body: hundreds of VGPRs
+  // spilled in a kernel that sits at 256 (profiles/r4_cc_experiments.txt).  An iteration then compiles like a kernel of its own.
+  int tid_l = threadIdx.x, N_l = N_a, L_l = L_a;
+  long long zl = 0;
+  if constexpr (PERSIST) {
+    int z = 0;
+    asm volatile("" : "+v"(z), "+v"(tid_l), "+s"(N_l), "+s"(L_l));
+    zl = z;
+  }
+  const int tid = tid_l, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, fg = lane >> 4;
+  const int N = N_l, L = L_l;
+  const u16* const Wpq = Wpq_a + zl;
+  const u16* const Wpkv = Wpkv_a + zl;
+  const u16* const Wp = Wp_a + zl;
+  const u16* const Wk2T = Wk2T_a + zl;
+  FfnArgs fa = fa_a;
+  OwnQkv oq = oq_a;
+  if constexpr (PERSIST) {
+    fa.W1 += zl; fa.W2 += zl;
+    oq.Wq += zl; oq.Wk += zl; oq.Wv += zl;
+  }
+  long long tile = PERSIST ? ptile : (long long)blockIdx.x;
   long long m0;                                                 // first sequence-order row of the tile
   int nvalid;                                                   // rows of the tile that exist
   if constexpr (NKS > 0) {
     const int tps = (N + ROWS - 1) / ROWS;                      // tiles per sequence
-    if (gridDim.x % (8 * tps) == 0) {
+    if (!PERSIST && gridDim.x % (8 * tps) == 0) {
       const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
       tile = ((long long)(j / tps) * 8 + xcd) * tps + (j % tps);
     }
@@ -1726,6 +1758,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   else if constexpr (MQ != 0) AXVS_STAMP_FLUSH(24);
   else AXVS_STAMP_FLUSH(16);
 #endif
+  if constexpr (!PERSIST) break;
+  else {
+    ptile += gridDim.x;
+    if (ptile >= (Mp / N) * ((N + ROWS - 1) / ROWS)) break;
+    __syncthreads();        // every wave is done with this tile's LDS (fp32 rows, parameters) before the next tile's gather overwrites it
+  }
+  }   // tile loop
 }
 
 

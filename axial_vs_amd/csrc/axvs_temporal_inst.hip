@@ -13,10 +13,10 @@
 
 namespace axvs {
 
-template <bool BF, int T, int MT, int NKS, bool FFN, bool VROW, bool QKVN, int MQ = 0>
+template <bool BF, int T, int MT, int NKS, bool FFN, bool VROW, bool QKVN, int MQ = 0, bool PERSIST = false>
 static int launch_one(unsigned grid, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
                       float scale, hipStream_t st, const FfnArgs* fa, int wt, const NextQkv* nq, const OwnQkv* oq = nullptr) {
-  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, VROW, QKVN, MQ>;
+  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, VROW, QKVN, MQ, PERSIST>;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern))) return rc;
   const size_t lds = temporal_lds_bytes<T, MT, FFN, QKVN, MQ>(FFN ? fa->F : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale,
@@ -39,6 +39,15 @@ static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* 
           return launch_one<BF, T, MT, NKS, false, false, false, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
         }
       }
+#ifdef AXVS_WITH_PERSIST                // diagnostic builds only (measured 24 % SLOWER: profiles/r5_persistent_merged.txt): the persistent team grid
+      if constexpr (NKS >= 2) {           // frames of 33 .. 96 keys on grids far beyond the chip: a fixed grid of teams that walks the tiles
+        if (oq->persist_grid > 0 && (unsigned)oq->persist_grid < grid) {
+          const unsigned pg = (unsigned)oq->persist_grid;
+          if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 1, true>(pg, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+          return launch_one<BF, T, MT, NKS, false, false, false, 1, true>(pg, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+        }
+      }
+#endif
       if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
       return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
     }

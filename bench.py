@@ -542,6 +542,8 @@ def main():
                        # one launch per pass (q/k/v merged into the trajectory kernel)
                        "h.qkv+traj": f_qkv(B * W, H) + f_traj(B * W, H), "w.qkv+traj": f_qkv(B * H, W) + f_traj(B * H, W),
                        "w.qkv+traj+ffn": f_qkv(B * H, W) + f_traj(B * H, W) + f_ffn}
+        for k_ in ("h.qkv+traj", "w.qkv+traj", "w.qkv+traj+ffn"):       # "/p": the same launch as a persistent team grid (large grids, frames != 64 keys)
+            stage_flops[k_ + "/p"] = stage_flops[k_]
         stage_frac = {k: round(stage_flops[k] / (v * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4) for k, v in kernels.items()
                       if k in stage_flops and v > 0}
         # the north star's sub-target: QK^T / softmax / AV alone.  Option "spatial_only" makes the fused trajectory kernels return
