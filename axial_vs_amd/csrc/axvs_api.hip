@@ -265,7 +265,8 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 }
 
 // Full fusion (spatial half inside the temporal kernel, x never leaves LDS) needs: the fused kernels, no attention-map
-// output, 16..128 keys per frame (L >= 16: the 32-key padding of V^T stays within 2x).  Any axis length: row tiles are cut
+// output, 8..128 keys per frame (frames are padded to multiples of 16 rows in the q/k/v row space, V^T to 32-key steps: within 2x of
+// the padded rows for every L; below 8 keys the padding would more than double the work).  Any axis length: row tiles are cut
 // per sequence, partial key tiles are masked.
 // Frame counts the fused trajectory kernels exist for: T <= 8 (64- / 32-row tiles), and 9 .. 12 on 16-row tiles (x tile T * 8 KiB)
 // for problems with few rows -- whole-video cross-clip inference with up to 12 clips (Q * Tc rows per video).
@@ -273,7 +274,7 @@ TrajWs carve_traj_ws(Carver& c, long long Mp, int T, int heads, bool lean = fals
 //  and a clip's result must not depend on how many other clips share its batch -- batch sharding is bit-exact.)
 bool fused_frames(int T, long long /*rows*/) { return T <= 8 || (T <= 12 && !g_no_small_tiles); }
 bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn, long long rows) {
-  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && fused_frames(T, rows) && !want_attn && L >= 16 && L <= 128;
+  return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && fused_frames(T, rows) && !want_attn && L >= 8 && L <= 128;
 }
 // The FFN rides in the width-pass kernel only when that kernel fills at least half the chip: with fewer 64-row tiles every
 // workgroup's private 1 MB FFN weight stream is pure latency (43 us per pass whether 16 or 64 workgroups run), and a 16-row
@@ -312,7 +313,8 @@ LayerPlan plan_layer(int B, int T, int H, int W, int C, int heads, int F, bool w
   p.lean_traj = can_fuse_attn(C, heads, T, H, want_attn, rows) && can_fuse_attn(C, heads, T, W, want_attn, rows);
   p.need_buf2 = !(can_fuse_attn(C, heads, T, W, want_attn, rows) && can_fuse_ffn_into_pass(T, F, rows));
   // height-pass kernel on 64-row tiles without the FFN, width pass on the row-form kernels
-  p.fuse_qkv = p.lean_traj && g_qkv_fusion && traj_mt4(T, traj_tiles64(rows, T * H), false) &&
+  // (the hand-over between the passes runs in the DENSE row space: frames below 16 keys exist on the fused tier only in the padded one)
+  p.fuse_qkv = p.lean_traj && g_qkv_fusion && H >= 16 && W >= 16 && traj_mt4(T, traj_tiles64(rows, T * H), false) &&
                can_vrow(T, W, rows, can_fuse_ffn_into_pass(T, F, rows), true);
   p.need_ffn_tmp = p.need_buf2 && !ffn_kernel_is_fused(C, heads, F);
   p.need_ffn_part = p.need_buf2 && ffn_split_applies(C, heads, F, rows);

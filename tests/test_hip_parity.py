@@ -1742,7 +1742,9 @@ RAGGED_MERGE_SHAPES = [(1, 2, 256, 49, 85, 1024),     # shipped VIPSeg res4 leve
                        (2, 2, 256, 25, 43, 1024),     # res5 level: 16-row tiles (two-launch form by default: merge_small is off)
                        (1, 3, 256, 17, 127, 512),     # 17 -> 32 (15 padding rows per frame), 127 -> 128 keys: the widest fused frame
                        (2, 4, 256, 23, 40, 1024),
-                       (1, 4, 256, 33, 70, 1024)]     # 33 -> 48: a frame of 2 full key tiles + 1 key
+                       (1, 4, 256, 33, 70, 1024),     # 33 -> 48: a frame of 2 full key tiles + 1 key
+                       (1, 5, 256, 12, 20, 1024),     # shipped Tube-Link stride-32 level (T = 5): frames of 12 keys -> 16 (the fused tier starts at 8 keys)
+                       (2, 4, 256, 8, 9, 512)]        # the smallest frames the fused tier takes
 
 
 @pytest.mark.gpu
