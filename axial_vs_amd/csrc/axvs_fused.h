@@ -255,7 +255,17 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
 #if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
   KStamps8 kst1{}, kst2{};
 #endif
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNC)     // unconditional stamps at 7 points of EVERY chunk (no loop unswitching): the last two chunks survive
+  KStamps8 ccur{}, cprev{};
+#define CSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ccur.t[i])::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CSTAMP(i)
+#endif
   for (int ci = 0; ci < nchunk; ++ci) {
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNC)
+    cprev = ccur;
+#endif
+    CSTAMP(0);
     const int c = (ci + crot) % nchunk;                 // hidden-unit chunk handled in this iteration
 #if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNK)
     if (ci == AXVS_STAMPS_FFNK) { FSTAMP(14); }
@@ -273,7 +283,9 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     gemm_phase_pf<BF, 2, 4, KB, 2>(acc1, w1f, l.ytile, fi, fg, rot, w2f, W2, C, c * 8, wave * 32, rot);
 #endif
     if (ci == 0) FSTAMP(3);
+    CSTAMP(1);
     if (ci > 0) __syncthreads();                         // every wave is done reading the previous chunk's h
+    CSTAMP(2);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int hn = c * 256 + wave * 32 + nt * 16 + fg * 4;          // global hidden index
@@ -292,7 +304,9 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
       }
     }
     if (ci == 0) FSTAMP(4);
+    CSTAMP(3);
     __syncthreads();
+    CSTAMP(4);
     if (ci == 0) FSTAMP(5);
     // ---- linear2 partial: W2[my 32 channels, chunk] . h, accumulated from zero and then added to the running sum (so the
     //      result is the ordered sum of per-chunk partials: exactly what the chunk-per-workgroup variant for few rows,
@@ -314,6 +328,7 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc2[a][b] = ci == 0 ? part[a][b] : acc2[a][b] + part[a][b];
+    CSTAMP(5);
     if (ci == 0) FSTAMP(6);
     if (ci == 1) FSTAMP(7);
     if (ci == 2) FSTAMP(8);
@@ -368,6 +383,13 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
     for (int i_ = 0; i_ < 8; ++i_) {
       ::axvs::g_stamps[(16 + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = kst1.t[i_];
       ::axvs::g_stamps[(24 + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = kst2.t[i_];
+    }
+#endif
+#if defined(AXVS_STAMPS) && defined(AXVS_STAMPS_FFNC)
+  if (blockIdx.x < 8 && (threadIdx.x & 63) == 0)
+    for (int i_ = 0; i_ < 8; ++i_) {
+      ::axvs::g_stamps[(32 + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = cprev.t[i_];
+      ::axvs::g_stamps[(40 + i_) * 64 + (blockIdx.x & 7) * 8 + (threadIdx.x >> 6)] = ccur.t[i_];
     }
 #endif
 }
