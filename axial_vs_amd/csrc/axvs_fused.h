@@ -14,8 +14,9 @@
 // The width-pass kernel's FFN half: 0 (shipped) = the lockstep body of rounds 1-4 (ffn_body); 1 = the wave-specialised body of round 5
 // (ffn_body_ws: linear1 and linear2 on different waves).  Same bits either way; a build switch for same-box A/B runs
 // (tools/ab_variants.py).  MEASURED SLOWER (profiles/r5_ffn_wave_specialised.txt: width-pass kernel 57.1 -> 60.2 us, config 5's share
-// +4 %): the FFN half is bound by the per-CU L2 -> register weight stream (~ 35 B/clk), not by the MFMA / VALU alternation the
-// specialisation removes, and the two-stage pipeline adds a fill and a drain step during which only half the waves stream.
+// +4 %): every step of the pipeline must pull BOTH matrices' fragments (256 KiB) through one phase time -- 62 B/clk, the limit of the
+// L2 -> CU path (profiles/r5_l2_stream_forms_probe.txt), so every hiccup stalls both wave groups -- and the two-stage pipeline adds a
+// fill and a drain step during which only half the waves work.
 #ifndef AXVS_FFN_WS
 #define AXVS_FFN_WS 0
 #endif
