@@ -392,6 +392,25 @@ static __device__ unsigned long long g_stamps[64 * 64];   // per translation uni
 #define AXVS_STAMP_FLUSH_AT(base, n)
 #endif
 
+// ---- per-workgroup wall times: diagnostic builds only (-DAXVS_STAMPS_WG; tools/r5/wg_times.py).  The 100 MHz real-time counter is the same on every
+//      CU, so start / end of all workgroups of a launch can be laid side by side: how long before the slowest workgroup the others finish.
+#ifdef AXVS_STAMPS_WG
+static __device__ unsigned long long g_wg[2 * 1024 * 4];      // [kernel kind][workgroup][start, end, XCC id, CU id]
+#define AXVS_WG_BEGIN unsigned long long wg_t0_ = __builtin_amdgcn_s_memrealtime()
+#define AXVS_WG_END(kind)                                                                                         \
+  do {                                                                                                            \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                                  \
+      unsigned long long* q_ = ::axvs::g_wg + ((kind) * 1024 + blockIdx.x) * 4;                                   \
+      q_[0] = wg_t0_; q_[1] = __builtin_amdgcn_s_memrealtime();                                                   \
+      q_[2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) /* HW_REG_XCC_ID[3:0] */;               \
+      q_[3] = __builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (3 << 11)) /* HW_REG_HW_ID: CU_ID[11:8] */;         \
+    }                                                                                                             \
+  } while (0)
+#else
+#define AXVS_WG_BEGIN
+#define AXVS_WG_END(kind)
+#endif
+
 // lgkmcnt is a 4-bit counter.  hipcc (ROCm 7.2) will happily leave 16 or more LDS/SMEM operations in flight before one
 // `s_waitcnt lgkmcnt(0)`; when the LDS is busy enough that none of them has returned by the time the 16th issues, the
 // counter wraps and the wait falls through early (observed on gfx950: intermittent stale reads in a fused epilogue with

@@ -876,6 +876,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // padded frames (RowMap): L is the frame length of the row space (a multiple of 16), Lr the number of keys / rows that exist
   [[maybe_unused]] const int Lr = rm.Lv ? rm.Lv : L;
   AXVS_STAMP_DECL;
+  AXVS_WG_BEGIN;
   AXVS_STAMP(0);
   // biases (and the FFN half's parameters) -> LDS
   auto stage_small = [&]() {
@@ -1776,6 +1777,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #endif
   }
   AXVS_STAMP(10);
+  AXVS_WG_END(FFN ? 0 : 1);
 #if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)
   if constexpr (QKVN || (MQ != 0 && !FFN)) AXVS_STAMP_FLUSH_AT(32, 24);      // the height-pass kernel's stamps: slots 32 .. 55 (the width pass's stay in 0 .. 23)
   else if constexpr (MQ != 0) AXVS_STAMP_FLUSH(24);
