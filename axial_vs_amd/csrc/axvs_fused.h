@@ -25,6 +25,9 @@
 #ifndef AXVS_LOGITS_VALU_KB
 #define AXVS_LOGITS_VALU_KB 0
 #endif
+#ifndef AXVS_FFN_ONEBAR   // 1: ffn_body2 (one barrier per chunk: single fragment ring refilled in place, y in registers, two h slots); bit-identical,
+#define AXVS_FFN_ONEBAR 0 // measured a wash (profiles/r5_ffn_wave_specialised.txt: B = 1 +-1 %, config 2 / 5 -0.6 %): the shipped body stays ffn_body
+#endif
 #ifndef AXVS_WS_PRIO      // s_setprio level of the linear1 waves during their MFMA phases (0: none)
 #define AXVS_WS_PRIO 2
 #endif
@@ -618,8 +621,189 @@ __device__ __forceinline__ void ffn_body_ws(const FfnLdsWs& l, const u16* __rest
   FSTAMP_FLUSH(13);
 }
 
-constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kTileElems * sizeof(u16);   // x | y | h
-inline size_t ffn_lds_bytes(int F) { return kFfnTiles + (size_t)(F + 5 * 256) * sizeof(float); }
+// =====================================================================================================
+// norm1 -> FFN -> norm2 with ONE barrier per 256-unit chunk (round 5, -DAXVS_FFN_ONEBAR=1).
+// ffn_body pays two barriers per chunk around its single h tile: one before the activation epilogue (every wave must have left the
+// previous chunk's h) and one behind it.  The first one costs ~ 0.9 k cycles per chunk of pure skew -- two waves share a SIMD's matrix
+// pipe and finish linear1 up to 1.7 k cycles apart (tools/r5/ffnc_stamps.py) -- with the pipe and the weight stream idle.  A second h
+// tile removes it, and LDS has no room for one beside the fp32 rows.  So:
+//   * ONE set of 16 weight fragments, refilled IN PLACE: slot (nt, j) is re-requested right behind its MFMAs with the fragment the NEXT
+//     phase needs at the same k-step (linear1 of a chunk -> its linear2 -> linear1 of the next chunk).  Same lead time and the same bytes
+//     in flight as ffn_body's two alternating sets, 64 VGPRs less.
+//   * the fp32 residual y (this wave's 32 channels x 64 rows, accumulator layout) rides in 32 of those VGPRs; the LDS tile that held it
+//     becomes the second h slot (its first 32 KiB) and the staging tile of the two row-wise passes (norm1 -> registers, registers -> norm2).
+// Same MFMA sequence per output element as ffn_body (k-blocks in order, chunk partials summed in chunk order): the same bits.
+// LDS: ytile 32 KiB | stage 65 KiB fp32 (first 32 KiB = h slot 1) | h slot 0 32 KiB -- ffn_body's footprint.
+// =====================================================================================================
+// one GEMM phase over 8 k-blocks: acc[nt][mt] += wf[nt][j] . B(tile, k-block j); slot (nt, j) is refilled behind its MFMAs with
+// fragment (kb0n + j, rows nrow0n + 16 nt) of Wn
+template <bool BF>
+__device__ __forceinline__ void gemm_phase_inplace(f32x4 (&acc)[2][4], u16x8 (&wf)[2][8], const u16* tile, int fi, int fg,
+                                                   const u16* __restrict__ Wn, int NRn, int kb0n, int nrow0n) {
+  u16x8 bcur[4], bnxt[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) bcur[mt] = act_frag(tile, 0, mt, fi, fg);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j + 1 < 8) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) bnxt[mt] = act_frag(tile, j + 1, mt, fi, fg);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], bcur[mt], acc[nt][mt]);
+      wf[nt][j] = w_frag(Wn, NRn, kb0n + j, nrow0n + nt * 16 + fi, fg);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // one k-step of B fragments ahead, never more (lgkmcnt); the loads stay spread between the MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) bcur[mt] = bnxt[mt];
+  }
+}
+
+template <bool BF, class RowOff, bool GELU = false, bool PRE = false>
+__device__ __forceinline__ void ffn_body2(const FfnLdsWs& l, u16x8 (&wf)[2][8] /* linear1 fragments of chunk 0, my 32 hidden units */,
+                                          const u16* __restrict__ W1, const u16* __restrict__ W2, float* __restrict__ out, RowOff row_off,
+                                          int F, int tid, int wt = 0, const NoRows& pre = NoRows{}) {
+  constexpr int C = 256;
+  const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const float* sb1 = l.par;
+  const float* sb2 = l.par + F;
+  const float *sg1 = sb2 + C, *sbe1 = sb2 + 2 * C, *sg2 = sb2 + 3 * C, *sbe2 = sb2 + 4 * C;
+  const int nchunk = F / 256;
+  u16* const h1 = reinterpret_cast<u16*>(l.stage);
+  // chunk c -> h slot: the LAST chunk uses slot 0, so that `stage` (= slot 1) is free for the last row-wise pass while waves still read slot 0
+  auto hslot = [&](int c) { return ((nchunk - 1 - c) & 1) ? h1 : l.h0; };
+  FSTAMP_DECL;
+  FSTAMP(0);
+  // ---- norm1, row-wise: y fp32 -> stage (my 8 rows), y 16-bit -> ytile ----
+  {
+    const float4 gg = *reinterpret_cast<const float4*>(sg1 + lane * 4), bb = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = wave * 8 + rr;
+      float4 v;
+      if constexpr (PRE) v = pre.v[rr];
+      else v = *reinterpret_cast<const float4*>(l.stage + r * kEpiLd + lane * 4);
+      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+      const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+      const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
+      const f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
+      *reinterpret_cast<float4*>(l.stage + r * kEpiLd + lane * 4) = float4{y[0], y[1], y[2], y[3]};
+      act_store4<BF>(l.ytile, lane * 4, r, y);
+      if (rr == 3) lds_fence();
+    }
+  }
+  FSTAMP(1);
+  __syncthreads();
+  FSTAMP(2);
+  // ---- my 32 channels of y, all 64 rows, into registers (accumulator layout: channel 32 wave + 16 nt + 4 fg + r, row 16 mt + fi) ----
+  f32x4 yreg[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float4 t = *reinterpret_cast<const float4*>(l.stage + (mt * 16 + fi) * kEpiLd + wave * 32 + nt * 16 + fg * 4);
+      yreg[nt][mt] = f32x4{t.x, t.y, t.z, t.w};
+    }
+  lds_fence();
+  __syncthreads();                         // every wave holds its y: h slot 1 (inside `stage`) may be written
+  FSTAMP(3);
+
+  f32x4 acc2[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int cn = min(ci + 1, nchunk - 1);
+    u16* const hb = hslot(ci);
+    // ---- linear1 + activation: my 32 hidden units of the chunk, all 64 rows; every slot re-requested with this chunk's linear2 fragment ----
+    f32x4 acc1[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_phase_inplace<BF>(acc1, wf, l.ytile, fi, fg, W2, C, ci * 8, wave * 32);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int hn = ci * 256 + wave * 32 + nt * 16 + fg * 4;          // global hidden index
+      const float4 bias = *reinterpret_cast<const float4*>(sb1 + hn);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4 v = acc1[nt][mt];
+        if constexpr (GELU) {
+          v[0] = gelu_exact(v[0] + bias.x); v[1] = gelu_exact(v[1] + bias.y);
+          v[2] = gelu_exact(v[2] + bias.z); v[3] = gelu_exact(v[3] + bias.w);
+        } else {
+          v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
+          v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
+        }
+        act_store4<BF>(hb, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
+      }
+    }
+    if (ci == 0) FSTAMP(4);
+    __syncthreads();                       // the chunk's ONLY barrier: h complete.  (This slot's previous readers -- linear2 two chunks ago -- had
+    if (ci == 0) FSTAMP(5);                //  finished in EVERY wave before any wave passed the previous chunk's barrier: no second barrier needed.)
+    // ---- linear2 partial (from zero, then added: the ordered sum of per-chunk partials every FFN kernel produces); every slot re-requested
+    //      with the next chunk's linear1 fragment (the last chunk re-loads its own: branch-free vmcnt bookkeeping) ----
+    f32x4 part[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) part[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_phase_inplace<BF>(part, wf, hb, fi, fg, W1, F, 0, cn * 256 + wave * 32);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc2[a][b] = ci == 0 ? part[a][b] : acc2[a][b] + part[a][b];
+    if (ci == 0) FSTAMP(6);
+    if (ci == 1) FSTAMP(7);
+    if (ci == 2) FSTAMP(8);
+  }
+  FSTAMP(9);
+  // ---- stage <- y + linear2 + b2 in the accumulator layout (plain stores: y comes from registers); then norm2 per whole row ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = wave * 32 + nt * 16 + fg * 4;
+    const float4 b = *reinterpret_cast<const float4*>(sb2 + n);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      epi_put(l.stage, mt * 16 + fi, n, f32x4{yreg[nt][mt][0] + acc2[nt][mt][0] + b.x, yreg[nt][mt][1] + acc2[nt][mt][1] + b.y,
+                                              yreg[nt][mt][2] + acc2[nt][mt][2] + b.z, yreg[nt][mt][3] + acc2[nt][mt][3] + b.w});
+    lds_fence();
+  }
+  FSTAMP(10);
+  __syncthreads();
+  FSTAMP(11);
+  {
+    const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i;
+      const float4 v = *reinterpret_cast<const float4*>(l.stage + r * kEpiLd + lane * 4);
+      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+      const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
+      const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
+      const long long off = row_off(r);
+      if (off >= 0) {
+        const float4 y = float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
+        if (wt & kOut16Mask) {
+          const f32x4 yv = {y.x, y.y, y.z, y.w};
+          const u16x4 h = (wt & kOutBf16) ? cvt4<true>(yv) : cvt4<false>(yv);
+          u16* o16 = reinterpret_cast<u16*>(out);
+          if (wt & 1) WtBuf(o16).store8((unsigned)((off + lane * 4) * 2), h);
+          else *reinterpret_cast<u16x4*>(o16 + off + lane * 4) = h;
+        } else if (wt & 1) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);
+        else *reinterpret_cast<float4*>(out + off + lane * 4) = y;
+      }
+      if (i == 3) lds_fence();
+    }
+  }
+  FSTAMP(12);
+  FSTAMP_FLUSH(13);
+}
 
 // stand-alone kernel: X fp32 [M][256] rows in, out rows out
 template <bool BF, bool GELU = false>
@@ -661,8 +845,17 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   }
   __syncthreads();                       // parameters staged
   auto row_off = [=](int r) { return m0 + r < M ? rs.row(m0 + r) * C : -1ll; };
+#if AXVS_FFN_ONEBAR
+  const FfnLdsWs lw{l.ytile, l.xtile, l.htile, l.par};
+  ffn_body2<BF, decltype(row_off), GELU>(lw, w1f, W1, W2, out, row_off, F, tid, oflags);
+#else
   ffn_body<BF, decltype(row_off), GELU>(l, w1f, W1, W2, out, row_off, F, rot, crot, tid, oflags);
+#endif
 }
+
+constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kTileElems * sizeof(u16);   // x | y | h
+inline size_t ffn_lds_bytes(int F) { return kFfnTiles + (size_t)(F + 5 * 256) * sizeof(float); }
+
 
 
 }  // namespace axvs
@@ -1772,6 +1965,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #if AXVS_FFN_WS
     const FfnLdsWs fw{fl.ytile, fl.xtile, fl.htile, fl.par};       // y tile | fp32 stage (= h slot 1) | h slot 0: ffn_body's footprint
     ffn_body_ws<BF, decltype(row_off_)>(fw, fa.W1, fa.W2, out, row_off_, fa.F, tid, wt, yrows);
+#elif AXVS_FFN_ONEBAR
+    const FfnLdsWs fw{fl.ytile, fl.xtile, fl.htile, fl.par};
+    ffn_body2<BF, decltype(row_off_), false, true>(fw, wf, fa.W1, fa.W2, out, row_off_, fa.F, tid, wt, yrows);
 #else
     ffn_body<BF, decltype(row_off_), false, true>(fl, wf, fa.W1, fa.W2, out, row_off_, fa.F, 0, crot, tid, wt, yrows);
 #endif
