@@ -147,6 +147,10 @@ class CrossClipTrackingModule(nn.Module):
         self._predictor = MaXTronCCPredictor(num_classes=num_classes + 1)
         self.mfma_dtype = mfma_dtype
         self.eval_outputs_on_cpu = True     # the reference's eval branch returns CPU tensors (CC:59,70)
+        # eval mode: True (default) = every layer's predictions are computed and returned under 'aux_outputs', as the reference does
+        # (CC:283-322); False = only the last layer's predictor heads run and 'aux_outputs' is [] -- what the reference's own inference
+        # path keeps (maxtron_cc_model.py reads aux_outputs under self.training only): 3/4 of the mask einsum's HBM writes less
+        self.eval_aux_outputs = True
         self._packed = None
         self._packed_key = None
 
@@ -226,17 +230,24 @@ class CrossClipTrackingModule(nn.Module):
         # the mask einsum of all layers in one pass over the pixel features.
         main = torch.cuda.current_stream(dev)
         ws = _workspace(dev, L.axvs_cc_module_workspace_bytes(B, Q, Tc, nl))
-        logits = torch.empty(nl, 1, Q, K1, dtype=torch.float32, device=dev)
-        masks = torch.empty(nl, B, Q, TV, H, W, dtype=torch.float32, device=dev)
+        nh = nl if self.eval_aux_outputs else 1          # layers whose predictor heads run (the last `nh`)
+        logits = torch.empty(nh, 1, Q, K1, dtype=torch.float32, device=dev)
+        masks = torch.empty(nh, B, Q, TV, H, W, dtype=torch.float32, device=dev)
         last = torch.empty_like(cq)
         pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
         _select_sync_words(dev)          # the layers' trajectory attention runs q/k/v + attention as one launch (include/axvs.h)
-        _lib.check(L.axvs_cc_module_fwd(cq.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
-                                        nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
-                   "axvs_cc_module_fwd")
+        if nh != nl:
+            _lib.check(L.axvs_set_option(b"cc_last_heads_only", 1), "axvs_set_option")
+        try:
+            _lib.check(L.axvs_cc_module_fwd(cq.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
+                                            nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
+                       "axvs_cc_module_fwd")
+        finally:
+            if nh != nl:
+                L.axvs_set_option(b"cc_last_heads_only", 0)
         cur = last
-        cls_all = [logits[i] for i in range(nl)]
-        mask_all = [masks[i] for i in range(nl)]
+        cls_all = [logits[i] for i in range(nh)]
+        mask_all = [masks[i] for i in range(nh)]
         if self.eval_outputs_on_cpu:
             cls_all = [c.cpu() for c in cls_all]
             mask_all = [m.cpu() for m in mask_all]

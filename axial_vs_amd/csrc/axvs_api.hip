@@ -67,6 +67,10 @@ thread_local int g_merge_small = 0;      // option "merge_small": 16-row-tile pr
 thread_local int g_out_dtype = 0;        // option "layer_out_dtype": 0 = the layer's output rows are fp32 (the reference's type); 1 / 2 = the kernel that ends the layer
                                          // (norm2 epilogue of the FFN) writes them as f16 / bf16 -- the map a batch-sharded caller gathers over the links
                                          // (BASELINE config 5 is worded "bf16"), written once instead of cast by a second pass
+thread_local int g_cc_last_only = 0;     // option "cc_last_heads_only": axvs_cc_module_fwd computes the predictor heads (class logits, mask einsum) of the LAST layer
+                                         // only; pred_logits / pred_masks then hold ONE layer.  The reference computes every layer's predictions in eval too
+                                         // (CC/...:283-318) and its inference path drops all but the last (maxtron_cc_model.py:301-: aux_outputs are read under
+                                         // self.training only): an inference pipeline that does not want them saves 3/4 of the mask einsum's HBM writes
 thread_local int g_no_persist = 0;       // option "no_persist": merged launches beyond ~2 rounds of the chip fall back to two launches per pass instead of the
                                          // persistent team grid (A/B, tests)
 thread_local int g_no_merge_qkv = 0;     // option "no_merge_qkv": keep qkv_fused_kernel + trajectory kernel as two launches (A/B, tests)
@@ -1254,6 +1258,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_merge_qkv")) { g_no_merge_qkv = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_persist")) { g_no_persist = value; return AXVS_OK; }
+  if (key && !strcmp(key, "cc_last_heads_only")) { g_cc_last_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   if (key && !strcmp(key, "layer_out_dtype")) {
@@ -1682,14 +1687,17 @@ int axvs_cc_module_fwd(const float* clip_query, const float* panoptic_features, 
   const ModuleWs w = carve_module_ws(wc, axvs_cc_layer_workspace_bytes(B, Q, Tc), (size_t)num_layers * R * 512 * sizeof(float), R, num_layers, 128);
   const long long mstride = (long long)B * Q * Tc * V * H * W;
   g_prof_next = 0;
+  // heads of all layers (the reference's return value), or of the last one only (option "cc_last_heads_only": outputs hold one layer)
+  const int hl = g_cc_last_only ? 1 : num_layers;
+  const float* hq = w.q + (size_t)(num_layers - hl) * R * 256;
   auto heads = [&](hipStream_t hs) {
     float* emb = static_cast<float*>(w.heads);
     if (dtype == AXVS_BF16) {
-      cc_heads_small_t<true>(w.q, pred_logits, w.kern, packed_heads, B, Q, Tc, K1, emb, hs, num_layers);
-      return cc_masks_t<true>(panoptic_features, w.kern, pred_masks, packed_heads, B, Q, Tc, V, H, W, K1, num_layers, R * 32, mstride, hs);
+      cc_heads_small_t<true>(hq, pred_logits, w.kern, packed_heads, B, Q, Tc, K1, emb, hs, hl);
+      return cc_masks_t<true>(panoptic_features, w.kern, pred_masks, packed_heads, B, Q, Tc, V, H, W, K1, hl, R * 32, mstride, hs);
     }
-    cc_heads_small_t<false>(w.q, pred_logits, w.kern, packed_heads, B, Q, Tc, K1, emb, hs, num_layers);
-    return cc_masks_t<false>(panoptic_features, w.kern, pred_masks, packed_heads, B, Q, Tc, V, H, W, K1, num_layers, R * 32, mstride, hs);
+    cc_heads_small_t<false>(hq, pred_logits, w.kern, packed_heads, B, Q, Tc, K1, emb, hs, hl);
+    return cc_masks_t<false>(panoptic_features, w.kern, pred_masks, packed_heads, B, Q, Tc, V, H, W, K1, hl, R * 32, mstride, hs);
   };
   return run_cc_module(clip_query, packed_layers, num_layers, last_query, B, Q, Tc, rates, dtype, w, static_cast<hipStream_t>(stream), heads);
 }

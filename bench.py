@@ -218,7 +218,7 @@ def main():
             pos = pos.clone()
         return layer, w, src, pos
 
-    def measure_cc(n_cc=30, graph=False):
+    def measure_cc(n_cc=30, graph=False, aux=True):
         """BASELINE config 4: CrossClipTrackingModule.forward over 4 clips x 4 frames, [C=256, H=W=64] features, 4 layers."""
         Q, Tc, V, Hc, Wc, layers_cc, ncls = 128, 4, 4, 64, 64, 4, 124
         cc = ax.CrossClipTrackingModule(num_layers=layers_cc, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3],
@@ -228,6 +228,7 @@ def main():
         cc.load_state_dict(sd, strict=True)
         cc = cc.to(dev)
         cc.eval_outputs_on_cpu = False          # time the device path (the reference's eval branch copies to the host afterwards)
+        cc.eval_aux_outputs = aux               # False: only the last layer's predictor heads (what the reference's inference path keeps)
         g = torch.Generator(device=dev).manual_seed(4)
         cq = torch.randn(1, Q, Tc, 256, device=dev, generator=g)
         pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, Hc, Wc, device=dev, generator=g), dim=1)
@@ -612,6 +613,11 @@ def main():
         if not args.no_extras and world == 1:
             try:
                 extras["cc_cfg4"] = measure_cc()
+                last_only = measure_cc(aux=False)
+                extras["cc_cfg4"]["us_per_forward_last_layer_heads_only"] = last_only["us_per_forward"]
+                extras["cc_cfg4"]["what"] += ("; us_per_forward_last_layer_heads_only: module.eval_aux_outputs = False -- the layer chain as it is, predictor "
+                                              "heads (class logits, mask einsum) of the last layer only: the reference's inference path reads no other layer's "
+                                              "predictions (maxtron_cc_model.py, aux_outputs under self.training only)")
             except RuntimeError as e:
                 extras["cc_cfg4"] = {"error": str(e)[:200]}
 

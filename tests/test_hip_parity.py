@@ -1790,3 +1790,33 @@ def test_ragged_frames_in_the_padded_row_space(shape):
     ax.check_status()
     for buf in modules._sync_buffers.values():
         assert int(buf.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_cross_clip_module_last_layer_heads_only():
+    """CrossClipTrackingModule.eval_aux_outputs = False: the layer chain runs as it is, the predictor heads (class logits, mask einsum)
+    only for the last layer -- what the reference's inference path keeps (maxtron_cc_model.py reads aux_outputs under self.training
+    only; CC/...:283-322 computes them regardless).  Same bits as the last layer of the full call; 'aux_outputs' is empty."""
+    import axial_vs_amd as ax
+    Q, Tc, V, H, W, nl, ncls = 32, 4, 2, 16, 24, 3, 19
+    cc = ax.CrossClipTrackingModule(num_layers=nl, num_classes=ncls, attn_drop=0.0, aspp_drop=0.0, kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3],
+                                    norm_fn="ln", num_clip_frames=V).eval()
+    g = torch.Generator().manual_seed(5)
+    sd = cc.state_dict()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point:
+            sd[k] = (torch.rand(v.shape, generator=g) * 0.5 + 0.75) if k.endswith("running_var") else torch.randn(v.shape, generator=g) * (0.05 if v.dim() > 1 else 0.1) + (1.0 if ("norm" in k and k.endswith("weight")) else 0.0)
+    cc.load_state_dict(sd, strict=True)
+    cc = cc.cuda()
+    cc.eval_outputs_on_cpu = False
+    cq = torch.randn(1, Q, Tc, 256, device="cuda")
+    pf = torch.nn.functional.normalize(torch.randn(1, 128, Tc * V, H, W, device="cuda"), dim=1)
+    full = cc(cq, pf)
+    assert len(full["aux_outputs"]) == nl - 1
+    cc.eval_aux_outputs = False
+    last = cc(cq, pf)
+    assert last["aux_outputs"] == []
+    assert torch.equal(last["pred_logits"], full["pred_logits"]) and torch.equal(last["pred_masks"], full["pred_masks"])
+    cc.eval_aux_outputs = True
+    again = cc(cq, pf)
+    assert torch.equal(again["pred_masks"], full["pred_masks"]) and len(again["aux_outputs"]) == nl - 1
