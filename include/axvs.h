@@ -82,7 +82,8 @@ int axvs_set_status_buffer(int* device_word);
 int axvs_check_status(void);
 
 /* Synchronisation words of the ONE-LAUNCH-PER-PASS form of the axial layer (axvs_axial_layer_fwd[_sine3d], axvs_axial_pass_fwd;
- * C = 256, 8 heads, T <= 4, axis lengths that are multiples of 16 up to 96).  Reference: WC/temporal_attention.py:197-213 -- the
+ * C = 256, 8 heads, T <= 4, axis lengths up to 96 -- any length since round 5: frames are padded to a multiple of 16 rows in the
+ * library's own q/k/v row space, the boundary tensors stay dense).  Reference: WC/temporal_attention.py:197-213 -- the
  * q/k/v Linear layers and the trajectory attention of a pass.  With a buffer registered, the trajectory kernel of a pass computes
  * q, k, v of its own 64 rows itself and the row tiles of one sequence hand K / V^T to each other INSIDE the launch, through one
  * arrival counter per sequence (B*W for the height pass, B*H for the width pass) taken from `device_words`; without one (the
