@@ -59,6 +59,9 @@ def axial_inputs(meta):
 
 AXIAL = ["g2_axial_B1_T2_C128_H32_W32", "g2_axial_B2_T3_C64_H5_W7", "g2_axial_B1_T5_C64_H6_W4",
          "g2_axial_B1_T1_C64_H4_W5", "g2_axial_B1_T4_C256_H64_W64"]
+# reference-generated fixtures at the map sizes the shipped configurations run (oracle/gen_golden_shipped.py, round 5): VIPSeg R50 (T = 2) and
+# Tube-Link YouTube-VIS (T = 5) temporal levels -- frame lengths that are not multiples of 16
+SHIPPED = ["g15_shipped_B1_T2_C256_H49_W85", "g15_shipped_B1_T2_C256_H25_W43", "g15_shipped_B1_T5_C256_H24_W40", "g15_shipped_B1_T5_C256_H12_W20"]
 TRAJ_LAYER = ["g2b_traj_layer_B1_T2_C64_H6_W5", "g2b_traj_layer_B1_T3_C256_H12_W16", "g2b_traj_layer_B2_T2_C256_H20_W24"]
 TRAJ = ["g1_traj_S3_T2_L7_C64", "g1_traj_S2_T5_L6_C64", "g1_traj_S2_T1_L9_C64", "g1_traj_S4_T4_L16_C256"]
 

@@ -1820,3 +1820,27 @@ def test_cross_clip_module_last_layer_heads_only():
     cc.eval_aux_outputs = True
     again = cc(cq, pf)
     assert torch.equal(again["pred_masks"], full["pred_masks"]) and len(again["aux_outputs"]) == nl - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", __import__("golden_util").SHIPPED)
+def test_shipped_map_sizes_golden(name):
+    """The HIP layer on its fused tier (padded-frame row space; one launch per pass where 64-row tiles run) against fixtures generated
+    from the REFERENCE at the temporal-level sizes of the shipped VIPSeg (T = 2: 49 x 85, 25 x 43) and Tube-Link (T = 5: 24 x 40,
+    12 x 20) configurations -- oracle/gen_golden_shipped.py; WC/temporal_attention.py:187-220."""
+    import axial_vs_amd as ax
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=m["heads"]).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    s = m["stride"]
+    for p in (dev(pos), ax.PositionEmbeddingSine3D(m["C"] // 2, normalize=True).channels_last(m["B"], m["T"], m["H"], m["W"], "cuda")):
+        out = layer(dev(src), p)[0]
+        names = _stage_names()
+        e, e2 = rel_err(out.cpu()[:, ::s], t(z["out"])), rel_l2(out.cpu()[:, ::s], t(z["out"]))
+        assert e < TOL_F16 and e2 < TOL_F16, (name, e, e2)
+        np.testing.assert_allclose(checks(out.cpu())[1:], z["out_checks"][1:], rtol=2e-3)
+    print(f"{name}: {names[1:]} max/max {e:.2e} relL2 {e2:.2e}")
+    assert not any("spatial_attn" in n for n in names), names          # fused tier: x[q, f, C] never reaches HBM

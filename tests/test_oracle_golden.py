@@ -43,6 +43,21 @@ def test_axial_layer_and_pos(name):
         assert rel_err(ha[::64, ::16], t(z["h_attn"])) < TOL and rel_err(wa[::64, ::16], t(z["w_attn"])) < TOL
 
 
+@pytest.mark.parametrize("name", __import__("golden_util").SHIPPED)
+def test_axial_layer_at_the_shipped_map_sizes(name):
+    """The oracle against the reference at the temporal-level sizes of the shipped VIPSeg (49 x 85, 25 x 43; T = 2) and Tube-Link
+    (24 x 40, 12 x 20; T = 5) configurations (oracle/gen_golden_shipped.py)."""
+    z, m = load(name)
+    w = weights(z, m)
+    src, pos = axial_inputs(m)
+    np.testing.assert_allclose(checks(pos), z["pos_checks"], rtol=1e-6)
+    out, ha, wa = orc.axial_layer(src, pos, w, m["heads"])
+    assert rel_err(out[:, ::m["stride"]], t(z["out"])) < TOL
+    np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=1e-4)
+    np.testing.assert_allclose(checks(ha), z["h_attn_checks"], rtol=1e-4)
+    np.testing.assert_allclose(checks(wa), z["w_attn_checks"], rtol=1e-4)
+
+
 def test_axial_layer_float64_is_closer_than_tol():
     """The float64 oracle agrees with the fp32 reference to fp32 noise (it is the tighter reference)."""
     z, m = load("g2_axial_B2_T3_C64_H5_W7")
