@@ -664,12 +664,43 @@ def main():
                         wc.forward_features(dict(feats3))
                     torch.cuda.synchronize(dev)
                 el32 = (time.perf_counter() - t3) / 10
+                # the same module at the SHIPPED VIPSeg ResNet-50 setting (maxtron_wc_r50.yaml: IMAGE_SIZE 769 x 1345, NUM_CLIP_FRAMES 2, 2 stages x
+                # (1 deformable layer + 2 axial-trajectory layers on res5 and res4)): res3 / res4 / res5 = 97 x 169 / 49 x 85 / 25 x 43 -- ragged maps
+                el_vip = None
+                try:
+                    chv, szv = {"res3": 512, "res4": 1024, "res5": 2048}, {"res3": (97, 169), "res4": (49, 85), "res5": (25, 43)}
+                    wv = ax.WithinClipTrackingModule(
+                        {k: _Shape(c, st_) for (k, c), st_ in zip(chv.items(), (8, 16, 32))}, transformer_dropout=0.0, transformer_attn_drop=0.0,
+                        transformer_nheads=8, transformer_dim_feedforward=1024, transformer_num_stages=2, transformer_spatial_layers=2,
+                        transformer_temporal_layers=4, transformer_temporal_attn_type="axial-trajectory", transformer_conv_dims=256,
+                        transformer_spatial_in_features=["res3", "res4", "res5"], transformer_temporal_in_features=["res4", "res5"],
+                        num_clip_frames=2, cross_clip_training=True).eval()
+                    sdv = wv.within_clip_tracking_module.state_dict()
+                    sdv.update(random_weights({k: tuple(v.shape) for k, v in sdv.items() if v.dtype.is_floating_point}, 5))
+                    wv.within_clip_tracking_module.load_state_dict(sdv, strict=True)
+                    wv = wv.to(dev)
+                    featsv = {k: torch.randn(2, chv[k], *szv[k], device=dev, generator=g3) for k in chv}
+                    with torch.no_grad():
+                        for _ in range(5):
+                            wv.forward_features(dict(featsv))
+                        torch.cuda.synchronize(dev)
+                        tv = time.perf_counter()
+                        for _ in range(20):
+                            ov = wv.forward_features(dict(featsv))
+                        torch.cuda.synchronize(dev)
+                    el_vip = (time.perf_counter() - tv) / 20
+                    del wv, featsv, ov
+                except RuntimeError as e:
+                    el_vip = str(e)[:200]
                 extras["wc_cfg3"] = {"ms_per_forward": round(el * 1e3, 3), "value": round(4 / el, 1), "unit": "frames/s",
+                                     "ms_per_forward_vipseg_r50_769x1345_T2": round(el_vip * 1e3, 3) if isinstance(el_vip, float) else el_vip,
                                      "ms_per_forward_f32_stack": round(el32 * 1e3, 3),
                                      "what": "BASELINE config 3: WithinClipTrackingModule.forward_features, res3/4/5 = [4,192,64,64] / [4,384,32,32] / "
                                              "[4,768,16,16], 2 stages x (1 deformable spatial layer + 2 axial-trajectory layers on res5 and res4); "
                                              "ms_per_forward: 16-bit operands (<= 1e-3 per layer and in relative L2, 1.4e-3 max-norm over the stack); "
-                                             "ms_per_forward_f32_stack: set_stack_precision('f32'), <= 1e-3 in max-norm as well"}
+                                             "ms_per_forward_f32_stack: set_stack_precision('f32'), <= 1e-3 in max-norm as well; "
+                                             "ms_per_forward_vipseg_r50_769x1345_T2: the same module at the shipped VIPSeg ResNet-50 setting (res3 / res4 / res5 = "
+                                             "[2,512,97,169] / [2,1024,49,85] / [2,2048,25,43], 2 frames per clip)"}
                 del wc, feats3
             except RuntimeError as e:
                 extras["wc_cfg3"] = {"error": str(e)[:200]}
