@@ -117,5 +117,24 @@ if __name__ == "__main__":
         e = errs(x16, x64)
         out["stack"].append({"layers": i + 1, "max_over_max": e[0], "rel_l2": e[1]})
         print(f"stack of {i + 1} layer(s), free-running: max/max {e[0]:.2e} relL2 {e[1]:.2e}")
+    # round 5 (review item 6): the same stack with the two activation sites of a "split" mode made exact (src + pos into q / k,
+    # norm1 output into linear1), and with the activation AND weight sites of those two GEMMs exact, over three weight seeds
+    if "--split" in sys.argv:
+        out["split_stack"] = []
+        variants = {"all_fp16": SITES, "split_a_qk_y": [t for t in SITES if t not in ("a_qk", "y")],
+                    "split_a_qk_y_h": [t for t in SITES if t not in ("a_qk", "y", "h")],
+                    "split_a_qk_y_h_and_their_weights": [t for t in SITES if t not in ("a_qk", "y", "h", "w_qkv", "w_ffn")]}
+        for seed in (10, 20, 30):
+            ws = [orc.random_weights(orc.axial_layer_param_shapes(C, F), seed + i) for i in range(6)]
+            x64 = src.double()
+            for wi in ws:
+                x64, _, _ = orc.axial_layer(x64, pos.double(), wi, 8, want_attn=False)
+            for name, on in variants.items():
+                x16 = src
+                for wi in ws:
+                    x16 = layer(x16, pos, wi, 8, Q(on))
+                e = errs(x16, x64)
+                out["split_stack"].append({"seed": seed, "variant": name, "max_over_max": e[0], "rel_l2": e[1]})
+                print(f"6-layer stack, seed {seed}, {name:34s}: max/max {e[0]:.2e} relL2 {e[1]:.2e}")
     if "--json" in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
