@@ -39,6 +39,11 @@ thread_local unsigned g_sync_spin_limit = axvs::kSyncSpinLimit;   // option "syn
 thread_local long long g_row_span = 0;   // rows spanned by the layer's row-addressed tensors when their frames are strided (0: natural)
 thread_local int g_ffn_wide = 0;         // option "ffn_wide": 0 = 128-row FFN tiles when they save a round of the chip (ffn_wide_pays), 1 = always, 2 = never
 thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
+constexpr int kSmallBelow = 65;          // problems with fewer 64-row tiles than this run the few-rows forms (16-row trajectory tiles, 3-way split q/k/v
+                                         // projection, chunk-per-workgroup FFN): their 4x workgroups fit one round of the 256 CUs up to 64 tiles, and from 65 on
+                                         // the 64-row forms (merged launch per pass, FFN riding in the width pass) are faster at every T -- round 5 sweep,
+                                         // profiles/r5_planner_threshold.txt (128 until then: [1,2,256,48,80] 93.4 -> 79.5 us, [1,5,256,24,40] 94.6 -> 82.8)
+thread_local int g_small_below = kSmallBelow;      // option "small_tiles_below" (A/B runs; <= 0 restores the default)
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
                                          // 2 = the merged q/k/v + trajectory kernels return after their q/k/v part (the two-launch kernels treat it as 1)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
@@ -280,23 +285,24 @@ bool fused_frames(int T, long long /*rows*/) { return T <= 8 || (T <= 12 && !g_n
 bool can_fuse_attn(int C, int heads, int T, int L, bool want_attn, long long rows) {
   return !g_generic_only && !g_no_attn_fusion && C == 256 && heads == 8 && fused_frames(T, rows) && !want_attn && L >= 8 && L <= 128;
 }
-// The FFN rides in the width-pass kernel only when that kernel fills at least half the chip: with fewer 64-row tiles every
+// The FFN rides in the width-pass kernel only when that kernel has more than 64 tiles (kSmallBelow): with fewer 64-row tiles every
 // workgroup's private 1 MB FFN weight stream is pure latency (43 us per pass whether 16 or 64 workgroups run), and a 16-row
 // trajectory kernel (4x the workgroups) + the stand-alone FFN kernel is faster (BASELINE config 3: res4 / res5 levels).
+inline int small_below(int /*T*/) { return g_small_below; }
 bool can_fuse_ffn_into_pass(int T, int F, long long M) {
-  return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096 && (M >= 128 * 64 || g_no_small_tiles);
+  return !g_no_ffn_fusion && !g_ffn_gelu && T <= 4 && F % 256 == 0 && F <= 4096 && (M >= (long long)small_below(T) * 64 || g_no_small_tiles);
 }
 // (activation = gelu: the stand-alone fused FFN kernels have a GELU instantiation; only the width-pass kernel does not carry it)
 bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
 // few rows: one workgroup per (64-row tile, 256-unit chunk of the hidden layer) + a row-wise finishing kernel (axvs_ffn_split.h);
 // bit-identical to the one-workgroup-per-tile kernels, so the row count may decide
 bool ffn_split_applies(int C, int heads, int F, long long M) {
-  return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < 128 * 64;
+  return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < (long long)g_small_below * 64;
 }
 
 // 64-row tiles (MT = 4) of the fused trajectory kernel: T <= 4, and either the FFN rides along or there are enough tiles to
 // fill the chip (few tiles take 16-row tiles: 4x the workgroups) -- the choice launch_temporal makes
-bool traj_mt4(int T, long long tiles64, bool with_ffn) { return T <= 4 && (with_ffn || tiles64 >= 128 || g_no_small_tiles); }
+bool traj_mt4(int T, long long tiles64, bool with_ffn) { return T <= 4 && (with_ffn || tiles64 >= small_below(T) || g_no_small_tiles); }
 long long traj_tiles64(long long Mp, int N) { return (Mp / N) * ((N + 63) / 64); }
 // V in row form (K's layout; staged through the x tile and read back transposed): 64-row tiles, at most 64 keys per frame
 bool can_vrow(int T, int L, long long Mp, bool with_ffn, bool forced = false) {
@@ -357,7 +363,7 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
   if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
   if (oq && !(nks > 0 && T <= 4)) return fail(AXVS_ERR_ARG, "internal: own q,k,v need the in-kernel spatial half and T <= 4");
-  if (fa == nullptr && (tiles64 < 128 || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
+  if (fa == nullptr && (tiles64 < small_below(T) || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
     switch (T) {
       case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
       case 2: return launch_temporal_n<BF, 2, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
@@ -436,7 +442,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   // measured (4 - 9 % from [1,2,256,64,64] to [8,4,256,64,64]); other frame lengths (MQ = 1) gain while the grid stays within
   // ~2 rounds of the chip (-3.5 % at 576 tiles, -7.5 % at 240) and LOSE beyond (+2.5 % at 1152 tiles, +8 % at 4608: sibling
   // tiles start staggered there and every tile waits for the last one) -- option "merge_qkv_any" lifts the limit for A/B runs.
-  // Problems with few rows run 16-row tiles (launch_temporal: fewer than 128 tiles of 64 rows and no FFN riding along -- pyramid
+  // Problems with few rows run 16-row tiles (launch_temporal: fewer than kSmallBelow tiles of 64 rows and no FFN riding along -- pyramid
   // levels of 32 x 32 and below, the cross-clip queries).  Their merged form exists (MQ = 1 on 16-row tiles, bit-identical) but
   // every 16-row workgroup then streams the 384 KB of q/k/v weights itself, which costs what the launch and the q round trip save:
   // layer at [1,4,256,32,32] 59.0 vs 59.2 us, [1,4,256,16,16] 53.1 vs 56.0, [3,4,256,16,32] 105.3 vs 97.8 (768 tiles: siblings
@@ -1252,6 +1258,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
+  if (key && !strcmp(key, "small_tiles_below")) { g_small_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_wide")) { g_ffn_wide = value; return AXVS_OK; }
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }
