@@ -17,6 +17,10 @@
 // +4 %): every step of the pipeline must pull BOTH matrices' fragments (256 KiB) through one phase time -- 62 B/clk, the limit of the
 // L2 -> CU path (profiles/r5_l2_stream_forms_probe.txt), so every hiccup stalls both wave groups -- and the two-stage pipeline adds a
 // fill and a drain step during which only half the waves work.
+#ifndef AXVS_V_AHEAD      // 1: 16- / 32-row trajectory tiles request their V^T fragments one frame ahead (round 5: bit-identical, no gain -- a frame of 16 queries is a
+                          // ~0.8 k-cycle chain of dependent MFMA / softmax / LDS steps, not the V^T request: profiles/r5_few_rows_timeline.txt)
+#define AXVS_V_AHEAD 0
+#endif
 #ifndef AXVS_FFN_WS
 #define AXVS_FFN_WS 0
 #endif
@@ -1098,7 +1102,10 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     u16x8 qf[MT];
     // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
     // the L2 latency of both hides behind MFMA + softmax work
-    u16x8 kb[2][2 * NKS], vf[2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
+    // AXVS_V_AHEAD builds, 16- / 32-row tiles without the in-kernel q/k/v (few rows: pyramid levels of up to 64 tiles, the cross-clip queries): the V^T fragments
+    // alternate between two sets like K's and are requested one frame ahead (measured: frames 1.0 k -> 0.8 k cycles, kernel and layer unchanged)
+    constexpr bool VPF = AXVS_V_AHEAD && MQ == 0 && !VROW && MT <= 2;
+    u16x8 kb[2][2 * NKS], vfs[VPF ? 2 : 1][2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
     // MQ: K / V^T written by the sibling tiles of this launch are read with sc1 buffer loads (per-lane byte offset + a
     // wave-uniform frame offset), and only after the hand-off
     [[maybe_unused]] const ScBuf kbuf(K16), vbuf(VT16);
@@ -1362,6 +1369,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     if constexpr (MQ == 0) {
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+    if constexpr (VPF) {
+#pragma unroll
+      for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) vfs[0][nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
+      vp += NKS * 1024;
+    }
     }
     AXVS_STAMP(11);
     if constexpr (MQ == 0) stage_small();   // behind the cold Q / K loads of the first frame instead of in front of the barrier
@@ -1381,6 +1395,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr bool OWN = decltype(own_tag)::value;
       constexpr bool VPRE = decltype(vpre_tag)::value;
+      auto& vf = vfs[VPF ? PAR : 0];
       u16x8 vr[NVL];
       if constexpr (MQ != 0) {
         if constexpr (!OWN) {
@@ -1402,7 +1417,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
           vr[n] = *reinterpret_cast<const u16x8*>(vrp[n]);
           vrp[n] += kstep;
         }
-      } else {
+      } else if constexpr (!VPF) {
 #pragma unroll
         for (int nd = 0; nd < 2; ++nd)
 #pragma unroll
@@ -1414,6 +1429,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
+        if constexpr (VPF) {               // the next frame's V^T fragments, behind its K fragments
+#pragma unroll
+          for (int nd = 0; nd < 2; ++nd)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) vfs[PAR ^ 1][nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
+          vp += NKS * 1024;
+        }
       }
       }
       f32x4 sc[MT][2 * NKS];

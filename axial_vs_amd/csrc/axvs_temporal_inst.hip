@@ -100,6 +100,13 @@ extern "C" int axvs_debug_read_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+#if defined(AXVS_STAMPS) && !defined(AXVS_STAMPS_QKV) && AXVS_INST_BF == 0 && AXVS_INST_T == 4 && AXVS_INST_MT == 1
+// ... and of the 16-row kernels of the same (f16, T = 4): the cross-clip queries (tools/r5/cc_traj_stamps.py)
+extern "C" int axvs_debug_read_stamps_mt1(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(axvs::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 #if defined(AXVS_STAMPS_WG) && AXVS_INST_BF == 0 && AXVS_INST_T == 4 && AXVS_INST_MT == 4
 // diagnostic builds: start / end of every workgroup of the last f16 / T = 4 launches (tools/r5/wg_times.py)
 extern "C" int axvs_debug_read_wg_times(unsigned long long* host, int n) {
