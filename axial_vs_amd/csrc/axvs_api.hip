@@ -38,12 +38,14 @@ thread_local volatile int* g_status_host = nullptr;   // the same word when the 
 thread_local unsigned g_sync_spin_limit = axvs::kSyncSpinLimit;   // option "sync_spin_limit": polls before a hand-off wait gives up (tests shorten it)
 thread_local long long g_row_span = 0;   // rows spanned by the layer's row-addressed tensors when their frames are strided (0: natural)
 thread_local int g_ffn_wide = 0;         // option "ffn_wide": 0 = 128-row FFN tiles when they save a round of the chip (ffn_wide_pays), 1 = always, 2 = never
+thread_local int g_merge_mid = 1;        // option "merge_mid": merged q/k/v + trajectory launch on 32-row tiles (T = 5 .. 8): 1 = while the pass fits one round of the chip, 0 never, 2 always
 thread_local int g_no_small_tiles = 0;   // option "no_small_tiles": never use the 16-row trajectory tiles
 constexpr int kSmallBelow = 65;          // problems with fewer 64-row tiles than this run the few-rows forms (16-row trajectory tiles, 3-way split q/k/v
                                          // projection, chunk-per-workgroup FFN): their 4x workgroups fit one round of the 256 CUs up to 64 tiles, and from 65 on
                                          // the 64-row forms (merged launch per pass, FFN riding in the width pass) are faster at every T -- round 5 sweep,
                                          // profiles/r5_planner_threshold.txt (128 until then: [1,2,256,48,80] 93.4 -> 79.5 us, [1,5,256,24,40] 94.6 -> 82.8)
 thread_local int g_small_below = kSmallBelow;      // option "small_tiles_below" (A/B runs; <= 0 restores the default)
+thread_local int g_ffn_split_below = kSmallBelow;  // option "ffn_split_below": the same switch for the stand-alone FFN alone (chunk-per-workgroup form below it)
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
                                          // 2 = the merged q/k/v + trajectory kernels return after their q/k/v part (the two-launch kernels treat it as 1)
 thread_local int g_no_wt_stores = 0;     // option "no_wt_stores": plain instead of write-through (sc1) stores of inter-kernel tensors (tuning)
@@ -297,7 +299,7 @@ bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && C 
 // few rows: one workgroup per (64-row tile, 256-unit chunk of the hidden layer) + a row-wise finishing kernel (axvs_ffn_split.h);
 // bit-identical to the one-workgroup-per-tile kernels, so the row count may decide
 bool ffn_split_applies(int C, int heads, int F, long long M) {
-  return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < (long long)g_small_below * 64;
+  return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < (long long)g_ffn_split_below * 64;
 }
 
 // 64-row tiles (MT = 4) of the fused trajectory kernel: T <= 4, and either the FFN rides along or there are enough tiles to
@@ -362,7 +364,7 @@ int launch_temporal(const TrajWs& w, const TrajPacked& p, const float* res, floa
   // few rows (cross-clip queries: 512 per video): 16-row tiles give 4x the workgroups -- the spatial half is per-query work
   const long long tiles64 = nks > 0 ? traj_tiles64(Mp, N) : (Mp + 63) / 64;
   if ((vrow || nq) && !(nks > 0 && traj_mt4(T, tiles64, fa != nullptr))) return fail(AXVS_ERR_ARG, "internal: row-form V / next-pass q,k,v need 64-row tiles");
-  if (oq && !(nks > 0 && T <= 4)) return fail(AXVS_ERR_ARG, "internal: own q,k,v need the in-kernel spatial half and T <= 4");
+  if (oq && !(nks > 0 && T <= 8)) return fail(AXVS_ERR_ARG, "internal: own q,k,v need the in-kernel spatial half and T <= 8");
   if (fa == nullptr && (tiles64 < small_below(T) || T > 8) && !g_no_small_tiles) {       // (T > 8 exists on 16-row tiles only: fused_frames)
     switch (T) {
       case 1: return launch_temporal_n<BF, 1, 1>(nks, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
@@ -460,10 +462,15 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   if (mt4 && !own_frame && tiles > 640 && !g_merge_qkv_any && !g_no_persist && nks_fused >= 2 && nks_fused <= 3 && tps <= cu_count())
     persist_grid = cu_count() / tps * tps;
 #endif
+  // 32-row tiles (5 .. 8 frames per clip, more than 64 tiles of 64 rows; Tube-Link's T = 5 levels): the merged form exists too (MQ = 1, round 5).  Their x tile
+  // (T * 16 KiB) leaves room for ONE workgroup per CU, so the siblings of a hand-off start together only while the pass fits one round of the chip: -4 .. -9 % per
+  // layer up to 256 tiles, +4 .. +15 % beyond (profiles/r5_merged_32row_tiles.txt) -- merged iff tiles <= CUs (option "merge_mid": 0 never, 2 always).
+  const bool mt2 = T > 4 && T <= 8 && (tiles >= small_below(T) || g_no_small_tiles);
+  const bool mid_ok = mt2 && g_merge_mid && (g_merge_mid == 2 || (long long)S * ((N + 31) / 32) <= cu_count());
   const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv &&
-                     g_sync != nullptr && (size_t)S <= g_sync_words && T <= 4 && L % 16 == 0 && nks_fused <= (mt4 ? 3 : 4) &&
+                     g_sync != nullptr && (size_t)S <= g_sync_words && (T <= 4 || mt2) && L % 16 == 0 && nks_fused <= (mt4 || mt2 ? 3 : 4) &&
                      2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
-                     (!mt4 || own_frame || tiles <= 640 || g_merge_qkv_any || persist_grid > 0) && (mt4 || g_merge_small);
+                     (!mt4 || own_frame || tiles <= 640 || g_merge_qkv_any || persist_grid > 0) && (mt4 || mid_ok || (!mt2 && g_merge_small));
   if (merge) {
     const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status, g_sync_spin_limit,
                     persist_grid};
@@ -1257,8 +1264,10 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "train_spatial_wgs")) { g_spatial_wgs = value > 0 ? value : 512; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
+  if (key && !strcmp(key, "merge_mid")) { g_merge_mid = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
-  if (key && !strcmp(key, "small_tiles_below")) { g_small_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
+  if (key && !strcmp(key, "small_tiles_below")) { g_small_below = g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
+  if (key && !strcmp(key, "ffn_split_below")) { g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_wide")) { g_ffn_wide = value; return AXVS_OK; }
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_fusion")) { g_qkv_fusion = value; return AXVS_OK; }

@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              OwnQkv oq_a = OwnQkv{}) {
   static_assert(!PERSIST || (MQ == 1 && MT == 4), "the tile loop exists for the merged launch on 64-row tiles");
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
-  static_assert(MQ == 0 || ((MT == 4 || MT == 1) && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64- or 16-row tiles, block-transposed V");
+  static_assert(MQ == 0 || ((MT == 4 || MT == 2 || MT == 1) && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64-, 32- or 16-row tiles, block-transposed V");
   static_assert(MQ != 2 || (MT == 4 && NKS == 2 && T >= 2), "own frame first: a 64-row tile is one 64-key frame");
   static_assert(!VROW || (MT == 4 && NKS >= 1 && NKS <= 2), "row-major V is staged in a 64-row x-tile block: 64 keys per frame at most");
   static_assert(!QKVN || (MT == 4 && !FFN && NKS > 0), "the next pass's q/k/v ride in the 64-row kernel without the FFN");

@@ -58,7 +58,13 @@ static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* 
       return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
     }
   }
-  if (oq) return fail(AXVS_ERR_ARG, "internal: merged q/k/v needs the in-kernel spatial half on 64- or 16-row tiles, T <= 4");
+  if constexpr (NKS > 0 && NKS <= 3 && MT == 2 && T >= 5) {
+    if (oq) {                           // 32-row tiles: 5 .. 8 frames per clip (Tube-Link's T = 5 levels)
+      if (vrow || nq || fa) return fail(AXVS_ERR_ARG, "internal: merged q/k/v on 32-row tiles excludes row-form V / next-pass q,k,v / the FFN");
+      return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+    }
+  }
+  if (oq) return fail(AXVS_ERR_ARG, "internal: merged q/k/v needs the in-kernel spatial half on 64- / 16-row tiles (T <= 4) or 32-row tiles (T = 5 .. 8)");
   if constexpr (NKS > 0 && MT == 4) {
     if constexpr (NKS <= 2) {           // V in row form (staged in the x tile: 64 keys per frame at most)
       if (vrow && fa) return launch_one<BF, T, MT, NKS, true, true, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);

@@ -1745,7 +1745,12 @@ RAGGED_MERGE_SHAPES = [(1, 2, 256, 49, 85, 1024),     # shipped VIPSeg res4 leve
                        (2, 4, 256, 23, 40, 1024),
                        (1, 4, 256, 33, 70, 1024),     # 33 -> 48: a frame of 2 full key tiles + 1 key
                        (1, 5, 256, 12, 20, 1024),     # shipped Tube-Link stride-32 level (T = 5): frames of 12 keys -> 16 (the fused tier starts at 8 keys)
-                       (2, 4, 256, 8, 9, 512)]        # the smallest frames the fused tier takes
+                       (2, 4, 256, 8, 9, 512),        # the smallest frames the fused tier takes
+                       # 5 .. 8 frames per clip on 32-row tiles: merged while a pass fits one round of the chip (<= 256 tiles of 32 rows)
+                       (1, 5, 256, 24, 40, 1024),     # shipped Tube-Link stride-16 level: 200 / 192 tiles -> both passes merged
+                       (2, 5, 256, 24, 40, 512),      # 400 / 384 tiles: two launches per pass; the clip alone runs merged -- same bits
+                       (1, 6, 256, 32, 32, 512),
+                       (1, 8, 256, 17, 40, 256)]      # height pass 320 tiles (two launches), width pass 204 (merged)
 
 
 @pytest.mark.gpu
@@ -1784,6 +1789,10 @@ def test_ragged_frames_in_the_padded_row_space(shape):
     assert not any("spatial_attn" in n for n in names_one), names_one
     if B * T * H * W >= 128 * 64 and T <= 4:          # 64-row tiles: one launch per pass for any frame length
         assert "h.qkv+traj" in names_one and any(n.startswith("w.qkv+traj") for n in names_one), names_one
+    if shape[:5] in ((1, 5, 256, 24, 40), (1, 6, 256, 32, 32)):      # 32-row tiles within one round of the chip
+        assert "h.qkv+traj" in names_one and "w.qkv+traj" in names_one, names_one
+    if shape[:5] == (1, 8, 256, 17, 40):
+        assert "h.qkv_proj" in names_one and "w.qkv+traj" in names_one, names_one
     if B > 1:                                          # batch sharding stays bit-exact
         alone = layer(s[:T].contiguous(), pg[:1].contiguous() if False else ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(1, T, H, W, "cuda"))[0]
         assert torch.equal(alone, layer(s, pg)[0][:T])
