@@ -70,7 +70,8 @@ thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass'
 thread_local unsigned* g_sync = nullptr;
 thread_local size_t g_sync_words = 0;
 thread_local int g_merge_qkv_any = 0;    // option "merge_qkv_any": merged launches at every grid size (A/B; see run_traj)
-thread_local int g_merge_small = 0;      // option "merge_small": 16-row-tile problems merge as well (built and bit-identical; measured a wash, see run_traj)
+constexpr int kMergeSmall = 128;         // 16-row-tile passes (T <= 4) of at most this many tiles run merged too (round 5, profiles/r5_merged_16row_tiles.txt)
+thread_local int g_merge_small = kMergeSmall;      // option "merge_small": 0 never, 1 at any size, n > 1: passes of at most n tiles of 16 rows, < 0: the default
 thread_local int g_out_dtype = 0;        // option "layer_out_dtype": 0 = the layer's output rows are fp32 (the reference's type); 1 / 2 = the kernel that ends the layer
                                          // (norm2 epilogue of the FFN) writes them as f16 / bf16 -- the map a batch-sharded caller gathers over the links
                                          // (BASELINE config 5 is worded "bf16"), written once instead of cast by a second pass
@@ -448,7 +449,11 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   // levels of 32 x 32 and below, the cross-clip queries).  Their merged form exists (MQ = 1 on 16-row tiles, bit-identical) but
   // every 16-row workgroup then streams the 384 KB of q/k/v weights itself, which costs what the launch and the q round trip save:
   // layer at [1,4,256,32,32] 59.0 vs 59.2 us, [1,4,256,16,16] 53.1 vs 56.0, [3,4,256,16,32] 105.3 vs 97.8 (768 tiles: siblings
-  // start staggered), cross-clip module 236.1 vs 237.3, BASELINE config 3 0.997 vs 0.989 ms -- off unless option "merge_small".
+  // start staggered), cross-clip module 236.1 vs 237.3, BASELINE config 3 0.997 vs 0.989 ms -- off unless option "merge_small" (rounds 3 - 4).
+  // Round 5: with the few-rows forms ending at 64 tiles of 64 rows (kSmallBelow) every 16-row grid fits one round of the chip and the case that lost is gone:
+  // back to back on warm weights the merged form gains at every size (-8 % per layer at 32 tiles of 16 rows, -7 % at 64, -3 % at 128, -1.5 % at 256), but in a
+  // stack of layers with their own, cold weights only up to 128 tiles (-3 %; +3 % at 256: 256 workgroups x 384 KB of q/k/v weights from HBM) -- merged up to
+  // kMergeSmall tiles per pass: BASELINE config 3 0.878 -> 0.864 ms, cross-clip module 226 -> 224.6 us (profiles/r5_merged_16row_tiles.txt).
   const bool mt4 = traj_mt4(T, traj_tiles64(Mp, N), with_ffn);
   const bool own_frame = mt4 && L == 64 && T >= 2;
   // Beyond ~2 rounds of the chip (frames other than 64 keys) the merged form can run as a PERSISTENT grid: one workgroup per CU, a whole
@@ -470,7 +475,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
   const bool merge = may_merge && fuse_attn && !have_qkv && !nq && !vrow && !g_generic_only && !g_no_merge_qkv &&
                      g_sync != nullptr && (size_t)S <= g_sync_words && (T <= 4 || mt2) && L % 16 == 0 && nks_fused <= (mt4 || mt2 ? 3 : 4) &&
                      2 * (long long)Cp * Mp * 2 < (1ll << 32) &&
-                     (!mt4 || own_frame || tiles <= 640 || g_merge_qkv_any || persist_grid > 0) && (mt4 || mid_ok || (!mt2 && g_merge_small));
+                     (!mt4 || own_frame || tiles <= 640 || g_merge_qkv_any || persist_grid > 0) && (mt4 || mid_ok || (!mt2 && g_merge_small && (g_merge_small == 1 || (long long)S * ((N + 15) / 16) <= g_merge_small)));
   if (merge) {
     const OwnQkv oq{qsrc, qk_add, posgen ? *posgen : PosGen{}, p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, scale * kLog2e, g_sync, g_status, g_sync_spin_limit,
                     persist_grid};
@@ -1275,7 +1280,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "merge_qkv_any")) { g_merge_qkv_any = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_persist")) { g_no_persist = value; return AXVS_OK; }
   if (key && !strcmp(key, "cc_last_heads_only")) { g_cc_last_only = value; return AXVS_OK; }
-  if (key && !strcmp(key, "merge_small")) { g_merge_small = value; return AXVS_OK; }
+  if (key && !strcmp(key, "merge_small")) { g_merge_small = value < 0 ? kMergeSmall : value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   if (key && !strcmp(key, "layer_out_dtype")) {
     if (value < 0 || value > 2) return fail(AXVS_ERR_ARG, "layer_out_dtype: 0 (fp32), 1 (f16) or 2 (bf16)");

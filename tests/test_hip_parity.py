@@ -1507,9 +1507,9 @@ def test_merged_qkv_on_two_streams_at_once():
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 4, 256, 32, 32, 1024), (1, 4, 256, 16, 16, 1024), (2, 3, 256, 32, 16, 512)])
 def test_merged_qkv_on_16_row_tiles_is_bit_identical(shape):
-    """Problems with few rows run the trajectory kernels on 16-row tiles; their one-launch-per-pass form (option `merge_small`:
-    measured no faster -- every 16-row workgroup streams the q/k/v weights itself -- so it is opt-in) must give the same bits as
-    q/k/v launch + trajectory launch, like the 64-row form does."""
+    """Problems with few rows run the trajectory kernels on 16-row tiles; their one-launch-per-pass form (option `merge_small`; the
+    default for passes of up to 128 tiles since round 5: profiles/r5_merged_16row_tiles.txt) must give the same
+    bits as q/k/v launch + trajectory launch, like the 64-row form does."""
     import axial_vs_amd as ax
     from axial_vs_amd import _lib
     B, T, C, H, W, F = shape
@@ -1523,14 +1523,15 @@ def test_merged_qkv_on_16_row_tiles_is_bit_identical(shape):
         g = torch.Generator(device="cuda").manual_seed(2000 + it)
         src = torch.randn(B * T, H * W, C, device="cuda", generator=g)
         for pos in (pg, pg.clone()):
-            two = layer(src, pos)[0].clone()
-            names_two = _stage_names()
-            _lib.check(L.axvs_set_option(b"merge_small", 1), "axvs_set_option")
+            _lib.check(L.axvs_set_option(b"merge_small", 1), "axvs_set_option")      # at any size ([1,4,256,32,32] has 256 tiles per pass)
+            one = layer(src, pos)[0].clone()
+            names_one = _stage_names()
+            _lib.check(L.axvs_set_option(b"merge_small", 0), "axvs_set_option")
             try:
-                one = layer(src, pos)[0].clone()
-                names_one = _stage_names()
+                two = layer(src, pos)[0].clone()
+                names_two = _stage_names()
             finally:
-                L.axvs_set_option(b"merge_small", 0)
+                L.axvs_set_option(b"merge_small", -1)        # back to the default (passes of up to 128 tiles of 16 rows)
             assert torch.equal(one, two), it
     assert "h.qkv_proj" in names_two and "h.qkv+traj" in names_one and "w.qkv+traj" in names_one, (names_two, names_one)
 
@@ -1740,7 +1741,7 @@ def test_layer_writes_its_output_map_in_16_bits(shape):
 # ---- round 5: padded frames -- any frame length gets 16-byte K / 8-byte V^T stores and the merged launch --------------------------------
 RAGGED_MERGE_SHAPES = [(1, 2, 256, 49, 85, 1024),     # shipped VIPSeg res4 level (T = 2): 49 -> 64 rows per frame (a tile IS a frame: MQ = 2), 85 -> 96
                        (1, 4, 256, 49, 85, 1024),
-                       (2, 2, 256, 25, 43, 1024),     # res5 level: 16-row tiles (two-launch form by default: merge_small is off)
+                       (2, 2, 256, 25, 43, 1024),     # res5 level: 16-row tiles
                        (1, 3, 256, 17, 127, 512),     # 17 -> 32 (15 padding rows per frame), 127 -> 128 keys: the widest fused frame
                        (2, 4, 256, 23, 40, 1024),
                        (1, 4, 256, 33, 70, 1024),     # 33 -> 48: a frame of 2 full key tiles + 1 key
