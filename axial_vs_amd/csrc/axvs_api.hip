@@ -70,6 +70,7 @@ thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass'
 thread_local unsigned* g_sync = nullptr;
 thread_local size_t g_sync_words = 0;
 thread_local int g_merge_qkv_any = 0;    // option "merge_qkv_any": merged launches at every grid size (A/B; see run_traj)
+thread_local int g_qkv_split_upto = 64;  // option "qkv_split_upto": the stand-alone q/k/v kernel runs one workgroup per (tile, q | k | v) up to this many tiles of 64 rows
 constexpr int kMergeSmall = 128;         // 16-row-tile passes (T <= 4) of at most this many tiles run merged too (round 5, profiles/r5_merged_16row_tiles.txt)
 thread_local int g_merge_small = kMergeSmall;      // option "merge_small": 0 never, 1 at any size, n > 1: passes of at most n tiles of 16 rows, < 0: the default
 thread_local int g_out_dtype = 0;        // option "layer_out_dtype": 0 = the layer's output rows are fp32 (the reference's type); 1 / 2 = the kernel that ends the layer
@@ -497,7 +498,7 @@ int run_traj(const float* qsrc, const float* ksrc, const float* vsrc, const floa
       // (the V^T padding keys of frames that are not multiples of 32 keys are cleared by the kernel itself)
       const unsigned qtiles = (unsigned)((Mp + 63) / 64);
       // few tiles (cross-clip queries): one workgroup per (tile, q | k | v) -- a third of the weight stream each
-      hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3(qtiles, (qtiles <= 64 && !g_no_small_tiles) ? 3 : 1), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
+      hipLaunchKernelGGL((qkv_fused_kernel<BF>), dim3(qtiles, ((int)qtiles <= g_qkv_split_upto && !g_no_small_tiles) ? 3 : 1), dim3(512), kQkvLdsBytes, st, qsrc, qk_add, rm,
                          p.wq, p.wk, p.wv, p.bq, p.bk, p.bv, w.q16, w.k16, vrow ? w.vt16 : w.v16, Mp, scale * kLog2e,
                          (fuse_attn && !vrow) ? w.vt16 : (u16*)nullptr, N, L, T, nks_fused, posgen ? *posgen : PosGen{},
                          (!g_no_wt_stores && 2 * (long long)Cp * Mp * 2 < (1ll << 32)) ? 1 : 0, g_status, vrow ? 1 : 0);
@@ -1269,6 +1270,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "train_spatial_wgs")) { g_spatial_wgs = value > 0 ? value : 512; return AXVS_OK; }
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
+  if (key && !strcmp(key, "qkv_split_upto")) { g_qkv_split_upto = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_mid")) { g_merge_mid = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   if (key && !strcmp(key, "small_tiles_below")) { g_small_below = g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }

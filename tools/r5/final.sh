@@ -10,7 +10,8 @@ python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2
 bash tools/kstats.sh r5_final > $O/kstats.txt 2>&1
 bash tools/kstats.sh r5_final_cfg5 --shape 8,4,256,96,96 --steps 40 > $O/kstats_cfg5.txt 2>&1
 bash tools/kstats.sh r5_final_vipseg --shape 1,2,256,49,85 > $O/kstats_vipseg.txt 2>&1
-cat $O/kstats.txt $O/kstats_cfg5.txt $O/kstats_vipseg.txt | grep -v "^W2026"
+bash tools/kstats.sh r5_final_tubelink --shape 1,5,256,24,40 > $O/kstats_tl.txt 2>&1
+cat $O/kstats.txt $O/kstats_cfg5.txt $O/kstats_vipseg.txt $O/kstats_tl.txt | grep -v "^W2026"
 bash tools/pmc_traffic.sh > $O/pmc_metric.txt 2>&1; tail -4 $O/pmc_metric.txt
 bash tools/pmc_traffic.sh --shape 1,2,256,49,85 _vipseg > $O/pmc_vipseg.txt 2>&1; tail -4 $O/pmc_vipseg.txt
 python3 bench.py > $O/bench_full.json 2> $O/bench_full.err
