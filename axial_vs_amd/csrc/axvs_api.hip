@@ -45,6 +45,7 @@ constexpr int kSmallBelow = 65;          // problems with fewer 64-row tiles tha
                                          // the 64-row forms (merged launch per pass, FFN riding in the width pass) are faster at every T -- round 5 sweep,
                                          // profiles/r5_planner_threshold.txt (128 until then: [1,2,256,48,80] 93.4 -> 79.5 us, [1,5,256,24,40] 94.6 -> 82.8)
 thread_local int g_small_below = kSmallBelow;      // option "small_tiles_below" (A/B runs; <= 0 restores the default)
+thread_local int g_ffn_split_pairs = 1;  // option "ffn_split_pairs": 65 .. 128 tiles run the chunk-per-workgroup FFN with two chunks per workgroup (0: the one-workgroup-per-tile kernel)
 thread_local int g_ffn_split_below = kSmallBelow;  // option "ffn_split_below": the same switch for the stand-alone FFN alone (chunk-per-workgroup form below it)
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
                                          // 2 = the merged q/k/v + trajectory kernels return after their q/k/v part (the two-launch kernels treat it as 1)
@@ -300,9 +301,14 @@ bool can_fuse_ffn_into_pass(int T, int F, long long M) {
 bool ffn_kernel_is_fused(int C, int heads, int F) { return !g_generic_only && C == 256 && heads == 8 && F % 256 == 0 && F <= 4096; }
 // few rows: one workgroup per (64-row tile, 256-unit chunk of the hidden layer) + a row-wise finishing kernel (axvs_ffn_split.h);
 // bit-identical to the one-workgroup-per-tile kernels, so the row count may decide
-bool ffn_split_applies(int C, int heads, int F, long long M) {
-  return ffn_kernel_is_fused(C, heads, F) && !g_no_small_tiles && F >= 512 && M < (long long)g_ffn_split_below * 64;
+// 65 .. 88 tiles (round 5): the same kernel with TWO consecutive chunks per workgroup -- tiles x F/512 workgroups, still one round of the chip -- where the
+// one-workgroup-per-tile kernel leaves half the CUs idle behind a private 1 MB stream (only reached when the FFN does not ride in the width pass: T >= 5, GELU)
+int ffn_split_mode(int C, int heads, int F, long long M) {      // 0: no split, 1: one chunk per workgroup, 2: two
+  if (!ffn_kernel_is_fused(C, heads, F) || g_no_small_tiles || F < 512) return 0;
+  if (M < (long long)g_ffn_split_below * 64) return 1;
+  return (g_ffn_split_pairs && F % 512 == 0 && M <= 88 * 64) ? 2 : 0;      // measured: -2.4 us at 75 tiles, -0.5 .. -0.9 at 80 .. 84, +0.9 at 96, +4.5 at 128 (partials + finishing kernel)
 }
+bool ffn_split_applies(int C, int heads, int F, long long M) { return ffn_split_mode(C, heads, F, M) != 0; }
 
 // 64-row tiles (MT = 4) of the fused trajectory kernel: T <= 4, and either the FFN rides along or there are enough tiles to
 // fill the chip (few tiles take 16-row tiles: 4x the workgroups) -- the choice launch_temporal makes
@@ -619,7 +625,21 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
   const int oflags = g_out_dtype ? (g_out_dtype == 1 ? kOutF16 : kOutBf16) : 0;
   if (oflags && !(ffn_kernel_is_fused(C, heads, F) && ffn_lds_bytes(F) <= 160 * 1024))
     return fail(AXVS_ERR_ARG, "layer_out_dtype: a 16-bit output map needs the fused FFN tier (C = 256, 8 heads, d_ffn a multiple of 256 up to 4096)");
-  if (!oflags && part != nullptr && ffn_split_applies(C, heads, F, M)) {
+  if (!oflags && part != nullptr && ffn_split_mode(C, heads, F, M) == 2) {
+    const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 512);
+    if (g_ffn_gelu) {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true, 2>))) return rc;
+      hipLaunchKernelGGL((ffn_split_kernel<BF, true, 2>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
+    } else {
+      if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, false, 2>))) return rc;
+      hipLaunchKernelGGL((ffn_split_kernel<BF, false, 2>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
+    }
+    hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
+                       p.g2, p.be2, out, M, F / 256, rs);
+    mark(st, "norm1+ffn+norm2");
+    return AXVS_OK;
+  }
+  if (!oflags && part != nullptr && ffn_split_mode(C, heads, F, M) == 1) {
     const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 256);
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true>))) return rc;
@@ -1274,6 +1294,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "merge_mid")) { g_merge_mid = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   if (key && !strcmp(key, "small_tiles_below")) { g_small_below = g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
+  if (key && !strcmp(key, "ffn_split_pairs")) { g_ffn_split_pairs = value; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_split_below")) { g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_wide")) { g_ffn_wide = value; return AXVS_OK; }
   if (key && !strcmp(key, "vrow")) { g_vrow = value; return AXVS_OK; }

@@ -16,7 +16,10 @@ namespace axvs {
 
 constexpr size_t kFfnSplitLds = 2 * 8 * kTileElems * sizeof(u16) + (size_t)kRows * kEpiLd * sizeof(float);   // y | h | fp32 rows
 
-template <bool BF, bool GELU = false>
+// CPW: chunks per workgroup.  1: one 256-unit chunk (up to 64 tiles: tiles x F/256 workgroups fit one round of the chip at one workgroup per CU);
+// 2: two consecutive chunks, one after the other (65 .. 128 tiles: tiles x F/512 workgroups still fit one round; the next chunk's linear1 fragments are
+// requested behind the linear2 products of the current one).  Every chunk's partial is accumulated from zero and written on its own: same bits.
+template <bool BF, bool GELU = false, int CPW = 1>
 __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict__ X, const u16* __restrict__ W1, const float* __restrict__ b1,
                                                         const u16* __restrict__ W2, const float* __restrict__ g1,
                                                         const float* __restrict__ be1, float* __restrict__ part /* [F/256][M][256] */,
@@ -28,9 +31,9 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
   float* etile = reinterpret_cast<float*>(htile + KB * kTileElems);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
   const long long m0 = (long long)blockIdx.x * kRows;
-  const int c = blockIdx.y;                                   // hidden-unit chunk
+  const int c0 = blockIdx.y * CPW;                            // first hidden-unit chunk of this workgroup
   u16x8 w1f[2][KB], w2f[2][KB];
-  load_wfrags<2, KB>(w1f, W1, F, 0, c * 256 + wave * 32, fi, fg, 0);
+  load_wfrags<2, KB>(w1f, W1, F, 0, c0 * 256 + wave * 32, fi, fg, 0);
   // ---- norm1 of my 8 rows -> y (16-bit) tile; the same expressions as ffn_body ----
   {
     const float4 gg = *reinterpret_cast<const float4*>(g1 + lane * 4), bb = *reinterpret_cast<const float4*>(be1 + lane * 4);
@@ -53,6 +56,9 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc) {
+  const int c = c0 + cc;
   // ---- linear1 + ReLU for the chunk (meanwhile fetch the chunk's linear2 fragments) ----
   f32x4 acc1[2][4];
 #pragma unroll
@@ -84,7 +90,8 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) p2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_phase<BF, 2, 4, KB>(p2, w2f, htile, fi, fg, 0);
+  if (cc + 1 < CPW) gemm_phase_pf<BF, 2, 4, KB, 2>(p2, w2f, htile, fi, fg, 0, w1f, W1, F, 0, (c + 1) * 256 + wave * 32, 0);
+  else gemm_phase<BF, 2, 4, KB>(p2, w2f, htile, fi, fg, 0);
   // accumulator layout -> fp32 rows in LDS -> one 1-KiB store per row
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -96,6 +103,8 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
   for (int i = 0; i < 8; ++i) {
     const int r = wave * 8 + i;
     if (m0 + r < M) *reinterpret_cast<float4*>(dst + (m0 + r) * C + lane * 4) = *reinterpret_cast<const float4*>(etile + r * kEpiLd + lane * 4);
+  }
+  if (cc + 1 < CPW) __syncthreads();        // the fp32 rows are read: the next chunk may write them (its h tile is fenced by the barriers above)
   }
 }
 

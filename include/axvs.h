@@ -104,7 +104,7 @@ const char* axvs_profile_stage_name(int i);
 
 /* ---- tuning / test switches (thread-local unless noted).  "generic_only" = 1: always use the shape-generic kernels
  *      instead of the fused C=256 ones (A/B comparisons, parity tests of both paths).  Others: "no_attn_fusion", "no_ffn_fusion",
- *      "no_small_tiles", "small_tiles_below", "ffn_split_below", "merge_mid" (merged launch on 32-row tiles, T = 5 .. 8: 1 = within one round of the chip [default], 0 never, 2 always), "no_reassoc", "no_wt_stores", "spatial_only" (timing), "ffn_gelu", "attn_waves";
+ *      "no_small_tiles", "small_tiles_below", "ffn_split_below", "ffn_split_pairs", "merge_mid" (merged launch on 32-row tiles, T = 5 .. 8: 1 = within one round of the chip [default], 0 never, 2 always), "no_reassoc", "no_wt_stores", "spatial_only" (timing), "ffn_gelu", "attn_waves";
  *      "vrow" = 1: the 64-row fused kernels read V in K's row layout (transposed on load) instead of block-transposed V^T;
  *      "qkv_fusion" = 1: the width pass's q/k/v are produced by the height-pass kernel (both bit-identical to the default,
  *      measured not faster: DESIGN.md 4a);  process-wide: "train_valu" (VALU instead of fp32-MFMA attention kernels of the

@@ -1298,6 +1298,35 @@ def test_small_problem_kernels_are_bit_identical_to_the_large_problem_ones(shape
     assert rel_err(out_small.cpu(), ref) < TOL_F16
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 256, 24, 40, 1024, "relu"), (1, 5, 256, 32, 32, 512, "relu"), (1, 5, 256, 25, 43, 2048, "relu"),
+                                   (1, 4, 256, 36, 36, 1024, "gelu"), (2, 5, 256, 17, 30, 1024, "relu")])
+def test_ffn_with_two_chunks_per_workgroup_is_bit_identical(shape):
+    """65 .. 88 tiles of 64 rows with a stand-alone FFN launch (T >= 5 or activation = gelu: the FFN does not ride in the width pass): the
+    chunk-per-workgroup kernel runs two consecutive 256-unit chunks per workgroup (ffn_split_kernel<.., CPW = 2>, round 5) so that its grid
+    still fits one round of the chip.  Same bits as the one-workgroup-per-tile kernel (option ffn_split_pairs = 0) -- the row count decides --
+    and inside 1e-3 of the float64 oracle."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib
+    B, T, C, H, W, F, act = shape
+    assert 65 * 64 <= B * T * H * W <= 88 * 64
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 83)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 83)
+    ref, _, _ = orc.axial_layer(src.double(), pos.double(), w, 8, want_attn=False, activation=act)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8, activation=act).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    pairs = layer(dev(src), dev(pos))[0].clone()
+    _lib.check(_lib.lib().axvs_set_option(b"ffn_split_pairs", 0), "axvs_set_option")
+    try:
+        whole = layer(dev(src), dev(pos))[0].clone()
+    finally:
+        _lib.lib().axvs_set_option(b"ffn_split_pairs", 1)
+    assert "norm1+ffn+norm2" in _stage_names()
+    assert torch.equal(pairs, whole)
+    assert torch.equal(pairs, layer(dev(src), dev(pos))[0])
+    assert rel_err(pairs.cpu(), ref) < TOL_F16
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 256, 64, 64, 1024), (2, 3, 256, 48, 40, 512), (2, 2, 256, 57, 61, 1024), (4, 1, 256, 64, 32, 256),
                                    (1, 4, 256, 96, 64, 1024), (1, 4, 256, 64, 96, 1024)])
 def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_default_kernels(shape):
