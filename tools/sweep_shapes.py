@@ -34,4 +34,7 @@ for i in range(n):
     print(f"{i:3d} B{B} T{T} C{C} H{H} W{W} F{F}: {e:.2e} repeat-equal {same}{flag}", flush=True)
     if e > worst[0]:
         worst = (e, (B, T, C, H, W, F))
-print("worst", worst, f"{time.time() - t0:.0f} s")
+torch.cuda.synchronize()
+ax.check_status()
+from axial_vs_amd import modules
+print("worst", worst, f"{time.time() - t0:.0f} s;  arrival counters all zero:", all(int(b.abs().sum()) == 0 for b in modules._sync_buffers.values()))
