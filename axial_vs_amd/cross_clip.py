@@ -78,8 +78,12 @@ class ASPP(nn.Module):                       # CC:176-190
         super().__init__()
         if list(kernel_sizes) != [3, 3, 3]:
             raise NotImplementedError("axial_vs_amd: ASPP kernel sizes other than [3,3,3] have no HIP path")
-        if norm_fn != "ln":
-            raise NotImplementedError("axial_vs_amd: ASPP norm_fn must be 'ln' (the shipped configuration)")
+        # the reference's ConvBN can be built with 'ln' and 'syncbn' (kmax_pixel_decoder.py:32-40, :68-69: 'none' / None fail in its __init__, 'bn' is unknown to
+        # get_norm); every shipped config uses 'ln'.  'syncbn' runs in eval mode only (running statistics folded into a per-channel scale / shift: library
+        # option cc_aspp_affine); its train() mode has no HIP path
+        if norm_fn not in ("ln", "syncbn"):
+            raise NotImplementedError(f"axial_vs_amd: ASPP norm_fn {norm_fn!r} (the reference's ConvBN builds with 'ln' or 'syncbn')")
+        self.norm_fn = norm_fn
         for i in range(3):
             setattr(self, f"_aspp_conv{i}", nn.Conv1d(in_channels, output_channels, kernel_size=3, dilation=atrous_rates[i],
                                                       padding="same", padding_mode="replicate"))
@@ -114,7 +118,13 @@ def _pack_cc_layers(mod, num_layers, f, keep, dt, dev):
             conv = getattr(asp, f"_aspp_conv{k}")
             ps.aspp_w[k], ps.aspp_b[k] = f(conv.weight), f(conv.bias)
         ps.aspp_proj_w = f(asp._proj_conv_bn_act.conv.weight)
-        ps.aspp_norm_w, ps.aspp_norm_b = f(asp._proj_conv_bn_act.norm.weight), f(asp._proj_conv_bn_act.norm.bias)
+        nrm = asp._proj_conv_bn_act.norm
+        if isinstance(nrm, nn.BatchNorm1d):      # 'syncbn', eval mode: y * scale + shift with the running statistics (eps 1e-3)
+            scale = (nrm.weight.detach().float() * torch.rsqrt(nrm.running_var.float() + nrm.eps)).contiguous()
+            shift = (nrm.bias.detach().float() - nrm.running_mean.float() * scale).contiguous()
+            ps.aspp_norm_w, ps.aspp_norm_b = f(scale), f(shift)
+        else:
+            ps.aspp_norm_w, ps.aspp_norm_b = f(nrm.weight), f(nrm.bias)
         ps.conv_norm_w, ps.conv_norm_b = f(cn.weight), f(cn.bias)
         buf = torch.empty(L.axvs_cc_layer_packed_bytes(), dtype=torch.uint8, device=dev)
         _lib.check(L.axvs_cc_layer_pack(C.byref(ps), buf.data_ptr(), _lib.DTYPES[dt], _stream(dev)), "axvs_cc_layer_pack")
@@ -209,6 +219,8 @@ class CrossClipTrackingModule(nn.Module):
     @_guarded
     def forward(self, clip_query: Tensor, panoptic_features: Tensor):
         if self.training:
+            if self.norm_fn != "ln":
+                raise NotImplementedError("axial_vs_amd: train() mode of the cross-clip module needs norm_fn='ln' (the shipped configuration)")
             return self._forward_train(clip_query, panoptic_features)
         cq = _dev_f32(clip_query, "clip_query")
         pf = _dev_f32(panoptic_features, "panoptic_features")
@@ -238,6 +250,9 @@ class CrossClipTrackingModule(nn.Module):
         _select_sync_words(dev)          # the layers' trajectory attention runs q/k/v + attention as one launch (include/axvs.h)
         if nh != nl:
             _lib.check(L.axvs_set_option(b"cc_last_heads_only", 1), "axvs_set_option")
+        affine = self.norm_fn != "ln"
+        if affine:
+            _lib.check(L.axvs_set_option(b"cc_aspp_affine", 1), "axvs_set_option")
         try:
             _lib.check(L.axvs_cc_module_fwd(cq.data_ptr(), pf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
                                             nl, B, Q, Tc, V, H, W, K1, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
@@ -245,6 +260,8 @@ class CrossClipTrackingModule(nn.Module):
         finally:
             if nh != nl:
                 L.axvs_set_option(b"cc_last_heads_only", 0)
+            if affine:
+                L.axvs_set_option(b"cc_aspp_affine", 0)
         cur = last
         cls_all = [logits[i] for i in range(nh)]
         mask_all = [masks[i] for i in range(nh)]
@@ -304,7 +321,7 @@ class TubeLinkCrossClipHead(nn.Module):
 
     def _pack(self):
         dt = self._dtype()
-        key = _param_key(self, dt)
+        key = _param_key(self, dt) + tuple((b.data_ptr(), b._version) for b in self.buffers())     # (running statistics of aspp_norm_fn = 'syncbn')
         if self._packed is not None and key == self._packed_key:
             return self._packed
         L = _lib.lib()
@@ -355,6 +372,8 @@ class TubeLinkCrossClipHead(nn.Module):
     @_guarded
     def forward(self, clip_query: Tensor, mask_features: Tensor):
         if self.training:
+            if self.conv_short_aggregate_layers[0].norm_fn != "ln":
+                raise NotImplementedError("axial_vs_amd: train() mode of the cross-clip head needs aspp_norm_fn='ln' (the shipped configuration)")
             return self._forward_train(clip_query, mask_features)
         cq = _dev_f32(clip_query, "clip_query")
         mf = _dev_f32(mask_features, "mask_features")
@@ -376,9 +395,16 @@ class TubeLinkCrossClipHead(nn.Module):
         last = torch.empty_like(cur)
         pl = (C.c_void_p * nl)(*[b.data_ptr() for b in layers])
         _select_sync_words(dev)
-        _lib.check(L.axvs_tl_cc_module_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
-                                           nl, B, Q, Tc, T // Tc, h, w, K1, Cm, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
-                   "axvs_tl_cc_module_fwd")
+        affine = self.conv_short_aggregate_layers[0].norm_fn != "ln"       # 'syncbn' (eval: folded running statistics)
+        if affine:
+            _lib.check(L.axvs_set_option(b"cc_aspp_affine", 1), "axvs_set_option")
+        try:
+            _lib.check(L.axvs_tl_cc_module_fwd(cur.data_ptr(), mf.data_ptr(), logits.data_ptr(), masks.data_ptr(), last.data_ptr(), pl, hbuf.data_ptr(),
+                                               nl, B, Q, Tc, T // Tc, h, w, K1, Cm, rates, dt, ws.data_ptr(), ws.numel(), main.cuda_stream),
+                       "axvs_tl_cc_module_fwd")
+        finally:
+            if affine:
+                L.axvs_set_option(b"cc_aspp_affine", 0)
         cls_all = [logits[i] for i in range(nl)]
         mask_all = [masks[i] for i in range(nl)]
         return tuple(cls_all), tuple(mask_all)

@@ -77,6 +77,8 @@ thread_local int g_merge_small = kMergeSmall;      // option "merge_small": 0 ne
 thread_local int g_out_dtype = 0;        // option "layer_out_dtype": 0 = the layer's output rows are fp32 (the reference's type); 1 / 2 = the kernel that ends the layer
                                          // (norm2 epilogue of the FFN) writes them as f16 / bf16 -- the map a batch-sharded caller gathers over the links
                                          // (BASELINE config 5 is worded "bf16"), written once instead of cast by a second pass
+thread_local int g_cc_aspp_affine = 0;   // option "cc_aspp_affine": the ASPP projection's norm is a per-channel affine (norm_fn 'syncbn' in eval mode, folded by the caller into
+                                         // aspp_norm_w / aspp_norm_b = scale / shift; 'none' = ones / zeros) instead of the channels-first LayerNorm of the shipped configs
 thread_local int g_cc_last_only = 0;     // option "cc_last_heads_only": axvs_cc_module_fwd computes the predictor heads (class logits, mask einsum) of the LAST layer
                                          // only; pred_logits / pred_masks then hold ONE layer.  The reference computes every layer's predictions in eval too
                                          // (CC/...:283-318) and its inference path drops all but the last (maxtron_cc_model.py:301-: aux_outputs are read under
@@ -940,7 +942,7 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
   ALoadBlocked<BF> ac{w.cat16, R, (int)R, 0, 1, 1};
   launch_gemm<BF>(ac, p.aspp_proj, EpiRowsF32{w.y, nullptr, nullptr, identity_map(R), 256, 1.f}, (int)R, 256, 768, st);
   mark(st, "cc.aspp");
-  hipLaunchKernelGGL(cc_aspp_post_kernel, dim3(lnblocks), dim3(256), 0, st, w.y, w.t2, p.an_w, p.an_b, p.cn_w, p.cn_b, out, R, out2);
+  hipLaunchKernelGGL(cc_aspp_post_kernel, dim3(lnblocks), dim3(256), 0, st, w.y, w.t2, p.an_w, p.an_b, p.cn_w, p.cn_b, out, R, out2, g_cc_aspp_affine);
   mark(st, "cc.aspp_post");
   return last_launch_status();
 }
@@ -1291,6 +1293,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_split_upto")) { g_qkv_split_upto = value; return AXVS_OK; }
+  if (key && !strcmp(key, "cc_aspp_affine")) { g_cc_aspp_affine = value ? 1 : 0; return AXVS_OK; }
   if (key && !strcmp(key, "merge_mid")) { g_merge_mid = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   if (key && !strcmp(key, "small_tiles_below")) { g_small_below = g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }

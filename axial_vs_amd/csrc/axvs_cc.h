@@ -30,20 +30,24 @@ __global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restr
 
 // ASPP tail + block residual (CC/...:186-201, :293-295), one wave per (bq, t) row, C = 256:
 //   z = GELU(LN_cf(y; eps 1e-6) * g_a + b_a);  out = LN(z + x; eps 1e-5) * g_n + b_n
+// affine != 0 (norm_fn 'syncbn' in eval mode / 'none': kmax_pixel_decoder.py:32-40): z = GELU(y * g_a + b_a) with g_a, b_a the folded running statistics
 __global__ __launch_bounds__(256) void cc_aspp_post_kernel(const float* __restrict__ Y, const float* __restrict__ Xin,
                                                            const float* __restrict__ ga, const float* __restrict__ ba,
                                                            const float* __restrict__ gn, const float* __restrict__ bn,
                                                            float* __restrict__ out, long long M,
-                                                           float* __restrict__ out2 = nullptr /* optional second copy of the rows */) {
+                                                           float* __restrict__ out2 = nullptr /* optional second copy of the rows */, int affine = 0) {
   constexpr int C = 256;
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float4 y = *reinterpret_cast<const float4*>(Y + row * C + lane * 4);
   const float4 x = *reinterpret_cast<const float4*>(Xin + row * C + lane * 4);
-  const float mu = wave_sum(y.x + y.y + y.z + y.w) * (1.f / C);
-  float d0 = y.x - mu, d1 = y.y - mu, d2 = y.z - mu, d3 = y.w - mu;
-  const float rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-6f);
+  float d0 = y.x, d1 = y.y, d2 = y.z, d3 = y.w, rstd = 1.f;
+  if (!affine) {
+    const float mu = wave_sum(y.x + y.y + y.z + y.w) * (1.f / C);
+    d0 = y.x - mu; d1 = y.y - mu; d2 = y.z - mu; d3 = y.w - mu;
+    rstd = 1.f / sqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-6f);
+  }
   const float4 g = *reinterpret_cast<const float4*>(ga + lane * 4), b = *reinterpret_cast<const float4*>(ba + lane * 4);
   auto gelu = [](float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); };
   const float z0 = gelu(d0 * rstd * g.x + b.x) + x.x, z1 = gelu(d1 * rstd * g.y + b.y) + x.y;

@@ -121,7 +121,7 @@ const char* axvs_profile_stage_name(int i);
  *      bit-identical either way); "layer_out_dtype" (default 0: axvs_axial_layer_fwd* / axvs_axial_pass_fwd(pass = 1) / axvs_traj_layer_fwd / axvs_ffn_fwd write
  *      their output rows as fp32, the reference's type; 1 / 2: `out` is a [rows, C] f16 / bf16 map, written by the epilogue of the
  *      kernel that ends the layer -- the map a batch-sharded caller gathers over xGMI (BASELINE config 5: "bf16"), without a cast
- *      pass; fused FFN tier only, contiguous frames only); "cc_last_heads_only" (default 0: axvs_cc_module_fwd computes the predictor heads of every layer, the reference's return value; 1:
+ *      pass; fused FFN tier only, contiguous frames only); "cc_aspp_affine" (default 0: the ASPP projection of a cross-clip layer is followed by the channels-first LayerNorm of the shipped configs; 1: by a per-channel scale / shift that the caller packed into aspp_norm_w / aspp_norm_b -- eval-mode SyncBatchNorm, norm_fn = 'syncbn'); "cc_last_heads_only" (default 0: axvs_cc_module_fwd computes the predictor heads of every layer, the reference's return value; 1:
  *      of the last layer only -- pred_logits / pred_masks then hold ONE layer); "sync_spin_limit" (polls before a hand-off wait of a merged launch gives up and sets
  *      AXVS_STATUS_SYNC_TIMEOUT; default 2^22, about one second; 0 restores the default). */
 int axvs_set_option(const char* key, int value);

@@ -379,6 +379,8 @@ def aspp(x: Tensor, w: Weights, kernel_sizes: Sequence[int], atrous_rates: Seque
         y = _channels_first_ln(y, w["_proj_conv_bn_act.norm.weight"], w["_proj_conv_bn_act.norm.bias"])
     elif norm_fn == "syncbn":
         y = _batch_norm_eval(y, w, "_proj_conv_bn_act.norm")
+    else:                                                          # (the reference's ConvBN cannot be built with any other norm: kmax_pixel_decoder.py:68-69)
+        raise ValueError(norm_fn)
     return _gelu(y)
 
 

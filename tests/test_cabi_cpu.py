@@ -101,13 +101,13 @@ def test_no_cpu_fallback_and_forward_only():
         full(src, pos)
 
 
-@pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2"])
+@pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2", "g16_cc_module_syncbn_Q16_Tc3_V2_H8_L2"])
 def test_cross_clip_state_dict_keys_match_reference(name):
     import axial_vs_amd as ax
     import axvs_oracle as orc
     z, m = load(name)
     mod = ax.CrossClipTrackingModule(num_layers=m["layers"], num_classes=m["num_classes"], attn_drop=0.0, aspp_drop=0.0,
-                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=m["V"])
+                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn=m.get("norm_fn", "ln"), num_clip_frames=m["V"])
     ref_keys = set(m["shapes"].keys())
     own = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
     assert set(own.keys()) == ref_keys

@@ -416,7 +416,9 @@ def test_layer_determinism_stress():
 
 
 @pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2", "g5_cc_module_Q16_Tc4_V2_H8_L2",
-                                  "g5_cc_module_Q128_Tc4_V4_H64_L4"])
+                                  "g5_cc_module_Q128_Tc4_V4_H64_L4",
+                                  # ASPP norm_fn = 'syncbn' in eval mode (folded running statistics; library option cc_aspp_affine)
+                                  "g16_cc_module_syncbn_Q16_Tc3_V2_H8_L2", "g16_cc_module_syncbn_Q24_Tc4_V2_H6_L3"])
 def test_cross_clip_module_golden(name):
     """CrossClipTrackingModule (trajectory attention over clip queries + temporal ASPP + predictor heads) against the
     reference's outputs; the last fixture is BASELINE config 4 (4 clips x 4 frames, 64x64, 4 layers)."""
@@ -427,13 +429,17 @@ def test_cross_clip_module_golden(name):
     cq = torch.randn(m["B"], m["Q"], m["Tc"], 256, generator=g)
     pf = torch.nn.functional.normalize(torch.randn(m["B"], 128, m["Tc"] * m["V"], m["H"], m["W"], generator=g), dim=1)
     mod = ax.CrossClipTrackingModule(num_layers=m["layers"], num_classes=m["num_classes"], attn_drop=0.0, aspp_drop=0.0,
-                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn="ln", num_clip_frames=m["V"]).eval()
+                                     kernel_sizes=[3, 3, 3], atrous_rates=[1, 2, 3], norm_fn=m.get("norm_fn", "ln"), num_clip_frames=m["V"]).eval()
     sd = mod.state_dict()
     sd.update(w)
     mod.load_state_dict(sd, strict=True)
     mod = mod.cuda()
     out = mod(dev(cq), dev(pf))
     assert out["pred_logits"].device.type == "cpu"          # the reference's eval branch hands back CPU tensors
+    if m.get("norm_fn", "ln") != "ln":
+        with pytest.raises(NotImplementedError):            # no HIP training path for this variant: refuse, do not fall back
+            mod.train()(dev(cq), dev(pf))
+        mod.eval()
     e_l, e_l2 = rel_err(out["pred_logits"], t(z["pred_logits"])), rel_l2(out["pred_logits"], t(z["pred_logits"]))
     print(f"{name}: logits max/max {e_l:.2e} relL2 {e_l2:.2e}")
     assert e_l < TOL_F16 and e_l2 < TOL_F16
@@ -500,6 +506,29 @@ def test_tube_link_cross_clip_head_golden(name):
         e_m, e_m0 = rel_err(masks[-1].cpu()[:, :, ::5, ::6, ::8], t(z["masks_last"])), 0.0
     print(f"{name}: masks {e_m:.2e} / first layer {e_m0:.2e}")
     assert e_m < TOL_F16 and e_m0 < TOL_F16
+
+
+def test_tube_link_cross_clip_head_with_syncbn_aspp():
+    """aspp_norm_fn = 'syncbn' in the Tube-Link head (TLCC:925-950 with the ASPP's projection on eval-mode SyncBatchNorm): the HIP path folds the running
+    statistics into a scale / shift (library option cc_aspp_affine) -- against the float64 oracle, whose ASPP is pinned to the reference by g16_cc_aspp_syncbn_*."""
+    import axial_vs_amd as ax
+    B, Tc, Q, fpc, h, w_, nl, K, Cm = 1, 3, 16, 2, 6, 10, 2, 7, 256
+    mod = ax.TubeLinkCrossClipHead(num_classes=K, out_channels=Cm, num_cc_layers=nl, aspp_norm_fn="syncbn").eval()
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point}
+    w = orc.random_weights(shapes, 67)
+    sd = mod.state_dict()
+    sd.update(w)
+    mod.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(68)
+    cq = torch.randn(B, Tc, Q, 256, generator=g)
+    mf = torch.nn.functional.normalize(torch.randn(B, Tc * fpc, Cm, h, w_, generator=g), dim=2)
+    cls_ref, masks_ref = orc.tl_cross_clip_head(cq.double(), mf.double(), {k: v.double() for k, v in w.items()}, nl, norm_fn="syncbn")
+    mod = mod.cuda()
+    cls, masks = mod(dev(cq), dev(mf))
+    for i in range(nl):
+        assert rel_err(cls[i].cpu(), cls_ref[i]) < TOL_F16 and rel_err(masks[i].cpu(), masks_ref[i]) < TOL_F16
+    with pytest.raises(NotImplementedError):
+        mod.train()(dev(cq), dev(mf))
 
 
 @pytest.mark.parametrize("Q,Tc,V,H,W,layers", [(32, 12, 2, 8, 12, 2), (128, 24, 2, 16, 16, 1), (16, 40, 1, 8, 8, 1)])

@@ -86,23 +86,25 @@ def test_cc_trajectory_layer(name):
     assert rel_err(y, t(z["out"])) < TOL
 
 
-@pytest.mark.parametrize("name", ["g5_cc_aspp_ln_BQ32_Tc3", "g5_cc_aspp_ln_BQ16_Tc4"])
+@pytest.mark.parametrize("name", ["g5_cc_aspp_ln_BQ32_Tc3", "g5_cc_aspp_ln_BQ16_Tc4", "g16_cc_aspp_syncbn_BQ32_Tc3", "g16_cc_aspp_syncbn_BQ16_Tc4"])
 def test_cc_aspp(name):
     z, m = load(name)
     w = weights(z, m)
-    y = orc.aspp(t(z["x"]), w, (3, 3, 3), (1, 2, 3), "ln")
+    y = orc.aspp(t(z["x"]), w, (3, 3, 3), (1, 2, 3), "syncbn" if "syncbn" in name else "ln")
     assert rel_err(y, t(z["out"])) < TOL
 
 
 @pytest.mark.parametrize("name", ["g5_cc_module_Q16_Tc3_V2_H8_L2", "g5_cc_module_Q16_Tc4_V2_H8_L2",
-                                  "g5_cc_module_Q128_Tc4_V4_H64_L4"])
+                                  "g5_cc_module_Q128_Tc4_V4_H64_L4",
+                                  # ASPP norm_fn = 'syncbn' (eval mode: running statistics), the reference's one alternative to 'ln'
+                                  "g16_cc_module_syncbn_Q16_Tc3_V2_H8_L2", "g16_cc_module_syncbn_Q24_Tc4_V2_H6_L3"])
 def test_cc_module(name):
     z, m = load(name)
     w = weights(z, m)
     g = torch.Generator().manual_seed(m["seed"] + 1)
     cq = torch.randn(m["B"], m["Q"], m["Tc"], 256, generator=g)
     pf = torch.nn.functional.normalize(torch.randn(m["B"], 128, m["Tc"] * m["V"], m["H"], m["W"], generator=g), dim=1)
-    out = orc.cross_clip_module(cq, pf, w, m["layers"], m["V"])
+    out = orc.cross_clip_module(cq, pf, w, m["layers"], m["V"], norm_fn=m.get("norm_fn", "ln"))
     assert rel_err(out["pred_logits"], t(z["pred_logits"])) < 5e-5
     np.testing.assert_allclose(checks(out["pred_masks"])[1:], z["masks_checks"][1:], rtol=1e-4)
     if "aux0_logits" in z:
