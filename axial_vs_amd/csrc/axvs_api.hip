@@ -1681,7 +1681,7 @@ int axvs_cc_heads_pack(const AxvsCCHeadParams* p, void* packed, int K1, int dtyp
   fold_bn(p->mask_proj_bn, h.emb_mul + 256, h.emb_add + 256, 256, st);
   fold_bn(p->mask_head_bn, h.mh_mul, h.mh_add, 128, st);
   fold_bn(p->pixel_bn, h.pix, h.pix + 1, 1, st);
-  copy_f32(p->class_head_w, h.wc, K1 * 256, st);
+  hipLaunchKernelGGL(transpose_k1x256_kernel, dim3((unsigned)((K1 * 256 + 255) / 256)), dim3(256), 0, st, p->class_head_w, h.wc, K1);      // [256][K1]: class index on the lanes
   copy_f32(p->class_head_b, h.bc, K1, st);
   copy_f32(p->act_head_w, h.wa, 256, st);
   copy_f32(p->act_head_b, h.ba, 1, st);
@@ -1817,7 +1817,7 @@ int axvs_tl_heads_pack(const AxvsTLHeadParams* p, void* packed, int K1, int Cm, 
   copy_f32(p->post_norm_b, h.pn_b, 256, st);
   copy_f32(p->activation_proj_w, h.wa, 256, st);
   copy_f32(p->activation_proj_b, h.ba, 1, st);
-  copy_f32(p->cls_embed_w, h.wc, (size_t)K1 * 256, st);
+  hipLaunchKernelGGL(transpose_k1x256_kernel, dim3((unsigned)((K1 * 256 + 255) / 256)), dim3(256), 0, st, p->cls_embed_w, h.wc, K1);
   copy_f32(p->cls_embed_b, h.bc, K1, st);
   return last_launch_status();
 }

@@ -61,11 +61,39 @@ __global__ __launch_bounds__(256) void cc_aspp_post_kernel(const float* __restri
   if (out2) *reinterpret_cast<float4*>(out2 + row * C + lane * 4) = o;
 }
 
+// [K1][256] fp32 -> [256][K1]: the class heads read their weight matrix with the CLASS index on the lanes (coalesced rows of K1 floats)
+__global__ void transpose_k1x256_kernel(const float* __restrict__ src, float* __restrict__ dst, int K1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K1 * 256) return;
+  const int k = i >> 8, c = i & 255;
+  dst[(long long)c * K1 + k] = src[i];
+}
+
+// logits[k] = bc[k] + sum_c wcT[c][k] * pooled[c] (+ extra on the last class), 256 threads: thread (k & 127, channel half).  Round 5: the weight rows used to
+// be read with the class index on the threads and a 1-KiB stride between them (12 us for the four layers of BASELINE config 4; now coalesced rows).
+__device__ __forceinline__ void class_logits_256(const float* __restrict__ wcT, const float* __restrict__ bc, const float* pooled /* LDS, [256] */,
+                                                 float* part /* LDS, [256] */, float* __restrict__ out, int K1, float last_extra, int tid) {
+  const int kk = tid & 127, h = tid >> 7;
+  for (int k0 = 0; k0 < K1; k0 += 128) {
+    const int k = k0 + kk;
+    float acc = 0.f;
+    if (k < K1) {
+      const float* w = wcT + (long long)(h * 128) * K1 + k;
+#pragma unroll 8
+      for (int c = 0; c < 128; ++c) acc += w[(long long)c * K1] * pooled[h * 128 + c];
+    }
+    part[tid] = acc;
+    __syncthreads();
+    if (h == 0 && k < K1) out[k] = bc[k] + (part[kk] + part[128 + kk]) + (k == K1 - 1 ? last_extra : 0.f);
+    __syncthreads();
+  }
+}
+
 // Class head of MaXTronCCPredictor (CC/...:48-52): per query q, softmax over ALL (b, clip) entries of a 256->1 activation
 // head, weighted sum of the class embeddings, 256->K1 class head, void bias on the last class.
 // emb: fp32 [(b q t)][ld] (class embedding = columns 0..255); out: fp32 [Q][K1].  One workgroup (256 threads) per q.
 __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restrict__ emb, int ld, const float* __restrict__ wa,
-                                                            const float* __restrict__ ba, const float* __restrict__ wc,
+                                                            const float* __restrict__ ba, const float* __restrict__ wc /* transposed: [256][K1] */,
                                                             const float* __restrict__ bc, float* __restrict__ out, int Bv, int Q,
                                                             int Tc, int K1, float void_bias) {
   constexpr int C = 256, MAXE = 1024;
@@ -95,11 +123,7 @@ __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restr
   }
   pooled[tid] = p;
   __syncthreads();
-  for (int k = tid; k < K1; k += 256) {
-    float acc = bc[k];
-    for (int c = 0; c < C; ++c) acc += wc[(long long)k * C + c] * pooled[c];
-    out[(long long)q * K1 + k] = acc + (k == K1 - 1 ? void_bias : 0.f);
-  }
+  class_logits_256(wc, bc, pooled, logit /* free now (>= 256 floats) */, out + (long long)q * K1, K1, void_bias, tid);
 }
 
 // Mask logits as a strided batched contraction over channels, shared by the two heads:
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(256) void mask_einsum_kernel(const float* __restric
         if constexpr (GEN) {
           if (qt * 16 + fi < Q && p < P) stg4(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p, o4, (int)(P - p < 4 ? P - p : 4), al);
         } else {
-          if (qt * 16 + fi < Q && p + 3 < P) *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) = o4;
+          if (qt * 16 + fi < Q && p + 3 < P) *reinterpret_cast<float4*>(ol + b * mp.o_b + u * mp.o_u + q * mp.o_q + p) = o4;      // (nontemporal stores: +2 us at config 4, round 5)
         }
       }
     }
@@ -224,11 +248,7 @@ __global__ __launch_bounds__(256) void tl_class_head_kernel(const float* __restr
   for (int t = 0; t < Tc; ++t) p += __expf(logit[t] - mx) / sum * xr[t * C + tid];
   pooled[tid] = p;
   __syncthreads();
-  for (int k = tid; k < K1; k += 256) {
-    float acc = bc[k];
-    for (int c = 0; c < C; ++c) acc += wc[(long long)k * C + c] * pooled[c];
-    out[(long long)bq * K1 + k] = acc;
-  }
+  class_logits_256(wc, bc, pooled, logit /* free now (>= 256 floats) */, out + (long long)bq * K1, K1, 0.f, tid);
 }
 
 }  // namespace axvs
