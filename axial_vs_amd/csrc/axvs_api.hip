@@ -1293,6 +1293,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_wt_stores")) { g_no_wt_stores = value; return AXVS_OK; }
   if (key && !strcmp(key, "spatial_only")) { g_spatial_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "qkv_split_upto")) { g_qkv_split_upto = value; return AXVS_OK; }
+  if (key && !strcmp(key, "gemm_small_upto")) { gemm_small_upto() = value > 0 ? value : 128; return AXVS_OK; }
   if (key && !strcmp(key, "cc_aspp_affine")) { g_cc_aspp_affine = value ? 1 : 0; return AXVS_OK; }
   if (key && !strcmp(key, "merge_mid")) { g_merge_mid = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }

@@ -79,8 +79,15 @@ __device__ __forceinline__ void class_logits_256(const float* __restrict__ wcT, 
     float acc = 0.f;
     if (k < K1) {
       const float* w = wcT + (long long)(h * 128) * K1 + k;
-#pragma unroll 8
-      for (int c = 0; c < 128; ++c) acc += w[(long long)c * K1] * pooled[h * 128 + c];
+      // 32 independent row loads in flight per thread: with 8 the loop was 16 dependent L2 round trips (the kernel's whole run time)
+#pragma unroll 1
+      for (int c0 = 0; c0 < 128; c0 += 32) {
+        float wv[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wv[j] = w[(long long)(c0 + j) * K1];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc += wv[j] * pooled[h * 128 + c0 + j];
+      }
     }
     part[tid] = acc;
     __syncthreads();
@@ -97,19 +104,25 @@ __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restr
                                                             const float* __restrict__ bc, float* __restrict__ out, int Bv, int Q,
                                                             int Tc, int K1, float void_bias) {
   constexpr int C = 256, MAXE = 1024;
-  __shared__ float logit[MAXE], pooled[C], red[4];
+  __shared__ float logit[MAXE], pooled[C], red[16];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   emb += (long long)blockIdx.y * Bv * Q * Tc * ld;    // blockIdx.y: layer (the module loop runs the heads of all layers in one launch)
   out += (long long)blockIdx.y * Q * K1;
   const int E = Bv * Tc;                              // entries the softmax runs over (dim 0 of the reference tensor)
   const float wac = wa[tid];
-  for (int e = 0; e < E; ++e) {
-    const int b = e / Tc, t = e - b * Tc;
-    const float v = emb[(((long long)b * Q + q) * Tc + t) * ld + tid] * wac;
-    const float s = wave_sum(v);
-    if (lane == 0) red[wave] = s;
+  auto row = [&](int e) { const int b = e / Tc, t = e - b * Tc; return emb + (((long long)b * Q + q) * Tc + t) * ld + tid; };
+  // entries in groups of 4: their loads are independent (one L2 round trip per group instead of one per entry), one barrier pair per group
+  for (int e0 = 0; e0 < E; e0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *row(min(e0 + j, E - 1)) * wac;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sj = wave_sum(v[j]);
+      if (lane == 0) red[j * 4 + wave] = sj;
+    }
     __syncthreads();
-    if (tid == 0) logit[e] = red[0] + red[1] + red[2] + red[3] + ba[0];
+    if (tid < 4 && e0 + tid < E) logit[e0 + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3] + ba[0];
     __syncthreads();
   }
   float mx = -INFINITY;
@@ -117,9 +130,13 @@ __global__ __launch_bounds__(256) void cc_class_head_kernel(const float* __restr
   float sum = 0.f;
   for (int e = 0; e < E; ++e) sum += __expf(logit[e] - mx);
   float p = 0.f;
-  for (int e = 0; e < E; ++e) {
-    const int b = e / Tc, t = e - b * Tc;
-    p += __expf(logit[e] - mx) / sum * emb[(((long long)b * Q + q) * Tc + t) * ld + tid];
+  for (int e0 = 0; e0 < E; e0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *row(min(e0 + j, E - 1));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (e0 + j < E) p += __expf(logit[e0 + j] - mx) / sum * v[j];
   }
   pooled[tid] = p;
   __syncthreads();
@@ -228,16 +245,22 @@ __global__ __launch_bounds__(256) void tl_class_head_kernel(const float* __restr
                                                             const float* __restrict__ ba, const float* __restrict__ wc,
                                                             const float* __restrict__ bc, float* __restrict__ out, int Tc, int K1) {
   constexpr int C = 256, MAXT = 1024;
-  __shared__ float logit[MAXT], pooled[C], red[4];
+  __shared__ float logit[MAXT], pooled[C], red[16];
   const int bq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xr = x + ((long long)blockIdx.y * gridDim.x + bq) * Tc * C;   // blockIdx.y: layer
   out += (long long)blockIdx.y * gridDim.x * K1;
   const float wac = wa[tid];
-  for (int t = 0; t < Tc; ++t) {
-    const float s = wave_sum(xr[t * C + tid] * wac);
-    if (lane == 0) red[wave] = s;
+  for (int t0 = 0; t0 < Tc; t0 += 4) {      // clips in groups of 4 (independent loads, one barrier pair per group)
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = xr[min(t0 + j, Tc - 1) * C + tid] * wac;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sj = wave_sum(v[j]);
+      if (lane == 0) red[j * 4 + wave] = sj;
+    }
     __syncthreads();
-    if (tid == 0) logit[t] = red[0] + red[1] + red[2] + red[3] + ba[0];
+    if (tid < 4 && t0 + tid < Tc) logit[t0 + tid] = red[tid * 4] + red[tid * 4 + 1] + red[tid * 4 + 2] + red[tid * 4 + 3] + ba[0];
     __syncthreads();
   }
   float mx = -INFINITY;
@@ -245,7 +268,14 @@ __global__ __launch_bounds__(256) void tl_class_head_kernel(const float* __restr
   float sum = 0.f;
   for (int t = 0; t < Tc; ++t) sum += __expf(logit[t] - mx);
   float p = 0.f;
-  for (int t = 0; t < Tc; ++t) p += __expf(logit[t] - mx) / sum * xr[t * C + tid];
+  for (int t0 = 0; t0 < Tc; t0 += 4) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = xr[min(t0 + j, Tc - 1) * C + tid];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (t0 + j < Tc) p += __expf(logit[t0 + j] - mx) / sum * v[j];
+  }
   pooled[tid] = p;
   __syncthreads();
   class_logits_256(wc, bc, pooled, logit /* free now (>= 256 floats) */, out + (long long)bq * K1, K1, 0.f, tid);

@@ -395,7 +395,8 @@ inline int gemm_direct_waves(int K) {
     if (nkb % (8 * ks) == 0) return ks;
   return 1;
 }
-inline bool gemm_is_small(int M, int Nout, int nb = 1) { return (long long)((M + 63) / 64) * ((Nout + 63) / 64) * nb <= 128; }
+inline int& gemm_small_upto() { static thread_local int v = 128; return v; }      // option "gemm_small_upto" (tiles of 64 x 64 outputs up to which the direct kernels run)
+inline bool gemm_is_small(int M, int Nout, int nb = 1) { return (long long)((M + 63) / 64) * ((Nout + 63) / 64) * nb <= gemm_small_upto(); }
 
 // NB independent GEMMs of the same shape in ONE launch (blockIdx.z picks the problem): small dependent-free GEMMs such as the
 // three dilated branches of the temporal ASPP fill the chip together instead of queueing behind each other.
