@@ -396,7 +396,12 @@ inline int gemm_direct_waves(int K) {
   return 1;
 }
 inline int& gemm_small_upto() { static thread_local int v = 128; return v; }      // option "gemm_small_upto" (tiles of 64 x 64 outputs up to which the direct kernels run)
-inline bool gemm_is_small(int M, int Nout, int nb = 1) { return (long long)((M + 63) / 64) * ((Nout + 63) / 64) * nb <= gemm_small_upto(); }
+// (round 5: with a long reduction -- K >= 1024: the split-precision 1x1 projections of the pixel decoder -- the direct kernels, which split K over their waves, pay up
+//  to twice as many tiles: the VIPSeg module's res5 projection [2150 x 256 x 6144] is 136 tiles; short reductions such as the cross-clip embeddings [2048 x 512 x 256] do not)
+inline bool gemm_is_small(int M, int Nout, int nb = 1, int K = 0) {
+  const long long tiles = (long long)((M + 63) / 64) * ((Nout + 63) / 64) * nb;
+  return tiles <= gemm_small_upto() || (K >= 1024 && tiles <= 2 * gemm_small_upto());
+}
 
 // NB independent GEMMs of the same shape in ONE launch (blockIdx.z picks the problem): small dependent-free GEMMs such as the
 // three dilated branches of the temporal ASPP fill the chip together instead of queueing behind each other.
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void gemm_direct_batched_kernel(GemmBatch<ALoa
 }
 template <bool BF, class ALoad, class Epi, int NB>
 inline void launch_gemm_batched(const GemmBatch<ALoad, Epi, NB>& b, int M, int Nout, int K, hipStream_t st) {
-  if (gemm_is_small(M, Nout, NB)) {
+  if (gemm_is_small(M, Nout, NB, K)) {
     dim3 grid((M + 15) / 16, (Nout + 31) / 32, NB);
     hipLaunchKernelGGL((gemm_direct_batched_kernel<BF, ALoad, Epi, NB>), grid, dim3(64 * gemm_direct_waves(K)), 0, st, b, M, Nout, K);
     return;
@@ -429,7 +434,7 @@ inline void launch_gemm_batched(const GemmBatch<ALoad, Epi, NB>& b, int M, int N
 
 template <bool BF, class ALoad, class Epi>
 inline void launch_gemm(const ALoad& al, const u16* Wp, const Epi& epi, int M, int Nout, int K, hipStream_t st) {
-  if (gemm_is_small(M, Nout)) {
+  if (gemm_is_small(M, Nout, 1, K)) {
     if ((long long)((M + 15) / 16) * ((Nout + 63) / 64) >= 256) {
       hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 4>), dim3((M + 15) / 16, (Nout + 63) / 64), dim3(64 * gemm_direct_waves(K)), 0, st, al, Wp, epi, M, Nout, K);
     } else {   // narrower tiles: twice the waves
