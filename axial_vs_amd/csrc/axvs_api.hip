@@ -64,6 +64,7 @@ thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kern
 // offset | weight projection, three pieces (fp32 accuracy) for output_proj, whose result enters the residual stream without a norm;
 // 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels of axvs_gemm.h.
 thread_local int g_msda_gemm = 4;
+thread_local int g_conv_nt128 = 192;     // option "conv_nt128": token-row 1x1 projections run the 128 x 128 three-piece GEMM from this many tiles per launch on (0: never)
 thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
 // Merged q/k/v + trajectory launches (temporal_fused_kernel<..., MQ>): one launch per axial pass.  The sibling row tiles of a
 // sequence hand K / V^T over inside the launch through arrival counters the CALLER provides (axvs_set_sync_buffer: device words
@@ -1133,8 +1134,8 @@ int msda_levels(const int* shapes, int L, int S, MsdaLevels* lv) {
 
 // Y[M][N] = epilogue(X[M][K] (+ X2) . W[N][K]^T) on the 128 x 128 split-precision kernel (axvs_gemm_nt.h), option msda_gemm = pieces
 int launch_nt128(const float* X, const float* X2, const float* W, float* Y, long long M, int N, int K, const tr::GemmEpi& e, hipStream_t st,
-                 bool feeds_residual = false) {
-  tr::GemmLd ld{K, K, N, 0, X2};
+                 bool feeds_residual = false, long long lda = 0 /* row stride of X in floats (0: K) */) {
+  tr::GemmLd ld{lda ? lda : K, K, N, 0, X2};
   const dim3 grid((unsigned)((M + tr::kGT - 1) / tr::kGT), (unsigned)((N + tr::kGT - 1) / tr::kGT));
   const bool exact = g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual), gen = tr::gemm_nt_general(ld, K), add = X2 != nullptr;
 #define AXVS_NT128(NS_, GEN_, ADD_)                                                                                                  \
@@ -1308,6 +1309,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_persist")) { g_no_persist = value; return AXVS_OK; }
   if (key && !strcmp(key, "cc_last_heads_only")) { g_cc_last_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value < 0 ? kMergeSmall : value; return AXVS_OK; }
+  if (key && !strcmp(key, "conv_nt128")) { g_conv_nt128 = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   if (key && !strcmp(key, "layer_out_dtype")) {
     if (value < 0 || value > 2) return fail(AXVS_ERR_ARG, "layer_out_dtype: 0 (fp32), 1 (f16) or 2 (bf16)");
@@ -2070,6 +2072,7 @@ size_t axvs_conv1x1_gn_packed_bytes(int Cin, int Cout) {
   Carver c(nullptr);
   c.take<u16>(3 * (size_t)Cin * ((Cout + 15) & ~15));
   c.take<float>(Cout); c.take<float>(Cout); c.take<float>(Cout);
+  c.take<float>((size_t)Cout * Cin);      // the fp32 weight as it is: the 128 x 128 split-precision GEMM splits its operands itself (token rows in, many rows)
   return c.off;
 }
 
@@ -2087,6 +2090,8 @@ int axvs_conv1x1_gn_pack(const AxvsConvGnParams* p, void* packed, int Cin, int C
   copy_f32(p->conv_b, b, Cout, st);
   copy_f32(p->gn_w, g, Cout, st);
   copy_f32(p->gn_b, be, Cout, st);
+  float* wf = c.take<float>((size_t)Cout * Cin);
+  if (hipMemcpyAsync(wf, p->conv_w, (size_t)Cout * Cin * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "copy failed");
   return last_launch_status();
 }
 
@@ -2112,6 +2117,7 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
   Carver pc(const_cast<void*>(packed));
   const u16* w = pc.take<u16>(3 * (size_t)Cin * ((Cout + 15) & ~15));
   const float* b = pc.take<float>(Cout); const float* g = pc.take<float>(Cout); const float* be = pc.take<float>(Cout);
+  const float* wf = pc.take<float>((size_t)Cout * Cin);
   Carver wc(workspace);
   const long long M = (long long)N * HW;
   float* y = wc.take<float>((size_t)M * Cout);
@@ -2122,6 +2128,17 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
   g_prof_next = 0;
   mark(st, "begin");
   const EpiRowsF32 ey{y, nullptr, b, identity_map(M), Cout, 1.f};
+  // token rows in, many of them (the output projections of the large pyramid levels: [32786 x 512 x 256] at the shipped VIPSeg setting): the 128 x 128
+  // three-piece kernel of the deformable attention's projections (fp32-grade like the split3 GEMM below; 143 against 60 - 115 TFLOP/s), one launch per
+  // frame when the frames are rows of a larger buffer
+  // (every launch has to fill the chip on its own: >= 192 tiles of 128 x 128 -- BASELINE config 3's 64 x 64 level, 64 tiles per frame, stays on the kernels below)
+  const bool one = in_batch_stride == (long long)HW * in_ld;
+  if (in_layout == 1 && g_msda_gemm && g_conv_nt128 && Cin % 4 == 0 && Cout % 4 == 0 && in_ld % 4 == 0 && in_batch_stride % 4 == 0 &&
+      (((one ? M : (long long)HW) + 127) / 128) * ((Cout + 127) / 128) >= g_conv_nt128 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const tr::GemmEpi e{b, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
+    for (int n = 0; n < (one ? 1 : N); ++n)
+      if (int rc = launch_nt128(x + (size_t)n * in_batch_stride, nullptr, wf, y + (size_t)n * HW * Cout, one ? M : HW, Cout, Cin, e, st, true, in_ld)) return rc;
+  } else
   if (dtype == AXVS_BF16) {
     if (in_layout == 0) launch_gemm<true>(ALoadNCHWSplit3<true>{x, (int)M, Cin, HW}, w, ey, (int)M, Cout, 3 * Cin, st);
     else launch_gemm<true>(ALoadTokensSplit3<true>{x, (int)M, Cin, HW, in_batch_stride, in_ld}, w, ey, (int)M, Cout, 3 * Cin, st);

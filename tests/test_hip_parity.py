@@ -1165,7 +1165,8 @@ def test_axial_layer_gelu_golden(name):
         ax.TemporalAxialTrajectoryAttentionLayer(m["C"], m["d_ffn"], n_heads=m["heads"], activation="glu").eval().cuda()(dev(src), dev(pos))
 
 
-@pytest.mark.parametrize("N,HW,Cin,Cout", [(4, 4096, 192, 256), (4, 256, 768, 256), (2, 64, 256, 96), (3, 16, 256, 64), (2, 100, 256, 384)])
+@pytest.mark.parametrize("N,HW,Cin,Cout", [(4, 4096, 192, 256), (4, 256, 768, 256), (2, 64, 256, 96), (3, 16, 256, 64), (2, 100, 256, 384),
+                                           (2, 16393, 256, 512)])      # 97 x 169: token rows in -> the 128 x 128 three-piece GEMM (>= 192 tiles per launch)
 def test_conv1x1_groupnorm_unit(N, HW, Cin, Cout):
     """The pixel decoder's projections on their own (WC/msdeformattn.py:349-375): Conv2d(k=1) + GroupNorm(32) through
     axvs_conv1x1_gn_fwd (NCHW in -> token rows out, and token rows in -> NCHW out) against float64 torch."""
