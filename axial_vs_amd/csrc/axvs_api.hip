@@ -64,6 +64,8 @@ thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kern
 // offset | weight projection, three pieces (fp32 accuracy) for output_proj, whose result enters the residual stream without a norm;
 // 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels of axvs_gemm.h.
 thread_local int g_msda_gemm = 4;
+thread_local int g_conv_nt128_nchw = 128;  // option "conv_nt128_nchw": the same for NCHW inputs (transposed to token rows first), tiles of the ONE launch over all frames
+thread_local int g_conv_nt128_exact = 0;  // option "conv_nt128_exact": 0 = two bf16 pieces per operand (5e-6 of the float64 projection + GroupNorm, 114 against 147 us at [32786 x 256 x 512]), 1 = three (9e-7)
 thread_local int g_conv_nt128 = 192;     // option "conv_nt128": token-row 1x1 projections run the 128 x 128 three-piece GEMM from this many tiles per launch on (0: never)
 thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
 // Merged q/k/v + trajectory launches (temporal_fused_kernel<..., MQ>): one launch per axial pass.  The sibling row tiles of a
@@ -1309,6 +1311,8 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "no_persist")) { g_no_persist = value; return AXVS_OK; }
   if (key && !strcmp(key, "cc_last_heads_only")) { g_cc_last_only = value; return AXVS_OK; }
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value < 0 ? kMergeSmall : value; return AXVS_OK; }
+  if (key && !strcmp(key, "conv_nt128_nchw")) { g_conv_nt128_nchw = value > 0 ? value : (1 << 30); return AXVS_OK; }
+  if (key && !strcmp(key, "conv_nt128_exact")) { g_conv_nt128_exact = value; return AXVS_OK; }
   if (key && !strcmp(key, "conv_nt128")) { g_conv_nt128 = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   if (key && !strcmp(key, "layer_out_dtype")) {
@@ -2098,6 +2102,7 @@ int axvs_conv1x1_gn_pack(const AxvsConvGnParams* p, void* packed, int Cin, int C
 size_t axvs_conv1x1_gn_workspace_bytes(int N, int HW, int Cout, int groups) {
   Carver c(nullptr);
   c.take<float>((size_t)N * HW * Cout);
+  c.take<float>((size_t)N * HW * Cout);      // token-row copy of an NCHW input (callers size with max(Cin, Cout); without the room the NCHW loader runs)
   c.take<float>((size_t)N * groups * 2);
   c.take<float>((size_t)N * ((HW + 63) / 64) * groups * 2);
   return c.off;
@@ -2137,7 +2142,15 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
       (((one ? M : (long long)HW) + 127) / 128) * ((Cout + 127) / 128) >= g_conv_nt128 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     const tr::GemmEpi e{b, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
     for (int n = 0; n < (one ? 1 : N); ++n)
-      if (int rc = launch_nt128(x + (size_t)n * in_batch_stride, nullptr, wf, y + (size_t)n * HW * Cout, one ? M : HW, Cout, Cin, e, st, true, in_ld)) return rc;
+      if (int rc = launch_nt128(x + (size_t)n * in_batch_stride, nullptr, wf, y + (size_t)n * HW * Cout, one ? M : HW, Cout, Cin, e, st, g_conv_nt128_exact != 0, in_ld)) return rc;
+  } else if (in_layout == 0 && g_msda_gemm && g_conv_nt128 && Cin % 4 == 0 && Cout % 4 == 0 &&
+             ((M + 127) / 128) * ((Cout + 127) / 128) >= g_conv_nt128_nchw && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+             workspace_bytes >= axvs_conv1x1_gn_workspace_bytes(N, HW, Cout, groups) - (size_t)M * Cout * sizeof(float) + (size_t)M * Cin * sizeof(float)) {
+    // NCHW in, many rows: transposed to token rows once (64 x 64 tiles through LDS), then the same 128 x 128 kernel in ONE launch over all frames
+    float* tok = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + axvs_conv1x1_gn_workspace_bytes(N, HW, Cout, groups) - (size_t)M * Cout * sizeof(float));
+    hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((Cin + 63) / 64), N), dim3(256), 0, st, x, tok, Cin, HW);
+    const tr::GemmEpi e{b, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
+    if (int rc = launch_nt128(tok, nullptr, wf, y, M, Cout, Cin, e, st, g_conv_nt128_exact != 0)) return rc;
   } else
   if (dtype == AXVS_BF16) {
     if (in_layout == 0) launch_gemm<true>(ALoadNCHWSplit3<true>{x, (int)M, Cin, HW}, w, ey, (int)M, Cout, 3 * Cin, st);

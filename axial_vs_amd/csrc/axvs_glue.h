@@ -30,6 +30,31 @@ struct ALoadNCHWSplit3 {
   }
 };
 
+// x [N][C][HW] fp32 (NCHW) -> token rows t [N][HW][C]: the transposing stage in front of the 128 x 128 three-piece GEMM for the input projections of the
+// large pyramid levels (round 5: ALoadNCHWSplit3 above reads every element three times, 64 bytes at a time -- 63 TFLOP/s at [32786 x 256 x 512]).
+// 64 channels x 64 pixels per workgroup through LDS; any HW (pixel rows start at 4-byte boundaries), C a multiple of 4.
+__global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __restrict__ x, float* __restrict__ t, int C, int HW) {
+  __shared__ float tile[64][65];
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, n = blockIdx.z;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // read: tx = pixel, 4 channel rows at a time
+  const float* src = x + ((long long)n * C + c0) * HW + p0;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int c = ty + 4 * i;
+    tile[c][tx] = (c0 + c < C && p0 + tx < HW) ? src[(long long)c * HW + tx] : 0.f;
+  }
+  __syncthreads();
+  // write: 16 threads x float4 cover the 64 channels of a pixel row (256 contiguous bytes), 16 pixels per round
+  const int wc = (threadIdx.x & 15) * 4, wp = threadIdx.x >> 4;
+  float* dst = t + ((long long)n * HW + p0) * C + c0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wp + 16 * i;
+    if (p0 + p < HW && c0 + wc < C)
+      *reinterpret_cast<float4*>(dst + (long long)p * C + wc) = float4{tile[wc][p], tile[wc + 1][p], tile[wc + 2][p], tile[wc + 3][p]};
+  }
+}
+
 // token rows that may be a slice of a wider buffer: row (n, p) at x + n*batch_stride + p*ld  (split precision as above)
 template <bool BF>
 struct ALoadTokensSplit3 {
