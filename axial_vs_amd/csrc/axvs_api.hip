@@ -66,6 +66,7 @@ thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kern
 thread_local int g_msda_gemm = 4;
 thread_local int g_conv_nt128_nchw = 128;  // option "conv_nt128_nchw": the same for NCHW inputs (transposed to token rows first), tiles of the ONE launch over all frames
 thread_local int g_conv_nt128_exact = 0;  // option "conv_nt128_exact": 0 = two bf16 pieces per operand (5e-6 of the float64 projection + GroupNorm, 114 against 147 us at [32786 x 256 x 512]), 1 = three (9e-7)
+thread_local int g_conv_nt128_splitk = 1; // option "conv_nt128_splitk": split-K for the NCHW projections with few row tiles and Cin >= 1024
 thread_local int g_conv_nt128 = 192;     // option "conv_nt128": token-row 1x1 projections run the 128 x 128 three-piece GEMM from this many tiles per launch on (0: never)
 thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
 // Merged q/k/v + trajectory launches (temporal_fused_kernel<..., MQ>): one launch per axial pass.  The sibling row tiles of a
@@ -1136,9 +1137,11 @@ int msda_levels(const int* shapes, int L, int S, MsdaLevels* lv) {
 
 // Y[M][N] = epilogue(X[M][K] (+ X2) . W[N][K]^T) on the 128 x 128 split-precision kernel (axvs_gemm_nt.h), option msda_gemm = pieces
 int launch_nt128(const float* X, const float* X2, const float* W, float* Y, long long M, int N, int K, const tr::GemmEpi& e, hipStream_t st,
-                 bool feeds_residual = false, long long lda = 0 /* row stride of X in floats (0: K) */) {
+                 bool feeds_residual = false, long long lda = 0 /* row stride of X in floats (0: K) */,
+                 int zsplit = 1 /* > 1: split-K -- workgroup z writes the partial product of its k-steps to Y + z M N (no epilogue terms) */) {
   tr::GemmLd ld{lda ? lda : K, K, N, 0, X2};
-  const dim3 grid((unsigned)((M + tr::kGT - 1) / tr::kGT), (unsigned)((N + tr::kGT - 1) / tr::kGT));
+  if (zsplit > 1) ld.ksteps = ((K + tr::kGK - 1) / tr::kGK + zsplit - 1) / zsplit;
+  const dim3 grid((unsigned)((M + tr::kGT - 1) / tr::kGT), (unsigned)((N + tr::kGT - 1) / tr::kGT), (unsigned)(zsplit > 1 ? zsplit : 1));
   const bool exact = g_msda_gemm == 3 || (g_msda_gemm == 4 && feeds_residual), gen = tr::gemm_nt_general(ld, K), add = X2 != nullptr;
 #define AXVS_NT128(NS_, GEN_, ADD_)                                                                                                  \
   {                                                                                                                                   \
@@ -1313,6 +1316,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "merge_small")) { g_merge_small = value < 0 ? kMergeSmall : value; return AXVS_OK; }
   if (key && !strcmp(key, "conv_nt128_nchw")) { g_conv_nt128_nchw = value > 0 ? value : (1 << 30); return AXVS_OK; }
   if (key && !strcmp(key, "conv_nt128_exact")) { g_conv_nt128_exact = value; return AXVS_OK; }
+  if (key && !strcmp(key, "conv_nt128_splitk")) { g_conv_nt128_splitk = value; return AXVS_OK; }
   if (key && !strcmp(key, "conv_nt128")) { g_conv_nt128 = value; return AXVS_OK; }
   if (key && !strcmp(key, "msda_gemm")) { g_msda_gemm = value; return AXVS_OK; }
   if (key && !strcmp(key, "layer_out_dtype")) {
@@ -2138,19 +2142,42 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
   // frame when the frames are rows of a larger buffer
   // (every launch has to fill the chip on its own: >= 192 tiles of 128 x 128 -- BASELINE config 3's 64 x 64 level, 64 tiles per frame, stays on the kernels below)
   const bool one = in_batch_stride == (long long)HW * in_ld;
+  // split-K factor of the NCHW path: few 128 x 128 tiles and a long reduction -> enough workgroups for one round of the chip (at most 8, at least 4 k-steps each)
+  int zs = 1;
+  if (in_layout == 0 && g_conv_nt128_splitk && Cin >= 1024) {
+    const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (tiles < g_conv_nt128_nchw && tiles >= 8) {
+      zs = (int)std::min<long long>(8, std::max<long long>(1, 256 / tiles));
+      zs = std::min(zs, Cin / 32 / 4);
+      // the partials live behind the token-row copy: as many as the caller's workspace has room for
+      const size_t off_tok = axvs_conv1x1_gn_workspace_bytes(N, HW, Cout, groups) - (size_t)M * Cout * sizeof(float), tok_end = off_tok + (size_t)M * Cin * sizeof(float);
+      const long long room = workspace_bytes > tok_end ? (long long)((workspace_bytes - tok_end) / ((size_t)M * Cout * sizeof(float))) : 0;
+      zs = (int)std::min<long long>(zs, room);
+      if (zs < 2) zs = 1;
+    }
+  }
   if (in_layout == 1 && g_msda_gemm && g_conv_nt128 && Cin % 4 == 0 && Cout % 4 == 0 && in_ld % 4 == 0 && in_batch_stride % 4 == 0 &&
       (((one ? M : (long long)HW) + 127) / 128) * ((Cout + 127) / 128) >= g_conv_nt128 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
     const tr::GemmEpi e{b, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
     for (int n = 0; n < (one ? 1 : N); ++n)
       if (int rc = launch_nt128(x + (size_t)n * in_batch_stride, nullptr, wf, y + (size_t)n * HW * Cout, one ? M : HW, Cout, Cin, e, st, g_conv_nt128_exact != 0, in_ld)) return rc;
   } else if (in_layout == 0 && g_msda_gemm && g_conv_nt128 && Cin % 4 == 0 && Cout % 4 == 0 &&
-             ((M + 127) / 128) * ((Cout + 127) / 128) >= g_conv_nt128_nchw && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+             (((M + 127) / 128) * ((Cout + 127) / 128) >= g_conv_nt128_nchw || zs > 1) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+
              workspace_bytes >= axvs_conv1x1_gn_workspace_bytes(N, HW, Cout, groups) - (size_t)M * Cout * sizeof(float) + (size_t)M * Cin * sizeof(float)) {
     // NCHW in, many rows: transposed to token rows once (64 x 64 tiles through LDS), then the same 128 x 128 kernel in ONE launch over all frames
     float* tok = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + axvs_conv1x1_gn_workspace_bytes(N, HW, Cout, groups) - (size_t)M * Cout * sizeof(float));
     hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)((Cin + 63) / 64), N), dim3(256), 0, st, x, tok, Cin, HW);
-    const tr::GemmEpi e{b, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
-    if (int rc = launch_nt128(tok, nullptr, wf, y, M, Cout, Cin, e, st, g_conv_nt128_exact != 0)) return rc;
+    if (zs > 1) {      // few row tiles, long reduction (the coarsest level: [2150 x 256 x 2048]): split-K partials behind the token rows, added in z order + bias
+      float* part = tok + (size_t)M * Cin;
+      const tr::GemmEpi e{nullptr, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
+      if (int rc = launch_nt128(tok, nullptr, wf, part, M, Cout, Cin, e, st, g_conv_nt128_exact != 0, 0, zs)) return rc;
+      const long long tot4 = M * Cout / 4;
+      hipLaunchKernelGGL(splitk_sum_bias_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, st, (const float*)part, y, zs, M * Cout, b, Cout, tot4);
+    } else {
+      const tr::GemmEpi e{b, 1.f, 0, tr::Drop{0, 0, 0, 1.f}, 0.f};
+      if (int rc = launch_nt128(tok, nullptr, wf, y, M, Cout, Cin, e, st, g_conv_nt128_exact != 0)) return rc;
+    }
   } else
   if (dtype == AXVS_BF16) {
     if (in_layout == 0) launch_gemm<true>(ALoadNCHWSplit3<true>{x, (int)M, Cin, HW}, w, ey, (int)M, Cout, 3 * Cin, st);

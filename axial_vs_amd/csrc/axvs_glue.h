@@ -55,6 +55,20 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __rest
   }
 }
 
+// y[i] = bias[col(i)] + p_0[i] + p_1[i] + ... (z order): the split-K partials of the 128 x 128 GEMM
+__global__ __launch_bounds__(256) void splitk_sum_bias_kernel(const float* __restrict__ part, float* __restrict__ y, int Z, long long stride, const float* __restrict__ bias,
+                                                              int N, long long tot4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= tot4) return;
+  float4 a = *reinterpret_cast<const float4*>(part + 4 * i);
+  for (int z = 1; z < Z; ++z) {
+    const float4 p = *reinterpret_cast<const float4*>(part + z * stride + 4 * i);
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+  }
+  const float4 b = *reinterpret_cast<const float4*>(bias + (int)((4 * i) % N));
+  *reinterpret_cast<float4*>(y + 4 * i) = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+}
+
 // token rows that may be a slice of a wider buffer: row (n, p) at x + n*batch_stride + p*ld  (split precision as above)
 template <bool BF>
 struct ALoadTokensSplit3 {

@@ -1166,7 +1166,8 @@ def test_axial_layer_gelu_golden(name):
 
 
 @pytest.mark.parametrize("N,HW,Cin,Cout", [(4, 4096, 192, 256), (4, 256, 768, 256), (2, 64, 256, 96), (3, 16, 256, 64), (2, 100, 256, 384),
-                                           (2, 16393, 256, 512)])      # 97 x 169: token rows in -> the 128 x 128 three-piece GEMM (>= 192 tiles per launch)
+                                           (2, 16393, 256, 512),       # 97 x 169: token rows in / NCHW in (transposed first) -> the 128 x 128 split-precision GEMM
+                                           (2, 1075, 2048, 256)])      # 25 x 43, the coarsest VIPSeg level: few row tiles, long reduction -> split-K partials
 def test_conv1x1_groupnorm_unit(N, HW, Cin, Cout):
     """The pixel decoder's projections on their own (WC/msdeformattn.py:349-375): Conv2d(k=1) + GroupNorm(32) through
     axvs_conv1x1_gn_fwd (NCHW in -> token rows out, and token rows in -> NCHW out) against float64 torch."""

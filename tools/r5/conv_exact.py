@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import torch
 from axial_vs_amd import _lib
 L = _lib.lib()
-for (N, HW, Cin, Cout) in [(2, 16393, 512, 256), (2, 4165, 1024, 256), (2, 16393, 256, 512), (4, 4096, 192, 256)]:
+for (N, HW, Cin, Cout) in [(2, 1075, 2048, 256), (4, 256, 768, 256), (2, 16393, 512, 256), (2, 4165, 1024, 256), (2, 16393, 256, 512), (4, 4096, 192, 256)]:
     g = torch.Generator().manual_seed(N * 1000 + HW)
     x = torch.randn(N, Cin, HW, generator=g)
     w = torch.randn(Cout, Cin, generator=g) / Cin ** 0.5
@@ -17,7 +17,7 @@ for (N, HW, Cin, Cout) in [(2, 16393, 512, 256), (2, 4165, 1024, 256), (2, 16393
     ws = torch.empty(L.axvs_conv1x1_gn_workspace_bytes(N, HW, max(Cin, Cout), 32), dtype=torch.uint8, device="cuda")
     rows = torch.empty(N, HW, Cout, device="cuda")
     for ex in (1, 0):
-        L.axvs_set_option(b"conv_nt128_exact", ex)
+        L.axvs_set_option(b"conv_nt128_splitk", ex)
         def run():
             _lib.check(L.axvs_conv1x1_gn_fwd(dx.data_ptr(), 0, 0, 0, rows.data_ptr(), 1, HW * Cout, Cout, packed.data_ptr(), N, HW, Cin, Cout, 32, 1e-5, 0, ws.data_ptr(), ws.numel(), st), "fwd")
         for _ in range(5): run()
@@ -27,5 +27,5 @@ for (N, HW, Cin, Cout) in [(2, 16393, 512, 256), (2, 4165, 1024, 256), (2, 16393
         for _ in range(50): run()
         e1.record(); torch.cuda.synchronize()
         err = float((rows.cpu().permute(0, 2, 1).double() - ref).abs().max() / ref.abs().max())
-        print(f"N={N} HW={HW} {Cin}->{Cout} exact={ex}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per conv+GN, max/max {err:.2e}", flush=True)
-    L.axvs_set_option(b"conv_nt128_exact", 0)
+        print(f"N={N} HW={HW} {Cin}->{Cout} splitk={ex}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per conv+GN, max/max {err:.2e}", flush=True)
+    L.axvs_set_option(b"conv_nt128_splitk", 1)
