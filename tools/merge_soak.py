@@ -21,7 +21,8 @@ layer.load_state_dict(w, strict=True)
 layer = layer.cuda()
 shapes = [(1, 4, 64, 64), (2, 4, 64, 64), (1, 2, 64, 64), (1, 4, 48, 80), (1, 3, 32, 64), (1, 4, 96, 96), (1, 4, 64, 32),
           (1, 2, 49, 85), (1, 4, 49, 85), (2, 3, 57, 61), (1, 4, 33, 70),      # round 5: ragged frames (padded row space) merge too
-          (1, 5, 24, 40), (1, 6, 32, 32), (1, 8, 32, 32), (1, 5, 25, 43)]     # ... and 5 .. 8 frames per clip on 32-row tiles (one round of the chip)
+          (1, 5, 24, 40), (1, 6, 32, 32), (1, 8, 32, 32), (1, 5, 25, 43),     # ... and 5 .. 8 frames per clip on 32-row tiles (one round of the chip)
+          (1, 4, 16, 16), (1, 2, 25, 43), (2, 4, 16, 16), (1, 3, 12, 20)]     # ... and few rows on 16-row tiles (passes of up to 128 tiles)
 side = torch.cuda.Stream()
 noise_a = torch.randn(4096, 4096, device="cuda")
 L = _lib.lib()
