@@ -60,10 +60,12 @@ thread_local int g_ffn_gelu = 0;         // option "ffn_gelu": the layer's FFN a
 // 838 us at B = 8) -- kept selectable, off by default:
 thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kernels read V in K's row layout (staged through the x tile, ds_read_b64_tr_b16) instead of V^T
 // option "msda_gemm": the deformable attention's three projections on the 128 x 128 split-precision GEMM of axvs_gemm_nt.h when the
-// level set has >= 2048 rows.  4 (default): two bf16 pieces for value_proj (its output is rounded to 16 bits anyway) and for the
+// level set has >= 2048 rows.  4 (the default of rounds 3 - 4): two bf16 pieces for value_proj (its output is rounded to 16 bits anyway) and for the
 // offset | weight projection, three pieces (fp32 accuracy) for output_proj, whose result enters the residual stream without a norm;
-// 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels of axvs_gemm.h.
-thread_local int g_msda_gemm = 4;
+// 2 (default since the end of round 5) / 3: two / three pieces everywhere; 0: the 64 x 64 kernels of axvs_gemm.h.
+// (Two pieces put 5e-6 on a projection; the free-running 16-bit stack's max-norm at BASELINE config 3 is chaotic in its 16-bit roundings either way -- 1.29e-3 with 2,
+//  1.38 - 1.48e-3 with 4, relative L2 5.7e-4 for both -- and 2 saves 2.5 % of the module: profiles/r5_planner_threshold.txt.)
+thread_local int g_msda_gemm = 2;
 thread_local int g_conv_nt128_nchw = 128;  // option "conv_nt128_nchw": the same for NCHW inputs (transposed to token rows first), tiles of the ONE launch over all frames
 thread_local int g_conv_nt128_exact = 0;  // option "conv_nt128_exact": 0 = two bf16 pieces per operand (5e-6 of the float64 projection + GroupNorm, 114 against 147 us at [32786 x 256 x 512]), 1 = three (9e-7)
 thread_local int g_conv_nt128_splitk = 1; // option "conv_nt128_splitk": split-K for the NCHW projections with few row tiles and Cin >= 1024

@@ -115,7 +115,7 @@ const char* axvs_profile_stage_name(int i);
  *      for the backward of their graphs), "train_attn_split" (default 1: the training tier's attention forward on split-precision
  *      16-bit MFMAs with a frame's score tiles in registers, axis length <= 128; 0: the fp32 MFMA kernel), "train_spatial_wgs" (default 512: workgroups the
  *      training tier's attention kernels are spread over -- measured flat from 512 to 8192 at the metric shape);
- *      "msda_gemm" (default 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
+ *      "msda_gemm" (default 2 since the end of round 5 [two pieces everywhere]; 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
  *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels);
  *      "ffn_wide" (default 0: the stand-alone FFN runs on 128-row tiles when that saves a round of the chip; 1: always; 2: never --
  *      bit-identical either way); "layer_out_dtype" (default 0: axvs_axial_layer_fwd* / axvs_axial_pass_fwd(pass = 1) / axvs_traj_layer_fwd / axvs_ffn_fwd write

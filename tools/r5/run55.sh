@@ -1,0 +1,3 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+timeout 2400 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4

@@ -7,6 +7,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 from golden_util import load, weights, rel_err, rel_l2, t
 from test_cabi_cpu import _decoder_from_meta
 
+for kv in sys.argv[1:]:          # library options: key=value (axvs_set_option)
+    from axial_vs_amd import _lib
+    k, v = kv.split("=")
+    _lib.check(_lib.lib().axvs_set_option(k.encode(), int(v)), k)
 z, m = load("g8_pixel_decoder_full_T4_S2")
 w = weights(z, m)
 g = torch.Generator().manual_seed(m["seed"] + 1)
