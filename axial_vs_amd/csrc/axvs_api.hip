@@ -68,7 +68,7 @@ thread_local int g_vrow = 0;             // option "vrow": the 64-row fused kern
 thread_local int g_msda_gemm = 2;
 thread_local int g_conv_nt128_nchw = 128;  // option "conv_nt128_nchw": the same for NCHW inputs (transposed to token rows first), tiles of the ONE launch over all frames
 thread_local int g_conv_nt128_exact = 0;  // option "conv_nt128_exact": 0 = two bf16 pieces per operand (5e-6 of the float64 projection + GroupNorm, 114 against 147 us at [32786 x 256 x 512]), 1 = three (9e-7)
-thread_local int g_conv_nt128_splitk = 1; // option "conv_nt128_splitk": split-K for the NCHW projections with few row tiles and Cin >= 1024
+thread_local int g_conv_nt128_splitk = 1024; // option "conv_nt128_splitk": split-K for the NCHW projections with few row tiles and Cin >= this (0: never)
 thread_local int g_conv_nt128 = 192;     // option "conv_nt128": token-row 1x1 projections run the 128 x 128 three-piece GEMM from this many tiles per launch on (0: never)
 thread_local int g_qkv_fusion = 0;       // option "qkv_fusion": the width pass's q/k/v are produced by the height-pass kernel from its output rows (implies vrow for that pass)
 // Merged q/k/v + trajectory launches (temporal_fused_kernel<..., MQ>): one launch per axial pass.  The sibling row tiles of a
@@ -2146,7 +2146,7 @@ int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride
   const bool one = in_batch_stride == (long long)HW * in_ld;
   // split-K factor of the NCHW path: few 128 x 128 tiles and a long reduction -> enough workgroups for one round of the chip (at most 8, at least 4 k-steps each)
   int zs = 1;
-  if (in_layout == 0 && g_conv_nt128_splitk && Cin >= 1024) {
+  if (in_layout == 0 && g_conv_nt128_splitk && Cin >= g_conv_nt128_splitk) {
     const long long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
     if (tiles < g_conv_nt128_nchw && tiles >= 8) {
       zs = (int)std::min<long long>(8, std::max<long long>(1, 256 / tiles));
