@@ -45,6 +45,8 @@ constexpr int kSmallBelow = 65;          // problems with fewer 64-row tiles tha
                                          // the 64-row forms (merged launch per pass, FFN riding in the width pass) are faster at every T -- round 5 sweep,
                                          // profiles/r5_planner_threshold.txt (128 until then: [1,2,256,48,80] 93.4 -> 79.5 us, [1,5,256,24,40] 94.6 -> 82.8)
 thread_local int g_small_below = kSmallBelow;      // option "small_tiles_below" (A/B runs; <= 0 restores the default)
+thread_local int g_ffn_split_fin = 0;    // option "ffn_split_finish": 1 = the chunk-per-workgroup FFN finishes its rows in the same launch (last workgroup of a tile to arrive; bit-identical,
+                                         // measured 8 - 9 us SLOWER per layer: one workgroup finishing 64 rows behind sc1 round trips is a longer tail than the finishing launch: profiles/r5_planner_threshold.txt)
 thread_local int g_ffn_split_pairs = 1;  // option "ffn_split_pairs": 65 .. 128 tiles run the chunk-per-workgroup FFN with two chunks per workgroup (0: the one-workgroup-per-tile kernel)
 thread_local int g_ffn_split_below = kSmallBelow;  // option "ffn_split_below": the same switch for the stand-alone FFN alone (chunk-per-workgroup form below it)
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
@@ -633,17 +635,23 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
   const int oflags = g_out_dtype ? (g_out_dtype == 1 ? kOutF16 : kOutBf16) : 0;
   if (oflags && !(ffn_kernel_is_fused(C, heads, F) && ffn_lds_bytes(F) <= 160 * 1024))
     return fail(AXVS_ERR_ARG, "layer_out_dtype: a 16-bit output map needs the fused FFN tier (C = 256, 8 heads, d_ffn a multiple of 256 up to 4096)");
+  // the chunk-per-workgroup forms finish their rows inside the launch (last workgroup of a tile to arrive: axvs_ffn_split.h) when the caller's arrival counters
+  // are registered (the layer calls register them for the merged trajectory launches; the same words, zero between launches) -- else the finishing kernel follows
+  FfnFinish fin{};
+  if (g_ffn_split_fin && g_sync != nullptr && (size_t)((M + kRows - 1) / kRows) <= g_sync_words && (size_t)(F / 256) * M * C * sizeof(float) < (1ull << 32))
+    fin = FfnFinish{g_sync, p.b2, p.g2, p.be2, out};
   if (!oflags && part != nullptr && ffn_split_mode(C, heads, F, M) == 2) {
     const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 512);
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true, 2>))) return rc;
-      hipLaunchKernelGGL((ffn_split_kernel<BF, true, 2>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
+      hipLaunchKernelGGL((ffn_split_kernel<BF, true, 2>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs, fin);
     } else {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, false, 2>))) return rc;
-      hipLaunchKernelGGL((ffn_split_kernel<BF, false, 2>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
+      hipLaunchKernelGGL((ffn_split_kernel<BF, false, 2>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs, fin);
     }
-    hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
-                       p.g2, p.be2, out, M, F / 256, rs);
+    if (!fin.cnt)
+      hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
+                         p.g2, p.be2, out, M, F / 256, rs);
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }
@@ -651,13 +659,14 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
     const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 256);
     if (g_ffn_gelu) {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF, true>))) return rc;
-      hipLaunchKernelGGL((ffn_split_kernel<BF, true>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
+      hipLaunchKernelGGL((ffn_split_kernel<BF, true>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs, fin);
     } else {
       if (int rc = ensure_max_lds(reinterpret_cast<const void*>(&ffn_split_kernel<BF>))) return rc;
-      hipLaunchKernelGGL((ffn_split_kernel<BF>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs);
+      hipLaunchKernelGGL((ffn_split_kernel<BF>), sgrid, dim3(512), kFfnSplitLds, st, (const float*)X, p.w1, p.b1, p.w2, p.g1, p.be1, part, M, F, rs, fin);
     }
-    hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
-                       p.g2, p.be2, out, M, F / 256, rs);
+    if (!fin.cnt)
+      hipLaunchKernelGGL(ffn_finish_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const float*)X, (const float*)part, p.b2, p.g1, p.be1,
+                         p.g2, p.be2, out, M, F / 256, rs);
     mark(st, "norm1+ffn+norm2");
     return AXVS_OK;
   }
@@ -1306,6 +1315,7 @@ int axvs_set_option(const char* key, int value) {
   if (key && !strcmp(key, "merge_mid")) { g_merge_mid = value; return AXVS_OK; }
   if (key && !strcmp(key, "no_small_tiles")) { g_no_small_tiles = value; return AXVS_OK; }
   if (key && !strcmp(key, "small_tiles_below")) { g_small_below = g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
+  if (key && !strcmp(key, "ffn_split_finish")) { g_ffn_split_fin = value; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_split_pairs")) { g_ffn_split_pairs = value; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_split_below")) { g_ffn_split_below = value > 0 ? value : kSmallBelow; return AXVS_OK; }
   if (key && !strcmp(key, "ffn_wide")) { g_ffn_wide = value; return AXVS_OK; }
