@@ -46,7 +46,7 @@ constexpr int kSmallBelow = 65;          // problems with fewer 64-row tiles tha
                                          // profiles/r5_planner_threshold.txt (128 until then: [1,2,256,48,80] 93.4 -> 79.5 us, [1,5,256,24,40] 94.6 -> 82.8)
 thread_local int g_small_below = kSmallBelow;      // option "small_tiles_below" (A/B runs; <= 0 restores the default)
 thread_local int g_ffn_split_fin = 0;    // option "ffn_split_finish": 1 = the chunk-per-workgroup FFN finishes its rows in the same launch (last workgroup of a tile to arrive; bit-identical,
-                                         // measured 8 - 9 us SLOWER per layer: one workgroup finishing 64 rows behind sc1 round trips is a longer tail than the finishing launch: profiles/r5_planner_threshold.txt)
+                                         // measured 1 - 4.5 us SLOWER per layer: write-through partials, drain + atomic + barriers and one workgroup's tail cost more than the finishing launch: profiles/r5_planner_threshold.txt)
 thread_local int g_ffn_split_pairs = 1;  // option "ffn_split_pairs": 65 .. 128 tiles run the chunk-per-workgroup FFN with two chunks per workgroup (0: the one-workgroup-per-tile kernel)
 thread_local int g_ffn_split_below = kSmallBelow;  // option "ffn_split_below": the same switch for the stand-alone FFN alone (chunk-per-workgroup form below it)
 thread_local int g_spatial_only = 0;     // option "spatial_only": 1 = the fused trajectory kernels return after QK^T / softmax / AV (timing only; outputs unwritten);
@@ -638,7 +638,7 @@ int run_ffn(float* X, float* out, const LayerPacked& p, long long M, int C, int 
   // the chunk-per-workgroup forms finish their rows inside the launch (last workgroup of a tile to arrive: axvs_ffn_split.h) when the caller's arrival counters
   // are registered (the layer calls register them for the merged trajectory launches; the same words, zero between launches) -- else the finishing kernel follows
   FfnFinish fin{};
-  if (g_ffn_split_fin && g_sync != nullptr && (size_t)((M + kRows - 1) / kRows) <= g_sync_words && (size_t)(F / 256) * M * C * sizeof(float) < (1ull << 32))
+  if (g_ffn_split_fin && F <= 1024 && g_sync != nullptr && (size_t)((M + kRows - 1) / kRows) <= g_sync_words && (size_t)(F / 256) * M * C * sizeof(float) < (1ull << 32))
     fin = FfnFinish{g_sync, p.b2, p.g2, p.be2, out};
   if (!oflags && part != nullptr && ffn_split_mode(C, heads, F, M) == 2) {
     const dim3 sgrid((unsigned)((M + kRows - 1) / kRows), F / 512);

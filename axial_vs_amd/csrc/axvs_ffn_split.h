@@ -139,29 +139,41 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
     const float4 gg = *reinterpret_cast<const float4*>(g1 + lane * 4), bb = *reinterpret_cast<const float4*>(be1 + lane * 4);
     const float4 bv = *reinterpret_cast<const float4*>(fin.b2 + lane * 4);
     const float4 g2v = *reinterpret_cast<const float4*>(fin.g2 + lane * 4), be2v = *reinterpret_cast<const float4*>(fin.be2 + lane * 4);
-#pragma unroll 2
-    for (int i = 0; i < 8; ++i) {
-      const long long m = m0 + wave * 8 + i;
-      if (m >= M) break;
-      const long long mrow = rs.row(m);
-      const float4 v = *reinterpret_cast<const float4*>(X + mrow * C + lane * 4);
-      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
-      const float a = v.x - mu, b = v.y - mu, c2 = v.z - mu, d = v.w - mu;
-      const float rstd = rsqrtf(wave_sum(a * a + b * b + c2 * c2 + d * d) * (1.f / C) + 1e-5f);
-      const float4 y = float4{a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c2 * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
-      const unsigned off = (unsigned)((m * C + lane * 4) * sizeof(float));
-      const unsigned cstride = (unsigned)(M * C * sizeof(float));
-      float4 acc = __builtin_bit_cast(float4, pr.load16(off, 0));
-      for (int c = 1; c < nchunk; ++c) {
-        const float4 p = __builtin_bit_cast(float4, pr.load16(off, (unsigned)c * cstride));
-        acc.x = acc.x + p.x; acc.y = acc.y + p.y; acc.z = acc.z + p.z; acc.w = acc.w + p.w;
+    // four rows at a time: all their loads (x row + every chunk's partial: sc1, memory-side latency) in flight before the first reduction
+    const unsigned cstride = (unsigned)(M * C * sizeof(float));
+#pragma unroll 1
+    for (int i0 = 0; i0 < 8; i0 += 4) {
+      float4 xv[4], pv[4][4];      // (the host enables this path for d_ffn <= 1024: at most 4 chunks)
+      long long mr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long m = min(m0 + wave * 8 + i0 + i, M - 1);
+        mr[i] = rs.row(m);
+        xv[i] = *reinterpret_cast<const float4*>(X + mr[i] * C + lane * 4);
+        const unsigned off = (unsigned)((m * C + lane * 4) * sizeof(float));
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nchunk) pv[i][c] = __builtin_bit_cast(float4, pr.load16(off, (unsigned)c * cstride));
       }
-      const float4 u = float4{y.x + acc.x + bv.x, y.y + acc.y + bv.y, y.z + acc.z + bv.z, y.w + acc.w + bv.w};
-      const float mu2 = wave_sum(u.x + u.y + u.z + u.w) * (1.f / C);
-      const float d0 = u.x - mu2, d1 = u.y - mu2, d2 = u.z - mu2, d3 = u.w - mu2;
-      const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
-      *reinterpret_cast<float4*>(fin.out + mrow * C + lane * 4) =
-          float4{d0 * rstd2 * g2v.x + be2v.x, d1 * rstd2 * g2v.y + be2v.y, d2 * rstd2 * g2v.z + be2v.z, d3 * rstd2 * g2v.w + be2v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (m0 + wave * 8 + i0 + i >= M) break;
+        const float4 v = xv[i];
+        const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
+        const float a = v.x - mu, b = v.y - mu, c2 = v.z - mu, d = v.w - mu;
+        const float rstd = rsqrtf(wave_sum(a * a + b * b + c2 * c2 + d * d) * (1.f / C) + 1e-5f);
+        const float4 y = float4{a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c2 * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
+        float4 acc = pv[i][0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+          if (c < nchunk) { acc.x = acc.x + pv[i][c].x; acc.y = acc.y + pv[i][c].y; acc.z = acc.z + pv[i][c].z; acc.w = acc.w + pv[i][c].w; }
+        const float4 u = float4{y.x + acc.x + bv.x, y.y + acc.y + bv.y, y.z + acc.z + bv.z, y.w + acc.w + bv.w};
+        const float mu2 = wave_sum(u.x + u.y + u.z + u.w) * (1.f / C);
+        const float d0 = u.x - mu2, d1 = u.y - mu2, d2 = u.z - mu2, d3 = u.w - mu2;
+        const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
+        *reinterpret_cast<float4*>(fin.out + mr[i] * C + lane * 4) =
+            float4{d0 * rstd2 * g2v.x + be2v.x, d1 * rstd2 * g2v.y + be2v.y, d2 * rstd2 * g2v.z + be2v.z, d3 * rstd2 * g2v.w + be2v.w};
+      }
     }
   }
 }
