@@ -1358,6 +1358,34 @@ def test_ffn_with_two_chunks_per_workgroup_is_bit_identical(shape):
     assert rel_err(pairs.cpu(), ref) < TOL_F16
 
 
+@pytest.mark.parametrize("shape", [(1, 4, 256, 16, 16, 1024), (1, 5, 256, 24, 40, 1024), (1, 2, 256, 25, 43, 512), (1, 4, 256, 32, 32, 1024), (1, 6, 256, 30, 30, 1024)])
+def test_ffn_in_launch_finishing_is_bit_identical(shape):
+    """Option ffn_split_finish (round 5; off by default -- measured slower than the finishing launch): the chunk-per-workgroup FFN writes its partials
+    write-through, every workgroup of a tile adds to the tile's arrival counter (the registered sync words) and the LAST one to arrive adds the partials in
+    chunk order and applies norm2.  Same bits as the two-launch form whichever workgroup arrives last, call after call; the counters are zero afterwards."""
+    import axial_vs_amd as ax
+    from axial_vs_amd import _lib, modules
+    B, T, C, H, W, F = shape
+    w = orc.random_weights(orc.axial_layer_param_shapes(C, F), 97)
+    src, pos = orc.synthetic_clip(B, T, C, H, W, 97)
+    layer = ax.TemporalAxialTrajectoryAttentionLayer(C, F, n_heads=8).eval()
+    layer.load_state_dict(w, strict=True)
+    layer = layer.cuda()
+    s, p = dev(src), dev(pos)
+    two = layer(s, p)[0].clone()
+    assert "norm1+ffn+norm2" in _stage_names()
+    _lib.check(_lib.lib().axvs_set_option(b"ffn_split_finish", 1), "axvs_set_option")
+    try:
+        outs = [layer(s, p)[0].clone() for _ in range(6)]
+    finally:
+        _lib.lib().axvs_set_option(b"ffn_split_finish", 0)
+    assert all(torch.equal(two, o) for o in outs)
+    torch.cuda.synchronize()
+    ax.check_status()
+    for buf in modules._sync_buffers.values():
+        assert int(buf.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 256, 64, 64, 1024), (2, 3, 256, 48, 40, 512), (2, 2, 256, 57, 61, 1024), (4, 1, 256, 64, 32, 256),
                                    (1, 4, 256, 96, 64, 1024), (1, 4, 256, 64, 96, 1024)])
 def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_default_kernels(shape):
