@@ -7,7 +7,7 @@ mkdir -p $OUT
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC SQ_INSTS_SALU" "GRBM_GUI_ACTIVE GRBM_COUNT" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/set$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --settle-ms 0 > $OUT/set$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/set$i -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-qkav --no-stages --settle-ms 0 "$@" > $OUT/set$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
