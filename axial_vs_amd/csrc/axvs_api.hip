@@ -864,15 +864,14 @@ int traj_layer_fwd_t(const float* src, const float* pos, float* out, const void*
 // ---------------- cross-clip module ----------------
 struct CCLayerPacked {
   TrajPacked t;
-  u16 *aspp[3], *aspp_proj;
-  float *aspp_b[3], *norm_w, *norm_b, *an_w, *an_b, *cn_w, *cn_b;
+  u16* aspp_taps;                      // the folded temporal ASPP (axvs_cc.h, pack_aspp_taps_kernel): blocked weights [K = 7 * 256][256]
+  float *aspp_bias, *norm_w, *norm_b, *an_w, *an_b, *cn_w, *cn_b;
 };
 CCLayerPacked carve_cc_layer(Carver& c) {
   CCLayerPacked l;
   l.t = carve_traj(c, 256, 8);
-  for (int i = 0; i < 3; ++i) l.aspp[i] = c.take<u16>(256 * 768);
-  l.aspp_proj = c.take<u16>(256 * 768);
-  for (int i = 0; i < 3; ++i) l.aspp_b[i] = c.take<float>(256);
+  l.aspp_taps = c.take<u16>(7 * 256 * 256);
+  l.aspp_bias = c.take<float>(256);
   l.norm_w = c.take<float>(256); l.norm_b = c.take<float>(256);
   l.an_w = c.take<float>(256); l.an_b = c.take<float>(256);
   l.cn_w = c.take<float>(256); l.cn_b = c.take<float>(256);
@@ -896,7 +895,6 @@ CCHeadsPacked carve_cc_heads(Carver& c, int K1) {
 struct CCLayerWs {
   TrajWs tw;
   float *t1, *t2, *y;
-  u16* cat16;
 };
 CCLayerWs carve_cc_layer_ws(Carver& c, long long R, int Tc, int Q) {
   CCLayerWs w;
@@ -904,7 +902,6 @@ CCLayerWs carve_cc_layer_ws(Carver& c, long long R, int Tc, int Q) {
   w.t1 = c.take<float>((size_t)R * 256);
   w.t2 = c.take<float>((size_t)R * 256);
   w.y = c.take<float>((size_t)R * 256);
-  w.cat16 = c.take<u16>((size_t)R * 768);
   return w;
 }
 
@@ -943,19 +940,12 @@ int cc_layer_fwd_t(const float* x, float* out, const void* packed, int B, int Q,
                        1e-5f);
     mark(st, "cc.norm");
   }
-  // temporal ASPP: three dilated 3-tap convs over the clip axis -> concat (blocked 16-bit) -> 1x1 projection
+  // temporal ASPP, folded at pack time into ONE linear map of the clip axis (three dilated 3-tap branches + concat + 1x1 projection:
+  // CC/maxtron_cross_clip_tracking_module.py:176-201): y[t] = sum_j M_j x[clamp(t + off_j)] + b', 7 taps, K = 1792
   {
-    GemmBatch<ALoadShift3<BF>, EpiBlocked16<BF>, 3> gb;
-    for (int br = 0; br < 3; ++br) {
-      gb.al[br] = ALoadShift3<BF>{w.t2, 256, Tc, rates[br], (int)R};
-      gb.W[br] = p.aspp[br];
-      gb.epi[br] = EpiBlocked16<BF>{w.cat16, R, p.aspp_b[br], 1.f, 0, 0};
-      gb.epi[br].n_off = br * 256;
-    }
-    launch_gemm_batched<BF>(gb, (int)R, 256, 768, st);        // the three dilated branches in one launch
+    ALoadTaps7<BF> at{w.t2, Tc, (int)R, {0, -rates[0], rates[0], -rates[1], rates[1], -rates[2], rates[2]}};
+    launch_gemm<BF>(at, p.aspp_taps, EpiRowsF32{w.y, nullptr, p.aspp_bias, identity_map(R), 256, 1.f}, (int)R, 256, 7 * 256, st, 7);
   }
-  ALoadBlocked<BF> ac{w.cat16, R, (int)R, 0, 1, 1};
-  launch_gemm<BF>(ac, p.aspp_proj, EpiRowsF32{w.y, nullptr, nullptr, identity_map(R), 256, 1.f}, (int)R, 256, 768, st);
   mark(st, "cc.aspp");
   hipLaunchKernelGGL(cc_aspp_post_kernel, dim3(lnblocks), dim3(256), 0, st, w.y, w.t2, p.an_w, p.an_b, p.cn_w, p.cn_b, out, R, out2, g_cc_aspp_affine);
   mark(st, "cc.aspp_post");
@@ -1642,18 +1632,15 @@ int axvs_cc_layer_pack(const AxvsCCLayerParams* p, void* packed, int dtype, void
   Carver c(packed);
   CCLayerPacked l = carve_cc_layer(c);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  PackDim n256{256, 256, 0, 0, 0}, k768{768, 768, 0, 0, 0};
-  const unsigned cb = (256 * 768 + 255) / 256;
+  const unsigned cb = (7 * 256 * 256 + 255) / 256;
   if (dtype == AXVS_BF16) {
     pack_traj<true>(p->attn, l.t, 256, 8, st);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pack_conv3_kernel<true>), dim3(cb), dim3(256), 0, st, p->aspp_w[i], l.aspp[i], 256, 256);
-    pack_w<true>(p->aspp_proj_w, l.aspp_proj, n256, k768, st);
+    hipLaunchKernelGGL((pack_aspp_taps_kernel<true>), dim3(cb), dim3(256), 0, st, p->aspp_w[0], p->aspp_w[1], p->aspp_w[2], p->aspp_proj_w, l.aspp_taps);
   } else {
     pack_traj<false>(p->attn, l.t, 256, 8, st);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pack_conv3_kernel<false>), dim3(cb), dim3(256), 0, st, p->aspp_w[i], l.aspp[i], 256, 256);
-    pack_w<false>(p->aspp_proj_w, l.aspp_proj, n256, k768, st);
+    hipLaunchKernelGGL((pack_aspp_taps_kernel<false>), dim3(cb), dim3(256), 0, st, p->aspp_w[0], p->aspp_w[1], p->aspp_w[2], p->aspp_proj_w, l.aspp_taps);
   }
-  for (int i = 0; i < 3; ++i) copy_f32(p->aspp_b[i], l.aspp_b[i], 256, st);
+  hipLaunchKernelGGL(pack_aspp_bias_kernel, dim3(1), dim3(256), 0, st, p->aspp_b[0], p->aspp_b[1], p->aspp_b[2], p->aspp_proj_w, l.aspp_bias);
   copy_f32(p->norm_w, l.norm_w, 256, st); copy_f32(p->norm_b, l.norm_b, 256, st);
   copy_f32(p->aspp_norm_w, l.an_w, 256, st); copy_f32(p->aspp_norm_b, l.an_b, 256, st);
   copy_f32(p->conv_norm_w, l.cn_w, 256, st); copy_f32(p->conv_norm_b, l.cn_b, 256, st);

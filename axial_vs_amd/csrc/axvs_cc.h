@@ -4,18 +4,40 @@
 
 namespace axvs {
 
-// conv weight [Cout][Cin][3] fp32 -> blocked 16-bit weight layout (wblk_off) with k = tap*Cin + ci
+// Temporal ASPP folded at pack time (CC/maxtron_cross_clip_tracking_module.py:176-201).  The three dilated Conv1d branches (bias, no
+// activation, no norm) feed the bias-free 1x1 projection directly, so branches + concat + projection are ONE linear map of the
+// clip axis:   y[t] = sum_j M_j x[clamp(t + off_j)] + b',   M_0 = sum_r P_r W_r[:,:,1] (the three centre taps, offset 0),
+// M_{1+2r} = P_r W_r[:,:,0] (offset -rate_r), M_{2+2r} = P_r W_r[:,:,2] (offset +rate_r), b' = sum_r P_r b_r, P_r = proj[:, 256r..256r+255].
+// 7 x 256 x 256 weights instead of 9 x 256 x 256 + 256 x 768, one GEMM with K = 1792 instead of three (K = 768) plus one (K = 768), no
+// [rows, 768] intermediate, and one 16-bit rounding of an intermediate less.  The products are formed in fp32 (<= 768 terms) and rounded
+// once to the operand type.  The rates enter at run time as the row offsets only (the packed buffer does not depend on them).
+// thread -> (j, n, c); out: blocked weight layout (wblk_off) [K = 7 * 256][256 rows]
 template <bool BF>
-__global__ void pack_conv3_kernel(const float* __restrict__ W, u16* __restrict__ out, int Cout, int Cin) {
-  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long total = (long long)Cout * Cin * 3;
-  if (idx >= total) return;
-  int kk = idx & 31;
-  long long t = idx >> 5;
-  int n = t % Cout;
-  int kb = t / Cout;
-  int k = kb * 32 + kk, tap = k / Cin, ci = k - tap * Cin;
-  out[wblk_off(Cout, n, k)] = H16<BF>::from_f32(W[((long long)n * Cin + ci) * 3 + tap]);
+__global__ void pack_aspp_taps_kernel(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
+                                      const float* __restrict__ P /* [256][768] */, u16* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 7 * 256 * 256) return;
+  const int c = idx & 255, n = (idx >> 8) & 255, j = idx >> 16;
+  const float* Wr[3] = {W0, W1, W2};
+  float acc = 0.f;
+  if (j == 0) {
+    for (int r = 0; r < 3; ++r)
+      for (int m = 0; m < 256; ++m) acc += P[n * 768 + r * 256 + m] * Wr[r][(m * 256 + c) * 3 + 1];
+  } else {
+    const int r = (j - 1) >> 1, tap = ((j - 1) & 1) * 2;
+    for (int m = 0; m < 256; ++m) acc += P[n * 768 + r * 256 + m] * Wr[r][(m * 256 + c) * 3 + tap];
+  }
+  out[wblk_off(256, n, j * 256 + c)] = H16<BF>::from_f32(acc);
+}
+__global__ void pack_aspp_bias_kernel(const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
+                                      const float* __restrict__ P, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= 256) return;
+  const float* br[3] = {b0, b1, b2};
+  float acc = 0.f;
+  for (int r = 0; r < 3; ++r)
+    for (int m = 0; m < 256; ++m) acc += P[n * 768 + r * 256 + m] * br[r][m];
+  out[n] = acc;
 }
 
 // eval-mode BatchNorm folded into a per-channel multiplier / bias:  y = (x - mean) / sqrt(var + eps) * w + b

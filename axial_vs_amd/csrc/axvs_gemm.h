@@ -76,21 +76,22 @@ struct ALoadRowsLd {
   }
 };
 
-// Dilated 3-tap Conv1d over the clip axis with replicate padding as a GEMM (CC/maxtron_cross_clip_tracking_module.py:180-182):
-// rows are (bq, t) of a [BQ, Tc, C] fp32 tensor; k = tap*C + ci reads channel ci of row (bq, clamp(t + (tap-1)*rate)).
+// The folded temporal ASPP as a GEMM (axvs_cc.h, pack_aspp_taps_kernel): rows are (bq, t) of a [BQ, Tc, 256] fp32 tensor;
+// k = j * 256 + ci reads channel ci of row (bq, clamp(t + off[j])) -- replicate padding (CC/maxtron_cross_clip_tracking_module.py:180-182).
 template <bool BF>
-struct ALoadShift3 {
+struct ALoadTaps7 {
   static constexpr int kPrefetch = 3;
   const float* src;
-  int C, Tc, rate, M;
+  int Tc, M;
+  int off[7];
   __device__ __forceinline__ u16x8 load(int m, int k) const { return conv(fetch(m, k)); }
   typedef F32x8 raw_t;
   __device__ __forceinline__ raw_t fetch(int m, int k) const {
     m = min(m, M - 1);
-    const int tap = k / C, ci = k - tap * C;
+    const int j = k >> 8, ci = k & 255;
     const int bq = m / Tc, t = m - bq * Tc;
-    const int tt = min(max(t + (tap - 1) * rate, 0), Tc - 1);
-    const float4* p = reinterpret_cast<const float4*>(src + ((long long)bq * Tc + tt) * C + ci);
+    const int tt = min(max(t + off[j], 0), Tc - 1);
+    const float4* p = reinterpret_cast<const float4*>(src + ((long long)bq * Tc + tt) * 256 + ci);
     return raw_t{p[0], p[1]};
   }
   static __device__ __forceinline__ u16x8 conv(const raw_t& r) {
@@ -303,11 +304,13 @@ __global__ __launch_bounds__(256) void gemm64_kernel(ALoad al, const u16* __rest
 // each walking K in dependent global -> LDS -> barrier -> MFMA steps (~0.5 us per k-step measured).  Here every wave owns a
 // 16-row x 16*NT-column tile and streams its operand fragments with D k-blocks in flight -- both blocked layouts make a fragment
 // 1 KiB contiguous --, no LDS, no barriers; the redundant activation loads of the waves sharing a row tile hit L1 / L2.
-template <bool BF, class ALoad, class Epi, int NT>
+// NFAST: the column tiles are the fast grid dimension -- workgroups b and b + 8 share an XCD (round-robin placement; speed only), so with
+// 8 column tiles every XCD's L2 fetches ONE column slice of the weights instead of all of them (cold weights: the cross-clip chain)
+template <bool BF, class ALoad, class Epi, int NT, bool NFAST = false>
 __device__ __forceinline__ void gemm_direct_body(const ALoad& al, const u16* __restrict__ Wp, const Epi& epi, int M, int Nout, int K) {
   constexpr int D = 8;
   const int lane = threadIdx.x & 63, fi = lane & 15, fg = lane >> 4;
-  const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16 * NT;
+  const int m0 = (NFAST ? blockIdx.y : blockIdx.x) * 16, n0 = (NFAST ? blockIdx.x : blockIdx.y) * 16 * NT;
   // split-K over the waves of the workgroup (1..4; the launcher picks K / 256 when that divides): the loop below is bound by
   // L2 round trips -- one per group of D k-blocks --, so K = 768 as three waves with 8 k-blocks each costs one round trip
   // instead of three; the partial tiles meet in LDS
@@ -363,7 +366,7 @@ __device__ __forceinline__ void gemm_direct_body(const ALoad& al, const u16* __r
     }
   }
   if (ks > 1) {
-    __shared__ f32x4 red[3][NT][64];
+    __shared__ f32x4 red[6][NT][64];      // up to 7 k-waves (the folded ASPP: K = 7 * 256)
     if (wave > 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) red[wave - 1][nt][lane] = acc[nt];
@@ -386,12 +389,16 @@ template <bool BF, class ALoad, class Epi, int NT>
 __global__ __launch_bounds__(256) void gemm_direct_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
   gemm_direct_body<BF, ALoad, Epi, NT>(al, Wp, epi, M, Nout, K);
 }
+template <bool BF, class ALoad, class Epi, int NT>      // 5 .. 7 k-waves
+__global__ __launch_bounds__(448) void gemm_direct_wide_kernel(ALoad al, const u16* __restrict__ Wp, Epi epi, int M, int Nout, int K) {
+  gemm_direct_body<BF, ALoad, Epi, NT, true>(al, Wp, epi, M, Nout, K);
+}
 
 // 64x64 tiles unless they would leave most of the chip idle
 // waves per workgroup of the direct kernels: K split into 256-wide shares when that divides (at most 4)
-inline int gemm_direct_waves(int K) {
+inline int gemm_direct_waves(int K, int max_ks = 4) {
   const int nkb = K >> 5;
-  for (int ks = 4; ks > 1; --ks)
+  for (int ks = max_ks; ks > 1; --ks)
     if (nkb % (8 * ks) == 0) return ks;
   return 1;
 }
@@ -433,12 +440,17 @@ inline void launch_gemm_batched(const GemmBatch<ALoad, Epi, NB>& b, int M, int N
 }
 
 template <bool BF, class ALoad, class Epi>
-inline void launch_gemm(const ALoad& al, const u16* Wp, const Epi& epi, int M, int Nout, int K, hipStream_t st) {
+inline void launch_gemm(const ALoad& al, const u16* Wp, const Epi& epi, int M, int Nout, int K, hipStream_t st, int max_ks = 4 /* k-waves of the direct kernels: up to 7 */) {
   if (gemm_is_small(M, Nout, 1, K)) {
-    if ((long long)((M + 15) / 16) * ((Nout + 63) / 64) >= 256) {
-      hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 4>), dim3((M + 15) / 16, (Nout + 63) / 64), dim3(64 * gemm_direct_waves(K)), 0, st, al, Wp, epi, M, Nout, K);
+    const int kw = gemm_direct_waves(K, max_ks);
+    const bool wide_n = (long long)((M + 15) / 16) * ((Nout + 63) / 64) >= 256;
+    if (kw > 4) {
+      if (wide_n) hipLaunchKernelGGL((gemm_direct_wide_kernel<BF, ALoad, Epi, 4>), dim3((Nout + 63) / 64, (M + 15) / 16), dim3(64 * kw), 0, st, al, Wp, epi, M, Nout, K);
+      else hipLaunchKernelGGL((gemm_direct_wide_kernel<BF, ALoad, Epi, 2>), dim3((Nout + 31) / 32, (M + 15) / 16), dim3(64 * kw), 0, st, al, Wp, epi, M, Nout, K);
+    } else if (wide_n) {
+      hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 4>), dim3((M + 15) / 16, (Nout + 63) / 64), dim3(64 * kw), 0, st, al, Wp, epi, M, Nout, K);
     } else {   // narrower tiles: twice the waves
-      hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 2>), dim3((M + 15) / 16, (Nout + 31) / 32), dim3(64 * gemm_direct_waves(K)), 0, st, al, Wp, epi, M, Nout, K);
+      hipLaunchKernelGGL((gemm_direct_kernel<BF, ALoad, Epi, 2>), dim3((M + 15) / 16, (Nout + 31) / 32), dim3(64 * kw), 0, st, al, Wp, epi, M, Nout, K);
     }
     return;
   }
