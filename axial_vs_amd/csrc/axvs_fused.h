@@ -1114,12 +1114,17 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     [[maybe_unused]] unsigned* const cnt = MQ != 0 ? oq.sync + m0 / N : nullptr;      // my sequence's arrival counter
     [[maybe_unused]] const unsigned tps_u = (unsigned)((N + ROWS - 1) / ROWS);
     [[maybe_unused]] u16x8 vown[2][NKS];          // MQ == 2: V^T fragments of my own frame
+    // A wait that runs out (a sibling tile that is not co-resident: another tenant, a profiler) must never turn into plausible numbers: the wave
+    // reports it (status bit 2) and POISONS every softmax it computes from then on (poison = NaN multiplies the reciprocal row sum; 1.0 otherwise:
+    // exact), so the rows of this tile come out NaN instead of being computed from stale K / V^T (round 6; rounds 4 - 5 computed on).
+    [[maybe_unused]] float poison = 1.f;
     auto wait_siblings = [&]() {            // every wave polls for itself (one dword, sc1) and loads only after its poll matched
       unsigned spins = 0;
       while (ld_sc1_u32(cnt) < tps_u) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > oq.spin_limit) {
           if (oq.status != nullptr && lane == 0) atomicOr(oq.status, 4);
+          poison = __uint_as_float(__builtin_amdgcn_readfirstlane(0x7fc00000u));      // (kept in a scalar register)
           break;
         }
       }
@@ -1493,6 +1498,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) ssum = H16<BF>::mfma(ones, pf[qt][ks], ssum);
         inv[qt] = __builtin_amdgcn_rcpf(ssum[0]);   // 1 ulp; the result is rounded to 16 bits right after
+        if constexpr (MQ != 0) inv[qt] *= poison;   // (x 1.0 unless a hand-off wait ran out)
       }
       if constexpr (VROW) {
         u16* vblk = xt + ((f * 8 + wave) * ROWS) * 32;

@@ -80,7 +80,7 @@ def chunked_clip_order(total: int, world: int, chunks: int) -> List[int]:
 
 def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, pos: Tensor, group=None,
                     gather: bool = True, replicated_inputs: bool = True, gather_dtype: Optional[torch.dtype] = None,
-                    chunks: int = 1) -> Tensor:
+                    chunks: int = 1, allow_permuted: bool = False):
     """Run `layer_fn(src_local, pos_local) -> out_local` on this rank's clips and (optionally) reassemble the output.
 
     ``replicated_inputs``: src / pos hold the whole batch on every rank (cut locally); otherwise they are already the
@@ -94,8 +94,13 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
       * replicated inputs: the clips are dealt to the ranks group by group -- rank r computes clips {c * world * cb + r * cb + i}
         (cb = clips per group) -- so group c of all ranks IS rows [c * world * cb * T, (c + 1) * world * cb * T) of the map in natural
         clip order;
-      * pre-sharded inputs (rank r holds its own clips): the map comes back ordered (group, rank, clip in group);
-        `chunked_clip_order(total, world, chunks)` names the clip at every position (also attached as `full.clip_order`).
+      * pre-sharded inputs (rank r holds its own clips): the groups land ordered (group, rank, clip in group).
+
+    **The returned order never depends on the shapes.**  ``allow_permuted=False`` (default): a Tensor in natural clip order (rank-major for
+    pre-sharded inputs) on every path -- the chunked pre-sharded path pays ONE reordering copy of the gathered map for it.
+    ``allow_permuted=True``: ALWAYS a tuple ``(full, order)`` with ``order[i]`` = the clip (rank-major numbering) at position i of ``full``:
+    `chunked_clip_order(total, world, chunks)` on the chunked pre-sharded path (no copy), the identity on every other path (replicated inputs,
+    one rank, unequal shards, a local clip count that `chunks` does not divide).
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -145,17 +150,24 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
             works.append(dist.all_gather_into_tensor(dst, o.contiguous(), group=group, async_op=True))
         for wk in works:
             wk.wait()
-        if not replicated_inputs:
-            full.clip_order = chunked_clip_order(total, world, chunks)
-        return full
+        if replicated_inputs:
+            return (full, list(range(total))) if allow_permuted else full
+        if allow_permuted:
+            return full, chunked_clip_order(total, world, chunks)
+        # (group, rank, clip) -> (rank, group, clip): one copy of the map, the price of the invariant order
+        tail = tuple(full.shape[1:])
+        return full.view((chunks, world, cb * T) + tail).transpose(0, 1).reshape((total * T,) + tail)
     if replicated_inputs:
         s_loc, p_loc = local_slice(src, pos, rank, world)
     else:
         s_loc, p_loc = src, pos
     out_local = layer_fn(s_loc, p_loc) if s_loc.shape[0] else s_loc.new_empty(s_loc.shape)
     if not gather or world == 1:
-        return out_local if gather_dtype is None or out_local.dtype == gather_dtype else out_local.to(gather_dtype)
-    return gather_clips(out_local, total, T, group, dtype=gather_dtype)
+        res = out_local if gather_dtype is None or out_local.dtype == gather_dtype else out_local.to(gather_dtype)
+        n_here = total if (gather and world == 1) else out_local.shape[0] // max(T, 1)
+        return (res, list(range(n_here))) if allow_permuted else res
+    res = gather_clips(out_local, total, T, group, dtype=gather_dtype)
+    return (res, list(range(total))) if allow_permuted else res
 
 
 def _exchange(blocks: List[Tensor], group=None) -> List[Tensor]:

@@ -17,6 +17,7 @@ import ctypes as C
 import functools
 import math
 import threading
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -204,9 +205,54 @@ def _guarded(fn):
             if isinstance(a, Tensor) and a.is_cuda:
                 with _on(a.device):
                     _select_status_word(a.device)
-                    return fn(*args, **kw)
+                    if _handoff_policy[0] != "verify" or getattr(_sync_tls, "depth", 0) or torch.cuda.is_current_stream_capturing():
+                        return fn(*args, **kw)
+                    return _verified(fn, a.device, args, kw)
         return fn(*args, **kw)
     return wrapper
+
+
+# ---- hand-off policy (round 6) -------------------------------------------------------------------------------------------------------
+# "async" (default): library calls never synchronise.  A merged launch whose hand-off wait ran out writes NaN rows (never numbers computed
+#     from stale K / V^T), sets the status bit, and the NEXT call on this thread raises after the handler has put the counters back in order.
+# "verify": the outermost module call waits for its own stream, reads the status word, and -- if a wait ran out -- zeroes the counters and runs
+#     the SAME call again with two launches per pass (bit-identical to the merged form by construction, tests/test_hip_parity.py): the caller gets
+#     correct bits and no exception.  Costs the host's run-ahead (one stream synchronisation per forward); meant for GPUs shared with other tenants.
+_handoff_policy: List[str] = ["async"]
+
+
+def set_handoff_policy(policy: str) -> str:
+    """'async' | 'verify' (see above).  Returns the previous policy."""
+    if policy not in ("async", "verify"):
+        raise ValueError("axial_vs_amd: handoff policy must be 'async' or 'verify'")
+    prev = _handoff_policy[0]
+    _handoff_policy[0] = policy
+    return prev
+
+
+def _verified(fn, device: torch.device, args, kw):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    _sync_tls.depth = 1
+    try:
+        out = fn(*args, **kw)
+        torch.cuda.current_stream(device).synchronize()
+        if not int(_status_word(idx)[0]) & 4:
+            return out
+        _on_sync_timeout()                                   # counters zeroed, bit cleared
+        _handoff_recoveries[0] += 1
+        L = _lib.lib()
+        _lib.check(L.axvs_set_option(b"no_merge_qkv", 1), "axvs_set_option")
+        try:
+            out = fn(*args, **kw)                            # two launches per pass: nothing to wait for
+            torch.cuda.current_stream(device).synchronize()
+        finally:
+            L.axvs_set_option(b"no_merge_qkv", 0)
+        return out
+    finally:
+        _sync_tls.depth = 0
+
+
+_handoff_recoveries: List[int] = [0]      # forwards re-run by the "verify" policy (tests, monitoring)
 
 
 class SineTag:
@@ -267,10 +313,15 @@ def _on_sync_timeout() -> None:
             for (kidx, _), buf in list(_sync_buffers.items()):
                 if kidx == idx:
                     buf.zero_()
+            for g in list(_live_graphs):                  # the counters baked into captured graphs (GraphedForward owns its sets)
+                for buf in g._sync:
+                    if buf.device.index == idx:
+                        buf.zero_()
             torch.cuda.synchronize(idx)
             w[0] = int(w[0]) & ~4
 
 
+_live_graphs: "weakref.WeakSet" = weakref.WeakSet()      # GraphedForward instances (their arrival counters are zeroed by the handler too)
 _lib._state_handler = _on_sync_timeout
 
 
@@ -916,9 +967,37 @@ class GraphedForward:
         finally:
             _sync_tls.override = prev_override
             _sync_tls.key = None                          # the next eager call registers its own (device, stream) words again
+        _live_graphs.add(self)
+
+    def _timed_out(self) -> bool:
+        w = _status_words.get(self.inputs[0].device.index)
+        return w is not None and bool(int(w[0]) & 4)
 
     def __call__(self, *inputs: Tensor):
+        # A replay bypasses the library's entry gate: read the (host-resident) status word here.  A hand-off timeout of an earlier replay left
+        # this graph's arrival counters non-zero -- every further replay would time out again: put them in order and fail loudly (no sync).
+        if self._timed_out():
+            _on_sync_timeout()
+            raise RuntimeError("axial_vs_amd: a merged q/k/v + trajectory launch of an earlier graph replay gave up waiting for its sibling row "
+                               "tiles (AXVS_STATUS_SYNC_TIMEOUT): that replay's outputs are NaN rows.  The arrival counters have been zeroed; replay again")
         for dst, src in zip(self.inputs, inputs):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        if _handoff_policy[0] == "verify":
+            dev = self.inputs[0].device
+            torch.cuda.current_stream(dev).synchronize()
+            if self._timed_out():                         # recover transparently: the same forward, eagerly, two launches per pass
+                _on_sync_timeout()
+                _handoff_recoveries[0] += 1
+                L = _lib.lib()
+                _lib.check(L.axvs_set_option(b"no_merge_qkv", 1), "axvs_set_option")
+                try:
+                    res = self.module(*self.inputs)
+                    for dst, src in zip(self.out if isinstance(self.out, (tuple, list)) else (self.out,),
+                                        res if isinstance(res, (tuple, list)) else (res,)):
+                        if isinstance(dst, Tensor) and isinstance(src, Tensor):
+                            dst.copy_(src)
+                    torch.cuda.current_stream(dev).synchronize()
+                finally:
+                    L.axvs_set_option(b"no_merge_qkv", 0)
         return self.out

@@ -410,7 +410,7 @@ def main():
                 g5 = {}
                 for key5, gdt in (("fp32_map", None), ("f16_map", torch.float16)):
                     layer5.out_dtype = gdt          # the 16-bit map is written by the epilogue of the layer's last kernel (no cast pass)
-                    el5, full5 = timed(lambda: axd.sharded_forward(fn5, src5, pos5, replicated_inputs=False, gather_dtype=gdt, chunks=4),
+                    el5, full5 = timed(lambda: axd.sharded_forward(fn5, src5, pos5, replicated_inputs=False, gather_dtype=gdt, chunks=4, allow_permuted=True)[0],
                                        steps5, 3, settle_ms=min(args.settle_ms, 100.0))
                     assert torch.isfinite(full5.float()).all() and full5.shape[0] == (world * B5 * T5 if world > 1 else B5 * T5)
                     mb_in = (world - 1) * B5 * T5 * H5 * W5 * C5 * (4 if gdt is None else 2) / 1e6      # bytes INTO each rank per step

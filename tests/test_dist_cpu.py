@@ -47,14 +47,23 @@ def _worker(rank, world, port, q):
             want = ref if dt is None else ref.to(dt)
             assert out.dtype == want.dtype
             q.put((rank, 8, float((out.float() - want.float()).abs().max()), tuple(out.shape)))
-        # pre-sharded inputs, chunked: every group's gather lands in ONE contiguous slice; the map is ordered (group, rank, clip)
-        # and `clip_order` names the clip at every position
+        # pre-sharded inputs, chunked: every group's gather lands in ONE contiguous slice.  Default: natural (rank-major) clip order on
+        # every path; allow_permuted=True: ALWAYS (map, order) -- (group, rank, clip) order without the reordering copy here ...
         s_loc, p_loc = axd.local_slice(src, pos, rank, world)
         out = axd.sharded_forward(fn, s_loc, p_loc, gather=True, replicated_inputs=False, chunks=2)
-        order = out.clip_order
-        assert order == axd.chunked_clip_order(8, world, 2) and sorted(order) == list(range(8))
+        assert isinstance(out, torch.Tensor)
+        q.put((rank, 8, float((out - ref).abs().max()), tuple(out.shape)))
+        out, order = axd.sharded_forward(fn, s_loc, p_loc, gather=True, replicated_inputs=False, chunks=2, allow_permuted=True)
+        assert order == axd.chunked_clip_order(8, world, 2) and sorted(order) == list(range(8)) and order != list(range(8))
         want = ref.reshape(8, T, H * W, C)[order].reshape(8 * T, H * W, C)
         q.put((rank, 8, float((out - want).abs().max()), tuple(out.shape)))
+        # ... and the identity order where the chunked path does not apply: a local clip count that `chunks` does not divide (4 per rank, 3 groups)
+        for kw in (dict(), dict(allow_permuted=True)):
+            got = axd.sharded_forward(fn, s_loc, p_loc, gather=True, replicated_inputs=False, chunks=3, **kw)
+            if kw:
+                assert got[1] == list(range(8))
+                got = got[0]
+            q.put((rank, 8, float((got - ref).abs().max()), tuple(got.shape)))
         # a layer_fn that already returns the 16-bit map (the kernel epilogue's out_dtype) is not cast again
         fn16 = lambda s, p: fn(s, p).to(torch.float16)
         out = axd.sharded_forward(fn16, src, pos, gather=True, chunks=2, gather_dtype=torch.float16)
@@ -71,11 +80,11 @@ def test_sharded_forward_matches_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world * (len(CASES) + 6))]
+    res = [q.get(timeout=300) for _ in range(world * (len(CASES) + 9))]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert len(res) == world * (len(CASES) + 6)
+    assert len(res) == world * (len(CASES) + 9)
     for rank, B, err, shape in res:
         assert shape == (B * 2, 20, 64)
         assert err < 1e-5, (rank, B, err)   # sharding never mixes clips (the 16-bit maps are compared with the cast reference)
