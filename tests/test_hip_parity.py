@@ -5,7 +5,7 @@ import torch
 
 import __graft_entry__ as ge
 import axvs_oracle as orc
-from golden_util import AXIAL, TRAJ, ELEM_FRAC, axial_inputs, checks, elem_report, load, rel_err, rel_l2, t, weights
+from golden_util import AXIAL, TRAJ, axial_inputs, checks, elem_check, load, rel_err, rel_l2, t, weights
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,7 @@ def test_trajectory_attention_golden(name):
     mod.return_attn = True
     out, attn = mod(dev(q), dev(q), dev(v), num_frames=m["T"])
     e, e2 = rel_err(out.cpu(), t(z["out"])), rel_l2(out.cpu(), t(z["out"]))
-    assert elem_report(out.cpu(), t(z["out"]), "line 50") <= ELEM_FRAC
+    elem_check(out.cpu(), t(z["out"]), "line 50")
     print(f"{name}: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
     assert rel_err(attn.cpu()[:: int(z["attn_stride"])], t(z["attn"])) < TOL_ATTN_MAP
@@ -70,7 +70,7 @@ def test_axial_layer_golden(name, dtype, tol):
     out, ha, wa = layer(dev(src), dev(pos))
     s = m["stride"]
     e, e2 = rel_err(out.cpu()[:, ::s], t(z["out"])), rel_l2(out.cpu()[:, ::s], t(z["out"]))
-    assert elem_report(out.cpu()[:, ::s], t(z["out"]), "line 72") <= ELEM_FRAC
+    elem_check(out.cpu()[:, ::s], t(z["out"]), "line 72", tol)
     print(f"{name} {dtype}: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < tol and e2 < tol
     if dtype == "f16":
@@ -100,7 +100,7 @@ def test_full_trajectory_layer_golden(name):
     out, ha, wa = layer(dev(src), dev(pos))
     assert ha is None and wa is None
     e, e2 = rel_err(out.cpu()[:, ::m["stride"]], t(z["out"])), rel_l2(out.cpu()[:, ::m["stride"]], t(z["out"]))
-    assert elem_report(out.cpu()[:, ::m["stride"]], t(z["out"]), "line 102") <= ELEM_FRAC
+    elem_check(out.cpu()[:, ::m["stride"]], t(z["out"]), "line 102")
     print(f"{name}: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
     np.testing.assert_allclose(checks(out.cpu())[1:], z["out_checks"][1:], rtol=2e-3)
@@ -121,7 +121,7 @@ def test_full_trajectory_layer_long_frames_vs_oracle():
     layer.load_state_dict(w, strict=True)
     out = layer.cuda()(dev(src), dev(pos))[0]
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
-    assert elem_report(out.cpu(), ref, "line 123") <= ELEM_FRAC
+    elem_check(out.cpu(), ref, "line 123")
     print(f"full trajectory layer, {H * W} keys per frame: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
 
@@ -137,7 +137,7 @@ def test_encoder_golden():
     out, ha, wa = enc(dev(src), dev(pos))
     assert ha is None and wa is None
     e, e2 = rel_err(out.cpu(), t(z["out"])), rel_l2(out.cpu(), t(z["out"]))
-    assert elem_report(out.cpu(), t(z["out"]), "line 139") <= ELEM_FRAC
+    elem_check(out.cpu(), t(z["out"]), "line 139")
     print(f"encoder ({m['layers']} layers): max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
 
@@ -165,7 +165,7 @@ def test_axial_layer_vs_float64_oracle_ragged(shape):
     layer.load_state_dict(w, strict=True)
     out, _, _ = layer.cuda()(dev(src), dev(pos))
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
-    assert elem_report(out.cpu(), ref, "line 167") <= ELEM_FRAC
+    elem_check(out.cpu(), ref, "line 167")
     print(f"{shape}: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
 
@@ -336,7 +336,7 @@ def test_ragged_axis_lengths_take_the_fused_tier(shape):
         assert "w.traj_fused" in names or "w.qkv+traj" in names, names
     assert not any("spatial_attn" in n for n in names), names
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
-    assert elem_report(out.cpu(), ref, "line 338") <= ELEM_FRAC
+    elem_check(out.cpu(), ref, "line 338")
     print(f"{shape}: {names[1:]} max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
     assert torch.equal(out, layer(dev(src), dev(pos))[0])
@@ -448,20 +448,20 @@ def test_cross_clip_module_golden(name):
             mod.train()(dev(cq), dev(pf))
         mod.eval()
     e_l, e_l2 = rel_err(out["pred_logits"], t(z["pred_logits"])), rel_l2(out["pred_logits"], t(z["pred_logits"]))
-    assert elem_report(out["pred_logits"], t(z["pred_logits"]), "line 450") <= ELEM_FRAC
+    elem_check(out["pred_logits"], t(z["pred_logits"]), "line 450")
     print(f"{name}: logits max/max {e_l:.2e} relL2 {e_l2:.2e}")
     assert e_l < TOL_F16 and e_l2 < TOL_F16
     np.testing.assert_allclose(checks(out["pred_masks"])[1:], z["masks_checks"][1:], rtol=5e-3)
     if "aux0_logits" in z:
         e_m, e_m2 = rel_err(out["pred_masks"], t(z["pred_masks"])), rel_l2(out["pred_masks"], t(z["pred_masks"]))
-        assert elem_report(out["pred_masks"], t(z["pred_masks"]), "line 456") <= ELEM_FRAC
+        elem_check(out["pred_masks"], t(z["pred_masks"]), "line 456")
         print(f"{name}: masks max/max {e_m:.2e} relL2 {e_m2:.2e}")
         assert e_m < TOL_F16 and e_m2 < TOL_F16
         assert rel_err(out["aux_outputs"][0]["pred_logits"], t(z["aux0_logits"])) < TOL_F16
         assert rel_err(out["aux_outputs"][0]["pred_masks"], t(z["aux0_masks"])) < TOL_F16
     else:
         e_m, e_m2 = rel_err(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"])), rel_l2(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]))
-        assert elem_report(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]), "line 463") <= ELEM_FRAC
+        elem_check(out["pred_masks"][:, ::8, :, ::8, ::8], t(z["pred_masks"]), "line 463")
         print(f"{name}: masks max/max {e_m:.2e} relL2 {e_m2:.2e}")
         assert e_m < TOL_F16 and e_m2 < TOL_F16
 
@@ -485,7 +485,7 @@ def test_cross_clip_module_any_pixel_count(V, H, W):
     mod = mod.cuda()
     out = mod(dev(cq), dev(pf))
     e_m, e_m2 = rel_err(out["pred_masks"], ref["pred_masks"]), rel_l2(out["pred_masks"], ref["pred_masks"])
-    assert elem_report(out["pred_masks"], ref["pred_masks"], "line 487") <= ELEM_FRAC
+    elem_check(out["pred_masks"], ref["pred_masks"], "line 487")
     e_a = rel_err(out["aux_outputs"][0]["pred_masks"], ref["aux_outputs"][0]["pred_masks"])
     print(f"P = {V * H * W}: masks max/max {e_m:.2e} relL2 {e_m2:.2e}, aux {e_a:.2e}")
     assert e_m < TOL_F16 and e_m2 < TOL_F16 and e_a < TOL_F16
@@ -744,7 +744,7 @@ def test_tube_link_plugin_golden(name):
               key_padding_mask=km.cuda() if km is not None else None, reference_points=dev(ref), spatial_shapes=ss)
     out = perm(out).cpu() if not m["batch_first"] else out.cpu()
     e, e2 = rel_err(out[:, ::m["stride"]], t(z["out"])), rel_l2(out[:, ::m["stride"]], t(z["out"]))
-    assert elem_report(out[:, ::m["stride"]], t(z["out"]), "line 746") <= ELEM_FRAC
+    elem_check(out[:, ::m["stride"]], t(z["out"]), "line 746")
     print(f"{name}: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
     np.testing.assert_allclose(checks(out)[1:], z["out_checks"][1:], rtol=2e-3)
@@ -841,7 +841,7 @@ def test_within_clip_module_golden(name):
     # 1.1e-3 .. 2.2e-3 on res4 / res5 of these toy maps (see the bounds below; the full-size decoder holds TOL_STACK = 1.5e-3).
     for k in m["chans"]:
         e, e2 = rel_err(out[k].cpu(), t(z["out_" + k])), rel_l2(out[k].cpu(), t(z["out_" + k]))
-        assert elem_report(out[k].cpu(), t(z["out_" + k]), "line 843") <= ELEM_FRAC
+        elem_check(out[k].cpu(), t(z["out_" + k]), "line 843")
         print(f"{name} {k}: max/max {e:.2e} relL2 {e2:.2e}")
         # toy maps (8x8, 4x4 positions): the output GroupNorm's statistics run over a few hundred values, so ONE flipped 16-bit
         # rounding upstream moves single outputs by whole 1e-3s -- the max-norm of these fixtures moves between 1.4e-3 and 3.2e-3
@@ -948,7 +948,7 @@ def test_within_clip_module_full_size_golden():
         sb = m["sub"][k]
         o = out[k].cpu()
         e, e2 = rel_err(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k])), rel_l2(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]))
-        assert elem_report(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]), "line 950") <= ELEM_FRAC
+        elem_check(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]), "line 950", TOL_F16 if k == "res3" else TOL_STACK)
         print(f"full-size decoder {k}: max/max {e:.2e} relL2 {e2:.2e}")
         assert e < (TOL_F16 if k == "res3" else TOL_STACK) and e2 < TOL_F16, k
         np.testing.assert_allclose(checks(o)[1:], z["chk_" + k][1:], rtol=5e-3)
@@ -968,7 +968,7 @@ def test_within_clip_module_full_size_fp32_stack_holds_the_bar_in_max_norm():
         sb = m["sub"][k]
         o = out[k].cpu()
         e, e2 = rel_err(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k])), rel_l2(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]))
-        assert elem_report(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]), "line 970") <= ELEM_FRAC
+        elem_check(o[:, ::m["csub"], ::sb, ::sb], t(z["out_" + k]), "line 970")
         print(f"full-size decoder, fp32 temporal layers, {k}: max/max {e:.2e} relL2 {e2:.2e}")
         assert e < TOL_F16 and e2 < TOL_F16, k
     with pytest.raises(ValueError):
@@ -1007,7 +1007,7 @@ def test_within_clip_stages_teacher_forced(name):
         else:
             o = enc.temporal_layers[stage](src=x_in.float().contiguous().cuda(), pos=pos3d[tag[-4:]])[0]
         e, e2 = rel_err(o.cpu(), y), rel_l2(o.cpu(), y)
-        assert elem_report(o.cpu(), y, "line 1009") <= ELEM_FRAC
+        elem_check(o.cpu(), y, "line 1009")
         print(f"{name} teacher-forced {tag}: max/max {e:.2e} relL2 {e2:.2e}")
         assert e < TOL_F16 and e2 < TOL_F16, tag
 
@@ -1035,7 +1035,7 @@ def test_cfg5_per_gpu_share():
     assert torch.equal(full[b * T:(b + 1) * T], alone)
     ref, _, _ = orc.axial_layer(src[b * T:(b + 1) * T].double().cpu(), pos[b:b + 1].double().cpu(), w, 8, want_attn=False)
     e, e2 = rel_err(alone.cpu(), ref), rel_l2(alone.cpu(), ref)
-    assert elem_report(alone.cpu(), ref, "line 1037") <= ELEM_FRAC
+    elem_check(alone.cpu(), ref, "line 1037")
     plain = layer(src[b * T:(b + 1) * T].contiguous(), pos[b:b + 1].clone())[0]       # `pos` read as a plain tensor
     assert rel_err(plain.cpu(), ref) < TOL_F16
     print(f"cfg5 share, clip {b}: max/max {e:.2e} relL2 {e2:.2e}")
@@ -1263,7 +1263,7 @@ def test_padding_keys_are_cleared_in_kernel(shape):
     out, _, _ = layer(dev(src), dev(pos))
     assert torch.isfinite(out).all()
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
-    assert elem_report(out.cpu(), ref, "line 1265") <= ELEM_FRAC
+    elem_check(out.cpu(), ref, "line 1265")
     print(f"{shape}: {_stage_names()[1:]} max/max {e:.2e} relL2 {e2:.2e}")
     assert e < TOL_F16 and e2 < TOL_F16
 
@@ -1434,7 +1434,7 @@ def test_fused_qkv_and_row_form_v_are_bit_identical_to_the_default_kernels(shape
             if opt:
                 _lib.lib().axvs_set_option(opt.encode(), 0)
     e, e2 = rel_err(outs[None].cpu(), ref), rel_l2(outs[None].cpu(), ref)
-    assert elem_report(outs[None].cpu(), ref, "line 1436") <= ELEM_FRAC
+    elem_check(outs[None].cpu(), ref, "line 1436")
     print(f"{shape}: {names[None][1:]} | {names['qkv_fusion'][1:]} | max/max {e:.2e} relL2 {e2:.2e}")
     if W <= 64:      # (the last shape's width pass has 96 keys per frame: V^T form, separate q/k/v launch)
         assert "h.traj_fused+w.qkv" in names["qkv_fusion"] and "w.qkv_proj" not in names["qkv_fusion"], names["qkv_fusion"]
@@ -1464,7 +1464,7 @@ def test_f32_tier_handles_operands_beyond_the_fp16_range():
     out = layer(dev(big), dev(pos))[0]
     assert not out.requires_grad and torch.isfinite(out).all()
     e, e2 = rel_err(out.cpu(), ref), rel_l2(out.cpu(), ref)
-    assert elem_report(out.cpu(), ref, "line 1466") <= ELEM_FRAC
+    elem_check(out.cpu(), ref, "line 1466", 1e-4)
     print(f"f32 tier on operands beyond fp16: max/max {e:.2e} relL2 {e2:.2e}")
     assert e < 1e-4 and e2 < 1e-4
     # and on ordinary inputs it is the exact counterpart of the 16-bit tier
@@ -2002,7 +2002,7 @@ def test_ragged_frames_in_the_padded_row_space(shape):
         assert torch.equal(one, two), (shape, names_one, names_two)
         assert torch.equal(one, layer(s, pos_d)[0])
         e, e2 = rel_err(one.cpu(), ref), rel_l2(one.cpu(), ref)
-        assert elem_report(one.cpu(), ref, "line 2004") <= ELEM_FRAC
+        elem_check(one.cpu(), ref, "line 2004")
         assert e < TOL_F16 and e2 < TOL_F16, (shape, e, e2)
     print(f"{shape}: {names_two[1:]} -> {names_one[1:]}  max/max {e:.2e}")
     assert not any("spatial_attn" in n for n in names_one), names_one
@@ -2069,7 +2069,7 @@ def test_shipped_map_sizes_golden(name):
         out = layer(dev(src), p)[0]
         names = _stage_names()
         e, e2 = rel_err(out.cpu()[:, ::s], t(z["out"])), rel_l2(out.cpu()[:, ::s], t(z["out"]))
-        assert elem_report(out.cpu()[:, ::s], t(z["out"]), "line 2071") <= ELEM_FRAC
+        elem_check(out.cpu()[:, ::s], t(z["out"]), "line 2071")
         assert e < TOL_F16 and e2 < TOL_F16, (name, e, e2)
         np.testing.assert_allclose(checks(out.cpu())[1:], z["out_checks"][1:], rtol=2e-3)
     print(f"{name}: {names[1:]} max/max {e:.2e} relL2 {e2:.2e}")
