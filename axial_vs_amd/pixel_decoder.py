@@ -61,31 +61,35 @@ def _conv_gn(in_channels: int, out_channels: int) -> nn.Sequential:
     return nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1), nn.GroupNorm(32, out_channels))
 
 
-_side_streams: Dict[str, "torch.cuda.Stream"] = {}
+_side_streams: Dict[str, list] = {}
 _IN_PLACE_LEVELS = True      # eval: the temporal levels of a stage are processed in place in the token buffer (tests switch it off to compare)
 
 
 def _run_levels_concurrently(fns):
-    """The temporal encoder of a stage is applied to each temporal level on its own (WC/msdeformattn.py:258-264: a Python loop over
-    the levels): the levels are independent and small (res5 = 16, res4 = 64 row tiles at BASELINE config 3, on a 256-CU chip), so
-    level 0 runs on a side stream beside level 1 on the caller's stream -- fork / join with events, no host synchronisation; each
-    stream has its own workspace (modules._workspace is keyed by stream).  Returns the results in order."""
+    """Independent small chains side by side: every fn but the last runs on a side stream of its own beside the last one on the caller's stream --
+    fork / join with events, no host synchronisation; each stream has its own workspace (modules._workspace is keyed by stream).  Used for
+    the temporal encoder of a stage, applied to each temporal level on its own (WC/msdeformattn.py:258-264: a Python loop over independent levels
+    of 16 and 64 row tiles at BASELINE config 3, on a 256-CU chip), and (round 6) for the 1x1 convolution + GroupNorm projections of the levels
+    (WC/msdeformattn.py:404-435: three independent GEMM -> statistics -> normalise chains of 30 - 40 us each).  Returns the results in order."""
     if len(fns) < 2:
         return [f() for f in fns]
     cur = torch.cuda.current_stream()
     key = str(cur.device)
-    side = _side_streams.get(key)
-    if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(cur.device)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        first = fns[0]()
-    rest = [f() for f in fns[1:]]
-    cur.wait_stream(side)
-    for t in first:
-        if isinstance(t, torch.Tensor):
-            t.record_stream(cur)
-    return [first] + rest
+    sides = _side_streams.setdefault(key, [])
+    while len(sides) < len(fns) - 1:
+        sides.append(torch.cuda.Stream(cur.device))
+    res = []
+    for f, side in zip(fns[:-1], sides):
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            res.append(f())
+    res.append(fns[-1]())
+    for r, side in zip(res[:-1], sides):
+        cur.wait_stream(side)
+        for t in (r if isinstance(r, (tuple, list)) else (r,)):
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+    return res
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -391,11 +395,19 @@ class MSDeformAttnPixelDecoder(nn.Module):
         cached = self._pos_cache if self._pos_cache is not None and self._pos_cache[0] == pkey else None
         pos, pos_3d = (cached[1], cached[2]) if cached else (torch.empty(BT, S, Cd, dtype=torch.float32, device=dev) if spatial else None, [])
         lvl2d = _dev_f32(lvl2d_p.detach(), "level_embed_2d") if spatial and not cached else None
+        starts = [sum(sizes[:i]) for i in range(len(sizes))]
+
+        def proj_in(idx):
+            # (own stream, own scratch: the levels' projections are independent chains and run side by side)
+            H, W = shapes[idx]
+            wsi = _workspace(dev, wsb)
+            _lib.check(L.axvs_conv1x1_gn_fwd(xs[idx].data_ptr(), 0, 0, 0, src.data_ptr() + starts[idx] * Cd * 4, 1, S * Cd, Cd, pin[idx].data_ptr(), BT,
+                                             H * W, xs[idx].shape[1], Cd, 32, 1e-5, dt, wsi.data_ptr(), wsi.numel(), _stream(dev)), "axvs_conv1x1_gn_fwd")
+            return ()
+        _run_levels_concurrently([(lambda i=i: proj_in(i)) for i in range(len(xs))])
         row0 = 0
         for idx, (f, x) in enumerate(zip(order, xs)):
             H, W = shapes[idx]
-            _lib.check(L.axvs_conv1x1_gn_fwd(x.data_ptr(), 0, 0, 0, src.data_ptr() + row0 * Cd * 4, 1, S * Cd, Cd, pin[idx].data_ptr(), BT,
-                                             H * W, x.shape[1], Cd, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
             if not cached:
                 if spatial:
                     self.pe_layer.tokens_into(pos, lvl2d[idx], BT, H, W, row0)
@@ -409,17 +421,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
             y, h_attn, w_attn = self.transformer.encoder(src, shapes, None, BT, pos, None, pos_3d)
         else:                                                           # temporal-only decoder (WC/msdeformattn.py:152-170)
             y, h_attn, w_attn = self.transformer.encoder(src, shapes, pos_3d)
-        out = {}
-        row0 = 0
-        for i, f in enumerate(order):
+        outs = [torch.empty(BT, xs[i].shape[1], shapes[i][0], shapes[i][1], dtype=torch.float32, device=dev) for i in range(len(order))]
+
+        def proj_out(i):
             H, W = shapes[i]
-            cin = xs[i].shape[1]
-            o = torch.empty(BT, cin, H, W, dtype=torch.float32, device=dev)
-            _lib.check(L.axvs_conv1x1_gn_fwd(y.data_ptr() + row0 * Cd * 4, 1, S * Cd, Cd, o.data_ptr(), 0, 0, 0, pout[i].data_ptr(), BT, H * W,
-                                             Cd, cin, 32, 1e-5, dt, ws.data_ptr(), ws.numel(), st), "axvs_conv1x1_gn_fwd")
-            out[f] = o
-            row0 += H * W
-        return out, h_attn, w_attn
+            wsi = _workspace(dev, wsb)
+            _lib.check(L.axvs_conv1x1_gn_fwd(y.data_ptr() + starts[i] * Cd * 4, 1, S * Cd, Cd, outs[i].data_ptr(), 0, 0, 0, pout[i].data_ptr(), BT, H * W,
+                                             Cd, xs[i].shape[1], 32, 1e-5, dt, wsi.data_ptr(), wsi.numel(), _stream(dev)), "axvs_conv1x1_gn_fwd")
+            return (outs[i],)
+        _run_levels_concurrently([(lambda i=i: proj_out(i)) for i in range(len(order))])
+        return {f: outs[i] for i, f in enumerate(order)}, h_attn, w_attn
 
 
 class WithinClipTrackingModule(nn.Module):

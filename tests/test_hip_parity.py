@@ -841,7 +841,7 @@ def test_within_clip_module_golden(name):
     # 1.1e-3 .. 2.2e-3 on res4 / res5 of these toy maps (see the bounds below; the full-size decoder holds TOL_STACK = 1.5e-3).
     for k in m["chans"]:
         e, e2 = rel_err(out[k].cpu(), t(z["out_" + k])), rel_l2(out[k].cpu(), t(z["out_" + k]))
-        elem_check(out[k].cpu(), t(z["out_" + k]), "line 843")
+        elem_check(out[k].cpu(), t(z["out_" + k]), "line 843", TOL_F16 if k == "res3" else 3.5e-3)      # (the toy decoders' own max-norm bound below)
         print(f"{name} {k}: max/max {e:.2e} relL2 {e2:.2e}")
         # toy maps (8x8, 4x4 positions): the output GroupNorm's statistics run over a few hundred values, so ONE flipped 16-bit
         # rounding upstream moves single outputs by whole 1e-3s -- the max-norm of these fixtures moves between 1.4e-3 and 3.2e-3

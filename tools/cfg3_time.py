@@ -37,7 +37,7 @@ with torch.no_grad():
     dt = (time.perf_counter() - t0) / n
 print(f"cfg3 within-clip module forward: {dt*1e3:.3f} ms ({m['B']*m['T']/dt:.0f} frames/s)")
 
-if os.environ.get("AXVS_CFG3_NO_GRAPH"):
+if os.environ.get("AXVS_CFG3_NO_GRAPH", "") not in ("", "0"):
     sys.exit(0)
 # the same forward replayed from a captured HIP graph (two streams inside: the temporal levels of a stage run side by side)
 keys = list(feats)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/cfg3trace
 rm -rf $OUT; mkdir -p $OUT
-AXVS_CFG3_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/cfg3_time.py 40 "$@" > $OUT/log.txt 2>&1
+AXVS_CFG3_NO_GRAPH=${AXVS_CFG3_NO_GRAPH-1} rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/cfg3_time.py 40 "$@" > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/*/*kernel_trace.csv")[0]
@@ -15,7 +15,7 @@ names = [r["Kernel_Name"] for r in rows]
 marks = [i for i, n in enumerate(names) if "msda_gather_kernel" in n]
 per = [marks[i + 1] - marks[i] for i in range(len(marks) - 1)]
 # take the 10th last full period (steady state)
-a, b = marks[-12], marks[-11]
+a, b = marks[-12 - (2 if "AXVS_TRACE_FWD" in __import__("os").environ else 0)], marks[-11] if "AXVS_TRACE_FWD" not in __import__("os").environ else marks[-12]
 seg = rows[a:b]
 t0 = int(seg[0]["Start_Timestamp"])
 busy_end = 0
