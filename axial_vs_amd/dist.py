@@ -69,6 +69,53 @@ def gather_clips(out_local: Tensor, n_clips_total: int, frames: int, group=None,
     return torch.cat([buf[k * mx: k * mx + sizes[k]] for k in range(world)], dim=0)
 
 
+class PeerMaps:
+    """Direct all-gather by PEER WRITES (round 6): the transport that can meet the 8-GPU target where a ring cannot.
+
+    xGMI is point-to-point: 7 links x ~153 GB/s per GPU.  A ring all-gather moves every rank's (world - 1) inbound shares over ONE inbound link
+    (BASELINE config 5, f16 maps: 528 MB per rank and step = 3.4 ms against 1.95 ms of compute); written DIRECTLY by their producers the same bytes
+    arrive over all seven links at once (0.49 ms).  Every rank owns one full output map; the ranks exchange the maps' IPC handles once
+    (hipIpcGetMemHandle / hipIpcOpenMemHandle through torch's CUDA IPC -- the dmabuf mode of this image: HSA_ENABLE_IPC_MODE_LEGACY=0) and from then on
+    `publish()` copies this rank's rows straight into EVERY rank's map: plain device-to-device copies (the SDMA engines / peer stores over xGMI), no
+    collective launch, no staging buffer.  The copies run on a side stream behind the kernels that produced the rows, so a group's rows cross the links
+    while the next group computes (`sharded_forward(..., peer_maps=...)`).  `wait()` = this rank's copies are done + a barrier: all ranks' rows have
+    landed in this rank's map.  One process per GPU; works the same with both processes on ONE device (the test: two ranks sharing cuda:0).
+    Not measured on more than one GPU (no multi-GPU node was available to this build): correctness by construction + the two-process test."""
+
+    def __init__(self, rows_total: int, tail: Tuple[int, ...], dtype: torch.dtype, device, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device)
+        # a block of its own from the caching allocator (IPC shares the whole allocation the tensor lives in)
+        self.map = torch.empty((rows_total,) + tuple(tail), dtype=dtype, device=self.device)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, reduce_tensor(self.map), group=group)
+        self.peers: List[Tensor] = []
+        for r, (rebuild, args) in enumerate(handles):
+            self.peers.append(self.map if r == self.rank else rebuild(*args))
+        self._side = torch.cuda.Stream(self.device)
+        dist.barrier(group)                      # every rank has opened every handle before anybody writes
+
+    def publish(self, rows: Tensor, row0: int) -> None:
+        """rows -> [row0, row0 + len(rows)) of every rank's map, asynchronously behind the work already queued on the current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            for k in range(self.world):
+                r = (self.rank + k) % self.world         # start with my own map, then ring order: the ranks do not all hit the same peer first
+                self.peers[r][row0:row0 + rows.shape[0]].copy_(rows, non_blocking=True)
+        rows.record_stream(self._side)
+
+    def wait(self) -> Tensor:
+        """All ranks' published rows are in this rank's map (returns it).  Host-synchronous: the step boundary of a batch-sharded forward."""
+        self._side.synchronize()
+        dist.barrier(self.group)
+        torch.cuda.current_stream(self.device).wait_stream(self._side)
+        return self.map
+
+
 def chunked_clip_order(total: int, world: int, chunks: int) -> List[int]:
     """Clip index (rank-major numbering: rank r owns clips [r*b, (r+1)*b), b = total / world) at every position of the map that
     `sharded_forward(..., replicated_inputs=False, chunks=k)` returns: the map is ordered (group, rank, clip in group) so that every
@@ -80,7 +127,7 @@ def chunked_clip_order(total: int, world: int, chunks: int) -> List[int]:
 
 def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, pos: Tensor, group=None,
                     gather: bool = True, replicated_inputs: bool = True, gather_dtype: Optional[torch.dtype] = None,
-                    chunks: int = 1, allow_permuted: bool = False):
+                    chunks: int = 1, allow_permuted: bool = False, peer_maps: Optional["PeerMaps"] = None):
     """Run `layer_fn(src_local, pos_local) -> out_local` on this rank's clips and (optionally) reassemble the output.
 
     ``replicated_inputs``: src / pos hold the whole batch on every rank (cut locally); otherwise they are already the
@@ -95,6 +142,10 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
         (cb = clips per group) -- so group c of all ranks IS rows [c * world * cb * T, (c + 1) * world * cb * T) of the map in natural
         clip order;
       * pre-sharded inputs (rank r holds its own clips): the groups land ordered (group, rank, clip in group).
+
+    ``peer_maps`` (a `PeerMaps` of [total * T rows, ...] in the map's dtype; equal shards): no collective at all -- every group's rows are written
+    straight into every rank's map at their natural (rank-major) position behind the group's kernels; the result is `peer_maps.map` in natural clip
+    order (valid until the next call that publishes into the same maps).
 
     **The returned order never depends on the shapes.**  ``allow_permuted=False`` (default): a Tensor in natural clip order (rank-major for
     pre-sharded inputs) on every path -- the chunked pre-sharded path pays ONE reordering copy of the gathered map for it.
@@ -131,6 +182,23 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
         total = int(sum(cl))
         equal = len(set(cl)) == 1
     b_each = total // world if world else total
+    if gather and world > 1 and peer_maps is not None:
+        if not (equal and total % world == 0 and b_each > 0):
+            raise RuntimeError("sharded_forward(peer_maps=...): equal shards only")
+        ch = chunks if (chunks > 0 and b_each % chunks == 0) else 1
+        cb = b_each // ch
+        for c in range(ch):
+            if replicated_inputs:                             # my own clips [rank * b_each, (rank + 1) * b_each), group by group
+                c0 = rank * b_each + c * cb
+                s_c, p_c = src[c0 * T:(c0 + cb) * T], retag(pos[c0:c0 + cb])
+            else:
+                s_c, p_c = src[c * cb * T:(c + 1) * cb * T], retag(pos[c * cb:(c + 1) * cb])
+            o = layer_fn(s_c.contiguous(), p_c)
+            if gather_dtype is not None and o.dtype != gather_dtype:
+                o = o.to(gather_dtype)
+            peer_maps.publish(o.contiguous(), (rank * b_each + c * cb) * T)
+        full = peer_maps.wait()
+        return (full, list(range(total))) if allow_permuted else full
     if gather and world > 1 and chunks > 1 and equal and total % world == 0 and b_each % chunks == 0 and b_each > 0:
         cb = b_each // chunks                                 # clips per group
         full = None

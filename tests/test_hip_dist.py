@@ -52,6 +52,14 @@ def _worker(rank, world, port, q):
         # generated positions keep their specification through the slicing (the layer evaluates them in its loaders)
         pg = ax.PositionEmbeddingSine3D(C // 2, normalize=True).channels_last(B, T, H, W, "cuda")
         res["sine_tag"] = bool(torch.equal(axd.sharded_forward(fn, s, pg, chunks=2), fn(s, pg)))
+        # direct all-gather by peer writes: the ranks exchange IPC handles of their output maps (hipIpcGetMemHandle through torch's CUDA IPC) and
+        # write their rows straight into each other's maps -- no collective; bit-equal to the gathered forward, fp32 and 16-bit maps, chunked
+        pm = axd.PeerMaps(B * T, (H * W, C), torch.float32, "cuda")
+        res["peer_maps"] = bool(torch.equal(axd.sharded_forward(fn, s, p, peer_maps=pm), full))
+        res["peer_maps_chunks2_presharded"] = bool(torch.equal(axd.sharded_forward(fn, s_loc, p_loc, replicated_inputs=False, chunks=2, peer_maps=pm), full))
+        pm16 = axd.PeerMaps(B * T, (H * W, C), torch.float16, "cuda")
+        res["peer_maps_f16"] = bool(torch.equal(axd.sharded_forward(fn, s, p, gather_dtype=torch.float16, chunks=2, peer_maps=pm16), full.half()))
+        del pm, pm16
         # one clip over both ranks: column blocks -> exchange -> row blocks
         one_s, one_p = s[:T].contiguous(), p[:1].contiguous()
         off = axd.offaxis_forward(layer.forward_pass, one_s, one_p, gather=True)
