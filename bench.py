@@ -424,6 +424,22 @@ def main():
                                 "frac_of_7x153_GBs": round(mb_in / 1e3 / (el5 / steps5) / link_peak, 3),
                                 "mfma_frac_per_gpu": round(fl5 / (el5 / steps5) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
                     del full5
+                if world > 1:
+                    # the same step with the maps written straight into the peers' maps (axial_vs_amd.dist.PeerMaps: IPC-mapped maps, no collective, all links)
+                    try:
+                        layer5.out_dtype = torch.float16
+                        pm5 = axd.PeerMaps(world * B5 * T5, (H5 * W5, C5), torch.float16, dev)
+                        el5, full5 = timed(lambda: axd.sharded_forward(fn5, src5, pos5, replicated_inputs=False, gather_dtype=torch.float16, chunks=4, peer_maps=pm5),
+                                           steps5, 3, settle_ms=min(args.settle_ms, 100.0))
+                        assert torch.isfinite(full5.float()).all() and full5.shape[0] == world * B5 * T5
+                        mb_in = (world - 1) * B5 * T5 * H5 * W5 * C5 * 2 / 1e6
+                        g5["f16_map_peer_writes"] = {"value": round(world * B5 * T5 * steps5 / el5, 1), "unit": "frames/s", "ms_per_step": round(el5 / steps5 * 1e3, 4),
+                                                     "inbound_MB_per_rank_per_step": round(mb_in, 1), "inbound_GBs_per_rank": round(mb_in / 1e3 / (el5 / steps5), 1),
+                                                     "frac_of_7x153_GBs": round(mb_in / 1e3 / (el5 / steps5) / link_peak, 3),
+                                                     "what": "no collective: every rank copies its rows into every rank's IPC-mapped map behind its kernels; a host barrier ends the step"}
+                        del full5, pm5
+                    except Exception as e:
+                        g5["f16_map_peer_writes"] = {"error": str(e)[:200]}
                 layer5.out_dtype = None
                 # Link budget of the gathered variant at 8 ranks (NOT a measurement: no multi-GPU node was available to this build).  Every rank
                 # receives the other 7 ranks' maps each step; xGMI is point-to-point, 7 links x ~153 GB/s per GPU.
