@@ -97,6 +97,7 @@ class AxvsConvGnParams(C.Structure):
 # name -> (restype, argtypes); must list every symbol of include/axvs.h
 SIGNATURES = {
     "axvs_version": (C.c_int, []),
+    "axvs_has_bf16": (C.c_int, []),
     "axvs_last_error": (C.c_char_p, []),
     "axvs_set_status_buffer": (C.c_int, [_fp]),
     "axvs_check_status": (C.c_int, []),

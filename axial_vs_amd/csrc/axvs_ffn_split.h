@@ -16,16 +16,6 @@ namespace axvs {
 
 constexpr size_t kFfnSplitLds = 2 * 8 * kTileElems * sizeof(u16) + (size_t)kRows * kEpiLd * sizeof(float);   // y | h | fp32 rows
 
-// fin.cnt != nullptr (round 5): no finishing launch -- the partials go out write-through (sc1), every workgroup of a tile adds to the tile's arrival counter
-// (zero before the launch, wraps back to zero with the last arrival: the registered sync words of the merged trajectory launches), and the LAST one to arrive
-// finishes the tile's rows: the partials of all chunks read back with sc1 loads and added in chunk order, + norm1(x) + b2, norm2 -- the arithmetic of
-// ffn_finish_kernel on the same lane <-> channel mapping, so the bits do not depend on which workgroup arrives last.  Nobody waits for anybody.
-struct FfnFinish {
-  unsigned* cnt = nullptr;          // [tiles]
-  const float *b2 = nullptr, *g2 = nullptr, *be2 = nullptr;
-  float* out = nullptr;
-};
-
 // CPW: chunks per workgroup.  1: one 256-unit chunk (up to 64 tiles: tiles x F/256 workgroups fit one round of the chip at one workgroup per CU);
 // 2: two consecutive chunks, one after the other (65 .. 128 tiles: tiles x F/512 workgroups still fit one round; the next chunk's linear1 fragments are
 // requested behind the linear2 products of the current one).  Every chunk's partial is accumulated from zero and written on its own: same bits.
@@ -33,7 +23,7 @@ template <bool BF, bool GELU = false, int CPW = 1>
 __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict__ X, const u16* __restrict__ W1, const float* __restrict__ b1,
                                                         const u16* __restrict__ W2, const float* __restrict__ g1,
                                                         const float* __restrict__ be1, float* __restrict__ part /* [F/256][M][256] */,
-                                                        long long M, int F, RowStride rs, FfnFinish fin = FfnFinish{}) {
+                                                        long long M, int F, RowStride rs) {
   constexpr int C = 256, KB = 8;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   u16* ytile = reinterpret_cast<u16*>(smem_c);
@@ -109,72 +99,12 @@ __global__ __launch_bounds__(512) void ffn_split_kernel(const float* __restrict_
     for (int mt = 0; mt < 4; ++mt) epi_put(etile, mt * 16 + fi, wave * 32 + nt * 16 + fg * 4, p2[nt][mt]);
   __syncthreads();
   float* dst = part + (long long)c * M * C;
-  if (fin.cnt != nullptr) {
-    const WtBuf pb(part);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      if (m0 + r < M) pb.store16((unsigned)((((long long)c * M + m0 + r) * C + lane * 4) * sizeof(float)), *reinterpret_cast<const float4*>(etile + r * kEpiLd + lane * 4));
-    }
-  } else {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = wave * 8 + i;
     if (m0 + r < M) *reinterpret_cast<float4*>(dst + (m0 + r) * C + lane * 4) = *reinterpret_cast<const float4*>(etile + r * kEpiLd + lane * 4);
   }
-  }
   if (cc + 1 < CPW) __syncthreads();        // the fp32 rows are read: the next chunk may write them (its h tile is fenced by the barriers above)
-  }
-  if (fin.cnt == nullptr) return;
-  // ---- last arriver finishes the tile ----
-  vm_drain();                                 // my partial rows are acknowledged by the memory side
-  __syncthreads();
-  unsigned* const flag = reinterpret_cast<unsigned*>(etile);      // (the fp32 rows are stored: free)
-  if (tid == 0) flag[0] = atomicInc(fin.cnt + blockIdx.x, gridDim.y - 1);
-  __syncthreads();
-  if (flag[0] != gridDim.y - 1) return;
-  {
-    const ScBuf pr(part);
-    const int nchunk = F / 256;
-    const float4 gg = *reinterpret_cast<const float4*>(g1 + lane * 4), bb = *reinterpret_cast<const float4*>(be1 + lane * 4);
-    const float4 bv = *reinterpret_cast<const float4*>(fin.b2 + lane * 4);
-    const float4 g2v = *reinterpret_cast<const float4*>(fin.g2 + lane * 4), be2v = *reinterpret_cast<const float4*>(fin.be2 + lane * 4);
-    // four rows at a time: all their loads (x row + every chunk's partial: sc1, memory-side latency) in flight before the first reduction
-    const unsigned cstride = (unsigned)(M * C * sizeof(float));
-#pragma unroll 1
-    for (int i0 = 0; i0 < 8; i0 += 4) {
-      float4 xv[4], pv[4][4];      // (the host enables this path for d_ffn <= 1024: at most 4 chunks)
-      long long mr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const long long m = min(m0 + wave * 8 + i0 + i, M - 1);
-        mr[i] = rs.row(m);
-        xv[i] = *reinterpret_cast<const float4*>(X + mr[i] * C + lane * 4);
-        const unsigned off = (unsigned)((m * C + lane * 4) * sizeof(float));
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c < nchunk) pv[i][c] = __builtin_bit_cast(float4, pr.load16(off, (unsigned)c * cstride));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (m0 + wave * 8 + i0 + i >= M) break;
-        const float4 v = xv[i];
-        const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
-        const float a = v.x - mu, b = v.y - mu, c2 = v.z - mu, d = v.w - mu;
-        const float rstd = rsqrtf(wave_sum(a * a + b * b + c2 * c2 + d * d) * (1.f / C) + 1e-5f);
-        const float4 y = float4{a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c2 * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
-        float4 acc = pv[i][0];
-#pragma unroll
-        for (int c = 1; c < 4; ++c)
-          if (c < nchunk) { acc.x = acc.x + pv[i][c].x; acc.y = acc.y + pv[i][c].y; acc.z = acc.z + pv[i][c].z; acc.w = acc.w + pv[i][c].w; }
-        const float4 u = float4{y.x + acc.x + bv.x, y.y + acc.y + bv.y, y.z + acc.z + bv.z, y.w + acc.w + bv.w};
-        const float mu2 = wave_sum(u.x + u.y + u.z + u.w) * (1.f / C);
-        const float d0 = u.x - mu2, d1 = u.y - mu2, d2 = u.z - mu2, d3 = u.w - mu2;
-        const float rstd2 = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
-        *reinterpret_cast<float4*>(fin.out + mr[i] * C + lane * 4) =
-            float4{d0 * rstd2 * g2v.x + be2v.x, d1 * rstd2 * g2v.y + be2v.y, d2 * rstd2 * g2v.z + be2v.z, d3 * rstd2 * g2v.w + be2v.w};
-      }
-    }
   }
 }
 

@@ -11,31 +11,6 @@
 
 #include "axvs_common.h"
 
-// The width-pass kernel's FFN half: 0 (shipped) = the lockstep body of rounds 1-4 (ffn_body); 1 = the wave-specialised body of round 5
-// (ffn_body_ws: linear1 and linear2 on different waves).  Same bits either way; a build switch for same-box A/B runs
-// (tools/ab_variants.py).  MEASURED SLOWER (profiles/r5_ffn_wave_specialised.txt: width-pass kernel 57.1 -> 60.2 us, config 5's share
-// +4 %): every step of the pipeline must pull BOTH matrices' fragments (256 KiB) through one phase time -- 62 B/clk, the limit of the
-// L2 -> CU path (profiles/r5_l2_stream_forms_probe.txt), so every hiccup stalls both wave groups -- and the two-stage pipeline adds a
-// fill and a drain step during which only half the waves work.
-#ifndef AXVS_V_AHEAD      // 1: 16- / 32-row trajectory tiles request their V^T fragments one frame ahead (round 5: bit-identical, no gain -- a frame of 16 queries is a
-                          // ~0.8 k-cycle chain of dependent MFMA / softmax / LDS steps, not the V^T request: profiles/r5_few_rows_timeline.txt)
-#define AXVS_V_AHEAD 0
-#endif
-#ifndef AXVS_FFN_WS
-#define AXVS_FFN_WS 0
-#endif
-// Temporal logits: mask of the channel blocks kb (kb & mask != 0) whose per-row dot products run on the VALU (v_dot2_f32_f16) instead of
-// as the diagonal of a 16 x 16 x 32 MFMA (round 4).  0 (shipped): all eight on the matrix pipe.
-#ifndef AXVS_LOGITS_VALU_KB
-#define AXVS_LOGITS_VALU_KB 0
-#endif
-#ifndef AXVS_FFN_ONEBAR   // 1: ffn_body2 (one barrier per chunk: single fragment ring refilled in place, y in registers, two h slots); bit-identical,
-#define AXVS_FFN_ONEBAR 0 // measured a wash (profiles/r5_ffn_wave_specialised.txt: B = 1 +-1 %, config 2 / 5 -0.6 %): the shipped body stays ffn_body
-#endif
-#ifndef AXVS_WS_PRIO      // s_setprio level of the linear1 waves during their MFMA phases (0: none)
-#define AXVS_WS_PRIO 2
-#endif
-
 namespace axvs {
 
 constexpr int kRows = 64;                       // token rows per workgroup
@@ -51,9 +26,6 @@ __device__ __forceinline__ u16x8 act_frag(const u16* tile, int kb, int mt, int f
 
 // A-operand fragment (weights) straight from the blocked weight layout (wblk_off: 16 bytes per lane, lanes in address order)
 __device__ __forceinline__ u16x8 w_frag(const u16* __restrict__ W, int NR, int kb, int nrow, int fg) {
-#ifdef AXVS_ABL_W   // diagnostic: every fragment load hits the same 1 KiB (L1-resident) -- results are wrong on purpose
-  return *reinterpret_cast<const u16x8*>(W + fg * 128 + (nrow & 15) * 8);
-#endif
   return *reinterpret_cast<const u16x8*>(W + wblk_off(NR, nrow, kb * 32 + fg * 8));
 }
 
@@ -402,413 +374,6 @@ __device__ __forceinline__ void ffn_body(const FfnLds& l, u16x8 (&w1f)[2][8], co
 #endif
 }
 
-// =====================================================================================================
-// The same norm1 -> FFN -> norm2 with the two GEMMs on DIFFERENT waves (round 5, "wave-specialised"; used by the width-pass kernel).
-// ffn_body above runs all 8 waves in lockstep: linear1 phase (matrix pipe), activation epilogue (VALU, pipe idle), barrier, linear2
-// phase, barrier -- per 256-unit chunk; its stamps (profiles/r4_phase_timeline_merged.json) put 4 x (1.3 k epilogue + barriers) and
-// ~6 k of weight stalls beside 16.4 k cycles of MFMA work.  Here waves 0-3 ("A") only ever run linear1 -- 64 hidden units of the chunk
-// each, all 64 rows -- and waves 4-7 ("B") only ever run linear2 -- 64 output channels each -- one chunk behind, through a two-slot h
-// ring in LDS: step s = { A: linear1(chunk s) -> ReLU -> h[s];  B: linear2(chunk s - 1) from h[s - 1] }, ONE barrier per step.  A SIMD
-// hosts one A and one B wave (waves w and w + 4), so A's activation epilogue runs beside B's MFMAs, and each wave streams ONE weight
-// matrix continuously through a 4-k-step ring of fragments (W1 rows for A, W2 rows for B: the same bytes per CU as before).
-// The fp32 residual y does not fit LDS beside two h slots: A's waves carry it in registers (their 64 channels x 64 rows, the
-// accumulator layout; A has no long-lived accumulators) from a staging tile written by norm1, and hand it back for norm2.
-// Same MFMA sequence per output element as ffn_body (k-blocks in order; the chunk partials `part` summed in chunk order): the SAME
-// BITS, so the row count may still decide which FFN kernel runs.
-// LDS: ytile 32 KiB | stage 65 KiB fp32 (its first 32 KiB double as h slot 1) | h slot 0 32 KiB  -- the footprint of ffn_body.
-// =====================================================================================================
-struct FfnLdsWs {
-  u16* ytile;     // [8][64][32] 16-bit y = norm1(x): B operand of linear1
-  float* stage;   // [64][kEpiLd] fp32: y on its way to A's registers, later y + linear2 + b2 on its way to norm2
-  u16* h0;        // [8][64][32] h ring slot 0; slot 1 = (u16*)stage
-  float* par;     // b1[F] | b2 | g1 | be1 | g2 | be2
-};
-
-template <bool BF, class RowOff>
-__device__ __forceinline__ void ffn_body_ws(const FfnLdsWs& l, const u16* __restrict__ W1, const u16* __restrict__ W2,
-                                            float* __restrict__ out, RowOff row_off, int F, int tid, int wt, const NoRows& pre) {
-  constexpr int C = 256;
-  const int lane = tid & 63, fi = lane & 15, fg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (SGPR): fragment addresses split into s[base] + lane (w_frag_u)
-  const bool isA = wave < 4;              // waves w and w + 4 sit on the same SIMD: one producer, one consumer each
-  const int wq = wave & 3;                // my block of 64 hidden units (A) / 64 output channels (B)
-  const float* sb1 = l.par;
-  const float* sb2 = l.par + F;
-  const float *sg1 = sb2 + C, *sbe1 = sb2 + 2 * C, *sg2 = sb2 + 3 * C, *sbe2 = sb2 + 4 * C;
-  const int nchunk = F / 256, G = nchunk * 8;      // k-steps of my GEMM over all chunks
-  u16* const h1 = reinterpret_cast<u16*>(l.stage);
-  // chunk c -> h slot: the LAST chunk uses slot 0, so that `stage` (= slot 1) is free again while B still reads the last chunk
-  auto hslot = [&](int c) { return ((nchunk - 1 - c) & 1) ? h1 : l.h0; };
-  FSTAMP_DECL;
-  FSTAMP(0);
-
-  // my fragment of k-step g (chunk g / 8, k-block g % 8), 16-row block nt of my 64 rows of the weight matrix
-  auto wfrag = [&](int g, int nt) {
-    g = min(g, G - 1);                     // (the ring's last refills re-load the last k-step: branch-free vmcnt bookkeeping)
-    const int c = g >> 3, kb = g & 7;
-    // everything but the lane is wave-uniform: `global_load_dwordx4 v, v_lane16, s[base]` -- ONE address VGPR for the whole ring (per-lane
-    // 64-bit fragment pointers get hoisted out of the step loop by LICM, 32 pairs of them, and spill this 256-VGPR kernel)
-    const u16* const Wm = isA ? W1 : W2;
-    const int NR = isA ? F : C, kbg = isA ? kb : c * 8 + kb, row16 = (isA ? c * 256 : 0) + wq * 64 + nt * 16;
-    return w_frag_u(Wm, NR, kbg, row16, lane);
-  };
-  u16x8 ring[4][4];                        // [k-step slot][nt]: 4 k-steps of fragments in flight
-#pragma unroll
-  for (int sl = 0; sl < 4; ++sl)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) ring[sl][nt] = wfrag(sl, nt);
-
-  // ---- norm1, row-wise (all 8 waves, 8 rows each, rows handed over in registers): y fp32 -> stage, y 16-bit -> ytile ----
-  {
-    const float4 gg = *reinterpret_cast<const float4*>(sg1 + lane * 4), bb = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr;
-      const float4 v = pre.v[rr];
-      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
-      const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
-      const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
-      const f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
-      *reinterpret_cast<float4*>(l.stage + r * kEpiLd + lane * 4) = float4{y[0], y[1], y[2], y[3]};
-      act_store4<BF>(l.ytile, lane * 4, r, y);
-      if (rr == 3) lds_fence();
-    }
-  }
-  FSTAMP(1);
-  __syncthreads();
-  FSTAMP(2);
-  // ---- A: my 64 channels of y, all 64 rows, into registers (accumulator layout: channel 64 wq + 16 nt + 4 fg + r, row 16 mt + fi);
-  //      B: its running sum over the chunks.  ONE register array for both roles (`keep`), and one for the GEMM phase's accumulators
-  //      (`acc`: linear1 of a chunk for A, the chunk's linear2 partial for B): the roles differ in addresses, not in registers ----
-  f32x4 keep[4][4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      keep[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (isA) {
-        const float4 t = *reinterpret_cast<const float4*>(l.stage + (mt * 16 + fi) * kEpiLd + wq * 64 + nt * 16 + fg * 4);
-        keep[nt][mt] = f32x4{t.x, t.y, t.z, t.w};
-      }
-    }
-    if (nt & 1) lds_fence();               // <= 8 LDS reads in flight (4-bit lgkmcnt)
-  }
-  __syncthreads();                         // every A wave holds its y: h slot 1 (inside `stage`) may be written
-  FSTAMP(3);
-
-  for (int s = 0; s <= nchunk; ++s) {
-    // A: linear1 of chunk s (B operand: the y tile) while s < nchunk;  B: linear2 of chunk s - 1 (B operand: its h slot) while s > 0
-    const bool active = isA ? s < nchunk : s > 0;
-    const int cs = isA ? s : s - 1;        // my chunk of this step
-    if (active) {
-      const u16* const tile = isA ? l.ytile : hslot(cs);
-      const int g0 = cs * 8;
-      f32x4 acc[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      {   // one GEMM phase of 8 k-steps: acc[nt][mt] += ring(g0 + j)[nt] . B(tile, k-block j); slot j & 3 is refilled with k-step g0 + j + 4.
-          // Row tiles outermost: B fragment mt is dead after its 4 MFMAs and is re-loaded for the next k-step at once (12 MFMAs ahead of
-          // its next use; ONE set of 4 B fragments, no second buffer: the kernel sits at 256 VGPRs); the ring slot's 4 fragments are
-          // refilled behind their last use, between the MFMAs of the last row tile.
-        // A's MFMAs first: the two waves of a SIMD share its matrix pipe; at equal priority A and B would finish their phases together and
-        // A's activation epilogue would follow with the pipe idle (measured: the lockstep body's time again, + 3 us).  With A ahead, its
-        // epilogue runs beside the second half of B's MFMAs.
-#if AXVS_WS_PRIO
-        if (isA) __builtin_amdgcn_s_setprio(AXVS_WS_PRIO);
-#endif
-        u16x8 bf[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) bf[mt] = act_frag(tile, 0, mt, fi, fg);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              acc[nt][mt] = H16<BF>::mfma(ring[j & 3][nt], bf[mt], acc[nt][mt]);
-              if (mt == 3) ring[j & 3][nt] = wfrag(g0 + j + 4, nt);
-            }
-            if (j + 1 < 8) bf[mt] = act_frag(tile, j + 1, mt, fi, fg);
-            __builtin_amdgcn_sched_barrier(0);   // keeps the loads where they are: spread between the MFMAs, <= 4 LDS reads in flight
-          }
-        }
-      }
-#if AXVS_WS_PRIO
-      if (isA) __builtin_amdgcn_s_setprio(0);
-#endif
-      if (isA) {
-        // ---- + b1, ReLU -> h slot of chunk s (chunk-local hidden index 64 wq + ...) ----
-        u16* const hb = hslot(cs);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const float4 bias = *reinterpret_cast<const float4*>(sb1 + cs * 256 + wq * 64 + nt * 16 + fg * 4);
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            f32x4 v = acc[nt][mt];
-            v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
-            v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
-            act_store4<BF>(hb, wq * 64 + nt * 16 + fg * 4, mt * 16 + fi, v);
-          }
-          lds_fence();
-        }
-      } else {
-        // ---- the chunk's partial (from zero) added to the running sum: the ordered sum of per-chunk partials that ffn_body and
-        //      ffn_split_kernel + ffn_finish_kernel produce, bit for bit ----
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) keep[a][b] = cs == 0 ? acc[a][b] : keep[a][b] + acc[a][b];
-      }
-    } else if (isA) {
-      // ---- last step (B still runs linear2 of the last chunk, from slot 0): y back into `stage`, accumulator layout ----
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) epi_put(l.stage, mt * 16 + fi, wq * 64 + nt * 16 + fg * 4, keep[nt][mt]);
-        lds_fence();
-      }
-    }
-    if (s == 0) FSTAMP(4);
-    if (s == 1) FSTAMP(5);
-    if (s == 2) FSTAMP(6);
-    if (s == 3) FSTAMP(7);
-    __syncthreads();
-    if (s == 0) FSTAMP(8);
-  }
-  FSTAMP(9);
-  // ---- B: stage (= y) += linear2 + b2, accumulator layout; then norm2 per whole row (all 8 waves) and one 1-KiB store per row ----
-  if (!isA) {
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = wq * 64 + nt * 16 + fg * 4;
-      const float4 b = *reinterpret_cast<const float4*>(sb2 + n);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        float* p = l.stage + (mt * 16 + fi) * kEpiLd + n;
-        const float4 y = *reinterpret_cast<const float4*>(p);
-        *reinterpret_cast<float4*>(p) = float4{y.x + keep[nt][mt][0] + b.x, y.y + keep[nt][mt][1] + b.y, y.z + keep[nt][mt][2] + b.z,
-                                               y.w + keep[nt][mt][3] + b.w};
-      }
-      lds_fence();
-    }
-  }
-  FSTAMP(10);
-  __syncthreads();
-  FSTAMP(11);
-  {
-    const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      const float4 v = *reinterpret_cast<const float4*>(l.stage + r * kEpiLd + lane * 4);
-      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
-      const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
-      const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
-      const long long off = row_off(r);
-      if (off >= 0) {
-        const float4 y = float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
-        if (wt & kOut16Mask) {
-          const f32x4 yv = {y.x, y.y, y.z, y.w};
-          const u16x4 h = (wt & kOutBf16) ? cvt4<true>(yv) : cvt4<false>(yv);
-          u16* o16 = reinterpret_cast<u16*>(out);
-          if (wt & 1) WtBuf(o16).store8((unsigned)((off + lane * 4) * 2), h);
-          else *reinterpret_cast<u16x4*>(o16 + off + lane * 4) = h;
-        } else if (wt & 1) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);
-        else *reinterpret_cast<float4*>(out + off + lane * 4) = y;
-      }
-      if (i == 3) lds_fence();
-    }
-  }
-  FSTAMP(12);
-  FSTAMP_FLUSH(13);
-}
-
-// =====================================================================================================
-// norm1 -> FFN -> norm2 with ONE barrier per 256-unit chunk (round 5, -DAXVS_FFN_ONEBAR=1).
-// ffn_body pays two barriers per chunk around its single h tile: one before the activation epilogue (every wave must have left the
-// previous chunk's h) and one behind it.  The first one costs ~ 0.9 k cycles per chunk of pure skew -- two waves share a SIMD's matrix
-// pipe and finish linear1 up to 1.7 k cycles apart (tools/r5/ffnc_stamps.py) -- with the pipe and the weight stream idle.  A second h
-// tile removes it, and LDS has no room for one beside the fp32 rows.  So:
-//   * ONE set of 16 weight fragments, refilled IN PLACE: slot (nt, j) is re-requested right behind its MFMAs with the fragment the NEXT
-//     phase needs at the same k-step (linear1 of a chunk -> its linear2 -> linear1 of the next chunk).  Same lead time and the same bytes
-//     in flight as ffn_body's two alternating sets, 64 VGPRs less.
-//   * the fp32 residual y (this wave's 32 channels x 64 rows, accumulator layout) rides in 32 of those VGPRs; the LDS tile that held it
-//     becomes the second h slot (its first 32 KiB) and the staging tile of the two row-wise passes (norm1 -> registers, registers -> norm2).
-// Same MFMA sequence per output element as ffn_body (k-blocks in order, chunk partials summed in chunk order): the same bits.
-// LDS: ytile 32 KiB | stage 65 KiB fp32 (first 32 KiB = h slot 1) | h slot 0 32 KiB -- ffn_body's footprint.
-// =====================================================================================================
-// one GEMM phase over 8 k-blocks: acc[nt][mt] += wf[nt][j] . B(tile, k-block j); slot (nt, j) is refilled behind its MFMAs with
-// fragment (kb0n + j, rows nrow0n + 16 nt) of Wn
-template <bool BF>
-__device__ __forceinline__ void gemm_phase_inplace(f32x4 (&acc)[2][4], u16x8 (&wf)[2][8], const u16* tile, int fi, int fg,
-                                                   const u16* __restrict__ Wn, int NRn, int kb0n, int nrow0n) {
-  u16x8 bcur[4], bnxt[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) bcur[mt] = act_frag(tile, 0, mt, fi, fg);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j + 1 < 8) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) bnxt[mt] = act_frag(tile, j + 1, mt, fi, fg);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = H16<BF>::mfma(wf[nt][j], bcur[mt], acc[nt][mt]);
-      wf[nt][j] = w_frag(Wn, NRn, kb0n + j, nrow0n + nt * 16 + fi, fg);
-    }
-    __builtin_amdgcn_sched_barrier(0);     // one k-step of B fragments ahead, never more (lgkmcnt); the loads stay spread between the MFMAs
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) bcur[mt] = bnxt[mt];
-  }
-}
-
-template <bool BF, class RowOff, bool GELU = false, bool PRE = false>
-__device__ __forceinline__ void ffn_body2(const FfnLdsWs& l, u16x8 (&wf)[2][8] /* linear1 fragments of chunk 0, my 32 hidden units */,
-                                          const u16* __restrict__ W1, const u16* __restrict__ W2, float* __restrict__ out, RowOff row_off,
-                                          int F, int tid, int wt = 0, const NoRows& pre = NoRows{}) {
-  constexpr int C = 256;
-  const int lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
-  const float* sb1 = l.par;
-  const float* sb2 = l.par + F;
-  const float *sg1 = sb2 + C, *sbe1 = sb2 + 2 * C, *sg2 = sb2 + 3 * C, *sbe2 = sb2 + 4 * C;
-  const int nchunk = F / 256;
-  u16* const h1 = reinterpret_cast<u16*>(l.stage);
-  // chunk c -> h slot: the LAST chunk uses slot 0, so that `stage` (= slot 1) is free for the last row-wise pass while waves still read slot 0
-  auto hslot = [&](int c) { return ((nchunk - 1 - c) & 1) ? h1 : l.h0; };
-  FSTAMP_DECL;
-  FSTAMP(0);
-  // ---- norm1, row-wise: y fp32 -> stage (my 8 rows), y 16-bit -> ytile ----
-  {
-    const float4 gg = *reinterpret_cast<const float4*>(sg1 + lane * 4), bb = *reinterpret_cast<const float4*>(sbe1 + lane * 4);
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = wave * 8 + rr;
-      float4 v;
-      if constexpr (PRE) v = pre.v[rr];
-      else v = *reinterpret_cast<const float4*>(l.stage + r * kEpiLd + lane * 4);
-      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
-      const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
-      const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + d * d) * (1.f / C) + 1e-5f);
-      const f32x4 y = {a * rstd * gg.x + bb.x, b * rstd * gg.y + bb.y, c * rstd * gg.z + bb.z, d * rstd * gg.w + bb.w};
-      *reinterpret_cast<float4*>(l.stage + r * kEpiLd + lane * 4) = float4{y[0], y[1], y[2], y[3]};
-      act_store4<BF>(l.ytile, lane * 4, r, y);
-      if (rr == 3) lds_fence();
-    }
-  }
-  FSTAMP(1);
-  __syncthreads();
-  FSTAMP(2);
-  // ---- my 32 channels of y, all 64 rows, into registers (accumulator layout: channel 32 wave + 16 nt + 4 fg + r, row 16 mt + fi) ----
-  f32x4 yreg[2][4];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const float4 t = *reinterpret_cast<const float4*>(l.stage + (mt * 16 + fi) * kEpiLd + wave * 32 + nt * 16 + fg * 4);
-      yreg[nt][mt] = f32x4{t.x, t.y, t.z, t.w};
-    }
-  lds_fence();
-  __syncthreads();                         // every wave holds its y: h slot 1 (inside `stage`) may be written
-  FSTAMP(3);
-
-  f32x4 acc2[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int ci = 0; ci < nchunk; ++ci) {
-    const int cn = min(ci + 1, nchunk - 1);
-    u16* const hb = hslot(ci);
-    // ---- linear1 + activation: my 32 hidden units of the chunk, all 64 rows; every slot re-requested with this chunk's linear2 fragment ----
-    f32x4 acc1[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_phase_inplace<BF>(acc1, wf, l.ytile, fi, fg, W2, C, ci * 8, wave * 32);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int hn = ci * 256 + wave * 32 + nt * 16 + fg * 4;          // global hidden index
-      const float4 bias = *reinterpret_cast<const float4*>(sb1 + hn);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        f32x4 v = acc1[nt][mt];
-        if constexpr (GELU) {
-          v[0] = gelu_exact(v[0] + bias.x); v[1] = gelu_exact(v[1] + bias.y);
-          v[2] = gelu_exact(v[2] + bias.z); v[3] = gelu_exact(v[3] + bias.w);
-        } else {
-          v[0] = fmaxf(v[0] + bias.x, 0.f); v[1] = fmaxf(v[1] + bias.y, 0.f);
-          v[2] = fmaxf(v[2] + bias.z, 0.f); v[3] = fmaxf(v[3] + bias.w, 0.f);
-        }
-        act_store4<BF>(hb, wave * 32 + nt * 16 + fg * 4, mt * 16 + fi, v);   // chunk-local hidden index
-      }
-    }
-    if (ci == 0) FSTAMP(4);
-    __syncthreads();                       // the chunk's ONLY barrier: h complete.  (This slot's previous readers -- linear2 two chunks ago -- had
-    if (ci == 0) FSTAMP(5);                //  finished in EVERY wave before any wave passed the previous chunk's barrier: no second barrier needed.)
-    // ---- linear2 partial (from zero, then added: the ordered sum of per-chunk partials every FFN kernel produces); every slot re-requested
-    //      with the next chunk's linear1 fragment (the last chunk re-loads its own: branch-free vmcnt bookkeeping) ----
-    f32x4 part[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) part[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_phase_inplace<BF>(part, wf, hb, fi, fg, W1, F, 0, cn * 256 + wave * 32);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc2[a][b] = ci == 0 ? part[a][b] : acc2[a][b] + part[a][b];
-    if (ci == 0) FSTAMP(6);
-    if (ci == 1) FSTAMP(7);
-    if (ci == 2) FSTAMP(8);
-  }
-  FSTAMP(9);
-  // ---- stage <- y + linear2 + b2 in the accumulator layout (plain stores: y comes from registers); then norm2 per whole row ----
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = wave * 32 + nt * 16 + fg * 4;
-    const float4 b = *reinterpret_cast<const float4*>(sb2 + n);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-      epi_put(l.stage, mt * 16 + fi, n, f32x4{yreg[nt][mt][0] + acc2[nt][mt][0] + b.x, yreg[nt][mt][1] + acc2[nt][mt][1] + b.y,
-                                              yreg[nt][mt][2] + acc2[nt][mt][2] + b.z, yreg[nt][mt][3] + acc2[nt][mt][3] + b.w});
-    lds_fence();
-  }
-  FSTAMP(10);
-  __syncthreads();
-  FSTAMP(11);
-  {
-    const float4 g2v = *reinterpret_cast<const float4*>(sg2 + lane * 4), be2v = *reinterpret_cast<const float4*>(sbe2 + lane * 4);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      const float4 v = *reinterpret_cast<const float4*>(l.stage + r * kEpiLd + lane * 4);
-      const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / C);
-      const float d0 = v.x - mu, d1 = v.y - mu, d2 = v.z - mu, d3 = v.w - mu;
-      const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / C) + 1e-5f);
-      const long long off = row_off(r);
-      if (off >= 0) {
-        const float4 y = float4{d0 * rstd * g2v.x + be2v.x, d1 * rstd * g2v.y + be2v.y, d2 * rstd * g2v.z + be2v.z, d3 * rstd * g2v.w + be2v.w};
-        if (wt & kOut16Mask) {
-          const f32x4 yv = {y.x, y.y, y.z, y.w};
-          const u16x4 h = (wt & kOutBf16) ? cvt4<true>(yv) : cvt4<false>(yv);
-          u16* o16 = reinterpret_cast<u16*>(out);
-          if (wt & 1) WtBuf(o16).store8((unsigned)((off + lane * 4) * 2), h);
-          else *reinterpret_cast<u16x4*>(o16 + off + lane * 4) = h;
-        } else if (wt & 1) WtBuf(out).store16((unsigned)((off + lane * 4) * 4), y);
-        else *reinterpret_cast<float4*>(out + off + lane * 4) = y;
-      }
-      if (i == 3) lds_fence();
-    }
-  }
-  FSTAMP(12);
-  FSTAMP_FLUSH(13);
-}
-
 // stand-alone kernel: X fp32 [M][256] rows in, out rows out
 template <bool BF, bool GELU = false>
 __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict__ X, const u16* __restrict__ W1,
@@ -849,12 +414,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const float* __restrict_
   }
   __syncthreads();                       // parameters staged
   auto row_off = [=](int r) { return m0 + r < M ? rs.row(m0 + r) * C : -1ll; };
-#if AXVS_FFN_ONEBAR
-  const FfnLdsWs lw{l.ytile, l.xtile, l.htile, l.par};
-  ffn_body2<BF, decltype(row_off), GELU>(lw, w1f, W1, W2, out, row_off, F, tid, oflags);
-#else
   ffn_body<BF, decltype(row_off), GELU>(l, w1f, W1, W2, out, row_off, F, rot, crot, tid, oflags);
-#endif
 }
 
 constexpr size_t kFfnTiles = (size_t)kRows * kEpiLd * sizeof(float) + 2 * 8 * kTileElems * sizeof(u16);   // x | y | h
@@ -879,35 +439,19 @@ namespace axvs {
 // Each wave streams exactly its own weight rows L2 -> VGPR (Wpq_h, Wk2_h, Wv2_h, Wp[32w..]: 64 KiB), one 64-VGPR fragment
 // set that is refilled in place, slot by slot, right after a slot's last use.
 // =====================================================================================================
-template <int T, int MT, bool FFN = false, bool QKVN = false>
+template <int T, int MT, bool FFN = false>
 constexpr size_t temporal_tile_bytes() {
   // x tile, re-used as: o tile | fp32 epilogue tile [| h tile of the FFN half; its y tile takes the o tile's place]
-  //                    [| value tile of the next pass's q/k/v projections (QKVN); their (rows + pos) tile takes the o tile's place]
   size_t xt = (size_t)T * 8 * MT * 16 * 32 * sizeof(u16);
   size_t epi = (size_t)8 * MT * 16 * 32 * sizeof(u16) + (size_t)MT * 16 * kEpiLd * sizeof(float);
-  if (FFN || QKVN) epi += (size_t)8 * MT * 16 * 32 * sizeof(u16);
+  if (FFN) epi += (size_t)8 * MT * 16 * 32 * sizeof(u16);
   return xt > epi ? xt : epi;
 }
-template <int T, int MT, bool FFN = false, bool QKVN = false, int MQ = 0>
+template <int T, int MT, bool FFN = false, int MQ = 0>
 constexpr size_t temporal_lds_bytes(int F = 0) {   // tiles | bpq, bv2, bp | FFN parameters | MQ: bq, bk, bv
-  return temporal_tile_bytes<T, MT, FFN, QKVN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0) +
+  return temporal_tile_bytes<T, MT, FFN>() + 3 * 256 * sizeof(float) + (FFN ? (size_t)(F + 5 * 256) * sizeof(float) : 0) +
          (MQ ? 3 * 256 * sizeof(float) : 0);
 }
-
-// QKVN: what the trajectory kernel of one pass needs to emit q, k, v of the NEXT pass from its own output rows (they are in LDS
-// anyway), instead of a separate qkv_fused_kernel launch that gathers the same rows from HBM again: packed weights / biases of
-// the next pass's q, k, v Linear layers, its blocked 16-bit outputs ([8][Mp][32], 32 channels of a head in perm32 order, V too),
-// the positional term (generated or read), and the fp16 range-check word.
-struct NextQkv {
-  const u16 *Wq, *Wk, *Wv;
-  const float *bq, *bk, *bv;
-  u16 *Q16, *K16, *V16;
-  const float* pos;       // nullable; read when pg.mode == 0
-  PosGen pg;              // pg.l_is_h refers to THIS pass's row map (the coordinates are taken from it)
-  float qscale;
-  int wt;                 // write-through stores (byte offsets < 4 GiB)
-  int* status;
-};
 
 // MQ ("merged q/k/v"): the trajectory kernel of a pass computes q, k, v of its OWN 64 rows first (the body of qkv_fused_kernel:
 // rows gathered through the RowMap, operand tiles in the not yet used x-tile space), keeps q in registers, stores K / V^T
@@ -923,7 +467,6 @@ struct OwnQkv {
   unsigned* sync;         // [sequences] arrival counters: zero before the launch, zero again after it (see the kernel)
   int* status;            // nullable: bit 0 <- an operand left the fp16 range, bit 2 <- a hand-off wait ran out
   unsigned spin_limit;    // polls (with s_sleep) before a hand-off wait gives up (kSyncSpinLimit; option "sync_spin_limit")
-  int persist_grid;       // host side only: > 0 = launch the PERSIST instantiation with this many workgroups (a whole number of teams)
 };
 constexpr unsigned kSyncSpinLimit = 1u << 22;    // ~ 1 s
 
@@ -971,23 +514,14 @@ __device__ __forceinline__ void sweep8(f32x4 (&acc)[2][MT], u16x8 (&wf)[2][8], c
 //          the T-expanded tensor never touches HBM.  Needs the tile inside one sequence (N % (16*MT) == 0), L % 16 == 0.
 // FFN: the rows do not go back to HBM after the residual; norm1 -> FFN -> norm2 (ffn_body) runs on them right here and `out`
 //      receives the layer output (MT = 4 only).
-// VROW: V arrives row-major, [8 heads][Mp][32 channels in perm32 order] -- the layout of K -- instead of block-transposed.  A frame's
-//       rows (L <= 64: 4 KiB per head) are staged in the wave's own, not yet written, block of the x tile and read back with the
-//       transposing LDS load (ds_read_b64_tr_b16) as the A operand of the AV products.  This is what lets a producer store V with
-//       16-byte rows from any tile shape (QKVN below); MT = 4, NKS <= 2 only.
-// QKVN: after the residual, q / k / v of the NEXT pass are computed from the 64 output rows still in LDS (NextQkv) and stored in
-//       that pass's sequence order.
 // MQ: 1 = the kernel computes q, k, v of its own rows first (OwnQkv; 64-row tiles, frames of a multiple of 16 keys); 2 = the same
 //     for frames of exactly 64 keys, where a row tile IS one frame of its sequence: that frame's K / V^T fragments are the
 //     accumulators of the k / v sweeps (same 16-bit values as the stored ones), so its QK^T / softmax / AV run first, from registers,
 //     while the sibling tiles' K / V^T stores drain (frames are visited in the order own, own + 1, ... mod T; x-tile blocks are
 //     independent, so the result does not depend on the order).
-// PERSIST (round 5; MQ = 1 on 64-row tiles): the grid is a fixed number of workgroups (one per CU, a whole number of TEAMS of
-//     ceil(N / 64) consecutive workgroups) and every workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...: a team processes the
-//     row tiles of ONE sequence in the same iteration, so the sibling tiles of the in-launch K / V^T hand-off start together at every
-//     grid size.  (Dispatched as one workgroup per tile, the siblings of a sequence start staggered once the grid exceeds ~2 rounds of
-//     the chip -- every tile then waits for the last of them: +8 % at 4608 tiles, DESIGN 4h -- and such grids ran two launches per pass.)
-template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, bool VROW = false, bool QKVN = false, int MQ = 0, bool PERSIST = false>
+// (Rounds 3 - 5 also carried a row-form-V variant, a variant that emitted the next pass's q/k/v from the epilogue, and a persistent team grid for
+//  merged launches beyond two rounds of the chip: all three bit-identical and measured slower -- DESIGN.md, profiles/r5_persistent_merged.txt -- removed in round 6.)
+template <bool BF, int T, int MT, int NKS = 0, bool FFN = false, int MQ = 0>
 __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restrict__ X16 /* [8][T][Mp][32] */,
                                                              const u16* __restrict__ Wpq_a, const float* __restrict__ bpq,
                                                              const u16* __restrict__ Wpkv_a, const float* __restrict__ bpkv,
@@ -1000,18 +534,15 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
                                                              int wt = 0 /* bit 0: write-through output rows (byte offsets < 4 GiB); FFN: bits 4 / 5 = 16-bit output map (kOutF16 / kOutBf16) */,
                                                              int spatial_only = 0 /* measurement: 1 = stop after the QK^T / AV half; MQ kernels also 2 = stop after their q/k/v part */,
                                                              const float* __restrict__ ln_g = nullptr /* post-norm LayerNorm(x + attn) */,
-                                                             const float* __restrict__ ln_b = nullptr, NextQkv nq = NextQkv{},
+                                                             const float* __restrict__ ln_b = nullptr,
                                                              OwnQkv oq_a = OwnQkv{}) {
-  static_assert(!PERSIST || (MQ == 1 && MT == 4), "the tile loop exists for the merged launch on 64-row tiles");
   static_assert(!FFN || MT == 4, "the FFN half works on 64-row tiles");
-  static_assert(MQ == 0 || ((MT == 4 || MT == 2 || MT == 1) && NKS > 0 && !VROW && !QKVN), "own q/k/v: 64-, 32- or 16-row tiles, block-transposed V");
+  static_assert(MQ == 0 || ((MT == 4 || MT == 2 || MT == 1) && NKS > 0), "own q/k/v: 64-, 32- or 16-row tiles");
   static_assert(MQ != 2 || (MT == 4 && NKS == 2 && T >= 2), "own frame first: a 64-row tile is one 64-key frame");
-  static_assert(!VROW || (MT == 4 && NKS >= 1 && NKS <= 2), "row-major V is staged in a 64-row x-tile block: 64 keys per frame at most");
-  static_assert(!QKVN || (MT == 4 && !FFN && NKS > 0), "the next pass's q/k/v ride in the 64-row kernel without the FFN");
   constexpr int C = 256, ROWS = MT * 16;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* xt = smem;                                              // [T][8][ROWS][32]; later re-used as the o tile [8][ROWS][32]
-  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN, QKVN>());   // bpq | bv2 | bp
+  float* sbias = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + temporal_tile_bytes<T, MT, FFN>());   // bpq | bv2 | bp
   float* const sqkvb = sbias + 3 * C + (FFN ? fa_a.F + 5 * C : 0);   // MQ: bq | bk | bv
   FfnLds fl;
   if constexpr (FFN) {
@@ -1026,38 +557,21 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   // Row tiles: with the spatial half in the kernel a tile never straddles two sequences (its queries share one K / V): every
   // sequence gets ceil(N / ROWS) tiles, the last one partly filled -- any axis length works, rows past the sequence's end are
   // clamped copies that are computed and never stored.  Without it (x staged from HBM) tiles are plain ROWS-row slices.
-  [[maybe_unused]] long long ptile = blockIdx.x;                // PERSIST: the tile of this iteration
-  for (;;) {                                                    // PERSIST: one iteration per tile; every other kernel: exactly one (the body below is not indented)
-  // Thread index, frame geometry and weight pointers of this iteration.  PERSIST: each passed through an empty asm the compiler cannot see
-  // through -- inside a tile loop LLVM hoists everything loop-invariant out of the loop (per-lane LDS offsets, dozens of 64-bit
-  // fragment addresses, the divisions of the tile arithmetic) and keeps it in registers across the whole body: hundreds of VGPRs
-  // spilled in a kernel that sits at 256 (profiles/r4_cc_experiments.txt).  An iteration then compiles like a kernel of its own.
-  int tid_l = threadIdx.x, N_l = N_a, L_l = L_a;
-  long long zl = 0;
-  if constexpr (PERSIST) {
-    int z = 0;
-    asm volatile("" : "+v"(z), "+v"(tid_l), "+s"(N_l), "+s"(L_l));
-    zl = z;
-  }
-  const int tid = tid_l, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, fg = lane >> 4;
-  const int N = N_l, L = L_l;
-  const u16* const Wpq = Wpq_a + zl;
-  const u16* const Wpkv = Wpkv_a + zl;
-  const u16* const Wp = Wp_a + zl;
-  const u16* const Wk2T = Wk2T_a + zl;
-  FfnArgs fa = fa_a;
-  OwnQkv oq = oq_a;
-  if constexpr (PERSIST) {
-    fa.W1 += zl; fa.W2 += zl;
-    oq.Wq += zl; oq.Wk += zl; oq.Wv += zl;
-  }
-  long long tile = PERSIST ? ptile : (long long)blockIdx.x;
+  const int N = N_a, L = L_a;
+  const u16* const Wpq = Wpq_a;
+  const u16* const Wpkv = Wpkv_a;
+  const u16* const Wp = Wp_a;
+  const u16* const Wk2T = Wk2T_a;
+  const FfnArgs& fa = fa_a;
+  const OwnQkv& oq = oq_a;
+  long long tile = blockIdx.x;
   long long m0;                                                 // first sequence-order row of the tile
   int nvalid;                                                   // rows of the tile that exist
   if constexpr (NKS > 0) {
     const int tps = (N + ROWS - 1) / ROWS;                      // tiles per sequence
-    if (!PERSIST && gridDim.x % (8 * tps) == 0) {
+    if (gridDim.x % (8 * tps) == 0) {
       const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
       tile = ((long long)(j / tps) * 8 + xcd) * tps + (j % tps);
     }
@@ -1098,14 +612,11 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     const u16* Qh = Q16 + (long long)wave * Mp * 32;
     const u16* Kh = K16 + (long long)wave * Mp * 32;
     const long long nsf = Mp / L;                               // frame slots (sequences x frames)
-    const u16* Vh = VROW ? VT16 + (long long)wave * Mp * 32 : VT16 + (long long)wave * nsf * NKS * 1024;
+    const u16* Vh = VT16 + (long long)wave * nsf * NKS * 1024;
     u16x8 qf[MT];
     // K fragments run one frame ahead, V^T fragments are requested at the top of their frame (before the scores):
     // the L2 latency of both hides behind MFMA + softmax work
-    // AXVS_V_AHEAD builds, 16- / 32-row tiles without the in-kernel q/k/v (few rows: pyramid levels of up to 64 tiles, the cross-clip queries): the V^T fragments
-    // alternate between two sets like K's and are requested one frame ahead (measured: frames 1.0 k -> 0.8 k cycles, kernel and layer unchanged)
-    constexpr bool VPF = AXVS_V_AHEAD && MQ == 0 && !VROW && MT <= 2;
-    u16x8 kb[2][2 * NKS], vfs[VPF ? 2 : 1][2][NKS];           // K fragments: two sets used alternately (frame parity), no copies
+    u16x8 kb[2][2 * NKS], vf[2][NKS];                         // K fragments: two sets used alternately (frame parity), no copies
     // MQ: K / V^T written by the sibling tiles of this launch are read with sc1 buffer loads (per-lane byte offset + a
     // wave-uniform frame offset), and only after the hand-off
     [[maybe_unused]] const ScBuf kbuf(K16), vbuf(VT16);
@@ -1351,36 +862,9 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] = Kh + (seq0 + min(kt * 16 + fi, Lr - 1)) * 32 + fg * 8;
     const u16* vp = Vh + (seq0 / L) * (NKS * 1024) + fi * 32 + fg * 8;
     const int kstep = L * 32;
-    // VROW: the frame's V rows go global -> registers -> the wave's own block [f][wave] of the x tile (free until the frame's x is
-    // stored there) -> transposed back into A fragments.  16-byte load n of a lane covers the 16 rows
-    // {32 (n >> 1) + 8 a + 4 (n & 1) + b : a, b = 0..3} of the frame (chunk = lane & 3): all of them have the same bit 2, so the
-    // bank swizzle of the LDS image -- the two 8-byte halves of a chunk swapped in rows with bit 2 set, which makes the
-    // transposed reads conflict-free (rows r and r + 4 would share banks) -- is a compile-time register permutation.
-    constexpr int NVL = VROW ? 2 * NKS : 1;
-    const u16* vrp[NVL];
-    int vwo[NVL], vtr[2];
-    if constexpr (VROW) {
-#pragma unroll
-      for (int n = 0; n < NVL; ++n) {
-        const int row = 32 * (n >> 1) + 8 * (lane >> 4) + 4 * (n & 1) + ((lane >> 2) & 3);
-        vrp[n] = Vh + (seq0 + min(row, L - 1)) * 32 + (lane & 3) * 8;
-        vwo[n] = row * 32 + (lane & 3) * 8;
-      }
-      // transposed read of fragment (nd, ks), key half hj: lane (fi, fg) supplies row 32 ks + 16 hj + 4 fg + (fi >> 2), positions
-      // 8 (fi & 3) + 4 nd .. + 3 and receives channel 16 nd + fi of the 4 keys 32 ks + 16 hj + 4 fg + (0..3)
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd) vtr[nd] = (4 * fg + (fi >> 2)) * 32 + 8 * (fi & 3) + 4 * (nd ^ (fg & 1));
-    }
     if constexpr (MQ == 0) {
 #pragma unroll
     for (int kt = 0; kt < 2 * NKS; ++kt) kb[0][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
-    if constexpr (VPF) {
-#pragma unroll
-      for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) vfs[0][nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
-      vp += NKS * 1024;
-    }
     }
     AXVS_STAMP(11);
     if constexpr (MQ == 0) stage_small();   // behind the cold Q / K loads of the first frame instead of in front of the barrier
@@ -1400,8 +884,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr bool OWN = decltype(own_tag)::value;
       constexpr bool VPRE = decltype(vpre_tag)::value;
-      auto& vf = vfs[VPF ? PAR : 0];
-      u16x8 vr[NVL];
       if constexpr (MQ != 0) {
         if constexpr (!OWN) {
           if constexpr (!VPRE) {
@@ -1416,31 +898,16 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
           }
         }
       } else {
-      if constexpr (VROW) {
 #pragma unroll
-        for (int n = 0; n < NVL; ++n) {
-          vr[n] = *reinterpret_cast<const u16x8*>(vrp[n]);
-          vrp[n] += kstep;
-        }
-      } else if constexpr (!VPF) {
+      for (int nd = 0; nd < 2; ++nd)
 #pragma unroll
-        for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-          for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
-        vp += NKS * 1024;
-      }
+        for (int ks = 0; ks < NKS; ++ks) vf[nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
+      vp += NKS * 1024;
       if constexpr (!LAST) {
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt) kp[kt] += kstep;
 #pragma unroll
         for (int kt = 0; kt < 2 * NKS; ++kt) kb[PAR ^ 1][kt] = *reinterpret_cast<const u16x8*>(kp[kt]);
-        if constexpr (VPF) {               // the next frame's V^T fragments, behind its K fragments
-#pragma unroll
-          for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) vfs[PAR ^ 1][nd][ks] = *reinterpret_cast<const u16x8*>(vp + (ks * 2 + nd) * 512);
-          vp += NKS * 1024;
-        }
       }
       }
       f32x4 sc[MT][2 * NKS];
@@ -1499,26 +966,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         for (int ks = 0; ks < NKS; ++ks) ssum = H16<BF>::mfma(ones, pf[qt][ks], ssum);
         inv[qt] = __builtin_amdgcn_rcpf(ssum[0]);   // 1 ulp; the result is rounded to 16 bits right after
         if constexpr (MQ != 0) inv[qt] *= poison;   // (x 1.0 unless a hand-off wait ran out)
-      }
-      if constexpr (VROW) {
-        u16* vblk = xt + ((f * 8 + wave) * ROWS) * 32;
-#pragma unroll
-        for (int n = 0; n < NVL; ++n)
-          *reinterpret_cast<u16x8*>(vblk + vwo[n]) =
-              (n & 1) ? __builtin_shufflevector(vr[n], vr[n], 4, 5, 6, 7, 0, 1, 2, 3) : vr[n];
-        asm volatile("" ::: "memory");      // the transposed reads below are an intrinsic: keep them behind the stores
-#pragma unroll
-        for (int nd = 0; nd < 2; ++nd)
-#pragma unroll
-          for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int hj = 0; hj < 2; ++hj) {
-              typedef short s16x4v __attribute__((ext_vector_type(4)));
-              const s16x4v t4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (s16x4v __attribute__((address_space(3)))*)(vblk + vtr[nd] + (32 * ks + 16 * hj) * 32));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) vf[nd][ks][4 * hj + e] = (u16)t4[e];
-            }
       }
       if constexpr (LAST) load_wfrags<2, 8>(wf, Wpq, C, 0, wave * 32, fi, fg);
       f32x4 xa[MT][2];
@@ -1669,13 +1116,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     q2f[mt] = cvt8<BF>(v);
   }
   float lg[T][MT];
-#if AXVS_LOGITS_VALU_KB
-  float lgv[T][MT];                                         // hybrid: the channel blocks with (kb & AXVS_LOGITS_VALU_KB) on the VALU (v_dot2), per-lane partials
-#pragma unroll
-  for (int f = 0; f < T; ++f)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) lgv[f][mt] = 0.f;
-#endif
   f32x4 lacc[T][MT];                                        // MFMA tiles whose diagonals are the logits (see below)
 #pragma unroll
   for (int f = 0; f < T; ++f)
@@ -1711,17 +1151,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
             // replaced by 128 MFMAs; -1.9 us on the width-pass kernel, and no register spills any more)
           float v8[8] = {qk[0][mt][0], qk[0][mt][1], qk[0][mt][2], qk[0][mt][3], qk[1][mt][0], qk[1][mt][1], qk[1][mt][2], qk[1][mt][3]};
           const u16x8 ua = cvt8<BF>(v8);
-#if AXVS_LOGITS_VALU_KB
-          if (kb & AXVS_LOGITS_VALU_KB) {
-            // this lane's 8 channels of the block (the same 8 in `ua` and in the x fragment: perm32 order) for token fi; the 4 lanes
-            // (fi, fg = 0..3) of a token are summed once at the end.  The matrix pipe carries the other blocks' diagonals meanwhile.
-#pragma unroll
-            for (int f = 0; f < T; ++f) {
-              lgv[f][mt] = dot8_acc<BF>(ua, xg[g % (PD + 1)][f], lgv[f][mt]);
-              asm volatile("" : "+v"(lgv[f][mt]));          // stays HERE, beside this block's MFMAs (left alone, the dot products of all blocks
-            }                                               // collect behind the last MFMA and their x fragments spill)
-          } else
-#endif
           {
 #pragma unroll
           for (int f = 0; f < T; ++f) lacc[f][mt] = H16<BF>::mfma(ua, xg[g % (PD + 1)][f], lacc[f][mt]);
@@ -1742,9 +1171,6 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
         const f32x4 a = lacc[f][mt];
         const float d = sel == 0 ? a[0] : sel == 1 ? a[1] : sel == 2 ? a[2] : a[3];
         lg[f][mt] = __int_as_float(__builtin_amdgcn_ds_bpermute(srcl, __float_as_int(d)));
-#if AXVS_LOGITS_VALU_KB
-        lg[f][mt] += groups_sum(lgv[f][mt]);                // + the VALU blocks: sum over the token's 4 lanes (v_permlane16/32_swap)
-#endif
       }
   }
   AXVS_STAMP(3);
@@ -1839,14 +1265,13 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   long long roff[RPW];
   // RowMap arithmetic (integer divisions) once per wave, lane i computing row i of the wave's RPW rows, then broadcast with
   // v_readlane -- instead of RPW unrolled copies of the same ~75-instruction sequence
-  int rcoords = 0;                                  // QKVN: (t, h, w) of the wave's row (lane % RPW), packed (nat_row_coords)
   [[maybe_unused]] int roff_lo = 0, roff_hi = 0;    // element offset of row (lane % RPW) of this wave, as two words (re-read with v_readlane)
   unsigned rok;                                     // bit i: row i of this wave exists (inside its sequence, not a padding row of its frame) -> stored
   {
     const int myrow = wave * RPW + (lane % RPW);
     const int mym = (int)m0 + min(myrow, nvalid - 1);
     rok = (unsigned)__builtin_amdgcn_ballot_w64(myrow < nvalid && row_exists(rm, mym)) & ((1u << RPW) - 1u);
-    const long long myoff = (QKVN ? nat_row_coords(rm, mym, nq.pg.l_is_h, &rcoords) : nat_row(rm, mym)) * C;
+    const long long myoff = nat_row(rm, mym) * C;
     const int lo = (int)(myoff & 0xffffffffll), hi = (int)(myoff >> 32);
     roff_lo = lo;
     roff_hi = hi;
@@ -1859,12 +1284,7 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
   }
   // with the FFN half following, the sweep leaves the first linear1 fragment set behind
   constexpr int crot = 0;                          // fixed chunk order: results do not depend on the tile index (see ffn_fused_kernel)
-#if AXVS_FFN_WS
-  if constexpr (FFN) sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);      // (ffn_body_ws fetches its own fragment ring)
-#else
   if constexpr (FFN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, fa.W1, fa.F, crot * 256 + wave * 32, fi, fg);
-#endif
-  else if constexpr (QKVN) sweep8<BF, MT, true>(po, wf, xt, bo, KBS, nq.Wq, C, wave * 32, fi, fg);       // leaves the next pass's Wq rows of my head behind
   else sweep8<BF, MT, false>(po, wf, xt, bo, KBS, Wp, C, 0, fi, fg);
   AXVS_STAMP(7);
   // ---- row-wise epilogue: accumulators (+bias) -> LDS fp32 tile (behind the o tile) -> whole rows: + residual -> out ----
@@ -1878,36 +1298,12 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
       epi_put(etile, mt * 16 + fi, n, f32x4{po[nt][mt][0] + b.x, po[nt][mt][1] + b.y, po[nt][mt][2] + b.z, po[nt][mt][3] + b.w});
   }
   __syncthreads();
-  // QKVN: the output rows also become the two 16-bit operand tiles of the next pass's projections -- (rows + pos) for q and k in
-  // the o tile's place (every wave is past the projection sweep), rows for v behind the fp32 tile; same image as qkv_fused_kernel's
-  u16* const tqk = xt;
-  u16* const tv = reinterpret_cast<u16*>(etile + ROWS * kEpiLd);
-  PosGenLane npl;
-  float namax = 0.f;
   [[maybe_unused]] NoRows yrows;                   // FFN: the wave's rows after the residual
-  if constexpr (QKVN) {
-    if (nq.pg.mode) npl.init(nq.pg, lane * 4);
-  }
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int row = wave * RPW + i;
     const float4 v = *reinterpret_cast<const float4*>(etile + row * kEpiLd + lane * 4);
     float4 y = float4{v.x + rres[i].x, v.y + rres[i].y, v.z + rres[i].z, v.w + rres[i].w};
-    if constexpr (QKVN) {
-      float4 pp = float4{0.f, 0.f, 0.f, 0.f};
-      if (nq.pg.mode) pp = npl.eval(nq.pg, __builtin_amdgcn_readlane(rcoords, i));
-      else if (nq.pos) pp = *reinterpret_cast<const float4*>(nq.pos + roff[i]);
-      const int n = lane * 4, kb = n >> 5, kk = n & 31;
-      const int o = (kb * ROWS + row) * 32 + swz_chunk(row, kk >> 3) * 8 + (kk & 7);
-      const f32x4 yq = {y.x + pp.x, y.y + pp.y, y.z + pp.z, y.w + pp.w};
-      *reinterpret_cast<u16x4*>(tv + o) = cvt4<BF>(f32x4{y.x, y.y, y.z, y.w});
-      *reinterpret_cast<u16x4*>(tqk + o) = cvt4<BF>(yq);
-      if (!BF) {
-        namax = fmaximum(namax, fmaximum(fmaximum(fabsf(y.x), fabsf(y.y)), fmaximum(fabsf(y.z), fabsf(y.w))));
-        namax = fmaximum(namax, fmaximum(fmaximum(fabsf(yq[0]), fabsf(yq[1])), fmaximum(fabsf(yq[2]), fabsf(yq[3]))));
-      }
-      if (i == 3) lds_fence();
-    }
     if constexpr (!FFN) {
       if (ln_g) {      // post-norm layer (cross-clip TrajectoryAttentionLayer.forward_post, CC/...:156-161): LayerNorm(x + attn(x)), eps 1e-5
         const float mu = wave_sum(y.x + y.y + y.z + y.w) * (1.f / C);
@@ -1924,96 +1320,18 @@ __global__ __launch_bounds__(512) void temporal_fused_kernel(const u16* __restri
     }
   }
   AXVS_STAMP(8);
-  if constexpr (QKVN) {
-    // ---- q, k, v of the NEXT pass (WC/temporal_attention.py:42-44 on this pass's output, :206-212): three sweeps over the tiles
-    //      just written; each refills the fragment set for the one after it.  Outputs in the next pass's sequence order: with
-    //      this pass's decomposition m' = ((b Loff + o) T + t) L + l of a row, the next pass (axes swapped: its on-axis
-    //      coordinate is o, its sequences are (b, l)) has m'' = ((b L + l) T + t) Loff + o.
-    if (!BF && nq.status != nullptr && !(namax <= 65504.f)) atomicOr(nq.status, 1);
-    lds_fence();
-    __syncthreads();
-    AXVS_STAMP(16);
-    int mnext;
-    {
-      const int m = (int)m0 + min(lane, nvalid - 1);
-      const int sq = m / rm.N, n = m - sq * rm.N;
-      const int b = sq / rm.Loff, o = sq - b * rm.Loff;
-      const int t = n / rm.L, l = n - t * rm.L;
-      mnext = ((b * rm.L + l) * T + t) * rm.Loff + o;
-    }
-    int mn[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) mn[mt] = __builtin_amdgcn_ds_bpermute((mt * 16 + fi) * 4, mnext);
-    const WtBuf wq(nq.Q16), wk(nq.K16), wv(nq.V16);
-#pragma unroll
-    for (int which = 0; which < 3; ++which) {
-      f32x4 acc[2][MT];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (which == 0) sweep8<BF, MT, true>(acc, wf, tqk, bo, KBS, nq.Wk, C, wave * 32, fi, fg);
-      else if (which == 1) sweep8<BF, MT, true>(acc, wf, tqk, bo, KBS, nq.Wv, C, wave * 32, fi, fg);
-      else sweep8<BF, MT, false>(acc, wf, tv, bo, KBS, nq.Wv, C, 0, fi, fg);
-#ifdef AXVS_STAMPS
-      if (which == 0) { AXVS_STAMP(17); } else if (which == 1) { AXVS_STAMP(19); } else { AXVS_STAMP(21); }
-#endif
-      const float* bias = which == 0 ? nq.bq : which == 1 ? nq.bk : nq.bv;
-      const float sc_ = which == 0 ? nq.qscale : 1.f;
-      const float4 b0 = *reinterpret_cast<const float4*>(bias + wave * 32 + fg * 4);
-      const float4 b1 = *reinterpret_cast<const float4*>(bias + wave * 32 + 16 + fg * 4);
-      u16* dst = which == 0 ? nq.Q16 : which == 1 ? nq.K16 : nq.V16;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (mt * 16 + fi < nvalid) {   // stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r (perm32): 16 contiguous bytes per lane
-          float v8[8] = {(acc[0][mt][0] + b0.x) * sc_, (acc[0][mt][1] + b0.y) * sc_, (acc[0][mt][2] + b0.z) * sc_,
-                         (acc[0][mt][3] + b0.w) * sc_, (acc[1][mt][0] + b1.x) * sc_, (acc[1][mt][1] + b1.y) * sc_,
-                         (acc[1][mt][2] + b1.z) * sc_, (acc[1][mt][3] + b1.w) * sc_};
-          const long long d = ((long long)wave * Mp + mn[mt]) * 32 + fg * 8;
-          if (nq.wt) (which == 0 ? wq : which == 1 ? wk : wv).store16((unsigned)(d * 2), cvt8<BF>(v8));
-          else *reinterpret_cast<u16x8*>(dst + d) = cvt8<BF>(v8);
-        }
-      }
-#ifdef AXVS_STAMPS
-      if (which == 0) { AXVS_STAMP(18); } else if (which == 1) { AXVS_STAMP(20); } else { AXVS_STAMP(22); }
-#endif
-    }
-  }
   if constexpr (FFN) {
     static_assert(RPW == 8, "the FFN half walks 8 rows per wave");
-#if AXVS_FFN_WS
-    // (row offsets re-assembled from the two lane-indexed words when norm2 stores: 2 VGPRs alive across the FFN half instead of 16)
-    auto row_off_ = [=](int row) {
-      const int i = row % RPW;
-      return ((rok >> i) & 1u) ? (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(roff_hi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(roff_lo, i)) : -1ll;
-    };
-#else
     auto row_off_ = [=](int row) { return ((rok >> (row % RPW)) & 1u) ? roff[row % RPW] - lane * 4 : -1ll; };       // rows of this wave
-#endif
-#if AXVS_FFN_WS
-    const FfnLdsWs fw{fl.ytile, fl.xtile, fl.htile, fl.par};       // y tile | fp32 stage (= h slot 1) | h slot 0: ffn_body's footprint
-    ffn_body_ws<BF, decltype(row_off_)>(fw, fa.W1, fa.W2, out, row_off_, fa.F, tid, wt, yrows);
-#elif AXVS_FFN_ONEBAR
-    const FfnLdsWs fw{fl.ytile, fl.xtile, fl.htile, fl.par};
-    ffn_body2<BF, decltype(row_off_), false, true>(fw, wf, fa.W1, fa.W2, out, row_off_, fa.F, tid, wt, yrows);
-#else
     ffn_body<BF, decltype(row_off_), false, true>(fl, wf, fa.W1, fa.W2, out, row_off_, fa.F, 0, crot, tid, wt, yrows);
-#endif
   }
   AXVS_STAMP(10);
   AXVS_WG_END(FFN ? 0 : 1);
 #if !defined(AXVS_STAMPS_QKV) && !defined(AXVS_STAMPS_FFN)
-  if constexpr (QKVN || (MQ != 0 && !FFN)) AXVS_STAMP_FLUSH_AT(32, 24);      // the height-pass kernel's stamps: slots 32 .. 55 (the width pass's stay in 0 .. 23)
+  if constexpr (MQ != 0 && !FFN) AXVS_STAMP_FLUSH_AT(32, 24);      // the height-pass kernel's stamps: slots 32 .. 55 (the width pass's stay in 0 .. 23)
   else if constexpr (MQ != 0) AXVS_STAMP_FLUSH(24);
   else AXVS_STAMP_FLUSH(16);
 #endif
-  if constexpr (!PERSIST) break;
-  else {
-    ptile += gridDim.x;
-    if (ptile >= (Mp / N) * ((N + ROWS - 1) / ROWS)) break;
-    __syncthreads();        // every wave is done with this tile's LDS (fp32 rows, parameters) before the next tile's gather overwrites it
-  }
-  }   // tile loop
 }
 
 
@@ -2045,8 +1363,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
                                                         u16* __restrict__ Q16, u16* __restrict__ K16, u16* __restrict__ V16,
                                                         long long Mp, float qscale, u16* __restrict__ VT16, int N, int L, int T,
                                                         int NKS, PosGen pg, int wt /* write-through q/k/V^T stores (offsets < 4 GiB) */,
-                                                        int* __restrict__ status /* nullable: bit 0 <- an operand left the fp16 range */,
-                                                        int vrow = 0 /* V16 <- v in K's layout (perm32 channel order): the VROW trajectory kernels */) {
+                                                        int* __restrict__ status /* nullable: bit 0 <- an operand left the fp16 range */) {
   constexpr int C = 256, MT = 4, ROWS = 64, KBS = ROWS * 32;
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   u16* tqk = smem;                       // (src + pos) tile [8][64][32]
@@ -2236,7 +1553,7 @@ __global__ __launch_bounds__(512) void qkv_fused_kernel(const float* __restrict_
     for (int mt = 0; mt < MT; ++mt) {
       const long long m = m0 + mt * 16 + fi;
       if (m < Mp) {
-        if (which < 2 || vrow) {   // q, k (v in row mode): stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r: 16 contiguous bytes per lane
+        if (which < 2) {   // q, k: stored position g*8 + nt*4 + r  <-  channel nt*16 + 4g + r: 16 contiguous bytes per lane
           float v[8] = {(acc[0][mt][0] + b0.x) * sc, (acc[0][mt][1] + b0.y) * sc, (acc[0][mt][2] + b0.z) * sc,
                         (acc[0][mt][3] + b0.w) * sc, (acc[1][mt][0] + b1.x) * sc, (acc[1][mt][1] + b1.y) * sc,
                         (acc[1][mt][2] + b1.z) * sc, (acc[1][mt][3] + b1.w) * sc};

@@ -74,15 +74,13 @@ struct TrajWs {
 };
 
 struct FfnArgs;   // axvs_fused.h
-struct NextQkv;   // axvs_fused.h
 struct OwnQkv;    // axvs_fused.h
 
 // nks = 0: x staged from global (after spatial_attn_kernel); nks > 0: spatial half inside the kernel.  `fa` non-null: the
-// layer's FFN rides along (needs nks > 0 and 64-row tiles).  vrow: w.vt16 holds V row-major in K's layout (64-row tiles, nks <= 2).
-// `nq` non-null: the kernel also emits q, k, v of the next pass (64-row tiles, no FFN).
+// layer's FFN rides along (needs nks > 0 and 64-row tiles).
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
                       int L, float scale, hipStream_t st, const FfnArgs* fa, int flags /* bit 0: write-through output rows, bits 1-2: stop after the spatial half / the q,k,v part, bits 4-5: 16-bit output map of the FFN-carrying kernel (kOutF16 / kOutBf16) */,
-                      int vrow, const NextQkv* nq, const OwnQkv* oq /* non-null: the kernel computes q, k, v of its own rows first (merged launch) */);
+                      const OwnQkv* oq /* non-null: the kernel computes q, k, v of its own rows first (merged launch) */);
 
 }  // namespace axvs

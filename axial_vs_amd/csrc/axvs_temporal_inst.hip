@@ -13,89 +13,71 @@
 
 namespace axvs {
 
-template <bool BF, int T, int MT, int NKS, bool FFN, bool VROW, bool QKVN, int MQ = 0, bool PERSIST = false>
+template <bool BF, int T, int MT, int NKS, bool FFN, int MQ = 0>
 static int launch_one(unsigned grid, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                      float scale, hipStream_t st, const FfnArgs* fa, int wt, const NextQkv* nq, const OwnQkv* oq = nullptr) {
-  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, VROW, QKVN, MQ, PERSIST>;
+                      float scale, hipStream_t st, const FfnArgs* fa, int wt, const OwnQkv* oq = nullptr) {
+  auto kern = &temporal_fused_kernel<BF, T, MT, NKS, FFN, MQ>;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern))) return rc;
-  const size_t lds = temporal_lds_bytes<T, MT, FFN, QKVN, MQ>(FFN ? fa->F : 0);
+  const size_t lds = temporal_lds_bytes<T, MT, FFN, MQ>(FFN ? fa->F : 0);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, w.x16, p.wpq, p.bpq, p.wpkv, p.bpkv, p.wp, p.bp, res, out, rm, Mp, N, L, scale,
                      w.q16, w.k16, w.vt16, FFN ? *fa : FfnArgs{}, p.wk2t, (wt & 1) | (FFN ? wt & kOut16Mask : 0), (wt >> 1) & 3, FFN ? nullptr : p.post_ln_g,
-                     FFN ? nullptr : p.post_ln_b, QKVN ? *nq : NextQkv{}, MQ ? *oq : OwnQkv{});
+                     FFN ? nullptr : p.post_ln_b, MQ ? *oq : OwnQkv{});
   return AXVS_OK;
 }
 
 template <bool BF, int T, int MT, int NKS>
 static int launch_temporal_t(const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N, int L,
-                             float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq, const OwnQkv* oq) {
+                             float scale, hipStream_t st, const FfnArgs* fa, int wt, const OwnQkv* oq) {
   // with the spatial half in the kernel every sequence gets its own ceil(N / rows) tiles (see temporal_fused_kernel)
   const unsigned grid = NKS > 0 ? (unsigned)((Mp / N) * ((N + MT * 16 - 1) / (MT * 16))) : (unsigned)((Mp + MT * 16 - 1) / (MT * 16));
   if constexpr (NKS > 0 && NKS <= 3 && MT == 4 && T <= 4) {
-    if (oq) {                           // merged q/k/v + trajectory launch (the caller checked: no row-form V, no next-pass q/k/v)
-      if (vrow || nq) return fail(AXVS_ERR_ARG, "internal: merged q/k/v excludes row-form V / next-pass q,k,v");
+    if (oq) {                           // merged q/k/v + trajectory launch
       if constexpr (NKS == 2 && T >= 2) {
         if (L == 64) {                  // a 64-row tile is one frame: own frame first, from registers
-          if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
-          return launch_one<BF, T, MT, NKS, false, false, false, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+          if (fa) return launch_one<BF, T, MT, NKS, true, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
+          return launch_one<BF, T, MT, NKS, false, 2>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
         }
       }
-#ifdef AXVS_WITH_PERSIST                // diagnostic builds only (measured 24 % SLOWER: profiles/r5_persistent_merged.txt): the persistent team grid
-      if constexpr (NKS >= 2) {           // frames of 33 .. 96 keys on grids far beyond the chip: a fixed grid of teams that walks the tiles
-        if (oq->persist_grid > 0 && (unsigned)oq->persist_grid < grid) {
-          const unsigned pg = (unsigned)oq->persist_grid;
-          if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 1, true>(pg, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
-          return launch_one<BF, T, MT, NKS, false, false, false, 1, true>(pg, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
-        }
-      }
-#endif
-      if (fa) return launch_one<BF, T, MT, NKS, true, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
-      return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+      if (fa) return launch_one<BF, T, MT, NKS, true, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
+      return launch_one<BF, T, MT, NKS, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
     }
   }
   if constexpr (NKS > 0 && MT == 1 && T <= 4) {
     if (oq) {                           // 16-row tiles (few rows: pyramid levels of 32 x 32 and below, cross-clip queries)
-      if (vrow || nq || fa) return fail(AXVS_ERR_ARG, "internal: merged q/k/v on 16-row tiles excludes row-form V / next-pass q,k,v / the FFN");
-      return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+      if (fa) return fail(AXVS_ERR_ARG, "internal: merged q/k/v on 16-row tiles excludes the FFN");
+      return launch_one<BF, T, MT, NKS, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
     }
   }
   if constexpr (NKS > 0 && NKS <= 3 && MT == 2 && T >= 5) {
     if (oq) {                           // 32-row tiles: 5 .. 8 frames per clip (Tube-Link's T = 5 levels)
-      if (vrow || nq || fa) return fail(AXVS_ERR_ARG, "internal: merged q/k/v on 32-row tiles excludes row-form V / next-pass q,k,v / the FFN");
-      return launch_one<BF, T, MT, NKS, false, false, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq, oq);
+      if (fa) return fail(AXVS_ERR_ARG, "internal: merged q/k/v on 32-row tiles excludes the FFN");
+      return launch_one<BF, T, MT, NKS, false, 1>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
     }
   }
   if (oq) return fail(AXVS_ERR_ARG, "internal: merged q/k/v needs the in-kernel spatial half on 64- / 16-row tiles (T <= 4) or 32-row tiles (T = 5 .. 8)");
   if constexpr (NKS > 0 && MT == 4) {
-    if constexpr (NKS <= 2) {           // V in row form (staged in the x tile: 64 keys per frame at most)
-      if (vrow && fa) return launch_one<BF, T, MT, NKS, true, true, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
-      if (vrow && nq) return launch_one<BF, T, MT, NKS, false, true, true>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
-      if (vrow) return launch_one<BF, T, MT, NKS, false, true, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
-    }
-    if (vrow) return fail(AXVS_ERR_ARG, "internal: row-major V needs nks <= 2");
-    if (fa) return launch_one<BF, T, MT, NKS, true, false, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);   // trajectory attention + FFN
-    if (nq) return launch_one<BF, T, MT, NKS, false, false, true>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);   // + next pass's q/k/v
+    if (fa) return launch_one<BF, T, MT, NKS, true>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);   // trajectory attention + FFN
   }
   if (fa) return fail(AXVS_ERR_ARG, "internal: FFN fusion needs the in-kernel spatial half and 64-row tiles");
-  if (vrow || nq) return fail(AXVS_ERR_ARG, "internal: row-major V / next-pass q,k,v need the in-kernel spatial half and 64-row tiles");
-  return launch_one<BF, T, MT, NKS, false, false, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, nq);
+  return launch_one<BF, T, MT, NKS, false>(grid, w, p, res, out, rm, Mp, N, L, scale, st, fa, wt);
 }
 
 template <bool BF, int T, int MT>
 int launch_temporal_n(int nks, const TrajWs& w, const TrajPacked& p, const float* res, float* out, RowMap rm, long long Mp, int N,
-                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt, int vrow, const NextQkv* nq, const OwnQkv* oq) {
+                      int L, float scale, hipStream_t st, const FfnArgs* fa, int wt, const OwnQkv* oq) {
   switch (nks) {
-    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
-    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
-    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
-    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
-    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, vrow, nq, oq);
+    case 0: return launch_temporal_t<BF, T, MT, 0>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
+    case 1: return launch_temporal_t<BF, T, MT, 1>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
+    case 2: return launch_temporal_t<BF, T, MT, 2>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
+    case 3: return launch_temporal_t<BF, T, MT, 3>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
+    case 4: return launch_temporal_t<BF, T, MT, 4>(w, p, res, out, rm, Mp, N, L, scale, st, fa, wt, oq);
     default: return fail(AXVS_ERR_ARG, "bad nks");
   }
 }
 
 template int launch_temporal_n<(AXVS_INST_BF != 0), AXVS_INST_T, AXVS_INST_MT>(
-    int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int, int,
-    const NextQkv*, const OwnQkv*);
+    int, const TrajWs&, const TrajPacked&, const float*, float*, RowMap, long long, int, int, float, hipStream_t, const FfnArgs*, int,
+    const OwnQkv*);
 
 }  // namespace axvs
 

@@ -59,6 +59,9 @@ typedef struct AxvsAxialLayerParams {
 } AxvsAxialLayerParams;
 
 int axvs_version(void);
+/* 1 if the library was built with the bf16 operand tier (-DAXVS_WITH_BF16; not part of the default build since round 6: the tier does not hold the
+ * 1e-3 parity bar -- every entry point refuses dtype = AXVS_BF16 with AXVS_ERR_ARG otherwise), else 0 */
+int axvs_has_bf16(void);
 const char* axvs_last_error(void);
 
 /* Asynchronous condition bits.  The entry points never synchronise, so conditions only a kernel can see are OR-ed into a word
