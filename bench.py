@@ -703,6 +703,29 @@ def main():
                         wc.forward_features(dict(feats3))
                     torch.cuda.synchronize(dev)
                 el = (time.perf_counter() - t3) / n3
+                # the same forward replayed from a captured HIP graph (axial_vs_amd.GraphedForward): the module forks onto side streams for its independent
+                # chains (the two temporal levels of a stage; since round 6 the three levels' projections); a replay has no host launch latency between them
+                el_graph = None
+                try:
+                    keys3 = list(feats3)
+
+                    class _Fwd(torch.nn.Module):
+                        def forward(self_, *ts):
+                            o3, _, _ = wc.forward_features({k: t_ for k, t_ in zip(keys3, ts)})
+                            return tuple(o3[k] for k in keys3)
+                    with torch.no_grad():
+                        gf3 = ax.GraphedForward(_Fwd(), *[feats3[k] for k in keys3])
+                        for _ in range(5):
+                            gf3()
+                        torch.cuda.synchronize(dev)
+                        t3 = time.perf_counter()
+                        for _ in range(n3):
+                            gf3()
+                        torch.cuda.synchronize(dev)
+                        el_graph = (time.perf_counter() - t3) / n3
+                    del gf3
+                except Exception as e:
+                    el_graph = str(e)[:200]
                 # the same module with the axial-trajectory layers on their fp32 tier: the setting under which the free-running
                 # stack holds 1e-3 in max-norm too (tests/test_hip_parity.py: ..._fp32_stack_holds_the_bar_in_max_norm)
                 wc.set_stack_precision("f32")
@@ -746,11 +769,13 @@ def main():
                 except RuntimeError as e:
                     el_vip = str(e)[:200]
                 extras["wc_cfg3"] = {"ms_per_forward": round(el * 1e3, 3), "value": round(4 / el, 1), "unit": "frames/s",
+                                     "ms_per_forward_graph_replay": round(el_graph * 1e3, 3) if isinstance(el_graph, float) else el_graph,
                                      "ms_per_forward_vipseg_r50_769x1345_T2": round(el_vip * 1e3, 3) if isinstance(el_vip, float) else el_vip,
                                      "ms_per_forward_f32_stack": round(el32 * 1e3, 3),
                                      "what": "BASELINE config 3: WithinClipTrackingModule.forward_features, res3/4/5 = [4,192,64,64] / [4,384,32,32] / "
                                              "[4,768,16,16], 2 stages x (1 deformable spatial layer + 2 axial-trajectory layers on res5 and res4); "
-                                             "ms_per_forward: 16-bit operands (<= 1e-3 per layer and in relative L2, 1.4e-3 max-norm over the stack); "
+                                             "ms_per_forward: 16-bit operands (<= 1e-3 per layer and in relative L2, 1.4e-3 max-norm over the stack), launched from Python; "
+                                             "ms_per_forward_graph_replay: the same forward as one HIP-graph replay (GraphedForward; bit-equal outputs); "
                                              "ms_per_forward_f32_stack: set_stack_precision('f32'), <= 1e-3 in max-norm as well; "
                                              "ms_per_forward_vipseg_r50_769x1345_T2: the same module at the shipped VIPSeg ResNet-50 setting (res3 / res4 / res5 = "
                                              "[2,512,97,169] / [2,1024,49,85] / [2,2048,25,43], 2 frames per clip)"}

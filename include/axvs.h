@@ -105,28 +105,30 @@ int axvs_profile_stages(void** events, int capacity);
 int axvs_profile_stage_count(void);
 const char* axvs_profile_stage_name(int i);
 
-/* ---- tuning / test switches (thread-local unless noted).  "generic_only" = 1: always use the shape-generic kernels
- *      instead of the fused C=256 ones (A/B comparisons, parity tests of both paths).  Others: "no_attn_fusion", "no_ffn_fusion",
- *      "no_small_tiles", "small_tiles_below", "ffn_split_below", "ffn_split_pairs", "merge_mid" (merged launch on 32-row tiles, T = 5 .. 8: 1 = within one round of the chip [default], 0 never, 2 always), "no_reassoc", "no_wt_stores", "spatial_only" (timing), "ffn_gelu", "attn_waves";
- *      "vrow" = 1: the 64-row fused kernels read V in K's row layout (transposed on load) instead of block-transposed V^T;
- *      "qkv_fusion" = 1: the width pass's q/k/v are produced by the height-pass kernel (both bit-identical to the default,
- *      measured not faster: DESIGN.md 4a);  process-wide: "train_valu" (VALU instead of fp32-MFMA attention kernels of the
- *      training tier), "train_exact" (default 1: forward GEMMs of the training tier with fp32 accuracy; 0: two-piece bf16
- *      products in the forward too; 2: three-piece input-gradient GEMMs as well), "train_amp" (default 0; 1 / 2: the X W^T GEMMs
- *      of the training tier -- forward, input gradients, weight gradients -- multiply ONE bf16 / fp16 piece per operand with fp32 accumulation:
- *      the products torch.autocast gives the reference's nn.Linear; the Python layer sets it for calls made under autocast and
- *      for the backward of their graphs), "train_attn_split" (default 1: the training tier's attention forward on split-precision
- *      16-bit MFMAs with a frame's score tiles in registers, axis length <= 128; 0: the fp32 MFMA kernel), "train_spatial_wgs" (default 512: workgroups the
- *      training tier's attention kernels are spread over -- measured flat from 512 to 8192 at the metric shape);
- *      "msda_gemm" (default 2 since the end of round 5 [two pieces everywhere]; 4: the deformable attention's projections on the 128 x 128 split-precision GEMM, three pieces for
- *      output_proj; 2 / 3: two / three pieces everywhere; 0: the 64 x 64 kernels);
- *      "ffn_wide" (default 0: the stand-alone FFN runs on 128-row tiles when that saves a round of the chip; 1: always; 2: never --
- *      bit-identical either way); "layer_out_dtype" (default 0: axvs_axial_layer_fwd* / axvs_axial_pass_fwd(pass = 1) / axvs_traj_layer_fwd / axvs_ffn_fwd write
- *      their output rows as fp32, the reference's type; 1 / 2: `out` is a [rows, C] f16 / bf16 map, written by the epilogue of the
- *      kernel that ends the layer -- the map a batch-sharded caller gathers over xGMI (BASELINE config 5: "bf16"), without a cast
- *      pass; fused FFN tier only, contiguous frames only); "cc_aspp_affine" (default 0: the ASPP projection of a cross-clip layer is followed by the channels-first LayerNorm of the shipped configs; 1: by a per-channel scale / shift that the caller packed into aspp_norm_w / aspp_norm_b -- eval-mode SyncBatchNorm, norm_fn = 'syncbn'); "cc_last_heads_only" (default 0: axvs_cc_module_fwd computes the predictor heads of every layer, the reference's return value; 1:
- *      of the last layer only -- pred_logits / pred_masks then hold ONE layer); "sync_spin_limit" (polls before a hand-off wait of a merged launch gives up and sets
- *      AXVS_STATUS_SYNC_TIMEOUT; default 2^22, about one second; 0 restores the default). */
+/* ---- options: 15 keys (round 6; rounds 2 - 5 exposed 37, most of them planner thresholds and forms measured slower: those are constants / gone).
+ *      Thread-local unless noted.  Unknown keys return AXVS_ERR_ARG.
+ *      Set by the host modules around their calls:
+ *        "ffn_gelu"            the layer's FFN activation is exact GELU instead of ReLU (activation = "gelu", WC/temporal_attention.py:9-17)
+ *        "layer_out_dtype"     0 (default): axvs_axial_layer_fwd* / axvs_axial_pass_fwd(pass = 1) / axvs_traj_layer_fwd / axvs_ffn_fwd write fp32 rows, the reference's
+ *                              type; 1 / 2: `out` is a [rows, C] f16 / bf16 map written by the epilogue of the kernel that ends the layer -- the map a batch-sharded
+ *                              caller sends over xGMI (BASELINE config 5), without a cast pass; fused FFN tier, contiguous frames only
+ *        "cc_aspp_affine"      the ASPP projection of a cross-clip layer is followed by a per-channel scale / shift packed into aspp_norm_w / aspp_norm_b
+ *                              (eval-mode SyncBatchNorm, norm_fn = 'syncbn') instead of the channels-first LayerNorm of the shipped configs
+ *        "cc_last_heads_only"  axvs_cc_module_fwd computes the predictor heads of the LAST layer only (pred_logits / pred_masks then hold one layer)
+ *        "train_amp"           process-wide; 1 / 2: the X W^T GEMMs of the training tier multiply ONE bf16 / fp16 piece per operand (what torch.autocast gives nn.Linear)
+ *        "no_merge_qkv"        two launches per axial pass (q/k/v kernel + trajectory kernel) instead of the merged launch with its in-launch hand-off: bit-identical;
+ *                              the 'verify' hand-off policy's re-run
+ *      Tier selection for parity tests and measurements:
+ *        "generic_only", "no_attn_fusion", "no_ffn_fusion"   the shape-generic kernels / separate attention and temporal kernels / the FFN in its own kernel
+ *        "merge_qkv_any"       merged launches at every grid size (default: up to ~2 rounds of the chip, or frames of 64 keys)
+ *        "spatial_only"        timing: 1 = the fused trajectory kernels return after QK^T / softmax / AV, 2 = the merged kernels after their q/k/v part (outputs unwritten)
+ *        "train_valu", "train_exact"   process-wide: VALU instead of fp32-MFMA attention in the training tier; 1 (default) / 0 / 2: three- / two-piece forward GEMMs / three-piece
+ *                              input-gradient GEMMs as well
+ *      Test hooks:
+ *        "sync_spin_limit"     polls before a hand-off wait gives up and sets AXVS_STATUS_SYNC_TIMEOUT (default 2^22, about one second; 0 restores it)
+ *        "plan_force"          ONE bit mask that forces the planner's size-dependent choices between forms that are bit-identical by construction (the bit-identity tests):
+ *                              1 never the 16-row trajectory tiles | 2 / 4 the 128-row FFN tiles always / never | 8 no two-chunk FFN workgroups |
+ *                              16 / 32 merged launch on 16-row tiles never / at any size | 64 generic tier without the reassociated temporal half; 0 = the planner's own choice */
 int axvs_set_option(const char* key, int value);
 
 /* ---- weight packing (once per load_state_dict; result is opaque, device-resident: 16-bit operands in MFMA-fragment order,
