@@ -728,16 +728,19 @@ def main():
                     el_graph = str(e)[:200]
                 # the same module with the axial-trajectory layers on their fp32 tier: the setting under which the free-running
                 # stack holds 1e-3 in max-norm too (tests/test_hip_parity.py: ..._fp32_stack_holds_the_bar_in_max_norm)
-                wc.set_stack_precision("f32")
-                with torch.no_grad():
-                    for _ in range(3):
-                        wc.forward_features(dict(feats3))
-                    torch.cuda.synchronize(dev)
-                    t3 = time.perf_counter()
-                    for _ in range(10):
-                        wc.forward_features(dict(feats3))
-                    torch.cuda.synchronize(dev)
-                el32 = (time.perf_counter() - t3) / 10
+                els = {}
+                for prec3, n3p in (("f16+final_f32", 20), ("f32", 10)):
+                    wc.set_stack_precision(prec3)
+                    with torch.no_grad():
+                        for _ in range(5):
+                            wc.forward_features(dict(feats3))
+                        torch.cuda.synchronize(dev)
+                        t3 = time.perf_counter()
+                        for _ in range(n3p):
+                            wc.forward_features(dict(feats3))
+                        torch.cuda.synchronize(dev)
+                    els[prec3] = (time.perf_counter() - t3) / n3p
+                el32, el_final32 = els["f32"], els["f16+final_f32"]
                 # the same module at the SHIPPED VIPSeg ResNet-50 setting (maxtron_wc_r50.yaml: IMAGE_SIZE 769 x 1345, NUM_CLIP_FRAMES 2, 2 stages x
                 # (1 deformable layer + 2 axial-trajectory layers on res5 and res4)): res3 / res4 / res5 = 97 x 169 / 49 x 85 / 25 x 43 -- ragged maps
                 el_vip = None
@@ -771,12 +774,15 @@ def main():
                 extras["wc_cfg3"] = {"ms_per_forward": round(el * 1e3, 3), "value": round(4 / el, 1), "unit": "frames/s",
                                      "ms_per_forward_graph_replay": round(el_graph * 1e3, 3) if isinstance(el_graph, float) else el_graph,
                                      "ms_per_forward_vipseg_r50_769x1345_T2": round(el_vip * 1e3, 3) if isinstance(el_vip, float) else el_vip,
+                                     "ms_per_forward_final_layer_f32": round(el_final32 * 1e3, 3),
                                      "ms_per_forward_f32_stack": round(el32 * 1e3, 3),
                                      "what": "BASELINE config 3: WithinClipTrackingModule.forward_features, res3/4/5 = [4,192,64,64] / [4,384,32,32] / "
                                              "[4,768,16,16], 2 stages x (1 deformable spatial layer + 2 axial-trajectory layers on res5 and res4); "
                                              "ms_per_forward: 16-bit operands (<= 1e-3 per layer and in relative L2, 1.4e-3 max-norm over the stack), launched from Python; "
                                              "ms_per_forward_graph_replay: the same forward as one HIP-graph replay (GraphedForward; bit-equal outputs); "
-                                             "ms_per_forward_f32_stack: set_stack_precision('f32'), <= 1e-3 in max-norm as well; "
+                                             "ms_per_forward_final_layer_f32: set_stack_precision('f16+final_f32') -- only the last temporal layer of the last stage on the fp32 tier: <= 1e-3 in MAX-NORM on "
+                                             "every level (8.7e-4 / 6.9e-4 / 5.2e-4 on res4 / res5 / res3 against the reference fixture); "
+                                             "ms_per_forward_f32_stack: set_stack_precision('f32'), every temporal layer on it (3.8e-4); "
                                              "ms_per_forward_vipseg_r50_769x1345_T2: the same module at the shipped VIPSeg ResNet-50 setting (res3 / res4 / res5 = "
                                              "[2,512,97,169] / [2,1024,49,85] / [2,2048,25,43], 2 frames per clip)"}
                 del wc, feats3
