@@ -300,6 +300,10 @@ def _select_status_word(device: torch.device) -> None:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if getattr(_sync_tls, "status_idx", None) == idx:
         return
+    if idx not in _status_words and torch.cuda.is_current_stream_capturing():
+        # a device's FIRST library call inside somebody's graph capture: pinning host memory (hipHostMalloc) would invalidate the capture -- no status
+        # word for this capture (nothing is registered: merged launches are off without arrival counters too, see _select_sync_words)
+        return
     _lib.check(_lib.lib().axvs_set_status_buffer(_status_word(idx).data_ptr()), "axvs_set_status_buffer")
     _sync_tls.status_idx = idx
 
@@ -577,6 +581,9 @@ class TemporalAxialTrajectoryAttentionLayer(nn.Module):
             # (head_dim 64 always runs here).
             if self.return_attn:
                 raise NotImplementedError("axial_vs_amd: attention maps are an output of the 16-bit tier (mfma_dtype 'f16' / 'bf16')")
+            if self.out_dtype is not None:
+                raise NotImplementedError("axial_vs_amd: out_dtype (a 16-bit output map written by the kernel epilogue) exists on the 16-bit tier only; "
+                                          "the fp32 tier (mfma_dtype='f32') returns fp32 rows")
             from .training import axial_layer_train
             with torch.no_grad(), torch.autocast(device_type="cuda", enabled=False):      # (the fp32 tier stays fp32 under autocast)
                 return axial_layer_train(self, src, pos, dropout=False), None, None
