@@ -156,6 +156,12 @@ SIGNATURES = {
     "axvs_conv1x1_gn_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "axvs_conv1x1_gn_fwd": (C.c_int, [_fp, C.c_int, C.c_longlong, C.c_longlong, _fp, C.c_int, C.c_longlong, C.c_longlong, _fp] +
                             [C.c_int] * 5 + [C.c_float, C.c_int, _fp, C.c_size_t, _fp]),
+    "axvs_conv1x1_gn_train_saved_bytes": (C.c_size_t, [C.c_int] * 6 + [C.c_longlong, C.c_longlong]),
+    "axvs_conv1x1_gn_train_scratch_bytes": (C.c_size_t, [C.c_int] * 6),
+    "axvs_conv1x1_gn_train_fwd": (C.c_int, [_fp, C.c_int, C.c_longlong, C.c_longlong, _fp, C.c_int, C.c_longlong, C.c_longlong, C.POINTER(AxvsConvGnParams)] +
+                                  [C.c_int] * 5 + [C.c_float, _fp, C.c_size_t, _fp, C.c_size_t, _fp]),
+    "axvs_conv1x1_gn_train_bwd": (C.c_int, [_fp, C.c_int, C.c_longlong, C.c_longlong, _fp, C.c_int, C.c_longlong, C.c_longlong, C.POINTER(AxvsConvGnParams),
+                                            C.POINTER(AxvsConvGnParams), _fp] + [C.c_int] * 5 + [_fp, C.c_size_t, _fp, C.c_size_t, _fp]),
     "axvs_linear_sum_assignment": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp]),
     "axvs_match_embds_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "axvs_match_embds": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_size_t, _fp]),

@@ -489,6 +489,43 @@ int forward(const Ctx& c, const float* src, const float* pos, float* out, const 
 }
 
 #include "axvs_cc_train_host.h"
+#include "axvs_glue_train.h"
+
+// ---- 1x1 convolution + GroupNorm in train() mode (axvs_glue_train.h) ----
+struct ConvGnBufs {
+  float *y, *stats;                // saved: conv output [M][Cout] (token rows), (mean, rstd) [N][G][2]
+  float* xt;                       // saved: the input as contiguous token rows [M][Cin] (null when the caller's x already is)
+  float *part, *ab, *S, *dy, *dxt, *otok;      // scratch
+  float *wpart, *part_a, *wt;      // scratch of the weight-gradient / input-gradient GEMMs
+};
+ConvGnBufs carve_convgn(Bump& sv, Bump& sc, long long N, long long HW, int Cin, int Cout, int G, bool copy_x, bool backward, bool out_nchw) {
+  ConvGnBufs b{};
+  const size_t M = (size_t)(N * HW);
+  const int nblk = (int)((HW + 63) / 64);
+  b.y = sv.f(M * Cout);
+  b.stats = sv.f((size_t)N * G * 2);
+  b.xt = copy_x ? sv.f(M * Cin) : nullptr;
+  b.part = sc.f((size_t)N * nblk * Cout * 2);
+  b.ab = sc.f((size_t)N * Cout * 2);
+  b.otok = out_nchw ? sc.f(M * Cout) : nullptr;
+  if (backward) {
+    b.S = sc.f((size_t)N * G * 2);
+    b.dy = sc.f(M * Cout);
+    b.dxt = sc.f(M * Cin);
+    b.wpart = sc.f((size_t)(Gemm::kSplit + 1) * Cout * Cin);
+    b.part_a = sc.f((size_t)kColsumBlocks * (Cout > Cin ? Cout : Cin));
+    b.wt = sc.f((size_t)Cout * Cin);
+  }
+  return b;
+}
+int convgn_check(int N, int HW, int Cin, int Cout, int G, int in_layout, int out_layout, long long in_bs, long long in_ld, long long out_bs, long long out_ld) {
+  if (N <= 0 || HW <= 0) return fail(AXVS_ERR_ARG, "empty shape");
+  if (Cin % 8 || Cout % 8 || G <= 0 || Cout % G) return fail(AXVS_ERR_ARG, "conv1x1 + GroupNorm training tier: Cin=%d and Cout=%d must be multiples of 8, Cout of groups=%d", Cin, Cout, G);
+  if ((in_layout != 0 && in_layout != 1) || (out_layout != 0 && out_layout != 1)) return fail(AXVS_ERR_ARG, "layout must be 0 (NCHW) or 1 (token rows)");
+  if (in_layout == 1 && (in_ld % 4 || in_bs % 4 || in_ld < Cin)) return fail(AXVS_ERR_ARG, "token rows: strides must be multiples of 4 floats");
+  if (out_layout == 1 && (out_ld % 4 || out_bs % 4 || out_ld < Cout)) return fail(AXVS_ERR_ARG, "token rows: strides must be multiples of 4 floats");
+  return AXVS_OK;
+}
 
 }  // namespace
 }  // namespace axvs
@@ -682,6 +719,115 @@ int axvs_cc_layers_train_bwd(const float* d_queries, const float* clip_query, co
   const size_t n = (size_t)k.s.nl * k.s.M * kCcC;            // the chain adds the next layer's input gradient into this buffer
   if (hipMemcpyAsync(k.x.dx2h, d_queries, n * sizeof(float), hipMemcpyDeviceToDevice, k.st) != hipSuccess) return fail(AXVS_ERR_LAUNCH, "hipMemcpyAsync failed");
   return cc_chain_backward(k, clip_query, layers, layer_grads, d_clip_query, sv);
+}
+
+// ---- 1x1 convolution + GroupNorm, train() mode (WC/msdeformattn.py:349-375 under autograd) ----
+size_t axvs_conv1x1_gn_train_saved_bytes(int N, int HW, int Cin, int Cout, int groups, int in_layout, long long in_batch_stride, long long in_ld) {
+  Bump sv(nullptr), sc(nullptr);
+  const bool copy_x = in_layout == 0 || !(in_ld == Cin && in_batch_stride == (long long)HW * Cin);
+  carve_convgn(sv, sc, N, HW, Cin, Cout, groups, copy_x, false, false);
+  return sv.off;
+}
+size_t axvs_conv1x1_gn_train_scratch_bytes(int N, int HW, int Cin, int Cout, int groups, int backward) {
+  Bump sv(nullptr), sc(nullptr);
+  carve_convgn(sv, sc, N, HW, Cin, Cout, groups, true, backward != 0, true);
+  return sc.off;
+}
+
+int axvs_conv1x1_gn_train_fwd(const float* x, int in_layout, long long in_batch_stride, long long in_ld, float* out, int out_layout,
+                              long long out_batch_stride, long long out_ld, const AxvsConvGnParams* p, int N, int HW, int Cin, int Cout, int groups,
+                              float eps, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!x || !out || !p || !p->conv_w || !p->conv_b || !p->gn_w || !p->gn_b || !saved || !scratch) return fail(AXVS_ERR_ARG, "null pointer");
+  if (int rc = convgn_check(N, HW, Cin, Cout, groups, in_layout, out_layout, in_batch_stride, in_ld, out_batch_stride, out_ld)) return rc;
+  const bool copy_x = in_layout == 0 || !(in_ld == Cin && in_batch_stride == (long long)HW * Cin);
+  Bump sv(saved), sc(scratch);
+  const ConvGnBufs b = carve_convgn(sv, sc, N, HW, Cin, Cout, groups, copy_x, false, out_layout == 0);
+  if (sv.off > saved_bytes || sc.off > scratch_bytes) return fail(AXVS_ERR_WORKSPACE, "training buffers too small: saved %zu < %zu or scratch %zu < %zu", saved_bytes, sv.off, scratch_bytes, sc.off);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Gemm g;
+  if (int rc = g.init(st)) return rc;
+  const long long M = (long long)N * HW;
+  const int nblk = (HW + 63) / 64;
+  const float* xt = x;
+  if (in_layout == 0) {
+    hipLaunchKernelGGL(gt_nchw_to_tokens_kernel, dim3((unsigned)nblk, (unsigned)((Cin + 63) / 64), (unsigned)N), dim3(256), 0, st, x, b.xt, Cin, HW);
+    xt = b.xt;
+  } else if (copy_x) {
+    const long long t4 = M * Cin / 4;
+    hipLaunchKernelGGL(gt_gather_tokens_kernel, dim3(blocks((size_t)t4)), dim3(256), 0, st, x, b.xt, HW, Cin, in_batch_stride, in_ld, t4);
+    xt = b.xt;
+  }
+  // y = x W^T + b: three bf16 pieces per operand (fp32 accuracy: the GroupNorm statistics are formed on it)
+  GemmEpi e{p->conv_b, 1.f, 0, Drop{0u, 0u, 0u, 1.f}, 0.f};
+  if (int rc = g.fwd(xt, p->conv_w, b.y, M, Cout, Cin, 0.f, &e, true)) return rc;
+  hipLaunchKernelGGL((gt_block_colsums_kernel<0>), dim3((unsigned)nblk, (unsigned)N), dim3(256), 0, st, (const float*)b.y, (const float*)nullptr, (const float*)nullptr, b.part,
+                     HW, Cout, groups);
+  hipLaunchKernelGGL(gt_sum_blocks_kernel, dim3(blocks((size_t)N * Cout)), dim3(256), 0, st, (const float*)b.part, b.ab, nblk, Cout, (long long)N * Cout);
+  hipLaunchKernelGGL(gt_group_stats_kernel, dim3(blocks((size_t)N * groups)), dim3(256), 0, st, (const float*)b.ab, b.stats, Cout, groups,
+                     (float)((double)HW * (Cout / groups)), eps, N * groups);
+  const long long t4 = M * Cout / 4;
+  if (out_layout == 1) {
+    hipLaunchKernelGGL(gt_gn_apply_kernel, dim3(blocks((size_t)t4)), dim3(256), 0, st, (const float*)b.y, (const float*)b.stats, p->gn_w, p->gn_b, out, HW, Cout, groups,
+                       out_batch_stride, out_ld, t4);
+  } else {
+    hipLaunchKernelGGL(gt_gn_apply_kernel, dim3(blocks((size_t)t4)), dim3(256), 0, st, (const float*)b.y, (const float*)b.stats, p->gn_w, p->gn_b, b.otok, HW, Cout, groups,
+                       (long long)HW * Cout, (long long)Cout, t4);
+    hipLaunchKernelGGL(gt_tokens_to_nchw_kernel, dim3((unsigned)nblk, (unsigned)((Cout + 63) / 64), (unsigned)N), dim3(256), 0, st, (const float*)b.otok, out, Cout, HW,
+                       (long long)HW * Cout, (long long)Cout);
+  }
+  return status();
+}
+
+/* d_out in the forward's out layout; x as in the forward (read only when it was contiguous token rows: otherwise the saved copy is used); grads: every
+ * buffer is written; d_x (nullable) in the forward's in layout. */
+int axvs_conv1x1_gn_train_bwd(const float* d_out, int out_layout, long long out_batch_stride, long long out_ld, const float* x, int in_layout,
+                              long long in_batch_stride, long long in_ld, const AxvsConvGnParams* p, const AxvsConvGnGrads* grads, float* d_x, int N, int HW,
+                              int Cin, int Cout, int groups, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d_out || !x || !p || !p->conv_w || !p->gn_w || !grads || !grads->conv_w || !grads->conv_b || !grads->gn_w || !grads->gn_b || !saved || !scratch)
+    return fail(AXVS_ERR_ARG, "null pointer");
+  if (int rc = convgn_check(N, HW, Cin, Cout, groups, in_layout, out_layout, in_batch_stride, in_ld, out_batch_stride, out_ld)) return rc;
+  const bool copy_x = in_layout == 0 || !(in_ld == Cin && in_batch_stride == (long long)HW * Cin);
+  Bump sv(saved), sc(scratch);
+  const ConvGnBufs b = carve_convgn(sv, sc, N, HW, Cin, Cout, groups, copy_x, true, out_layout == 0);
+  if (sv.off > saved_bytes || sc.off > scratch_bytes) return fail(AXVS_ERR_WORKSPACE, "training buffers too small: saved %zu < %zu or scratch %zu < %zu", saved_bytes, sv.off, scratch_bytes, sc.off);
+  Ctx c{};
+  c.st = static_cast<hipStream_t>(stream);
+  if (int rc = c.g.init(c.st)) return rc;
+  c.sc.wpart = b.wpart; c.sc.part_a = b.part_a; c.sc.wt = b.wt;
+  hipStream_t st = c.st;
+  const long long M = (long long)N * HW;
+  const int nblk = (HW + 63) / 64;
+  const float* xt = copy_x ? b.xt : x;
+  // d_out -> contiguous token rows (they are overwritten with d_y below)
+  if (out_layout == 0) {
+    hipLaunchKernelGGL(gt_nchw_to_tokens_kernel, dim3((unsigned)nblk, (unsigned)((Cout + 63) / 64), (unsigned)N), dim3(256), 0, st, d_out, b.dy, Cout, HW);
+  } else {
+    const long long t4 = M * Cout / 4;
+    hipLaunchKernelGGL(gt_gather_tokens_kernel, dim3(blocks((size_t)t4)), dim3(256), 0, st, d_out, b.dy, HW, Cout, out_batch_stride, out_ld, t4);
+  }
+  hipLaunchKernelGGL((gt_block_colsums_kernel<1>), dim3((unsigned)nblk, (unsigned)N), dim3(256), 0, st, (const float*)b.dy, (const float*)b.y, (const float*)b.stats, b.part,
+                     HW, Cout, groups);
+  hipLaunchKernelGGL(gt_sum_blocks_kernel, dim3(blocks((size_t)N * Cout)), dim3(256), 0, st, (const float*)b.part, b.ab, nblk, Cout, (long long)N * Cout);
+  hipLaunchKernelGGL(gt_gn_bwd_params_kernel, dim3(blocks((size_t)Cout)), dim3(256), 0, st, (const float*)b.ab, grads->gn_w, grads->gn_b, N, Cout);
+  hipLaunchKernelGGL(gt_gn_bwd_groups_kernel, dim3(blocks((size_t)N * groups)), dim3(256), 0, st, (const float*)b.ab, p->gn_w, b.S, Cout, groups, N * groups);
+  const long long t4 = M * Cout / 4;
+  hipLaunchKernelGGL(gt_gn_bwd_apply_kernel, dim3(blocks((size_t)t4)), dim3(256), 0, st, b.dy, (const float*)b.y, (const float*)b.stats, (const float*)b.S, p->gn_w, HW, Cout,
+                     groups, (float)(1.0 / ((double)HW * (Cout / groups))), t4);
+  // d_W = d_y^T x, d_b = column sums of d_y (same launch), d_x = d_y W
+  if (int rc = c.wgrad(b.dy, xt, grads->conv_w, M, Cout, Cin, grads->conv_b)) return rc;
+  if (d_x != nullptr) {
+    float* dxt = (in_layout == 1 && !copy_x) ? d_x : b.dxt;
+    // three-piece operands: where a level passes through no layer between two projections (the temporal-only decoder's res3) this gradient feeds the GroupNorm
+    // backward of the projection in front of it, whose bias gradient is a sum that cancels analytically (the second GroupNorm removes a constant shift)
+    if (int rc = c.dgrad(b.dy, p->conv_w, dxt, M, Cout, Cin, 0.f, 0, true)) return rc;
+    if (in_layout == 0) {
+      hipLaunchKernelGGL(gt_tokens_to_nchw_kernel, dim3((unsigned)nblk, (unsigned)((Cin + 63) / 64), (unsigned)N), dim3(256), 0, st, (const float*)dxt, d_x, Cin, HW,
+                         (long long)HW * Cin, (long long)Cin);
+    } else if (copy_x) {      // strided token rows: scatter back through the apply kernel's addressing (identity statistics)
+      return fail(AXVS_ERR_ARG, "conv1x1 + GroupNorm backward: an input gradient in strided token rows is not built (pass contiguous rows or NCHW)");
+    }
+  }
+  return status();
 }
 
 }  // extern "C"

@@ -332,8 +332,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             return self._forward_features(features)
 
     def _forward_features_train(self, features):
-        """train() mode (WC/msdeformattn.py:404-437, :91-174 under autograd): the 1x1 convolutions + GroupNorm and the level embeddings
-        are the reference's torch modules; the sine embeddings come from the library's kernels (constants); the encoder's layers run
+        from .glue_training import conv_gn_train
+        """train() mode (WC/msdeformattn.py:404-437, :91-174 under autograd): the 1x1 convolutions + GroupNorm run the library's training tier
+        (round 6: axial_vs_amd.glue_training, forward and backward in HIP; rounds 3 - 5 used torch's kernels here), the level embeddings are torch parameters added by torch; the sine embeddings come from the library's kernels (constants); the encoder's layers run
         their training tiers (deformable attention: HIP forward / backward of the op; axial-trajectory layers: axvs_axial_layer_train_*)."""
         order = self.transformer_spatial_in_features[::-1]
         xs = [features[f] for f in order]
@@ -346,7 +347,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         srcs, poss, pos_3d = [], [], []
         for idx, (f, x) in enumerate(zip(order, xs)):
             H, W = shapes[idx]
-            srcs.append(self.input_proj[idx](x.float()).flatten(2).transpose(1, 2))
+            srcs.append(conv_gn_train(x, self.input_proj[idx][0], self.input_proj[idx][1], out_layout="tokens"))      # [BT, HW, Cd], in the library (round 6)
             if spatial:
                 sine = torch.empty(BT, H * W, self.conv_dims, dtype=torch.float32, device=dev)
                 self.pe_layer.tokens_into(sine, None, BT, H, W, 0)
@@ -362,7 +363,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         out = {}
         for i, (f, z) in enumerate(zip(order, torch.split(y, [h * w for h, w in shapes], dim=1))):
             H, W = shapes[i]
-            out[f] = self.output_proj[i](z.transpose(1, 2).contiguous().view(BT, -1, H, W))
+            out[f] = conv_gn_train(z.contiguous(), self.output_proj[i][0], self.output_proj[i][1], out_layout="nchw", hw=(H, W))
         return out, h_attn, w_attn
 
     def _forward_features(self, features):

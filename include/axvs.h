@@ -376,6 +376,19 @@ size_t axvs_conv1x1_gn_workspace_bytes(int N, int HW, int Cout, int groups);
 int axvs_conv1x1_gn_fwd(const float* x, int in_layout, long long in_batch_stride, long long in_ld, float* out, int out_layout,
                         long long out_batch_stride, long long out_ld, const void* packed, int N, int HW, int Cin, int Cout,
                         int groups, float eps, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The same projection in train() mode under autograd (round 6): forward on the raw fp32 parameters (three-piece bf16 GEMM: fp32 accuracy; GroupNorm statistics
+ * in fp32, fixed summation order) and backward (d_gamma, d_beta, d_W, d_b, d_x).  `saved` travels from the forward to the backward call (conv output, statistics,
+ * the input as token rows when it was not); `scratch` is free between calls.  Layouts / strides as above; Cin, Cout multiples of 8.
+ * An input gradient is produced in NCHW or contiguous token rows (d_x may be NULL). */
+typedef struct AxvsConvGnGrads { float *conv_w, *conv_b, *gn_w, *gn_b; } AxvsConvGnGrads;   /* field order of AxvsConvGnParams */
+size_t axvs_conv1x1_gn_train_saved_bytes(int N, int HW, int Cin, int Cout, int groups, int in_layout, long long in_batch_stride, long long in_ld);
+size_t axvs_conv1x1_gn_train_scratch_bytes(int N, int HW, int Cin, int Cout, int groups, int backward);
+int axvs_conv1x1_gn_train_fwd(const float* x, int in_layout, long long in_batch_stride, long long in_ld, float* out, int out_layout,
+                              long long out_batch_stride, long long out_ld, const AxvsConvGnParams* p, int N, int HW, int Cin, int Cout, int groups,
+                              float eps, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
+int axvs_conv1x1_gn_train_bwd(const float* d_out, int out_layout, long long out_batch_stride, long long out_ld, const float* x, int in_layout,
+                              long long in_batch_stride, long long in_ld, const AxvsConvGnParams* p, const AxvsConvGnGrads* grads, float* d_x, int N, int HW,
+                              int Cin, int Cout, int groups, void* saved, size_t saved_bytes, void* scratch, size_t scratch_bytes, void* stream);
 /* x[i] += v[i % C] in place (level_embed_3d on a channels-last position embedding, WC/msdeformattn.py:117-118) */
 int axvs_add_channel_vector(float* x, const float* v, size_t n, int C, void* stream);
 /* pos[n][row0 + y*W + x][c] (+ add[c] if add != NULL) inside a fp32 [N][S][C] buffer */

@@ -88,7 +88,8 @@ def test_within_clip_module_trains(name):
     """WithinClipTrackingModule in train() mode (dropout 0): forward_features equals the reference decoder's fixture outputs at fp32
     accuracy (the training tiers are fp32), and the gradients of the backbone maps and of every parameter equal autograd on the
     float64 oracle decoder -- the whole within-clip stage of the reference trains on this package's kernels (deformable attention:
-    HIP forward / backward of the native op; axial-trajectory layers: their training tier; 1x1 conv + GroupNorm: torch)."""
+    HIP forward / backward of the native op; axial-trajectory layers: their training tier; 1x1 conv + GroupNorm: the library's training tier since round 6,
+    axial_vs_amd.glue_training)."""
     from golden_util import weights
     from test_cabi_cpu import _decoder_from_meta
     z, m = load(name)
@@ -118,9 +119,9 @@ def test_within_clip_module_trains(name):
           for k, p in mod.within_clip_tracking_module.named_parameters() if wd[k].grad is not None}
     worst = max(pe, key=pe.get)
     print(f"{name}: feature gradients {e}, worst parameter gradient {worst} {pe[worst]:.2e} ({len(pe)} parameters)")
-    # the 1x1 convolution + GroupNorm glue runs on torch's own fp32 kernels; where a level passes through no layer (temporal-only
-    # decoder: res3) the GroupNorm bias of its input projection feeds a second GroupNorm that removes most of it -- a gradient that
-    # nearly cancels, left with torch's fp32 rounding (1.5e-4 of the floor)
+    # where a level passes through no layer (temporal-only decoder: res3) the GroupNorm bias of its input projection feeds a second GroupNorm that
+    # removes most of it -- a gradient that nearly cancels, left with fp32 rounding (torch's own kernels: 1.5e-4 of the floor; the library's input-gradient
+    # GEMM of the projections runs three-piece operands for this reason)
     glue = {k: v for k, v in pe.items() if k.startswith(("input_proj", "output_proj"))}
     ours = {k: v for k, v in pe.items() if k not in glue}
     assert max(e.values()) < 1e-4 and max(ours.values()) < 1e-4 and max(glue.values()) < 5e-4, (e, worst, pe[worst])
