@@ -20,8 +20,8 @@ for F in (1024, 512, 2048):
         xs = torch.randn(M, C, device="cuda") * 1.7 + 0.3
         outs, times = [], []
         ws = torch.empty(L.axvs_ffn_workspace_bytes(M, C, F), dtype=torch.uint8, device="cuda")
-        for mode in (2, 1):
-            _lib.check(L.axvs_set_option(b"ffn_wide", mode), "opt")
+        for mode in (4, 2):                       # plan_force: 4 = never the 128-row tiles, 2 = always
+            _lib.check(L.axvs_set_option(b"plan_force", mode), "opt")
             out = torch.full_like(xs, float("nan"))
             def run(): _lib.check(L.axvs_ffn_fwd(xs.data_ptr(), out.data_ptr(), packed.data_ptr(), M, C, 8, F, 0, ws.data_ptr(), ws.numel(), st), "ffn")
             for _ in range(20): run()
@@ -31,7 +31,7 @@ for F in (1024, 512, 2048):
             e1.record(); torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 5)
             outs.append(out.clone())
-        _lib.check(L.axvs_set_option(b"ffn_wide", 0), "opt")
+        _lib.check(L.axvs_set_option(b"plan_force", 0), "opt")
         same = torch.equal(outs[0], outs[1])
         print(f"F={F} M={M:6d}: 64-row {times[0]:7.2f} us   128-row {times[1]:7.2f} us (both incl. the input copy)   bit-identical: {same}"
               + ("" if same else f"  max diff {float((outs[0]-outs[1]).abs().max()):.3e} nan {int(torch.isnan(outs[1]).sum())}"))
