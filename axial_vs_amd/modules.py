@@ -16,6 +16,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import math
+import operator
 import threading
 import weakref
 from typing import Dict, List, Optional, Tuple
@@ -54,7 +55,7 @@ _sync_tls = threading.local()       # per calling thread: which sync words / sta
 def _workspace(device: torch.device, nbytes: int, stream_handle: Optional[int] = None) -> Tensor:
     """Grow-only scratch buffer per (device, stream) from torch's caching allocator.  `stream_handle`: the current stream's handle
     when the caller has it already (torch.cuda.current_stream costs ~4 us per call)."""
-    key = (str(device), stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream)
+    key = (str(device), stream_handle if stream_handle is not None else _stream(device))
     ov = getattr(_sync_tls, "override", None)
     store = _workspaces if ov is None else ov["ws"]      # a graph under construction owns its scratch (GraphedForward): graphs captured on
     buf = store.get(key)                                 # torch's shared capture stream must not bake one common workspace in
@@ -64,7 +65,14 @@ def _workspace(device: torch.device, nbytes: int, stream_handle: Optional[int] =
     return buf
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device: torch.device) -> int:
+    """Handle of torch's current stream on `device`.  torch.cuda.current_stream builds a Stream object (~3 us, and a forward of the
+    within-clip module asks ~36 times); the raw getter behind it returns the handle itself."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -79,7 +87,7 @@ def _select_sync_words(device: torch.device, stream_handle: Optional[int] = None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     override = getattr(_sync_tls, "override", None)
     if override is not None:             # GraphedForward: the graph being warmed up / captured owns its counters (see there)
-        sh = stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream
+        sh = stream_handle if stream_handle is not None else _stream(device)
         key = ("graph", idx, sh, id(override))
         if getattr(_sync_tls, "key", None) == key:
             return
@@ -92,7 +100,7 @@ def _select_sync_words(device: torch.device, stream_handle: Optional[int] = None
             _lib.check(_lib.lib().axvs_set_sync_buffer(buf.data_ptr(), buf.numel()), "axvs_set_sync_buffer")
         _sync_tls.key = key
         return
-    key = (idx, stream_handle if stream_handle is not None else torch.cuda.current_stream(device).cuda_stream)
+    key = (idx, stream_handle if stream_handle is not None else _stream(device))
     if getattr(_sync_tls, "key", None) == key:
         return
     buf = _sync_buffers.get(key)
@@ -127,6 +135,10 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_tensor_data_ptr = torch.Tensor.data_ptr
+_tensor_version = operator.attrgetter("_version")
+
+
 def _param_key(mod: nn.Module, dtype: str):
     """Cheap change detector for the packed-weight caches: (storage pointer, version counter) of every parameter.
     Walking `mod.modules()` / `mod.parameters()` costs ~75 us for a layer (more than half of the GPU time of a forward), so the
@@ -150,11 +162,11 @@ def _param_key(mod: nn.Module, dtype: str):
                 prefs.append((m._parameters, name))
         cache = (mods, prefs)
         d["_axvs_refs"] = cache
-    key = [dtype]
-    for pd, name in cache[1]:
-        p = pd.get(name)
-        key.append(None if p is None else (p.data_ptr(), p._version))
-    return tuple(key)
+    ps = [pd.get(name) for pd, name in cache[1]]
+    try:            # the two C-level sweeps cost a third of a Python loop over the parameters (14 such keys per forward of the within-clip module)
+        return (dtype, tuple(map(_tensor_data_ptr, ps)), tuple(map(_tensor_version, ps)))
+    except (TypeError, AttributeError):          # a parameter slot holding None (bias=False)
+        return (dtype, tuple([None if p is None else (p.data_ptr(), p._version) for p in ps]))
 
 
 def _has_hooks(mod: nn.Module) -> bool:
