@@ -213,5 +213,9 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     assert g5["ranks"] == 2 and g5["fp32_map"]["value"] > 0 and g5["f16_map"]["value"] > 0
     assert g5["fp32_map"]["inbound_MB_per_rank_per_step"] == pytest.approx(8 * 4 * 96 * 96 * 256 * 4 / 1e6, rel=1e-3)     # one other rank's maps
     assert g5["f16_map"]["inbound_MB_per_rank_per_step"] == pytest.approx(8 * 4 * 96 * 96 * 256 * 2 / 1e6, rel=1e-3)
+    # the transport without a collective (dist.PeerMaps: every rank writes its rows into every rank's IPC-mapped map) ran as well
+    pw = g5.get("f16_map_peer_writes")
+    assert pw is not None and "error" not in pw and pw["value"] > 0, pw
+    assert pw["inbound_MB_per_rank_per_step"] == pytest.approx(8 * 4 * 96 * 96 * 256 * 2 / 1e6, rel=1e-3)
     assert j["extras"]["tensor_pos"]["value"] > 0
-    print("cfg5_gather:", g5["fp32_map"], g5["f16_map"])
+    print("cfg5_gather:", g5["fp32_map"], g5["f16_map"], pw)
