@@ -82,38 +82,55 @@ class PeerMaps:
     landed in this rank's map.  One process per GPU; works the same with both processes on ONE device (the test: two ranks sharing cuda:0).
     Not measured on more than one GPU (no multi-GPU node was available to this build): correctness by construction + the two-process test."""
 
-    def __init__(self, rows_total: int, tail: Tuple[int, ...], dtype: torch.dtype, device, group=None):
+    def __init__(self, rows_total: int, tail: Tuple[int, ...], dtype: torch.dtype, device, group=None, buffers: int = 2):
+        """`buffers` maps used in turn, one per step (a step = the publishes up to a `wait()`).  Why two by default: a peer that has passed step i's
+        barrier may publish step i + 1's rows while this rank's consumers of step i's map are still running -- into the SAME map that would be a race no
+        stream order on this rank can prevent.  With two maps a peer writes into step i's map again only at step i + 2, i.e. after step i + 1's barrier,
+        which this rank enters after its own step-(i + 1) copies have completed -- and those were queued behind everything this rank had queued on the
+        publishing stream before, the consumers of step i's map included.  (Consumers on OTHER streams must be joined before the next step's first
+        publish; `buffers=1` is for callers that synchronise themselves, e.g. a barrier of their own before each step.)"""
         from torch.multiprocessing.reductions import reduce_tensor
+        if buffers < 1:
+            raise ValueError("PeerMaps: buffers >= 1")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = torch.device(device)
-        # a block of its own from the caching allocator (IPC shares the whole allocation the tensor lives in)
-        self.map = torch.empty((rows_total,) + tuple(tail), dtype=dtype, device=self.device)
+        # blocks of their own from the caching allocator (IPC shares the whole allocation a tensor lives in)
+        self.maps: List[Tensor] = [torch.empty((rows_total,) + tuple(tail), dtype=dtype, device=self.device) for _ in range(buffers)]
         handles = [None] * self.world
-        dist.all_gather_object(handles, reduce_tensor(self.map), group=group)
-        self.peers: List[Tensor] = []
-        for r, (rebuild, args) in enumerate(handles):
-            self.peers.append(self.map if r == self.rank else rebuild(*args))
+        dist.all_gather_object(handles, [reduce_tensor(m) for m in self.maps], group=group)
+        self.peers: List[List[Tensor]] = []              # [buffer][rank]
+        for b in range(buffers):
+            self.peers.append([self.maps[b] if r == self.rank else handles[r][b][0](*handles[r][b][1]) for r in range(self.world)])
+        self._cur = 0
         self._side = torch.cuda.Stream(self.device)
         dist.barrier(group)                      # every rank has opened every handle before anybody writes
 
+    @property
+    def map(self) -> Tensor:
+        """The map of the step being published (what the next `wait()` returns)."""
+        return self.maps[self._cur]
+
     def publish(self, rows: Tensor, row0: int) -> None:
-        """rows -> [row0, row0 + len(rows)) of every rank's map, asynchronously behind the work already queued on the current stream."""
+        """rows -> [row0, row0 + len(rows)) of every rank's map of this step, asynchronously behind the work already queued on the current stream."""
         cur = torch.cuda.current_stream(self.device)
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             for k in range(self.world):
                 r = (self.rank + k) % self.world         # start with my own map, then ring order: the ranks do not all hit the same peer first
-                self.peers[r][row0:row0 + rows.shape[0]].copy_(rows, non_blocking=True)
+                self.peers[self._cur][r][row0:row0 + rows.shape[0]].copy_(rows, non_blocking=True)
         rows.record_stream(self._side)
 
     def wait(self) -> Tensor:
-        """All ranks' published rows are in this rank's map (returns it).  Host-synchronous: the step boundary of a batch-sharded forward."""
+        """All ranks' published rows of this step are in this rank's map (returns it; the next step publishes into the next map).  Host-synchronous:
+        the step boundary of a batch-sharded forward."""
         self._side.synchronize()
         dist.barrier(self.group)
         torch.cuda.current_stream(self.device).wait_stream(self._side)
-        return self.map
+        full = self.maps[self._cur]
+        self._cur = (self._cur + 1) % len(self.maps)
+        return full
 
 
 def chunked_clip_order(total: int, world: int, chunks: int) -> List[int]:
@@ -144,8 +161,8 @@ def sharded_forward(layer_fn: Callable[[Tensor, Tensor], Tensor], src: Tensor, p
       * pre-sharded inputs (rank r holds its own clips): the groups land ordered (group, rank, clip in group).
 
     ``peer_maps`` (a `PeerMaps` of [total * T rows, ...] in the map's dtype; equal shards): no collective at all -- every group's rows are written
-    straight into every rank's map at their natural (rank-major) position behind the group's kernels; the result is `peer_maps.map` in natural clip
-    order (valid until the next call that publishes into the same maps).
+    straight into every rank's map at their natural (rank-major) position behind the group's kernels; the result is the step's map in natural clip
+    order, valid until the same buffer comes round again (`PeerMaps(buffers=2)`: until the call after the next one).
 
     **The returned order never depends on the shapes.**  ``allow_permuted=False`` (default): a Tensor in natural clip order (rank-major for
     pre-sharded inputs) on every path -- the chunked pre-sharded path pays ONE reordering copy of the gathered map for it.

@@ -59,6 +59,12 @@ def _worker(rank, world, port, q):
         res["peer_maps_chunks2_presharded"] = bool(torch.equal(axd.sharded_forward(fn, s_loc, p_loc, replicated_inputs=False, chunks=2, peer_maps=pm), full))
         pm16 = axd.PeerMaps(B * T, (H * W, C), torch.float16, "cuda")
         res["peer_maps_f16"] = bool(torch.equal(axd.sharded_forward(fn, s, p, gather_dtype=torch.float16, chunks=2, peer_maps=pm16), full.half()))
+        # two maps in turn: step 1's map still holds step 1's result after step 2 (other inputs) has been published by both ranks
+        s2 = s * 0.5 + 0.25
+        full2 = fn(s2, p)
+        m1 = axd.sharded_forward(fn, s, p, peer_maps=pm16, gather_dtype=torch.float16)
+        m2 = axd.sharded_forward(fn, s2, p, peer_maps=pm16, gather_dtype=torch.float16)
+        res["peer_maps_two_buffers"] = bool(m1.data_ptr() != m2.data_ptr() and torch.equal(m1, full.half()) and torch.equal(m2, full2.half()))
         del pm, pm16
         # one clip over both ranks: column blocks -> exchange -> row blocks
         one_s, one_p = s[:T].contiguous(), p[:1].contiguous()
