@@ -38,11 +38,14 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_kernel(const float* __rest
   const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64, n = blockIdx.z;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // read: tx = pixel, 4 channel rows at a time
   const float* src = x + ((long long)n * C + c0) * HW + p0;
-#pragma unroll 4
+  float v[16];                 // all 16 loads of a thread in flight before the first LDS store (round 6: four at a time left the kernel at 1.7 TB/s)
+#pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = ty + 4 * i;
-    tile[c][tx] = (c0 + c < C && p0 + tx < HW) ? src[(long long)c * HW + tx] : 0.f;
+    v[i] = (c0 + c < C && p0 + tx < HW) ? src[(long long)c * HW + tx] : 0.f;
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tile[ty + 4 * i][tx] = v[i];
   __syncthreads();
   // write: 16 threads x float4 cover the 64 channels of a pixel row (256 contiguous bytes), 16 pixels per round
   const int wc = (threadIdx.x & 15) * 4, wp = threadIdx.x >> 4;
@@ -149,9 +152,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int g_first = c0 / cg, g_last = min(c0 + 63, C - 1) / cg, lane = tid & 63;
     for (int g = g_first + (tid >> 6); g <= g_last; g += 4) {
       float s = 0.f, q = 0.f;
-      for (int b = lane; b < nblk; b += 64) {
-        const float* p = partial + (((long long)n * nblk + b) * G + g) * 2;
-        s += p[0]; q += p[1];
+      // eight partials per lane in flight at a time, added in block order as before (round 6: one dependent load per 64 blocks made this prologue a
+      // chain of L2 round trips in front of EVERY workgroup's 16 KB of work on the large maps: 257 blocks at the shipped VIPSeg res3 size)
+      for (int b0 = lane; b0 < nblk; b0 += 64 * 8) {
+        float2 pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int b = b0 + 64 * u;
+          pv[u] = b < nblk ? *reinterpret_cast<const float2*>(partial + (((long long)n * nblk + b) * G + g) * 2) : float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += pv[u].x; q += pv[u].y; }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
