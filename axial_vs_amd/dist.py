@@ -101,11 +101,20 @@ class PeerMaps:
         handles = [None] * self.world
         dist.all_gather_object(handles, [reduce_tensor(m) for m in self.maps], group=group)
         self.peers: List[List[Tensor]] = []              # [buffer][rank]
-        for b in range(buffers):
-            self.peers.append([self.maps[b] if r == self.rank else handles[r][b][0](*handles[r][b][1]) for r in range(self.world)])
+        err = None
+        try:
+            for b in range(buffers):
+                self.peers.append([self.maps[b] if r == self.rank else handles[r][b][0](*handles[r][b][1]) for r in range(self.world)])
+        except Exception as e:                   # e.g. hipIpcOpenMemHandle refused (legacy IPC mode, no peer access): every rank has to learn of it,
+            err = e                              # or the others would wait in the barrier below for a rank that has left
+        oks = [None] * self.world
+        dist.all_gather_object(oks, err is None, group=group)     # (also the barrier: every rank has opened every handle before anybody writes)
+        if not all(oks):
+            self.peers = []
+            raise RuntimeError(f"PeerMaps: opening the peers' maps failed on rank(s) {[r for r, ok in enumerate(oks) if not ok]}"
+                               + (f" (this rank: {err})" if err is not None else "")) from err
         self._cur = 0
         self._side = torch.cuda.Stream(self.device)
-        dist.barrier(group)                      # every rank has opened every handle before anybody writes
 
     @property
     def map(self) -> Tensor:
