@@ -225,3 +225,25 @@ def test_bench_launcher_two_ranks_on_one_gpu():
     assert pw["inbound_MB_per_rank_per_step"] == pytest.approx(8 * 4 * 96 * 96 * 256 * 2 / 1e6, rel=1e-3)
     assert j["extras"]["tensor_pos"]["value"] > 0
     print("cfg5_gather:", g5["fp32_map"], g5["f16_map"], pw)
+
+
+def test_bench_watchdog_prints_the_headline_when_a_multi_rank_extra_does_not_return():
+    """N > 1: the secondary measurements of bench.py contain collectives; if one hangs, the headline must still reach the driver.  With a 2-second limit
+    the watchdog fires during the extras: rank 0 prints the headline line (extras.watchdog says why it is alone), every rank exits 0."""
+    import json
+    import subprocess
+    import sys
+    import __graft_entry__ as ge
+    ge.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AXVS_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", AXVS_BENCH_EXTRAS_TIMEOUT_S="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--settle-ms", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "watchdog" in j["extras"], j.get("extras")
+    print("watchdog line:", j["value"], j["unit"], "|", j["extras"]["watchdog"])
